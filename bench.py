@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BN254-Fr sumcheck field-ops/sec on 2^20-point multilinear
+tables (BASELINE.json metric, configs[2]), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch: `--batch` independent
+2^n-point multilinear sumchecks (prove_sumcheck, rust/src/gkr/sumcheck.rs:158-214),
+tables resident in HBM before the timed region, MiMC7 transcript included.
+Independent sumchecks shard across ranks with no data-path collective (weak
+scaling: every rank proves its own batch).
+
+field-ops: 5 (2^n - 1) per sumcheck; algorithmic bytes 128 * 2^n per sumcheck
+(SURVEY.md section 8d).  The JSON line also carries
+  roofline      the dominant kernel (mle_fold_sum) timed with HIP events on the
+                library's stream during the timed steps
+  cpu_baseline  the plain-C oracle (oracle/c, OpenMP over the host cores) on a
+                bounded sample of the same workload; rank 0, N = 1 only
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
+    ap.add_argument("--batch", type=int, default=64, help="independent sumchecks per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+
+    from gkr_amd import Context
+
+    n, batch = args.n, args.batch
+    count = 1 << n
+    ctx = Context(local_rank)
+    tables = ctx.alloc(batch * count * 32)
+    for b in range(batch):
+        ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, 0xC0FFEE + 2 + 1000 * rank + b)
+    ctx.synchronize()
+
+    def step():
+        return ctx.sumcheck_mle_batch_device(tables, n, batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ops_per_sumcheck = 5 * (count - 1)
+    total_ops = ops_per_sumcheck * batch * args.steps * world
+    value = total_ops / elapsed
+
+    if rank == 0:
+        fold = ctx.profile_get("mle_fold_sum")
+        first = ctx.profile_get("mle_sum_first")
+        hsh = ctx.profile_get("mle_round_hash")
+        achieved = fold["bytes"] / (fold["total_ms"] * 1e-3) / 1e9 if fold["total_ms"] > 0 else 0.0
+        peak = 8000.0
+        line = {
+            "metric": "BN254-Fr sumcheck field-ops/sec @ 2^20 vars",
+            "value": value,
+            "unit": "field-ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (BN254 Fr, 254-bit modular integers)",
+            "data": "synthetic",
+            "config": {"workload": "plain MLE sumcheck (prove_sumcheck), 2^%d points per table, BASELINE configs[2]" % n,
+                       "log2_points": n, "batch_per_gpu": batch, "sumchecks_per_step": batch * world,
+                       "transcript": "MiMC7-91 on device, included in the timed region",
+                       "parallelism": "independent sumchecks per rank, no collective"},
+            "sumchecks_per_sec": batch * args.steps * world / elapsed,
+            "roofline": {
+                "bound": "hbm", "kernel": "k_mle_fold_sum",
+                "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                "traffic": None,
+                "launches": fold["launches"], "avg_launch_us": (fold["total_ms"] * 1e3 / fold["launches"]) if fold["launches"] else None,
+                "algorithmic_bytes_per_launch": (fold["bytes"] / fold["launches"]) if fold["launches"] else None,
+            },
+            "kernel_ms": {"mle_fold_sum": fold["total_ms"], "mle_sum_first": first["total_ms"],
+                          "mle_round_hash": hsh["total_ms"]},
+        }
+        if first["total_ms"] > 0:
+            line["roofline"]["sum_first_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    ctx.free(tables)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(n, seconds):
+    """The oracle's dense C prover (a port of the reference algorithm's dense form;
+    the reference itself is Rust and cannot be built here) on the host cores."""
+    from oracle import cdense
+    cores = cdense.max_threads()
+    table = cdense.fill_table(1 << n, 0xC0FFEE + 2)
+    cdense.sumcheck_mle_raw(table, n)          # warm-up (constants, page faults)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        cdense.sumcheck_mle_raw(table, n)
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or done >= 2000:
+            break
+    return {"value": done * 5 * ((1 << n) - 1) / dt, "unit": "field-ops/s", "cores": cores, "kind": "port",
+            "sample": "%d sequential 2^%d-point sumchecks (MiMC7 included) in %.1f s, OpenMP over %d threads"
+                      % (done, n, dt, cores)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""ctypes binding of libgkr_amd.so (include/gkr_amd.h).
+
+The library is the product; there is no Python or CPU fallback.  Importing this
+module without the built library raises, and every compute call needs a gfx950
+device.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgkr_amd.so")
+
+GKR_OK = 0
+GKR_ERR_INVALID = 1
+GKR_ERR_NON_CANONICAL = 2
+GKR_ERR_NO_DEVICE = 3
+GKR_ERR_HIP = 4
+GKR_ERR_NOMEM = 5
+GKR_ERR_DEGENERATE = 6
+
+GKR_TRANSCRIPT_DEVICE = 0
+GKR_TRANSCRIPT_HOST = 1
+
+# every symbol include/gkr_amd.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "gkr_strerror", "gkr_version", "gkr_ctx_create", "gkr_ctx_destroy", "gkr_last_error",
+    "gkr_ctx_set_transcript", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get",
+    "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
+    "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
+    "gkr_sumcheck_layer", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove",
+    "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
+    "gkr_device_fill_table", "gkr_device_synchronize",
+]
+
+
+class CircuitDesc(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_uint32),
+        ("k", ctypes.POINTER(ctypes.c_uint32)),
+        ("gate_type", ctypes.POINTER(ctypes.c_void_p)),
+        ("left", ctypes.POINTER(ctypes.c_void_p)),
+        ("right", ctypes.POINTER(ctypes.c_void_p)),
+    ]
+
+
+class ProofBuf(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("sumcheck_coeffs", "sumcheck_len", "sumcheck_r", "q", "q_len", "z", "r", "d_coeffs", "input_coeffs")]
+
+
+class ProofSizes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in ("rounds", "q_slots", "z_values", "d_coeffs", "input_coeffs")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "gkr_amd: %s is missing -- build it with `make -C gkr_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.gkr_strerror.restype = ctypes.c_char_p
+        L.gkr_version.restype = ctypes.c_char_p
+        L.gkr_last_error.restype = ctypes.c_char_p
+        L.gkr_last_error.argtypes = [ctypes.c_void_p]
+        L.gkr_ctx_destroy.restype = None
+        L.gkr_ctx_destroy.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib

@@ -1,0 +1,53 @@
+// Launchers of the CDNA4 kernels (kernels.hip).  Internal to the library; the
+// public surface is include/gkr_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fr32.h"
+
+namespace gkr {
+
+constexpr uint32_t kMaxBlocksPerTable = 2048;
+constexpr uint32_t kMaxLayerBlocks = 2048;
+
+struct MlePartial {
+    Acc<9> lo, hi;
+    uint32_t dep, pad;
+};
+
+struct LayerPartial {
+    Acc<9> c0, g1, c2;
+    uint32_t pad;
+};
+
+void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
+
+uint32_t mle_blocks_per_table(uint32_t items, uint32_t batch);
+void launch_mle_sum_first(const Fr* tables, size_t stride, uint32_t h, uint32_t batch, uint32_t nblk,
+                          MlePartial* partials, hipStream_t s);
+void launch_mle_fold_sum(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
+                         uint32_t nblk, const Fr* r_mont, uint32_t r_stride, MlePartial* partials, hipStream_t s);
+void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t round, uint32_t n, uint32_t batch,
+                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, Fr* r_mont, uint32_t* dep_last,
+                           hipStream_t s);
+
+void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                       const Fr* prev, Fr* out, hipStream_t s);
+void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
+void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s);
+void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
+                              const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
+                              unsigned long long* wideM, uint32_t* bad, hipStream_t s);
+void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s);
+
+uint32_t layer_blocks(uint32_t h);
+void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
+                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s);
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const Fr* r_mont, hipStream_t s);
+void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
+                             const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
+                             Fr* r_mont, Fr* Wb, Fr* Wc, hipStream_t s);
+
+}  // namespace gkr

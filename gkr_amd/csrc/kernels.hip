@@ -1,0 +1,512 @@
+// CDNA4 (gfx950) kernels of the GKR sumcheck hot path.
+//
+// All kernels work on dense evaluation tables whose index is the bit string of
+// the variables with variable 1 as the MOST significant bit (the reference's
+// convention, rust/src/gkr/poly.rs:507,117-131).  Binding the leading variable
+// therefore pairs entry i with entry i + h (h = half the table): two contiguous,
+// perfectly coalesced streams.  One lane owns one 32-byte element
+// (2 x global_load_dwordx4).
+//
+// Data parallel work only -- no MFMA: this is 254-bit modular integer arithmetic
+// (v_mad_u64_u32 chains); the roofline is HBM bandwidth.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "mimc7.h"
+
+namespace gkr {
+
+// ---------------------------------------------------------------------------
+// wave64 / block reductions of wide accumulators
+// ---------------------------------------------------------------------------
+
+template <int NL>
+__device__ __forceinline__ Acc<NL> wave_sum(Acc<NL> a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Acc<NL> o;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) o.l[i] = __shfl_down(a.l[i], off, 64);
+        acc_add_acc(a, o);
+    }
+    return a;  // lane 0 holds the wave total
+}
+
+// Sum NA accumulators over the block; thread 0 gets the totals.  smem must hold
+// (blockDim.x / 64) * NA accumulators.
+template <int NL, int NA>
+__device__ __forceinline__ void block_sum(Acc<NL> (&acc)[NA], Acc<NL>* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        acc[k] = wave_sum(acc[k]);
+        if (lane == 0) smem[wave * NA + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nwaves; ++w)
+#pragma unroll
+            for (int k = 0; k < NA; ++k) acc_add_acc(acc[k], smem[w * NA + k]);
+    }
+}
+
+__device__ __forceinline__ Fr load_fr(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr f;
+    f.l[0] = a.x; f.l[1] = a.y; f.l[2] = a.z; f.l[3] = a.w;
+    f.l[4] = b.x; f.l[5] = b.y; f.l[6] = b.z; f.l[7] = b.w;
+    return f;
+}
+
+__device__ __forceinline__ void store_fr(Fr* p, const Fr& f) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(f.l[0], f.l[1], f.l[2], f.l[3]);
+    q[1] = make_uint4(f.l[4], f.l[5], f.l[6], f.l[7]);
+}
+
+// ---------------------------------------------------------------------------
+// synthetic workload (bench / parity at full size)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ void k_fill_table(Fr* table, size_t count, uint64_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        Fr f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t w = mix64(seed + (4 * (uint64_t)i + (uint64_t)j + 1) * 0x9E3779B97F4A7C15ULL);
+            if (j == 3) w &= 0x1FFFFFFFFFFFFFFFULL;
+            f.l[2 * j] = (uint32_t)w;
+            f.l[2 * j + 1] = (uint32_t)(w >> 32);
+        }
+        store_fr(table + i, f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plain multilinear sumcheck (reference: prove_sumcheck, sumcheck.rs:158-214)
+// ---------------------------------------------------------------------------
+
+// Round 1: S_lo = sum T[0..h), S_hi = sum T[h..2h) per table, plus "does the
+// table depend on its last variable" (needed by the last round's length rule).
+// grid = (blocks_per_table, batch)
+__global__ void __launch_bounds__(256) k_mle_sum_first(const Fr* __restrict__ tables, size_t table_stride,
+                                                       uint32_t h, MlePartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4 * 2];
+    __shared__ uint32_t s_dep;
+    const Fr* t = tables + (size_t)blockIdx.y * table_stride;
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) s_dep = 0;
+    __syncthreads();
+    // h is a power of two >= 2 here; blockDim-strided indices keep even/odd lanes adjacent
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
+        Fr lo = load_fr(t + i), hi = load_fr(t + i + h);
+        acc_add_fr(acc[0], lo);
+        acc_add_fr(acc[1], hi);
+        // element 2m vs 2m+1: neighbour lane holds the partner (i and i^1 are in the same wave)
+        uint32_t dl = 0, dh = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            dl |= lo.l[k] ^ __shfl_xor(lo.l[k], 1, 64);
+            dh |= hi.l[k] ^ __shfl_xor(hi.l[k], 1, 64);
+        }
+        dep |= dl | dh;
+    }
+    if (dep) atomicOr(&s_dep, 1u);
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        MlePartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->lo = acc[0];
+        p->hi = acc[1];
+        p->dep = s_dep;   // valid: block_sum's __syncthreads ordered the atomicOr before this read
+    }
+}
+
+// Rounds 2..n: fold T_{j-1} with r_{j-1} into T_j and accumulate the two half
+// sums of T_j in the same pass.  src has 4q elements, dst 2q.  In-place
+// (dst == src) is safe: a thread writes only slots it alone has read.
+// grid = (blocks_per_table, batch)
+__global__ void __launch_bounds__(256) k_mle_fold_sum(const Fr* __restrict__ src, size_t src_stride,
+                                                      Fr* __restrict__ dst, size_t dst_stride, uint32_t q,
+                                                      const Fr* __restrict__ r_mont, uint32_t r_stride,
+                                                      MlePartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4 * 2];
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    const Fr r = r_mont[(size_t)blockIdx.y * r_stride];   // wave-uniform -> scalar loads
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q; i += gridDim.x * blockDim.x) {
+        Fr x0 = load_fr(s + i), x1 = load_fr(s + i + 2 * (size_t)q);
+        Fr x2 = load_fr(s + i + q), x3 = load_fr(s + i + 3 * (size_t)q);
+        Fr y0 = fr_fold(x0, x1, r);
+        Fr y1 = fr_fold(x2, x3, r);
+        store_fr(d + i, y0);
+        store_fr(d + i + q, y1);
+        acc_add_fr(acc[0], y0);
+        acc_add_fr(acc[1], y1);
+    }
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        MlePartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->lo = acc[0];
+        p->hi = acc[1];
+        p->dep = 0;
+    }
+}
+
+// One wave per table: add up the per-block partials, apply the reference's
+// length rule, hash the round vector with MiMC7, publish r (canonical + Montgomery).
+//   rounds 1..n-1: [c1, c0] unless c1 == 0 (add_poly drops the zero term,
+//                  poly.rs:324-327) -> [c0]
+//   round n:       [c1, c0] iff the table depends on x_n (no merge, sumcheck.rs:206-207)
+// grid = (batch), block = 64
+__global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restrict__ partials, uint32_t nblk,
+                                                       uint32_t round, uint32_t n, const Fr* __restrict__ cts,
+                                                       Fr* __restrict__ out_coeffs, uint32_t* __restrict__ out_len,
+                                                       Fr* __restrict__ out_r, Fr* __restrict__ r_mont,
+                                                       uint32_t* __restrict__ dep_last) {
+    const uint32_t b = blockIdx.x;
+    const MlePartial* p = partials + (size_t)b * nblk;
+    Acc<10> lo = acc_zero<10>(), hi = acc_zero<10>();
+    uint32_t dep = 0;
+    for (uint32_t i = threadIdx.x; i < nblk; i += 64) {
+        acc_add_acc(lo, p[i].lo);
+        acc_add_acc(hi, p[i].hi);
+        dep |= p[i].dep;
+    }
+    lo = wave_sum(lo);
+    hi = wave_sum(hi);
+    dep = __any(dep) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        if (round == 0) dep_last[b] = dep;
+        Fr c0 = acc_reduce(lo);
+        Fr c1 = fr_sub(acc_reduce(hi), c0);
+        uint32_t len;
+        if (round + 1 < n)
+            len = fr_is_zero(c1) ? 1u : 2u;
+        else
+            len = dep_last[b] ? 2u : 1u;
+        Fr vec[2];
+        vec[0] = (len == 2) ? c1 : c0;
+        vec[1] = c0;
+        Fr r = mimc7_multi_hash(vec, (int)len, cts);
+        Fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
+        oc[0] = (len == 2) ? c1 : fr_zero();
+        oc[1] = c0;
+        out_len[(size_t)b * n + round] = len;
+        out_r[(size_t)b * n + round] = r;
+        r_mont[(size_t)b * n + round] = to_mont(r);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward evaluation of one circuit layer (reference: calculate_input,
+// rust/src/convert.rs:812-831): out[g] = prev[l] (+|*) prev[r]
+// ---------------------------------------------------------------------------
+
+__global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_type,
+                             const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                             const Fr* __restrict__ prev, Fr* __restrict__ out) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < gates; g += gridDim.x * blockDim.x) {
+        Fr a = load_fr(prev + left[g]), b = load_fr(prev + right[g]);
+        store_fr(out + g, gate_type[g] ? fr_mul(a, b) : fr_add(a, b));
+    }
+}
+
+// canonical -> Montgomery copy of a small table (W for the layer kernel)
+__global__ void k_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, uint32_t count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+        store_fr(out + i, to_mont(load_fr(in + i)));
+}
+
+// dep[b] = 1 iff W differs somewhere across bit (k-1-b), i.e. iff a stored
+// monomial of the MLE carries variable b+1 (length rule, poly.rs:388-420)
+__global__ void k_depends(const Fr* __restrict__ W, uint32_t k, uint32_t* __restrict__ dep) {
+    const uint32_t n = 1u << k;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Fr a = load_fr(W + i);
+        for (uint32_t b = 0; b < k; ++b) {
+            const uint32_t bit = 1u << (k - 1 - b);
+            if (!(i & bit) && !fr_eq(a, load_fr(W + (i ^ bit)))) atomicOr(dep + b, 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// wiring predicates (reference: chi_w_for_binary + add_poly at build time,
+// convert.rs:715-767, then partial_eval_binary_form at z, prover.rs:24-37)
+//   E[g] = prod_i (bit_i(g) ? z_i : 1 - z_i);  A[(l << k) | r] += E[g] (add gates),
+//   M[...] += E[g] (mult gates).
+// No modular atomic exists: scatter the eight 32-bit limbs with 64-bit integer
+// atomics into a widened cell (8 x u64), then normalise.  Integer adds commute,
+// so the result is exact and order independent.
+// ---------------------------------------------------------------------------
+
+// zfac[2*i] = (1 - z_i) R, zfac[2*i+1] = z_i R  (Montgomery), i = 0..k_i-1
+__global__ void k_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* __restrict__ gate_type,
+                                    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                    const Fr* __restrict__ zfac, unsigned long long* __restrict__ wideA,
+                                    unsigned long long* __restrict__ wideM, uint32_t* __restrict__ bad) {
+    const uint64_t gates = 1ull << k_i;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        Fr e = fr_zero();
+        e.l[0] = 1;  // canonical 1; each factor is Montgomery so the product stays canonical
+        for (uint32_t i = 0; i < k_i; ++i) {
+            const uint32_t bit = (uint32_t)(g >> (k_i - 1 - i)) & 1u;
+            e = mont_mul(e, zfac[2 * i + bit]);
+        }
+        const uint32_t l = left[g], r = right[g];
+        if ((l >> k_next) | (r >> k_next)) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        unsigned long long* cell = (gate_type[g] ? wideM : wideA) + (((size_t)l << k_next) | r) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(cell + j, (unsigned long long)e.l[j]);
+    }
+}
+
+// widened cell -> canonical Fr.  limb sums < 2^32 * 2^32; value < 2^32 r.
+__global__ void k_predicate_normalise(const unsigned long long* __restrict__ wide, Fr* __restrict__ out, size_t cells) {
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+        Acc<10> a = acc_zero<10>();
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned long long w = wide[c * 8 + j];
+            unsigned long long lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            a.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        a.l[8] = (uint32_t)carry;
+        a.l[9] = (uint32_t)(carry >> 32);
+        store_fr(out + c, acc_reduce(a));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GKR layer sumcheck (reference: prove_sumcheck_opt, sumcheck.rs:36-156) on
+//   f(b, c) = A(b,c) (W(b) + W(c)) + M(b,c) W(b) W(c),   index = b * 2^k + c.
+// A, M are streamed (canonical); the W copies are tiny, folded separately and
+// kept in Montgomery form:
+//   phase 0 (binding a b variable): p0 = Wb[row], p1 = Wb[row + hb], q0 = q1 = Wc[col]
+//   phase 1 (binding a c variable): p0 = p1 = Wb[0],   q0 = Wc[col], q1 = Wc[col + h]
+// Per pair (entry i, entry i + h):
+//   c0   += a0 (p0 + q0) + m0 p0 q0
+//   g(1) += a1 (p1 + q1) + m1 p1 q1
+//   c2   += (a1 - a0)((p1 + q1) - (p0 + q0)) + (m1 - m0)(p1 q1 - p0 q0)
+// (p q is linear in the bound variable because only one of p, q depends on it;
+//  c1 = g(1) - c0 - c2.)
+// FOLD: also fold A, M with the previous challenge while reading (fused pass).
+// ---------------------------------------------------------------------------
+
+struct PairTerms {
+    Fr c0, g1, c2;
+};
+
+__device__ __forceinline__ PairTerms layer_pair(const Fr& a0, const Fr& a1, const Fr& m0, const Fr& m1, const Fr& p0,
+                                                const Fr& p1, const Fr& q0, const Fr& q1) {
+    // p*, q* are Montgomery: s = (p+q) R, pq = mont_mul(pR, qR) = pq R
+    Fr s0 = fr_add(p0, q0), s1 = fr_add(p1, q1);
+    Fr pq0 = mont_mul(p0, q0), pq1 = mont_mul(p1, q1);
+    PairTerms t;
+    t.c0 = fr_add(mont_mul(a0, s0), mont_mul(m0, pq0));
+    t.g1 = fr_add(mont_mul(a1, s1), mont_mul(m1, pq1));
+    t.c2 = fr_add(mont_mul(fr_sub(a1, a0), fr_sub(s1, s0)), mont_mul(fr_sub(m1, m0), fr_sub(pq1, pq0)));
+    return t;
+}
+
+// Sums of one round over the current A, M (each 2h entries).
+//   phase 0: h = hb * 2^k entries per half; row = i >> k, col = i & (2^k - 1)
+//   phase 1: h entries per half, col = i
+// grid = (blocks), partial per block
+__global__ void __launch_bounds__(256) k_layer_round(const Fr* __restrict__ A, const Fr* __restrict__ M, uint32_t h,
+                                                     uint32_t k, uint32_t phase, uint32_t hb,
+                                                     const Fr* __restrict__ Wb, const Fr* __restrict__ Wc,
+                                                     LayerPartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4 * 3];
+    Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
+    const uint32_t cmask = (1u << k) - 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
+        Fr a0 = load_fr(A + i), a1 = load_fr(A + i + h);
+        Fr m0 = load_fr(M + i), m1 = load_fr(M + i + h);
+        Fr p0, p1, q0, q1;
+        if (phase == 0) {
+            const uint32_t row = i >> k, col = i & cmask;
+            p0 = load_fr(Wb + row);
+            p1 = load_fr(Wb + row + hb);
+            q0 = load_fr(Wc + col);
+            q1 = q0;
+        } else {
+            p0 = load_fr(Wb);
+            p1 = p0;
+            q0 = load_fr(Wc + i);
+            q1 = load_fr(Wc + i + h);
+        }
+        PairTerms t = layer_pair(a0, a1, m0, m1, p0, p1, q0, q1);
+        acc_add_fr(acc[0], t.c0);
+        acc_add_fr(acc[1], t.g1);
+        acc_add_fr(acc[2], t.c2);
+    }
+    block_sum<9, 3>(acc, smem);
+    if (threadIdx.x == 0) {
+        LayerPartial* p = partials + blockIdx.x;
+        p->c0 = acc[0];
+        p->g1 = acc[1];
+        p->c2 = acc[2];
+    }
+}
+
+// fold A and M in place with the challenge of the round just hashed: T[i] += r (T[i+h] - T[i])
+__global__ void __launch_bounds__(256) k_layer_fold(Fr* __restrict__ A, Fr* __restrict__ M, uint32_t h,
+                                                    const Fr* __restrict__ r_mont) {
+    const Fr r = *r_mont;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
+        store_fr(A + i, fr_fold(load_fr(A + i), load_fr(A + i + h), r));
+        store_fr(M + i, fr_fold(load_fr(M + i), load_fr(M + i + h), r));
+    }
+}
+
+// One wave: total the partials, build the round vector with the reference's
+// length (2 + dep of the variable), hash it, publish r, and fold the small W
+// copy that depends on the bound variable (Montgomery fold: both operands
+// Montgomery gives a Montgomery result).
+__global__ void __launch_bounds__(64) k_layer_round_hash(const LayerPartial* __restrict__ partials, uint32_t nblk,
+                                                         uint32_t round, uint32_t k, const uint32_t* __restrict__ dep,
+                                                         const Fr* __restrict__ cts, Fr* __restrict__ out_coeffs,
+                                                         uint32_t* __restrict__ out_len, Fr* __restrict__ out_r,
+                                                         Fr* __restrict__ r_mont, Fr* __restrict__ Wb,
+                                                         Fr* __restrict__ Wc) {
+    __shared__ Fr s_r;
+    Acc<10> c0 = acc_zero<10>(), g1 = acc_zero<10>(), c2 = acc_zero<10>();
+    for (uint32_t i = threadIdx.x; i < nblk; i += 64) {
+        acc_add_acc(c0, partials[i].c0);
+        acc_add_acc(g1, partials[i].g1);
+        acc_add_acc(c2, partials[i].c2);
+    }
+    c0 = wave_sum(c0);
+    g1 = wave_sum(g1);
+    c2 = wave_sum(c2);
+    if (threadIdx.x == 0) {
+        Fr f0 = acc_reduce(c0), f1 = acc_reduce(g1), f2 = acc_reduce(c2);
+        Fr lin = fr_sub(fr_sub(f1, f0), f2);
+        const uint32_t len = 2u + (dep[round % k] ? 1u : 0u);
+        Fr vec[3] = {f2, lin, f0};
+        Fr r = mimc7_multi_hash(vec + (3 - len), (int)len, cts);
+        Fr* oc = out_coeffs + (size_t)round * 3;
+        oc[0] = (len == 3) ? f2 : fr_zero();
+        oc[1] = lin;
+        oc[2] = f0;
+        out_len[round] = len;
+        out_r[round] = r;
+        Fr rm = to_mont(r);
+        r_mont[round] = rm;
+        s_r = rm;
+    }
+    __syncthreads();
+    const Fr rm = s_r;
+    // fold the W copy bound in this round: rounds 0..k-1 bind b (Wb), k..2k-1 bind c (Wc)
+    Fr* W = (round < k) ? Wb : Wc;
+    const uint32_t hw = 1u << (k - 1 - (round % k));
+    // in place: lane i reads i and i + hw, writes i; a grid-stride loop inside one wave
+    // would let a later iteration read a slot an earlier one wrote only if
+    // i + hw < hw, which cannot happen
+    for (uint32_t i = threadIdx.x; i < hw; i += 64) {
+        Fr lo = load_fr(W + i), hi = load_fr(W + i + hw);
+        store_fr(W + i, fr_fold(lo, hi, rm));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------
+
+static inline uint32_t blocks_for(uint64_t items, uint32_t cap) {
+    uint64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (uint32_t)b;
+}
+
+void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_table, dim3(blocks_for(count, 4096)), dim3(256), 0, s, table, count, seed);
+}
+
+uint32_t mle_blocks_per_table(uint32_t items, uint32_t batch) {
+    // fill the chip (256 CUs x 8 blocks) across the batch, at most one block per 256 items
+    uint32_t want = (2048 + batch - 1) / batch;
+    if (want < 1) want = 1;
+    if (want > kMaxBlocksPerTable) want = kMaxBlocksPerTable;
+    uint32_t b = blocks_for(items, want);
+    return b;
+}
+
+void launch_mle_sum_first(const Fr* tables, size_t stride, uint32_t h, uint32_t batch, uint32_t nblk,
+                          MlePartial* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_sum_first, dim3(nblk, batch), dim3(256), 0, s, tables, stride, h, partials);
+}
+
+void launch_mle_fold_sum(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
+                         uint32_t nblk, const Fr* r_mont, uint32_t r_stride, MlePartial* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_fold_sum, dim3(nblk, batch), dim3(256), 0, s, src, src_stride, dst, dst_stride, q, r_mont,
+                       r_stride, partials);
+}
+
+void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t round, uint32_t n, uint32_t batch,
+                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, Fr* r_mont, uint32_t* dep_last,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_round_hash, dim3(batch), dim3(64), 0, s, partials, nblk, round, n, cts, out_coeffs,
+                       out_len, out_r, r_mont, dep_last);
+}
+
+void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                       const Fr* prev, Fr* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096)), dim3(256), 0, s, gates, gate_type, left, right,
+                       prev, out);
+}
+
+void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s) {
+    hipLaunchKernelGGL(k_to_mont, dim3(blocks_for(count, 1024)), dim3(256), 0, s, in, out, count);
+}
+
+void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s) {
+    hipLaunchKernelGGL(k_depends, dim3(blocks_for(1u << k, 1024)), dim3(256), 0, s, W, k, dep);
+}
+
+void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
+                              const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
+                              unsigned long long* wideM, uint32_t* bad, hipStream_t s) {
+    hipLaunchKernelGGL(k_predicate_scatter, dim3(blocks_for(1ull << k_i, 4096)), dim3(256), 0, s, k_i, k_next,
+                       gate_type, left, right, zfac, wideA, wideM, bad);
+}
+
+void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
+    hipLaunchKernelGGL(k_predicate_normalise, dim3(blocks_for(cells, 4096)), dim3(256), 0, s, wide, out, cells);
+}
+
+uint32_t layer_blocks(uint32_t h) { return blocks_for(h, kMaxLayerBlocks); }
+
+void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
+                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_round, dim3(nblk), dim3(256), 0, s, A, M, h, k, phase, hb, Wb, Wc, partials);
+}
+
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const Fr* r_mont, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_fold, dim3(blocks_for(h, 4096)), dim3(256), 0, s, A, M, h, r_mont);
+}
+
+void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
+                             const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
+                             Fr* r_mont, Fr* Wb, Fr* Wc, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_round_hash, dim3(1), dim3(64), 0, s, partials, nblk, round, k, dep, cts, out_coeffs,
+                       out_len, out_r, r_mont, Wb, Wc);
+}
+
+}  // namespace gkr

@@ -1,0 +1,200 @@
+/* gkr_amd -- C ABI of the MI355X (gfx950) GKR sumcheck prover.
+ *
+ * Drop-in boundary for ONE path of jeong0982/gkr: the GKR prover's per-layer
+ * sumcheck and what feeds it.  The reference has no FFI; its boundary is two
+ * crate-internal Rust functions, and every entry point below names the one it
+ * replaces.  INTEGRATION.md shows the Rust-side binding.
+ *
+ *   reference                                                    this library
+ *   -----------------------------------------------------------  ----------------------------
+ *   prover::prove(&GKRCircuit,&Input) -> Proof                    gkr_prove
+ *       rust/src/gkr/prover.rs:6-96 (called aggregator.rs:354,415)
+ *   sumcheck::prove_sumcheck_opt(add_wire,mult_wire,add_i,...)    gkr_sumcheck_layer
+ *       rust/src/gkr/sumcheck.rs:36-156 (called prover.rs:52-60)
+ *   sumcheck::prove_sumcheck(g, v)                                gkr_sumcheck_mle[_batch_device]
+ *       rust/src/gkr/sumcheck.rs:158-214 (python/sumcheck.py:6-53)
+ *   convert::calculate_input (forward step)                       gkr_layer_eval
+ *       rust/src/convert.rs:812-831
+ *   wiring predicates add_i/mult_i restricted to z                gkr_predicate_tables
+ *       rust/src/convert.rs:715-767 + prover.rs:24-37 (poly.rs:28-62)
+ *   poly::reduce_multiple_polynomial / l_function                 inside gkr_prove
+ *       rust/src/gkr/poly.rs:469-500, 538-551
+ *   Mimc7::new(91).multi_hash(v, &Fr::from(0))  (mimc-rs)         gkr_mimc7_multi_hash
+ *       call sites sumcheck.rs:45,84,129,152; prover.rs:10,78
+ *
+ * Data: a field element is halo2curves bn256::Fr exchanged as its 32-byte
+ * little-endian canonical repr (sumcheck.rs:10-22): gkr_fr, 4 LE u64 limbs,
+ * value < r.  Never Montgomery at this ABI.
+ *
+ * Tables are dense evaluation tables over the boolean hypercube, index = the
+ * variables' bit string with variable 1 most significant (poly.rs:507).
+ *
+ * Round vectors: the reference returns Vec<S> of varying length, highest degree
+ * first (poly.rs:260-267).  Here every round has a fixed row of slots (2 for the
+ * plain sumcheck, 3 for the layer sumcheck), RIGHT-aligned: the last slot is the
+ * constant term, out_len says how many trailing slots form the reference's
+ * vector, unused leading slots are zero.
+ *
+ * Ownership: the caller allocates every output; the library owns device memory
+ * inside the context.  Errors: the reference panics; this ABI returns a status
+ * and never aborts.  Threading: a context is single-owner (one HIP stream);
+ * distinct contexts may be used concurrently (the reference calls prove from a
+ * rayon par_iter, aggregator.rs:350-355).
+ *
+ * There is no CPU fallback: every compute entry point needs a gfx950 device and
+ * returns GKR_ERR_NO_DEVICE / GKR_ERR_HIP otherwise.
+ */
+#ifndef GKR_AMD_H
+#define GKR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } gkr_fr;
+
+typedef struct gkr_ctx gkr_ctx;
+
+enum {
+    GKR_OK = 0,
+    GKR_ERR_INVALID = 1,      /* bad sizes / null pointers / operand index out of range */
+    GKR_ERR_NON_CANONICAL = 2,/* a field element >= r (the reference unwrap()s from_repr, sumcheck.rs:16,21) */
+    GKR_ERR_NO_DEVICE = 3,
+    GKR_ERR_HIP = 4,          /* a HIP runtime call failed; see gkr_last_error */
+    GKR_ERR_NOMEM = 5,
+    GKR_ERR_DEGENERATE = 6    /* v == 0: the reference underflows (sumcheck.rs:49) */
+};
+
+/* transcript placement: where the per-round MiMC7 hash runs */
+enum {
+    GKR_TRANSCRIPT_DEVICE = 0, /* one wave per sumcheck on the GPU; no host sync per round */
+    GKR_TRANSCRIPT_HOST = 1    /* host computes r_j between launches (lowest single-proof latency) */
+};
+
+const char *gkr_strerror(int status);
+const char *gkr_version(void);
+
+/* ---- context ---------------------------------------------------------- */
+int  gkr_ctx_create(int device_id, gkr_ctx **out);
+void gkr_ctx_destroy(gkr_ctx *ctx);
+const char *gkr_last_error(const gkr_ctx *ctx);
+int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
+int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's
+ * roofline leg).  kernel: "mle_fold_sum", "mle_sum_first", "mle_round_hash",
+ * "layer_round", "layer_fold", "layer_round_hash". */
+int  gkr_ctx_profile(gkr_ctx *ctx, int enable);
+int  gkr_ctx_profile_get(gkr_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms,
+                         double *algorithmic_bytes);
+int  gkr_ctx_profile_reset(gkr_ctx *ctx);
+
+/* ---- MiMC7 (host; no device needed) ------------------------------------ */
+/* multi_hash(arr, key): r = key; for a in arr: r += a + hash(a, r) */
+int  gkr_mimc7_multi_hash(const gkr_fr *arr, size_t n, const gkr_fr *key, gkr_fr *out);
+int  gkr_mimc7_hash(const gkr_fr *x, const gkr_fr *k, gkr_fr *out);
+int  gkr_mimc7_constant(int i, gkr_fr *out);     /* i in 0..90 */
+/* the device arithmetic (8x32-bit Montgomery) run on the host, for CPU-side unit tests */
+int  gkr_selftest_mul(const gkr_fr *a, const gkr_fr *b, gkr_fr *out);
+int  gkr_selftest_wide_sum(const gkr_fr *vals, size_t n, gkr_fr *out);
+
+/* ---- plain multilinear sumcheck: prove_sumcheck(g, v), sumcheck.rs:158-161 --- */
+/* table: 2^n canonical evaluations on the host.  out_coeffs: n rows x 2 slots;
+ * out_len[j] in {1,2}; out_r: n challenges.  n >= 2. */
+int  gkr_sumcheck_mle(gkr_ctx *ctx, const gkr_fr *table, int n, gkr_fr *out_coeffs, uint32_t *out_len,
+                      gkr_fr *out_r);
+
+/* `batch` independent sumchecks whose tables already sit in device memory,
+ * contiguous (table b starts at d_tables + b * 2^n elements).  Inputs are not
+ * modified.  Outputs are host arrays of batch x n rows. */
+int  gkr_sumcheck_mle_batch_device(gkr_ctx *ctx, const void *d_tables, int n, int batch,
+                                   gkr_fr *out_coeffs, uint32_t *out_len, gkr_fr *out_r);
+
+/* ---- GKR layer sumcheck: prove_sumcheck_opt, sumcheck.rs:36-44 ----------- */
+/* Layer i has 2^k_i gates; gate g is add (0) or mult (1) of entries left[g],
+ * right[g] of layer i+1, which has 2^k_next entries W.  z: k_i challenges.
+ * out_coeffs: 2*k_next rows x 3 slots; out_len[j] in {2,3}; out_r: 2*k_next. */
+int  gkr_sumcheck_layer(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_type,
+                        const uint32_t *left, const uint32_t *right, const gkr_fr *z,
+                        const gkr_fr *W, gkr_fr *out_coeffs, uint32_t *out_len, gkr_fr *out_r);
+
+/* dense predicate tables A, M (2^{2 k_next} each) = add_i / mult_i restricted to z */
+int  gkr_predicate_tables(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_type,
+                          const uint32_t *left, const uint32_t *right, const gkr_fr *z,
+                          gkr_fr *out_A, gkr_fr *out_M);
+
+/* out[g] = prev[left[g]] (+ | *) prev[right[g]] */
+int  gkr_layer_eval(gkr_ctx *ctx, size_t gates, const uint8_t *gate_type, const uint32_t *left,
+                    const uint32_t *right, const gkr_fr *prev, size_t n_prev, gkr_fr *out);
+
+/* ---- full GKR proof: prover::prove, prover.rs:6-9 ----------------------- */
+/* A layered circuit as the reference's GKRCircuit holds it after
+ * convert_r1cs_wtns_gkr (gkr.rs:53-114): layer 0 is the output layer; layer i
+ * has 2^k[i] gates wired into layer i+1; the input layer has 2^k[depth] values. */
+typedef struct {
+    uint32_t depth;                 /* number of gate layers L (Proof.depth = L + 1) */
+    const uint32_t *k;              /* L + 1 entries: k[0..L-1] gate layers, k[L] input layer */
+    const uint8_t *const *gate_type;/* L arrays of 2^k[i] */
+    const uint32_t *const *left;    /* L arrays of 2^k[i], values < 2^k[i+1] */
+    const uint32_t *const *right;
+} gkr_circuit_desc;
+
+/* Caller-allocated proof buffers (sizes from the k list; gkr_proof_sizes fills
+ * the counts).  Mirrors gkr.rs:7-19:
+ *   sumcheck_coeffs  sum_i 2 k[i+1] rows x 3 slots (layer i's rows contiguous)
+ *   sumcheck_len     one per row
+ *   sumcheck_r       one per row
+ *   q                per layer k[i+1]+1 slots right-aligned; q_len per layer
+ *   z                k[0] + k[1] + ... + k[L] values (z[0] = 0s, prover.rs:16-21)
+ *   r                L values (r*)
+ *   d_coeffs         2^k[0] monomial coefficients of the output layer's MLE
+ *                    (index bit pattern = which variables the monomial carries;
+ *                    Proof.d is its non-zero entries, get_multi_ext poly.rs:502-536)
+ *   input_coeffs     2^k[L] monomial coefficients of the input layer (Proof.input_func)
+ */
+typedef struct {
+    gkr_fr *sumcheck_coeffs;
+    uint32_t *sumcheck_len;
+    gkr_fr *sumcheck_r;
+    gkr_fr *q;
+    uint32_t *q_len;
+    gkr_fr *z;
+    gkr_fr *r;
+    gkr_fr *d_coeffs;
+    gkr_fr *input_coeffs;
+} gkr_proof_buf;
+
+typedef struct {
+    size_t rounds;        /* sum_i 2 k[i+1] */
+    size_t q_slots;       /* sum_i (k[i+1] + 1) */
+    size_t z_values;      /* sum_i k[i], i = 0..L */
+    size_t d_coeffs;      /* 2^k[0] */
+    size_t input_coeffs;  /* 2^k[L] */
+} gkr_proof_sizes_t;
+
+int  gkr_proof_sizes(const gkr_circuit_desc *circuit, gkr_proof_sizes_t *out);
+
+/* input_values: the 2^k[L] values of the input layer (constants and witness
+ * entries already gathered, convert.rs:796-810).  require_zero_output != 0
+ * reproduces the reference's assert that output 0 is zero (convert.rs:838). */
+int  gkr_prove(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values,
+               int require_zero_output, gkr_proof_buf *out);
+
+/* ---- device memory helpers (so callers need no HIP of their own) -------- */
+int  gkr_device_alloc(gkr_ctx *ctx, size_t bytes, void **d_ptr);
+int  gkr_device_free(gkr_ctx *ctx, void *d_ptr);
+int  gkr_device_upload(gkr_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int  gkr_device_download(gkr_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* synthetic table generator used by bench.py and the full-size parity tests
+ * (definition: element i, limb j = mix64(seed + (4 i + j + 1) * 0x9E3779B97F4A7C15),
+ * top limb masked to 61 bits; mix64 = splitmix64's finaliser) */
+int  gkr_device_fill_table(gkr_ctx *ctx, void *d_table, size_t count, uint64_t seed);
+int  gkr_device_synchronize(gkr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKR_AMD_H */

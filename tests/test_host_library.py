@@ -1,0 +1,110 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the
+header declares, and its host-resident pieces (MiMC7, the device arithmetic run
+on the host) agree with big-int arithmetic.  No compute entry point that needs
+a GPU is called here."""
+
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import gkr_amd
+from gkr_amd import _native as N
+from gkr_amd.field import from_limbs, to_limbs
+from oracle import mimc7
+from oracle.field import P
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "gkr_amd.h")).read()
+    declared = set(re.findall(r"\b(gkr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gkr_fr", "gkr_ctx"}
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    lib = N.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(gkr_amd.GkrError) as e:
+        gkr_amd.Context(0)
+    assert e.value.status == N.GKR_ERR_NO_DEVICE
+
+
+def test_product_does_not_import_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "gkr_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(root, f)
+
+
+def test_device_arithmetic_on_host_matches_bigints():
+    lib = N.lib()
+    rng = random.Random(3)
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 253) - 1, 1 << 253, 0xFFFFFFFF, 1 << 32, (1 << 224) - 1]
+    pairs = [(a, b) for a in edge for b in edge] + [(rng.randrange(P), rng.randrange(P)) for _ in range(500)]
+    for a, b in pairs:
+        A, B, O = to_limbs([a]), to_limbs([b]), np.zeros((1, 4), dtype=np.uint64)
+        assert lib.gkr_selftest_mul(_p(A), _p(B), _p(O)) == 0
+        assert from_limbs(O)[0] == a * b % P
+    for n in (0, 1, 1023, 1024, 5000):
+        vals = [rng.randrange(P) for _ in range(n)] if n != 1024 else [P - 1] * n
+        V = to_limbs(vals) if n else np.zeros((0, 4), dtype=np.uint64)
+        O = np.zeros((1, 4), dtype=np.uint64)
+        assert lib.gkr_selftest_wide_sum(_p(V), ctypes.c_size_t(n), _p(O)) == 0
+        assert from_limbs(O)[0] == sum(vals) % P
+
+
+def test_non_canonical_inputs_are_rejected():
+    lib = N.lib()
+    bad = np.full((1, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    ok = to_limbs([5])
+    O = np.zeros((1, 4), dtype=np.uint64)
+    assert lib.gkr_selftest_mul(_p(bad), _p(ok), _p(O)) == N.GKR_ERR_NON_CANONICAL
+    exactly_r = to_limbs([0])
+    for j in range(4):
+        exactly_r[0, j] = (P >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    assert lib.gkr_mimc7_multi_hash(_p(exactly_r), ctypes.c_size_t(1), None, _p(O)) == N.GKR_ERR_NON_CANONICAL
+
+
+def test_library_mimc7_matches_public_vectors_and_oracle():
+    lib = N.lib()
+    O = np.zeros((1, 4), dtype=np.uint64)
+    for i in (0, 1, 2, 90):
+        assert lib.gkr_mimc7_constant(ctypes.c_int(i), _p(O)) == 0
+        assert from_limbs(O)[0] == mimc7.CTS[i]
+    assert lib.gkr_mimc7_hash(_p(to_limbs([1])), _p(to_limbs([2])), _p(O)) == 0
+    assert from_limbs(O)[0] == 0x176C6EEFC3FDF8D6136002D8E6F7A885BBD1C4E3957B93DDC1EC3AE7859F1A08
+    assert gkr_amd.multi_hash([]) == 0
+    assert gkr_amd.multi_hash([12, 45, 78, 41]) == 0x284BC1F34F335933A23A433B6FF3EE179D682CD5E5E2FCDD2D964AFA85104BEB
+    rng = random.Random(4)
+    for n in (1, 2, 3):
+        xs = [rng.randrange(P) for _ in range(n)]
+        assert gkr_amd.multi_hash(xs) == mimc7.multi_hash(xs)
+    assert gkr_amd.multi_hash([7], key=9) == mimc7.multi_hash([7], 9)
+
+
+def test_proof_sizes_host_only():
+    lib = N.lib()
+    k = np.asarray([1, 2, 2], dtype=np.uint32)
+    dummy = (ctypes.c_void_p * 2)(0, 0)
+    desc = N.CircuitDesc(2, k.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), dummy, dummy, dummy)
+    s = N.ProofSizes()
+    assert lib.gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(s)) == 0
+    assert (s.rounds, s.q_slots, s.z_values, s.d_coeffs, s.input_coeffs) == (8, 6, 5, 2, 4)
+    k0 = np.asarray([1, 0], dtype=np.uint32)
+    desc = N.CircuitDesc(1, k0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), dummy, dummy, dummy)
+    assert lib.gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(s)) == N.GKR_ERR_DEGENERATE
