@@ -33,10 +33,13 @@ sys.path.insert(0, REPO)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
     ap.add_argument("--batch", type=int, default=64, help="independent sumchecks per rank per step")
+    ap.add_argument("--transcript", choices=["host", "device"], default="host",
+                    help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -60,13 +63,19 @@ def main():
     n, batch = args.n, args.batch
     count = 1 << n
     ctx = Context(local_rank)
+    ctx.set_transcript(1 if args.transcript == "host" else 0)
     tables = ctx.alloc(batch * count * 32)
     for b in range(batch):
         ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, 0xC0FFEE + 2 + 1000 * rank + b)
     ctx.synchronize()
 
+    step_times = []
+
     def step():
-        return ctx.sumcheck_mle_batch_device(tables, n, batch)
+        t = time.perf_counter()
+        r = ctx.sumcheck_mle_batch_device(tables, n, batch)
+        step_times.append(time.perf_counter() - t)
+        return r
 
     def barrier():
         if world > 1:
@@ -74,9 +83,9 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    ctx.profile(not args.no_profile)        # on during warm-up too: the event pool is created lazily
     for _ in range(args.warmup):
         step()
-    ctx.profile(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -97,7 +106,7 @@ def main():
     if rank == 0:
         fold = ctx.profile_get("mle_fold_sum")
         first = ctx.profile_get("mle_sum_first")
-        hsh = ctx.profile_get("mle_round_hash")
+        hsh = ctx.profile_get("mle_round_hash" if args.transcript == "device" else "mle_round_reduce")
         achieved = fold["bytes"] / (fold["total_ms"] * 1e-3) / 1e9 if fold["total_ms"] > 0 else 0.0
         peak = 8000.0
         line = {
@@ -115,9 +124,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "plain MLE sumcheck (prove_sumcheck), 2^%d points per table, BASELINE configs[2]" % n,
                        "log2_points": n, "batch_per_gpu": batch, "sumchecks_per_step": batch * world,
-                       "transcript": "MiMC7-91 on device, included in the timed region",
+                       "transcript": "MiMC7-91 on %s, included in the timed region" % args.transcript,
                        "parallelism": "independent sumchecks per rank, no collective"},
             "sumchecks_per_sec": batch * args.steps * world / elapsed,
+            "step_ms_each": [round(x * 1e3, 3) for x in step_times[args.warmup:]],
             "roofline": {
                 "bound": "hbm", "kernel": "k_mle_fold_sum",
                 "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
@@ -126,7 +136,7 @@ def main():
                 "algorithmic_bytes_per_launch": (fold["bytes"] / fold["launches"]) if fold["launches"] else None,
             },
             "kernel_ms": {"mle_fold_sum": fold["total_ms"], "mle_sum_first": first["total_ms"],
-                          "mle_round_hash": hsh["total_ms"]},
+                          "mle_round_tail": hsh["total_ms"]},
         }
         if first["total_ms"] > 0:
             line["roofline"]["sum_first_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
@@ -140,16 +150,29 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """Affinity mask capped by the cgroup CPU quota (the GPU box runs this in a
+    container with cpu.max = 16 CPUs although 256 are visible)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(n, seconds):
     """The oracle's dense C prover (a port of the reference algorithm's dense form;
     the reference itself is Rust and cannot be built here) on the host cores."""
     from oracle import cdense
-    cores = cdense.max_threads()
+    cores = min(cdense.max_threads(), usable_cpus())
     table = cdense.fill_table(1 << n, 0xC0FFEE + 2)
-    cdense.sumcheck_mle_raw(table, n)          # warm-up (constants, page faults)
+    cdense.sumcheck_mle_raw(table, n, cores)   # warm-up (constants, page faults)
     done, t0 = 0, time.perf_counter()
     while True:
-        cdense.sumcheck_mle_raw(table, n)
+        cdense.sumcheck_mle_raw(table, n, cores)
         done += 1
         dt = time.perf_counter() - t0
         if dt >= seconds or done >= 2000:

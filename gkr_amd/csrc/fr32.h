@@ -111,7 +111,7 @@ GKR_HD bool fr_is_canonical(const Fr& a) {
     return sub_mod_raw(a, d) != 0;
 }
 
-GKR_HD Fr fr_add(const Fr& a, const Fr& b) {
+GKR_HD Fr fr_add_portable(const Fr& a, const Fr& b) {
     Fr s;
     uint64_t carry = 0;
 #pragma unroll
@@ -123,7 +123,7 @@ GKR_HD Fr fr_add(const Fr& a, const Fr& b) {
     return fr_reduce_once(s);  // a, b < r < 2^254: no carry out of 256 bits
 }
 
-GKR_HD Fr fr_sub(const Fr& a, const Fr& b) {
+GKR_HD Fr fr_sub_portable(const Fr& a, const Fr& b) {
     constexpr uint32_t m[8] = GKR_MOD_LIMBS;
     Fr d;
     uint64_t borrow = 0;
@@ -144,9 +144,11 @@ GKR_HD Fr fr_sub(const Fr& a, const Fr& b) {
     return d;
 }
 
-// Montgomery product a * b * 2^-256 mod r; a, b < r.  Coarsely integrated operand
-// scanning on 32-bit limbs; every (u64)x*y + c maps to one v_mad_u64_u32.
-GKR_HD Fr mont_mul(const Fr& a, const Fr& b) {
+// Montgomery product a * b * 2^-256 mod r; a, b < r.
+//
+// Portable form (host, and the reference for the device form): coarsely
+// integrated operand scanning on 32-bit limbs.
+GKR_HD Fr mont_mul_portable(const Fr& a, const Fr& b) {
     constexpr uint32_t m[8] = GKR_MOD_LIMBS;
     uint32_t t[10];
 #pragma unroll
@@ -183,6 +185,157 @@ GKR_HD Fr mont_mul(const Fr& a, const Fr& b) {
     return fr_reduce_once(out);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---------------------------------------------------------------------------
+// gfx950 forms.  Two facts shape them (measured, tools/ubench_fold.hip):
+//  * hipcc turns the portable 64-bit-carry C into ~690 instructions per Montgomery
+//    product (zero-extending moves around every 64-bit add);
+//  * on gfx950 a VALU that reads a carry (VCC or an SGPR pair) needs two wait
+//    states after the VALU that wrote it.  The pads are written into the asm
+//    strings (s_nop 1); with several waves per SIMD they cost no throughput.
+// Product scanning: one column at a time into a 96-bit accumulator (lo:hi in a
+// VGPR pair, ex in a third VGPR); each partial product is ONE v_mad_u64_u32 whose
+// carry-out feeds ex through ONE v_addc_co_u32.
+// ---------------------------------------------------------------------------
+__device__ inline __attribute__((always_inline)) void mac96(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
+        : "+v"(acc), "+v"(ex), "=&s"(carry)
+        : "v"(x), "v"(y));
+}
+// y wave-uniform (an SGPR or a constant the compiler puts in one)
+__device__ inline __attribute__((always_inline)) void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y_uniform) {
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
+        : "+v"(acc), "+v"(ex), "=&s"(carry)
+        : "v"(x), "s"(y_uniform));
+}
+
+// o = a + b over 256 bits (carry out dropped: callers keep sums below 2^256)
+__device__ inline __attribute__((always_inline)) void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %9, %17, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %10, %18, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %11, %19, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %12, %20, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %13, %21, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %14, %22, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %15, %23, vcc"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+        : "vcc");
+}
+// o = a - b over 256 bits; borrow_mask = all ones iff a < b
+__device__ inline __attribute__((always_inline)) void sub256(uint32_t (&o)[8], uint32_t& borrow_mask, const uint32_t (&a)[8],
+                                       const uint32_t (&b)[8]) {
+    uint32_t bm;
+    asm("v_sub_co_u32_e32 %0, vcc, %9, %17\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %10, %18, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %11, %19, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %12, %20, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %4, vcc, %13, %21, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %14, %22, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %6, vcc, %15, %23, vcc\n\ts_nop 1\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %16, %24, vcc\n\ts_nop 1\n\t"
+        "v_cndmask_b32_e64 %8, 0, -1, vcc"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+          "=&v"(bm)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+        : "vcc");
+    borrow_mask = bm;
+}
+
+#else
+// Portable twins of the four primitives (host builds and the host pass of hipcc);
+// everything built on them below is shared, so the CPU unit tests exercise the
+// same column schedule the device runs.
+GKR_HD void mac96(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
+    const uint64_t p = (uint64_t)x * y, s = acc + p;
+    ex += (s < acc) ? 1u : 0u;
+    acc = s;
+}
+GKR_HD void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) { mac96(acc, ex, x, y); }
+GKR_HD void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    uint64_t carry = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t t = (uint64_t)a[i] + b[i] + carry;
+        o[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+}
+GKR_HD void sub256(uint32_t (&o)[8], uint32_t& borrow_mask, const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t t = (uint64_t)a[i] - b[i] - borrow;
+        o[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    borrow_mask = borrow ? 0xffffffffu : 0u;
+}
+#endif
+
+// s in [0, 2r) -> [0, r)
+GKR_HD Fr cond_sub_mod(const uint32_t (&s)[8]) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t pl[8], d[8], bm;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pl[i] = p[i];
+    sub256(d, bm, s, pl);
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = bm ? s[i] : d[i];
+    return r;
+}
+
+GKR_HD Fr fr_add(const Fr& a, const Fr& b) {
+    uint32_t s[8];
+    add256(s, a.l, b.l);
+    return cond_sub_mod(s);
+}
+
+GKR_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t d[8], bm, pm[8];
+    sub256(d, bm, a.l, b.l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pm[i] = p[i] & bm;
+    Fr r;
+    add256(r.l, d, pm);
+    return r;
+}
+
+GKR_HD Fr mont_mul(const Fr& a, const Fr& b) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t m[8], t[8];
+    uint64_t acc = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int i = 0; i <= c; ++i) mac96(acc, ex, a.l[i], b.l[c - i]);
+#pragma unroll
+        for (int i = 0; i < c; ++i) mac96_s(acc, ex, m[i], p[c - i]);
+        m[c] = (uint32_t)acc * GKR_INV32;
+        mac96_s(acc, ex, m[c], p[0]);     // low word becomes 0
+        acc = (acc >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+#pragma unroll
+    for (int c = 8; c < 15; ++c) {
+#pragma unroll
+        for (int i = c - 7; i < 8; ++i) mac96(acc, ex, a.l[i], b.l[c - i]);
+#pragma unroll
+        for (int i = c - 7; i < 8; ++i) mac96_s(acc, ex, m[i], p[c - i]);
+        t[c - 8] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+    t[7] = (uint32_t)acc;   // the total is < 2r < 2^255: nothing above t[7]
+    return cond_sub_mod(t);
+}
+
 GKR_HD Fr to_mont(const Fr& a) { return mont_mul(a, fr_r2()); }
 
 GKR_HD Fr from_mont(const Fr& a) {
@@ -200,6 +353,83 @@ GKR_HD Fr fr_fold(const Fr& lo, const Fr& hi, const Fr& r_mont) {
     return fr_add(lo, mont_mul(fr_sub(hi, lo), r_mont));
 }
 
+// ---------------------------------------------------------------- fixed multiplier
+// Every fold of a round multiplies by the SAME challenge r.  With the table
+//     R_i = r * 2^(32 i) * 2^64 mod p      (i = 0..7, canonical, wave-uniform)
+// d * r = (sum_i d_i R_i) * 2^-64: 64 partial products for the sum (< 2^291) and
+// two 32-bit Montgomery steps (16 more) leave a value < 2p -- 80 v_mad_u64_u32
+// instead of the 128 of a general Montgomery product, and the table rides in
+// SGPRs.  Works on canonical and on Montgomery-form d alike (it is a plain
+// modular product by r).
+struct FixedMul {
+    uint32_t w[8][8];
+};
+
+// host: build the table from canonical r
+GKR_HD FixedMul make_fixed_mul(const Fr& r_canonical) {
+    Fr two32 = fr_zero(), two64 = fr_zero();
+    two32.l[1] = 1;
+    two64.l[2] = 1;
+    FixedMul T;
+    Fr cur = mont_mul_portable(mont_mul_portable(r_canonical, fr_r2()), two64);   // r * 2^64
+    const Fr two32_m = mont_mul_portable(two32, fr_r2());
+    for (int i = 0; i < 8; ++i) {
+        for (int c = 0; c < 8; ++c) T.w[i][c] = cur.l[c];
+        cur = mont_mul_portable(cur, two32_m);
+    }
+    return T;
+}
+
+GKR_HD Fr mul_fixed(const Fr& d, const FixedMul& T) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t s[11];
+    uint64_t acc = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mac96_s(acc, ex, d.l[i], T.w[i][c]);
+        s[c] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+    s[8] = (uint32_t)acc;
+    s[9] = (uint32_t)(acc >> 32);
+    s[10] = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {   // two 32-bit Montgomery steps
+        const uint32_t m = s[k] * GKR_INV32;
+        uint64_t a2 = s[k];
+        uint32_t e2 = 0;
+        mac96_s(a2, e2, m, p[0]);
+        a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+        e2 = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            a2 += s[k + j];   // a2 < 2^33 here: no overflow
+            mac96_s(a2, e2, m, p[j]);
+            s[k + j] = (uint32_t)a2;
+            a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+            e2 = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 11; ++j) {
+            a2 += s[j];
+            s[j] = (uint32_t)a2;
+            a2 >>= 32;
+        }
+    }
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = s[i + 2];
+    return cond_sub_mod(t);   // (2^35 + 2^64) p / 2^64 < 2p and s[10] == 0
+}
+
+// T + r (H - T) through the round's fixed-multiplier table
+GKR_HD Fr fr_fold_fixed(const Fr& lo, const Fr& hi, const FixedMul& T) {
+    return fr_add(lo, mul_fixed(fr_sub(hi, lo), T));
+}
+
 // ---------------------------------------------------------------- wide sums
 // Unreduced accumulator: NL 32-bit limbs.  Acc<9> takes 2^32 canonical addends,
 // Acc<10> takes 2^32 Acc<9> values.
@@ -215,6 +445,25 @@ GKR_HD Acc<NL> acc_zero() {
     for (int i = 0; i < NL; ++i) a.l[i] = 0;
     return a;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// 288-bit accumulate as one padded carry chain (see the hazard note above)
+__device__ inline __attribute__((always_inline)) void acc_add_fr(Acc<9>& a, const Fr& x) {
+    asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %4, %13, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %5, %14, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %6, %15, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %16, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %8, vcc, 0, %8, vcc"
+        : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]),
+          "+v"(a.l[7]), "+v"(a.l[8])
+        : "v"(x.l[0]), "v"(x.l[1]), "v"(x.l[2]), "v"(x.l[3]), "v"(x.l[4]), "v"(x.l[5]), "v"(x.l[6]), "v"(x.l[7])
+        : "vcc");
+}
+#endif
 
 template <int NL>
 GKR_HD void acc_add_fr(Acc<NL>& a, const Fr& x) {

@@ -7,13 +7,19 @@
 // stream of launches with a single copy-back at the end.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gkr_amd.h"
+#include "fr64.h"
+#include "hostpool.h"
 #include "kernels.h"
 #include "keccak.h"
 #include "mimc7.h"
@@ -46,6 +52,64 @@ const Fr* host_mimc_constants() {
     return cts;
 }
 
+// the same 91 constants for the 4 x 64-bit host arithmetic (identical bytes: same Montgomery radix)
+const gkr::h64::F* host_mimc_constants64() {
+    static gkr::h64::F cts[gkr::kMimcRounds];
+    static bool ready = false;
+    if (!ready) {
+        memcpy(cts, host_mimc_constants(), sizeof cts);
+        ready = true;
+    }
+    return cts;
+}
+
+// CPUs this process may really use: the affinity mask, capped by the cgroup CPU
+// quota (cgroup v2 cpu.max / v1 cfs_quota).  Spinning on more threads than the
+// quota allows gets the whole process throttled for the rest of a 100 ms period.
+int usable_cpus() {
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    double quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        double p = 0;
+        if (fscanf(f, "%63s %lf", q, &p) == 2 && strcmp(q, "max") != 0) {
+            quota = atof(q);
+            period = p;
+        }
+        fclose(f);
+    } else {
+        FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%lf", &quota) == 1 && fscanf(fp, "%lf", &period) == 1) {
+        } else {
+            quota = -1;
+        }
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) {
+        int q = (int)(quota / period);
+        if (q < 1) q = 1;
+        if (q < hw) hw = q;
+    }
+    return hw;
+}
+
+int default_host_threads() {
+    if (const char* e = getenv("GKR_HOST_THREADS")) {
+        int v = atoi(e);
+        if (v >= 1) return v;
+    }
+    int cpus = usable_cpus();
+    int local = 1;   // one process per GPU: share the host cores between the ranks of this node
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) local = atoi(e) > 0 ? atoi(e) : 1;
+    int t = cpus / local - 2;   // leave room for the HIP runtime's own threads and the interpreter
+    if (t < 1) t = 1;
+    if (t > 64) t = 64;
+    return t;
+}
+
 inline Fr to_dev(const gkr_fr& x) {
     Fr f;
     memcpy(&f, &x, 32);
@@ -70,13 +134,58 @@ struct gkr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     Fr* d_cts = nullptr;
-    int transcript = GKR_TRANSCRIPT_DEVICE;
+    int transcript = GKR_TRANSCRIPT_HOST;
     std::string err;
     bool profile = false;
     std::map<std::string, ProfileRow> prof;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     char name[256] = {0};
+    uint32_t ticket = 0;                       // unique per hand-off, never reused within a context
+    std::unique_ptr<gkr::SpinPool> pool;       // host transcript workers (lazy)
+    std::map<std::string, std::pair<void*, size_t>> ws;        // grow-only device workspaces
+    std::map<std::string, std::pair<void*, size_t>> pinned;    // grow-only pinned host buffers
+
+    // cached device workspace: hipMalloc / hipFree of multi-GiB buffers costs milliseconds per call
+    hipError_t workspace(const char* slot, size_t bytes, void** out) {
+        auto& e = ws[slot];
+        if (e.second < bytes) {
+            if (e.first) (void)hipFree(e.first);
+            e.first = nullptr;
+            e.second = 0;
+            hipError_t rc = hipMalloc(&e.first, bytes);
+            if (rc != hipSuccess) return rc;
+            e.second = bytes;
+        }
+        *out = e.first;
+        return hipSuccess;
+    }
+    hipError_t pinned_host(const char* slot, size_t bytes, void** out) {
+        auto& e = pinned[slot];
+        if (e.second < bytes) {
+            if (e.first) (void)hipHostFree(e.first);
+            e.first = nullptr;
+            e.second = 0;
+            hipError_t rc = hipHostMalloc(&e.first, bytes, hipHostMallocCoherent | hipHostMallocMapped);
+            if (rc != hipSuccess) return rc;
+            memset(e.first, 0, bytes);
+            e.second = bytes;
+        }
+        *out = e.first;
+        return hipSuccess;
+    }
+    void release_buffers() {
+        for (auto& kv : ws)
+            if (kv.second.first) (void)hipFree(kv.second.first);
+        ws.clear();
+        for (auto& kv : pinned)
+            if (kv.second.first) (void)hipHostFree(kv.second.first);
+        pinned.clear();
+    }
+    gkr::SpinPool* host_pool() {
+        if (!pool) pool.reset(new gkr::SpinPool(default_host_threads() - 1));
+        return pool.get();
+    }
 
     int fail(int status, const std::string& what) {
         err = what;
@@ -152,62 +261,252 @@ struct DevBuf {
     hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)); }
 };
 
+// ------------------------------------------------------------- hand-off waiting
+// Spin on the seq words the reduce kernel stores last (system-scope release) into
+// pinned host memory.  Bounded: a device fault or a lost launch turns into an
+// error status instead of a hang.
+template <typename Rec>
+int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t ticket) {
+    const auto t0 = std::chrono::steady_clock::now();
+    static const int wait_mode = [] { const char* e = getenv("GKR_WAIT_MODE"); return e ? atoi(e) : 0; }();
+    if (wait_mode == 1) {   // diagnostic: classic stream synchronisation instead of polling the records
+        hipError_t q = hipStreamSynchronize(ctx->stream);
+        if (q != hipSuccess) return ctx->hip_fail(q, "hipStreamSynchronize");
+    }
+    for (int b = 0; b < count; ++b) {
+        uint32_t spins = 0;
+        while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
+            GKR_CPU_RELAX();
+            if ((++spins & 0xFFFF) == 0) {
+                hipError_t q = wait_mode == 2 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return ctx->hip_fail(q, "stream failed while waiting for a round");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                    if (q == hipSuccess && __atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) == ticket) break;
+                    return ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a round");
+                }
+            }
+        }
+    }
+    return GKR_OK;
+}
+
+constexpr int kMaxGroups = 16;
+
+#define WS(ctx, slot, type, count, ptr) \
+    HIP_TRY(ctx, (ctx)->workspace(slot, (size_t)(count) * sizeof(type), reinterpret_cast<void**>(&(ptr))))
+
 // ------------------------------------------------------------- plain MLE sumcheck
+// Length rule of prove_sumcheck (sumcheck.rs:158-214): rounds 1..n-1 drop a zero
+// linear coefficient (add_poly, poly.rs:324-327); the last round has two
+// coefficients iff the table depends on x_n (no merge, sumcheck.rs:206-207).
 int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,
                   gkr_fr* out_r) {
     const size_t len = (size_t)1 << n;
     const size_t rounds = (size_t)batch * n;
-    DevBuf<Fr> work, d_coeffs, d_r, d_rmont;
-    DevBuf<uint32_t> d_len, d_dep;
-    DevBuf<gkr::MlePartial> partials;
-    const uint32_t max_nblk = gkr::mle_blocks_per_table((uint32_t)(len / 2), (uint32_t)batch);
-    HIP_TRY(ctx, work.alloc((size_t)batch * (len / 2)));
-    HIP_TRY(ctx, d_coeffs.alloc(rounds * 2));
-    HIP_TRY(ctx, d_r.alloc(rounds));
-    HIP_TRY(ctx, d_rmont.alloc(rounds));
-    HIP_TRY(ctx, d_len.alloc(rounds));
-    HIP_TRY(ctx, d_dep.alloc(batch));
-    HIP_TRY(ctx, partials.alloc((size_t)batch * max_nblk));
+    const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
+    Fr *work = nullptr, *d_coeffs = nullptr, *d_r = nullptr;
+    uint32_t *d_len = nullptr, *d_dep = nullptr;
+    gkr::MlePartial* partials = nullptr;
+    // groups of the host pipeline are smaller than the batch and may use more blocks per table
+    const uint32_t max_nblk = gkr::mle_blocks_per_table((uint32_t)(len / 2), 1u);
+    WS(ctx, "mle.work", Fr, (size_t)batch * (len / 2), work);
+    WS(ctx, "mle.partials", gkr::MlePartial, (size_t)batch * max_nblk, partials);
     hipStream_t s = ctx->stream;
 
-    if (ctx->transcript != GKR_TRANSCRIPT_DEVICE)
-        return ctx->fail(GKR_ERR_INVALID, "host transcript mode is not available for this entry point yet");
+    if (host_tx) {
+        gkr::MleHostRec* rec = nullptr;
+        gkr::FixedMul* h_rtab = nullptr;   // pinned: host writes r_j's multiplier table, the next fold kernel reads it
+        HIP_TRY(ctx, ctx->pinned_host("mle.rec", sizeof(gkr::MleHostRec) * batch, reinterpret_cast<void**>(&rec)));
+        HIP_TRY(ctx, ctx->pinned_host("mle.rtab", sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
+        const gkr::h64::F* cts = host_mimc_constants64();
+        std::vector<uint32_t> dep_last(batch, 0);
+        gkr::SpinPool* pool = ctx->host_pool();
 
+        // The batch is cut into groups that advance through their rounds independently:
+        //   GPU (one in-order stream):  sums/fold of group g, round j  ->  reduce -> pinned records
+        //   host workers:               MiMC7 of every sumcheck of a group whose records have landed
+        //   this thread:                notices landed records, hands them to the workers, launches the
+        //                               next round of a group as soon as its hashes are done
+        // so one group's hash-bound late rounds overlap another group's bandwidth-bound early rounds.
+        // Few, large groups: every group-round costs two launches.  A group starts once its
+        // predecessor has left the bandwidth-bound rounds (round >= stagger).
+        int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
+        if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
+        int stagger = 0;   // measured on MI355X + 16 host CPUs: starting every group at once is best
+        if (const char* e = getenv("GKR_STAGGER")) stagger = atoi(e);
+        int groups = (batch + group_size - 1) / group_size;
+        if (groups > kMaxGroups) groups = kMaxGroups;
+        struct Group {
+            int b0 = 0, nb = 0, round = 0;
+            int state = 0;                     // 0 waiting for the GPU, 1 hashing, 2 finished
+            uint32_t ticket = 0;
+            std::atomic<uint64_t> claim{0};    // (generation << 32) | next table to hash; generation = round + 1
+            std::atomic<int> done{0};
+        };
+        std::vector<Group> grp(groups);
+        for (int g = 0; g < groups; ++g) {
+            grp[g].b0 = (int)((long long)batch * g / groups);
+            grp[g].nb = (int)((long long)batch * (g + 1) / groups) - grp[g].b0;
+        }
+        auto launch_round = [&](Group& G, int round) {
+            const int b0 = G.b0, nb = G.nb;
+            uint32_t nblk;
+            gkr::MlePartial* part = partials + (size_t)b0 * max_nblk;
+            if (round == 0) {
+                const uint32_t h = (uint32_t)(len / 2);
+                nblk = gkr::mle_blocks_per_table(h, nb);
+                Timed t(ctx, "mle_sum_first", (double)nb * len * 32.0);
+                gkr::launch_mle_sum_first(d_tables + (size_t)b0 * len, len, h, nb, nblk, part, s);
+            } else {
+                const uint32_t q = (uint32_t)(len >> (round + 1));
+                nblk = gkr::mle_blocks_per_table(q, nb);
+                const Fr* src = (round == 1) ? d_tables + (size_t)b0 * len : work + (size_t)b0 * (len / 2);
+                const size_t src_stride = (round == 1) ? len : len / 2;
+                Timed t(ctx, "mle_fold_sum", (double)nb * 6.0 * q * 32.0);
+                gkr::launch_mle_fold_sum(src, src_stride, work + (size_t)b0 * (len / 2), len / 2, q, nb, nblk, h_rtab + b0, 1,
+                                         part, s);
+            }
+            G.ticket = ++ctx->ticket;
+            Timed t(ctx, "mle_round_reduce", 0.0);
+            gkr::launch_mle_round_reduce(part, nblk, nb, rec + b0, G.ticket, s);
+        };
+        auto hash_one = [&](int b, int round) {
+            gkr::h64::F c0, c1;
+            memcpy(&c0, &rec[b].c0, 32);
+            memcpy(&c1, &rec[b].c1, 32);
+            if (round == 0) dep_last[b] = rec[b].dep;
+            uint32_t ln;
+            if (round + 1 < n)
+                ln = gkr::h64::is_zero(c1) ? 1u : 2u;
+            else
+                ln = dep_last[b] ? 2u : 1u;
+            gkr::h64::F vec[2] = {c1, c0};
+            gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (2 - ln), (int)ln, cts, nullptr);
+            gkr_fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
+            memset(&oc[0], 0, 32);
+            if (ln == 2) memcpy(&oc[0], &c1, 32);
+            memcpy(&oc[1], &c0, 32);
+            out_len[(size_t)b * n + round] = ln;
+            memcpy(&out_r[(size_t)b * n + round], &r, 32);
+            if (round + 1 < n) gkr::h64::make_fixed_mul(r, h_rtab[b].w);
+        };
+        // one unit of work = one sumcheck's hash of the round its group is in
+        const std::function<bool()> try_work = [&]() -> bool {
+            for (int g = 0; g < groups; ++g) {
+                Group& G = grp[g];
+                uint64_t c = G.claim.load(std::memory_order_acquire);
+                while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
+                    if (G.claim.compare_exchange_weak(c, c + 1, std::memory_order_acq_rel)) {
+                        hash_one(G.b0 + (int)(uint32_t)c, (int)(c >> 32) - 1);
+                        G.done.fetch_add(1, std::memory_order_release);
+                        return true;
+                    }
+                }
+            }
+            return false;
+        };
+        auto records_landed = [&](const Group& G) {
+            for (int i = G.nb - 1; i >= 0; --i)
+                if (__atomic_load_n(&rec[G.b0 + i].seq, __ATOMIC_ACQUIRE) != G.ticket) return false;
+            return true;
+        };
+        pool->begin_session(&try_work);
+        int rc = GKR_OK;
+        int started = 1;
+        launch_round(grp[0], 0);
+        int active = groups;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t idle = 0;
+        while (active > 0 && rc == GKR_OK) {
+            bool progress = false;
+            if (started < groups && (grp[started - 1].round >= stagger || grp[started - 1].state == 2)) {
+                launch_round(grp[started], 0);
+                ++started;
+                progress = true;
+            }
+            for (int g = 0; g < started; ++g) {
+                Group& G = grp[g];
+                if (G.state == 0 && records_landed(G)) {
+                    G.done.store(0, std::memory_order_relaxed);
+                    G.claim.store(((uint64_t)(G.round + 1) << 32), std::memory_order_release);
+                    G.state = 1;
+                    progress = true;
+                } else if (G.state == 1 && G.done.load(std::memory_order_acquire) == G.nb) {
+                    G.claim.store(0, std::memory_order_release);
+                    if (++G.round < n) {
+                        launch_round(G, G.round);
+                        G.state = 0;
+                    } else {
+                        G.state = 2;
+                        --active;
+                    }
+                    progress = true;
+                }
+            }
+            if (progress) {
+                idle = 0;
+                continue;
+            }
+            if (try_work()) continue;   // nothing to schedule: help with the hashing
+            GKR_CPU_RELAX();
+            if ((++idle & 0xFFFF) == 0) {
+                hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) rc = ctx->hip_fail(q, "stream failed during a sumcheck round");
+                else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                    rc = ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a round");
+            }
+        }
+        pool->end_session();
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->drain_events();
+        return GKR_OK;
+    }
+
+    gkr::FixedMul* d_rtab = nullptr;
+    WS(ctx, "mle.coeffs", Fr, rounds * 2, d_coeffs);
+    WS(ctx, "mle.r", Fr, rounds, d_r);
+    WS(ctx, "mle.rtab", gkr::FixedMul, rounds, d_rtab);
+    WS(ctx, "mle.len", uint32_t, rounds, d_len);
+    WS(ctx, "mle.dep", uint32_t, batch, d_dep);
     // round 1: sums only
     {
         const uint32_t h = (uint32_t)(len / 2);
         const uint32_t nblk = gkr::mle_blocks_per_table(h, batch);
         {
             Timed t(ctx, "mle_sum_first", (double)batch * len * 32.0);
-            gkr::launch_mle_sum_first(d_tables, len, h, batch, nblk, partials.p, s);
+            gkr::launch_mle_sum_first(d_tables, len, h, batch, nblk, partials, s);
         }
         {
             Timed t(ctx, "mle_round_hash", 0.0);
-            gkr::launch_mle_round_hash(partials.p, nblk, 0, n, batch, ctx->d_cts, d_coeffs.p, d_len.p, d_r.p, d_rmont.p,
-                                       d_dep.p, s);
+            gkr::launch_mle_round_hash(partials, nblk, 0, n, batch, ctx->d_cts, d_coeffs, d_len, d_r, d_rtab, d_dep, s);
         }
     }
     // rounds 2..n: fold with r_{j-1}, sum T_j in the same pass
     for (int round = 1; round < n; ++round) {
         const uint32_t q = (uint32_t)(len >> (round + 1));  // quarter of the source table
         const uint32_t nblk = gkr::mle_blocks_per_table(q, batch);
-        const Fr* src = (round == 1) ? d_tables : work.p;
+        const Fr* src = (round == 1) ? d_tables : work;
         const size_t src_stride = (round == 1) ? len : len / 2;
         {
             Timed t(ctx, "mle_fold_sum", (double)batch * 6.0 * q * 32.0);
-            gkr::launch_mle_fold_sum(src, src_stride, work.p, len / 2, q, batch, nblk, d_rmont.p + (round - 1), n,
-                                     partials.p, s);
+            gkr::launch_mle_fold_sum(src, src_stride, work, len / 2, q, batch, nblk, d_rtab + (round - 1), n, partials,
+                                     s);
         }
         {
             Timed t(ctx, "mle_round_hash", 0.0);
-            gkr::launch_mle_round_hash(partials.p, nblk, round, n, batch, ctx->d_cts, d_coeffs.p, d_len.p, d_r.p,
-                                       d_rmont.p, d_dep.p, s);
+            gkr::launch_mle_round_hash(partials, nblk, round, n, batch, ctx->d_cts, d_coeffs, d_len, d_r, d_rtab, d_dep,
+                                       s);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(out_coeffs, d_coeffs.p, rounds * 2 * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len.p, rounds * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(out_r, d_r.p, rounds * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out_coeffs, d_coeffs, rounds * 2 * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len, rounds * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out_r, d_r, rounds * sizeof(Fr), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->drain_events();
     return GKR_OK;
@@ -260,26 +559,39 @@ int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t*
               const gkr_fr* z, const Fr* d_W, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
     const size_t N = (size_t)1 << (2 * k);
     const uint32_t v = 2 * k;
+    const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     hipStream_t s = ctx->stream;
-    DevBuf<Fr> A, M, Wb, Wc, d_coeffs, d_r_out, d_rmont;
-    DevBuf<uint32_t> d_len, dep;
-    DevBuf<gkr::LayerPartial> partials;
-    HIP_TRY(ctx, A.alloc(N));
-    HIP_TRY(ctx, M.alloc(N));
-    HIP_TRY(ctx, Wb.alloc((size_t)1 << k));
-    HIP_TRY(ctx, Wc.alloc((size_t)1 << k));
-    HIP_TRY(ctx, d_coeffs.alloc((size_t)v * 3));
-    HIP_TRY(ctx, d_r_out.alloc(v));
-    HIP_TRY(ctx, d_rmont.alloc(v));
-    HIP_TRY(ctx, d_len.alloc(v));
-    HIP_TRY(ctx, dep.alloc(k));
-    HIP_TRY(ctx, partials.alloc(gkr::kMaxLayerBlocks));
-    int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A.p, M.p);
+    Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr, *d_coeffs = nullptr, *d_r_out = nullptr;
+    gkr::FixedMul* d_rtab = nullptr;
+    uint32_t *d_len = nullptr, *dep = nullptr;
+    gkr::LayerPartial* partials = nullptr;
+    WS(ctx, "layer.A", Fr, N, A);
+    WS(ctx, "layer.M", Fr, N, M);
+    WS(ctx, "layer.Wb", Fr, (size_t)1 << k, Wb);
+    WS(ctx, "layer.Wc", Fr, (size_t)1 << k, Wc);
+    WS(ctx, "layer.coeffs", Fr, (size_t)v * 3, d_coeffs);
+    WS(ctx, "layer.r", Fr, v, d_r_out);
+    WS(ctx, "layer.rtab", gkr::FixedMul, v, d_rtab);
+    WS(ctx, "layer.len", uint32_t, v, d_len);
+    WS(ctx, "layer.dep", uint32_t, 32, dep);
+    WS(ctx, "layer.partials", gkr::LayerPartial, gkr::kMaxLayerBlocks, partials);
+    int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(dep.p, 0, sizeof(uint32_t) * k, s));
-    gkr::launch_to_mont(d_W, Wb.p, 1u << k, s);
-    HIP_TRY(ctx, hipMemcpyAsync(Wc.p, Wb.p, sizeof(Fr) << k, hipMemcpyDeviceToDevice, s));
-    gkr::launch_depends(d_W, k, dep.p, s);
+    HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32, s));
+    gkr::launch_to_mont(d_W, Wb, 1u << k, s);
+    HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) << k, hipMemcpyDeviceToDevice, s));
+    gkr::launch_depends(d_W, k, dep, s);
+
+    gkr::LayerHostRec* rec = nullptr;
+    gkr::FixedMul* h_rtab = nullptr;
+    uint32_t h_dep[32] = {0};
+    const gkr::h64::F* cts64 = host_mimc_constants64();
+    if (host_tx) {
+        HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec), reinterpret_cast<void**>(&rec)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", sizeof(gkr::FixedMul), reinterpret_cast<void**>(&h_rtab)));
+        HIP_TRY(ctx, hipMemcpyAsync(h_dep, dep, sizeof(uint32_t) * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
     for (uint32_t round = 0; round < v; ++round) {
         const uint32_t h = (uint32_t)(N >> (round + 1));
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
@@ -287,22 +599,54 @@ int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t*
         const uint32_t nblk = gkr::layer_blocks(h);
         {
             Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0);
-            gkr::launch_layer_round(A.p, M.p, h, k, phase, hb, Wb.p, Wc.p, nblk, partials.p, s);
+            gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, s);
         }
-        {
+        const gkr::FixedMul* r_ptr;
+        if (host_tx) {
+            const uint32_t ticket = ++ctx->ticket;
+            {
+                Timed t(ctx, "layer_round_reduce", 0.0);
+                gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, s);
+            }
+            rc = wait_records(ctx, rec, 1, ticket);
+            if (rc) return rc;
+            // g = [c2, c1, c0] with c1 = g(1) - c0 - c2; length 2 + dep (get_univariate_coeff, poly.rs:388-420)
+            gkr::h64::F c0, g1, c2;
+            memcpy(&c0, &rec->c0, 32);
+            memcpy(&g1, &rec->g1, 32);
+            memcpy(&c2, &rec->c2, 32);
+            gkr::h64::F lin = gkr::h64::sub(gkr::h64::sub(g1, c0), c2);
+            const uint32_t ln = 2u + (h_dep[round % k] ? 1u : 0u);
+            gkr::h64::F vec[3] = {c2, lin, c0};
+            gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (3 - ln), (int)ln, cts64, nullptr);
+            gkr_fr* oc = out_coeffs + (size_t)round * 3;
+            memset(&oc[0], 0, 32);
+            if (ln == 3) memcpy(&oc[0], &c2, 32);
+            memcpy(&oc[1], &lin, 32);
+            memcpy(&oc[2], &c0, 32);
+            out_len[round] = ln;
+            memcpy(&out_r[round], &r, 32);
+            gkr::h64::make_fixed_mul(r, h_rtab->w);
+            r_ptr = h_rtab;
+            // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc)
+            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), r_ptr, s);
+        } else {
             Timed t(ctx, "layer_round_hash", 0.0);
-            gkr::launch_layer_round_hash(partials.p, nblk, round, k, dep.p, ctx->d_cts, d_coeffs.p, d_len.p, d_r_out.p,
-                                         d_rmont.p, Wb.p, Wc.p, s);
+            gkr::launch_layer_round_hash(partials, nblk, round, k, dep, ctx->d_cts, d_coeffs, d_len, d_r_out, d_rtab, Wb,
+                                         Wc, s);
+            r_ptr = d_rtab + round;
         }
         if (round + 1 < v) {
             Timed t(ctx, "layer_fold", (double)h * 6.0 * 32.0);
-            gkr::launch_layer_fold(A.p, M.p, h, d_rmont.p + round, s);
+            gkr::launch_layer_fold(A, M, h, r_ptr, s);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(out_coeffs, d_coeffs.p, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len.p, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(out_r, d_r_out.p, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    if (!host_tx) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_coeffs, d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_r, d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->drain_events();
     return GKR_OK;
@@ -413,6 +757,7 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ctx->drain_events();
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    ctx->release_buffers();
     if (ctx->d_cts) hipFree(ctx->d_cts);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -490,6 +835,20 @@ int gkr_selftest_mul(const gkr_fr* a, const gkr_fr* b, gkr_fr* out) {
     if (!a || !b || !out) return GKR_ERR_INVALID;
     if (!all_canonical(a, 1) || !all_canonical(b, 1)) return GKR_ERR_NON_CANONICAL;
     *out = to_abi(gkr::fr_mul(to_dev(*a), to_dev(*b)));
+    return GKR_OK;
+}
+
+int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_fr* out) {
+    if (!lo || !hi || !r || !out) return GKR_ERR_INVALID;
+    if (!all_canonical(lo, 1) || !all_canonical(hi, 1) || !all_canonical(r, 1)) return GKR_ERR_NON_CANONICAL;
+    // the round's fixed-multiplier table built both ways (8x32-bit and the host's 4x64-bit code) must agree
+    const gkr::FixedMul T = gkr::make_fixed_mul(to_dev(*r));
+    gkr::FixedMul T64;
+    gkr::h64::F r64;
+    memcpy(&r64, r, 32);
+    gkr::h64::make_fixed_mul(r64, T64.w);
+    if (memcmp(&T, &T64, sizeof T) != 0) return GKR_ERR_INVALID;
+    *out = to_abi(gkr::fr_fold_fixed(to_dev(*lo), to_dev(*hi), T));
     return GKR_OK;
 }
 

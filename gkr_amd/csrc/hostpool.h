@@ -1,0 +1,96 @@
+// Worker pool for the host transcript.
+//
+// Each sumcheck round needs one MiMC7 hash (~10 us) per sumcheck between two
+// kernel launches, so wake-up latency matters more than fairness: while a
+// session is open (inside one API call) the workers spin on a caller-supplied
+// "try to find and do one unit of work" function; outside a session they sleep.
+// The caller sizes the pool from the CPUs the process may really use (cgroup
+// quota included): spinning on more threads than the quota allows gets the
+// whole process throttled for the rest of a scheduler period.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define GKR_CPU_RELAX() _mm_pause()
+#else
+#define GKR_CPU_RELAX() ((void)0)
+#endif
+
+namespace gkr {
+
+class SpinPool {
+   public:
+    explicit SpinPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { worker(); });
+    }
+    ~SpinPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_.store(true);
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int workers() const { return (int)threads_.size(); }
+
+    // try_work: returns true if it did something.  Must be safe to call from many threads.
+    void begin_session(const std::function<bool()>* try_work) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = try_work;
+            session_.fetch_add(1, std::memory_order_release);   // odd = open
+        }
+        cv_.notify_all();
+    }
+    // returns once no worker is inside try_work any more
+    void end_session() {
+        session_.fetch_add(1, std::memory_order_release);       // even = closed
+        while (inside_.load(std::memory_order_acquire) != 0) GKR_CPU_RELAX();
+    }
+
+   private:
+    void worker() {
+        for (;;) {
+            uint64_t s = session_.load(std::memory_order_acquire);
+            if (!(s & 1)) {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return stop_.load() || (session_.load() & 1); });
+                if (stop_.load()) return;
+                continue;
+            }
+            inside_.fetch_add(1, std::memory_order_acq_rel);
+            // re-check after announcing: end_session() may have closed in between
+            if (session_.load(std::memory_order_acquire) == s) {
+                const std::function<bool()>* fn = fn_;
+                unsigned idle = 0;
+                while (session_.load(std::memory_order_acquire) == s) {
+                    if ((*fn)()) {
+                        idle = 0;
+                    } else {
+                        GKR_CPU_RELAX();
+                        if (++idle > 64) {   // back off a little: keeps the memory system quiet while the GPU works
+                            for (int k = 0; k < 16; ++k) GKR_CPU_RELAX();
+                        }
+                    }
+                }
+            }
+            inside_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> session_{0};
+    std::atomic<int> inside_{0};
+    std::atomic<bool> stop_{false};
+    const std::function<bool()>* fn_ = nullptr;
+};
+
+}  // namespace gkr

@@ -22,16 +22,35 @@ struct LayerPartial {
     uint32_t pad;
 };
 
+// pinned-host hand-off records of the host transcript (128 B each, seq written last)
+struct MleHostRec {
+    Fr c0, c1;
+    uint32_t dep, seq;
+    uint32_t pad[14];
+};
+struct LayerHostRec {
+    Fr c0, g1, c2;
+    uint32_t seq;
+    uint32_t pad[7];
+};
+static_assert(sizeof(MleHostRec) == 128 && sizeof(LayerHostRec) == 128, "hand-off records are one 128-byte line");
+
+void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,
+                             uint32_t ticket, hipStream_t s);
+void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
+                               hipStream_t s);
+void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, hipStream_t s);
+
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
 
 uint32_t mle_blocks_per_table(uint32_t items, uint32_t batch);
 void launch_mle_sum_first(const Fr* tables, size_t stride, uint32_t h, uint32_t batch, uint32_t nblk,
                           MlePartial* partials, hipStream_t s);
 void launch_mle_fold_sum(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
-                         uint32_t nblk, const Fr* r_mont, uint32_t r_stride, MlePartial* partials, hipStream_t s);
+                         uint32_t nblk, const FixedMul* rtab, uint32_t r_stride, MlePartial* partials, hipStream_t s);
 void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t round, uint32_t n, uint32_t batch,
-                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, Fr* r_mont, uint32_t* dep_last,
-                           hipStream_t s);
+                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, FixedMul* rtab,
+                           uint32_t* dep_last, hipStream_t s);
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        const Fr* prev, Fr* out, hipStream_t s);
@@ -45,9 +64,9 @@ void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t 
 uint32_t layer_blocks(uint32_t h);
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
                         const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s);
-void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const Fr* r_mont, hipStream_t s);
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s);
 void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
                              const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
-                             Fr* r_mont, Fr* Wb, Fr* Wc, hipStream_t s);
+                             FixedMul* rtab, Fr* Wb, Fr* Wc, hipStream_t s);
 
 }  // namespace gkr

@@ -65,6 +65,20 @@ __device__ __forceinline__ void store_fr(Fr* p, const Fr& f) {
     q[1] = make_uint4(f.l[4], f.l[5], f.l[6], f.l[7]);
 }
 
+// device-side build of the round's fixed-multiplier table (device transcript only):
+// R_i = r * 2^(32 i) * 2^64 mod p, canonical
+__device__ __forceinline__ void store_fixed_mul(FixedMul* out, const Fr& r_canonical) {
+    Fr two32 = fr_zero(), two64 = fr_zero();
+    two32.l[1] = 1;
+    two64.l[2] = 1;
+    Fr cur = mont_mul(to_mont(r_canonical), two64);
+    const Fr two32_m = to_mont(two32);
+    for (int i = 0; i < 8; ++i) {
+        for (int c = 0; c < 8; ++c) out->w[i][c] = cur.l[c];
+        cur = mont_mul(cur, two32_m);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // synthetic workload (bench / parity at full size)
 // ---------------------------------------------------------------------------
@@ -110,12 +124,13 @@ __global__ void __launch_bounds__(256) k_mle_sum_first(const Fr* __restrict__ ta
         Fr lo = load_fr(t + i), hi = load_fr(t + i + h);
         acc_add_fr(acc[0], lo);
         acc_add_fr(acc[1], hi);
-        // element 2m vs 2m+1: neighbour lane holds the partner (i and i^1 are in the same wave)
+        // element 2m vs 2m+1: the neighbour lane holds the partner (i and i^1 are in the same
+        // wave and both active); DPP quad_perm [1,0,3,2] swaps neighbours in the VALU, no LDS trip
         uint32_t dl = 0, dh = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            dl |= lo.l[k] ^ __shfl_xor(lo.l[k], 1, 64);
-            dh |= hi.l[k] ^ __shfl_xor(hi.l[k], 1, 64);
+            dl |= lo.l[k] ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)lo.l[k], 0xB1, 0xF, 0xF, true);
+            dh |= hi.l[k] ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)hi.l[k], 0xB1, 0xF, 0xF, true);
         }
         dep |= dl | dh;
     }
@@ -135,18 +150,18 @@ __global__ void __launch_bounds__(256) k_mle_sum_first(const Fr* __restrict__ ta
 // grid = (blocks_per_table, batch)
 __global__ void __launch_bounds__(256) k_mle_fold_sum(const Fr* __restrict__ src, size_t src_stride,
                                                       Fr* __restrict__ dst, size_t dst_stride, uint32_t q,
-                                                      const Fr* __restrict__ r_mont, uint32_t r_stride,
+                                                      const FixedMul* __restrict__ rtab, uint32_t r_stride,
                                                       MlePartial* __restrict__ partials) {
     __shared__ Acc<9> smem[4 * 2];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
     Fr* d = dst + (size_t)blockIdx.y * dst_stride;
-    const Fr r = r_mont[(size_t)blockIdx.y * r_stride];   // wave-uniform -> scalar loads
+    const FixedMul T = rtab[(size_t)blockIdx.y * r_stride];   // wave-uniform -> scalar loads, lives in SGPRs
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q; i += gridDim.x * blockDim.x) {
         Fr x0 = load_fr(s + i), x1 = load_fr(s + i + 2 * (size_t)q);
         Fr x2 = load_fr(s + i + q), x3 = load_fr(s + i + 3 * (size_t)q);
-        Fr y0 = fr_fold(x0, x1, r);
-        Fr y1 = fr_fold(x2, x3, r);
+        Fr y0 = fr_fold_fixed(x0, x1, T);
+        Fr y1 = fr_fold_fixed(x2, x3, T);
         store_fr(d + i, y0);
         store_fr(d + i + q, y1);
         acc_add_fr(acc[0], y0);
@@ -170,7 +185,7 @@ __global__ void __launch_bounds__(256) k_mle_fold_sum(const Fr* __restrict__ src
 __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restrict__ partials, uint32_t nblk,
                                                        uint32_t round, uint32_t n, const Fr* __restrict__ cts,
                                                        Fr* __restrict__ out_coeffs, uint32_t* __restrict__ out_len,
-                                                       Fr* __restrict__ out_r, Fr* __restrict__ r_mont,
+                                                       Fr* __restrict__ out_r, FixedMul* __restrict__ rtab,
                                                        uint32_t* __restrict__ dep_last) {
     const uint32_t b = blockIdx.x;
     const MlePartial* p = partials + (size_t)b * nblk;
@@ -202,7 +217,37 @@ __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restr
         oc[1] = c0;
         out_len[(size_t)b * n + round] = len;
         out_r[(size_t)b * n + round] = r;
-        r_mont[(size_t)b * n + round] = to_mont(r);
+        store_fixed_mul(rtab + (size_t)b * n + round, r);
+    }
+}
+
+// Host-transcript variant of the round tail: one wave per table totals the
+// partials and hands the canonical sums to the host through pinned, fine-grained
+// memory; the host applies the length rule and hashes (fr64.h).  The record's
+// seq word is stored last with a system-scope release; the host spins on it.
+// grid = (batch), block = 64
+__global__ void __launch_bounds__(64) k_mle_round_reduce(const MlePartial* __restrict__ partials, uint32_t nblk,
+                                                         MleHostRec* __restrict__ host_rec, uint32_t ticket) {
+    const uint32_t b = blockIdx.x;
+    const MlePartial* p = partials + (size_t)b * nblk;
+    Acc<10> lo = acc_zero<10>(), hi = acc_zero<10>();
+    uint32_t dep = 0;
+    for (uint32_t i = threadIdx.x; i < nblk; i += 64) {
+        acc_add_acc(lo, p[i].lo);
+        acc_add_acc(hi, p[i].hi);
+        dep |= p[i].dep;
+    }
+    lo = wave_sum(lo);
+    hi = wave_sum(hi);
+    dep = __any(dep) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        Fr c0 = acc_reduce(lo);
+        Fr c1 = fr_sub(acc_reduce(hi), c0);
+        MleHostRec* r = host_rec + b;
+        r->c0 = c0;
+        r->c1 = c1;
+        r->dep = dep;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -366,11 +411,11 @@ __global__ void __launch_bounds__(256) k_layer_round(const Fr* __restrict__ A, c
 
 // fold A and M in place with the challenge of the round just hashed: T[i] += r (T[i+h] - T[i])
 __global__ void __launch_bounds__(256) k_layer_fold(Fr* __restrict__ A, Fr* __restrict__ M, uint32_t h,
-                                                    const Fr* __restrict__ r_mont) {
-    const Fr r = *r_mont;
+                                                    const FixedMul* __restrict__ rtab) {
+    const FixedMul T = *rtab;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
-        store_fr(A + i, fr_fold(load_fr(A + i), load_fr(A + i + h), r));
-        store_fr(M + i, fr_fold(load_fr(M + i), load_fr(M + i + h), r));
+        store_fr(A + i, fr_fold_fixed(load_fr(A + i), load_fr(A + i + h), T));
+        store_fr(M + i, fr_fold_fixed(load_fr(M + i), load_fr(M + i + h), T));
     }
 }
 
@@ -382,7 +427,7 @@ __global__ void __launch_bounds__(64) k_layer_round_hash(const LayerPartial* __r
                                                          uint32_t round, uint32_t k, const uint32_t* __restrict__ dep,
                                                          const Fr* __restrict__ cts, Fr* __restrict__ out_coeffs,
                                                          uint32_t* __restrict__ out_len, Fr* __restrict__ out_r,
-                                                         Fr* __restrict__ r_mont, Fr* __restrict__ Wb,
+                                                         FixedMul* __restrict__ rtab, Fr* __restrict__ Wb,
                                                          Fr* __restrict__ Wc) {
     __shared__ Fr s_r;
     Acc<10> c0 = acc_zero<10>(), g1 = acc_zero<10>(), c2 = acc_zero<10>();
@@ -407,7 +452,7 @@ __global__ void __launch_bounds__(64) k_layer_round_hash(const LayerPartial* __r
         out_len[round] = len;
         out_r[round] = r;
         Fr rm = to_mont(r);
-        r_mont[round] = rm;
+        store_fixed_mul(rtab + round, r);
         s_r = rm;
     }
     __syncthreads();
@@ -421,6 +466,40 @@ __global__ void __launch_bounds__(64) k_layer_round_hash(const LayerPartial* __r
     for (uint32_t i = threadIdx.x; i < hw; i += 64) {
         Fr lo = load_fr(W + i), hi = load_fr(W + i + hw);
         store_fr(W + i, fr_fold(lo, hi, rm));
+    }
+}
+
+// Host-transcript tail of a layer round: totals -> pinned host record.
+__global__ void __launch_bounds__(64) k_layer_round_reduce(const LayerPartial* __restrict__ partials, uint32_t nblk,
+                                                           LayerHostRec* __restrict__ host_rec, uint32_t ticket) {
+    Acc<10> c0 = acc_zero<10>(), g1 = acc_zero<10>(), c2 = acc_zero<10>();
+    for (uint32_t i = threadIdx.x; i < nblk; i += 64) {
+        acc_add_acc(c0, partials[i].c0);
+        acc_add_acc(g1, partials[i].g1);
+        acc_add_acc(c2, partials[i].c2);
+    }
+    c0 = wave_sum(c0);
+    g1 = wave_sum(g1);
+    c2 = wave_sum(c2);
+    if (threadIdx.x == 0) {
+        host_rec->c0 = acc_reduce(c0);
+        host_rec->g1 = acc_reduce(g1);
+        host_rec->c2 = acc_reduce(c2);
+        __hip_atomic_store(&host_rec->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// In-place fold of a small Montgomery table (the W copy bound in this round):
+// W[i] += r (W[i + hw] - W[i]).  One block; see k_layer_round_hash for why the
+// strided in-place loop is safe.
+__global__ void __launch_bounds__(256) k_fold_small(Fr* __restrict__ W, uint32_t hw, const FixedMul* __restrict__ rtab) {
+    const FixedMul T = *rtab;
+    for (uint32_t base = 0; base < hw; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        Fr v = fr_zero();
+        if (i < hw) v = fr_fold_fixed(load_fr(W + i), load_fr(W + i + hw), T);
+        __syncthreads();   // all reads of this stripe done before any write lands in [0, hw)
+        if (i < hw) store_fr(W + i, v);
     }
 }
 
@@ -454,16 +533,16 @@ void launch_mle_sum_first(const Fr* tables, size_t stride, uint32_t h, uint32_t 
 }
 
 void launch_mle_fold_sum(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
-                         uint32_t nblk, const Fr* r_mont, uint32_t r_stride, MlePartial* partials, hipStream_t s) {
-    hipLaunchKernelGGL(k_mle_fold_sum, dim3(nblk, batch), dim3(256), 0, s, src, src_stride, dst, dst_stride, q, r_mont,
+                         uint32_t nblk, const FixedMul* rtab, uint32_t r_stride, MlePartial* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_fold_sum, dim3(nblk, batch), dim3(256), 0, s, src, src_stride, dst, dst_stride, q, rtab,
                        r_stride, partials);
 }
 
 void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t round, uint32_t n, uint32_t batch,
-                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, Fr* r_mont, uint32_t* dep_last,
-                           hipStream_t s) {
+                           const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r, FixedMul* rtab,
+                           uint32_t* dep_last, hipStream_t s) {
     hipLaunchKernelGGL(k_mle_round_hash, dim3(batch), dim3(64), 0, s, partials, nblk, round, n, cts, out_coeffs,
-                       out_len, out_r, r_mont, dep_last);
+                       out_len, out_r, rtab, dep_last);
 }
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
@@ -491,6 +570,20 @@ void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t 
     hipLaunchKernelGGL(k_predicate_normalise, dim3(blocks_for(cells, 4096)), dim3(256), 0, s, wide, out, cells);
 }
 
+void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,
+                             uint32_t ticket, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_round_reduce, dim3(batch), dim3(64), 0, s, partials, nblk, host_rec, ticket);
+}
+
+void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_round_reduce, dim3(1), dim3(64), 0, s, partials, nblk, host_rec, ticket);
+}
+
+void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_small, dim3(1), dim3(256), 0, s, W, hw, rtab);
+}
+
 uint32_t layer_blocks(uint32_t h) { return blocks_for(h, kMaxLayerBlocks); }
 
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
@@ -498,15 +591,15 @@ void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32
     hipLaunchKernelGGL(k_layer_round, dim3(nblk), dim3(256), 0, s, A, M, h, k, phase, hb, Wb, Wc, partials);
 }
 
-void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const Fr* r_mont, hipStream_t s) {
-    hipLaunchKernelGGL(k_layer_fold, dim3(blocks_for(h, 4096)), dim3(256), 0, s, A, M, h, r_mont);
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_fold, dim3(blocks_for(h, 4096)), dim3(256), 0, s, A, M, h, rtab);
 }
 
 void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
                              const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
-                             Fr* r_mont, Fr* Wb, Fr* Wc, hipStream_t s) {
+                             FixedMul* rtab, Fr* Wb, Fr* Wc, hipStream_t s) {
     hipLaunchKernelGGL(k_layer_round_hash, dim3(1), dim3(64), 0, s, partials, nblk, round, k, dep, cts, out_coeffs,
-                       out_len, out_r, r_mont, Wb, Wc);
+                       out_len, out_r, rtab, Wb, Wc);
 }
 
 }  // namespace gkr

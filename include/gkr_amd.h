@@ -68,10 +68,13 @@ enum {
     GKR_ERR_DEGENERATE = 6    /* v == 0: the reference underflows (sumcheck.rs:49) */
 };
 
-/* transcript placement: where the per-round MiMC7 hash runs */
+/* Transcript placement: where the per-round MiMC7 hash runs.  The hash is a
+ * 728-deep serial chain of modular products per round vector with no data
+ * parallelism inside it; all table work stays on the GPU in both modes. */
 enum {
-    GKR_TRANSCRIPT_DEVICE = 0, /* one wave per sumcheck on the GPU; no host sync per round */
-    GKR_TRANSCRIPT_HOST = 1    /* host computes r_j between launches (lowest single-proof latency) */
+    GKR_TRANSCRIPT_DEVICE = 0, /* one GPU lane per sumcheck; no host involvement per round */
+    GKR_TRANSCRIPT_HOST = 1    /* default: the device publishes the round sums to pinned memory, host
+                                  cores hash (one sumcheck per thread), the next launch reads r_j */
 };
 
 const char *gkr_strerror(int status);
@@ -100,6 +103,8 @@ int  gkr_mimc7_constant(int i, gkr_fr *out);     /* i in 0..90 */
 /* the device arithmetic (8x32-bit Montgomery) run on the host, for CPU-side unit tests */
 int  gkr_selftest_mul(const gkr_fr *a, const gkr_fr *b, gkr_fr *out);
 int  gkr_selftest_wide_sum(const gkr_fr *vals, size_t n, gkr_fr *out);
+/* lo + r (hi - lo) through the fixed-multiplier table the fold kernels use */
+int  gkr_selftest_fold(const gkr_fr *lo, const gkr_fr *hi, const gkr_fr *r, gkr_fr *out);
 
 /* ---- plain multilinear sumcheck: prove_sumcheck(g, v), sumcheck.rs:158-161 --- */
 /* table: 2^n canonical evaluations on the host.  out_coeffs: n rows x 2 slots;

@@ -19,9 +19,12 @@ from helpers import ints, layers_of, right_aligned_equal, terms_as_set
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["host", "device"])
+def ctx(request):
+    """Every parity test runs with both transcript placements: MiMC7 on the host
+    cores between launches (default) and MiMC7 on the device."""
     c = Context(0)
+    c.set_transcript(N.GKR_TRANSCRIPT_HOST if request.param == "host" else N.GKR_TRANSCRIPT_DEVICE)
     yield c
     c.close()
 

@@ -68,6 +68,19 @@ def test_device_arithmetic_on_host_matches_bigints():
         assert from_limbs(O)[0] == sum(vals) % P
 
 
+def test_fixed_multiplier_fold_on_host_matches_bigints():
+    """lo + r (hi - lo) via the round's multiplier table (80-product schedule of the fold kernels)."""
+    lib = N.lib()
+    rng = random.Random(5)
+    edge = [0, 1, P - 1, (1 << 253) + 12345, P - 2]
+    cases = [(a, b, r) for a in edge for b in edge for r in edge]
+    cases += [(rng.randrange(P), rng.randrange(P), rng.randrange(P)) for _ in range(400)]
+    for lo, hi, r in cases:
+        L, H, R, O = to_limbs([lo]), to_limbs([hi]), to_limbs([r]), np.zeros((1, 4), dtype=np.uint64)
+        assert lib.gkr_selftest_fold(_p(L), _p(H), _p(R), _p(O)) == 0
+        assert from_limbs(O)[0] == (lo + r * (hi - lo)) % P
+
+
 def test_non_canonical_inputs_are_rejected():
     lib = N.lib()
     bad = np.full((1, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
