@@ -359,9 +359,17 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
                 gkr::launch_mle_sum_first(d_tables + (size_t)b0 * len, len, h, nb, nblk, part, s);
             } else {
                 const uint32_t q = (uint32_t)(len >> (round + 1));
-                nblk = gkr::mle_blocks_per_table(q, nb);
                 const Fr* src = (round == 1) ? d_tables + (size_t)b0 * len : work + (size_t)b0 * (len / 2);
                 const size_t src_stride = (round == 1) ? len : len / 2;
+                if (q <= gkr::kSmallFoldQuarter) {
+                    // small table: fold + sums + publish in one launch
+                    G.ticket = ++ctx->ticket;
+                    Timed t(ctx, "mle_fold_sum_small", (double)nb * 6.0 * q * 32.0);
+                    gkr::launch_mle_fold_sum_small(src, src_stride, work + (size_t)b0 * (len / 2), len / 2, q, nb, h_rtab + b0,
+                                                   rec + b0, G.ticket, s);
+                    return;
+                }
+                nblk = gkr::mle_blocks_per_table(q, nb);
                 Timed t(ctx, "mle_fold_sum", (double)nb * 6.0 * q * 32.0);
                 gkr::launch_mle_fold_sum(src, src_stride, work + (size_t)b0 * (len / 2), len / 2, q, nb, nblk, h_rtab + b0, 1,
                                          part, s);

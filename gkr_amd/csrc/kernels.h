@@ -35,6 +35,9 @@ struct LayerHostRec {
 };
 static_assert(sizeof(MleHostRec) == 128 && sizeof(LayerHostRec) == 128, "hand-off records are one 128-byte line");
 
+constexpr uint32_t kSmallFoldQuarter = 2048;   // rounds whose output half has <= this many entries use one block per sumcheck
+void launch_mle_fold_sum_small(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
+                               const FixedMul* rtab, MleHostRec* host_rec, uint32_t ticket, hipStream_t s);
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,
                              uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,

@@ -221,6 +221,42 @@ __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restr
     }
 }
 
+// Late rounds (host transcript): the table is small, so ONE block per sumcheck folds
+// it, totals the two half sums and publishes the host record itself -- one launch
+// per round instead of fold + reduce, and no partials round trip.
+// grid = (batch), block = 256
+__global__ void __launch_bounds__(256) k_mle_fold_sum_small(const Fr* __restrict__ src, size_t src_stride,
+                                                            Fr* __restrict__ dst, size_t dst_stride, uint32_t q,
+                                                            const FixedMul* __restrict__ rtab,
+                                                            MleHostRec* __restrict__ host_rec, uint32_t ticket) {
+    __shared__ Acc<9> smem[4 * 2];
+    const uint32_t b = blockIdx.x;
+    const Fr* s = src + (size_t)b * src_stride;
+    Fr* d = dst + (size_t)b * dst_stride;
+    const FixedMul T = rtab[b];
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = threadIdx.x; i < q; i += blockDim.x) {
+        Fr x0 = load_fr(s + i), x1 = load_fr(s + i + 2 * (size_t)q);
+        Fr x2 = load_fr(s + i + q), x3 = load_fr(s + i + 3 * (size_t)q);
+        Fr y0 = fr_fold_fixed(x0, x1, T);
+        Fr y1 = fr_fold_fixed(x2, x3, T);
+        store_fr(d + i, y0);
+        store_fr(d + i + q, y1);
+        acc_add_fr(acc[0], y0);
+        acc_add_fr(acc[1], y1);
+    }
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        Fr c0 = acc_reduce(acc[0]);
+        Fr c1 = fr_sub(acc_reduce(acc[1]), c0);
+        MleHostRec* r = host_rec + b;
+        r->c0 = c0;
+        r->c1 = c1;
+        r->dep = 0;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Host-transcript variant of the round tail: one wave per table totals the
 // partials and hands the canonical sums to the host through pinned, fine-grained
 // memory; the host applies the length rule and hashes (fr64.h).  The record's
@@ -568,6 +604,12 @@ void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
     hipLaunchKernelGGL(k_predicate_normalise, dim3(blocks_for(cells, 4096)), dim3(256), 0, s, wide, out, cells);
+}
+
+void launch_mle_fold_sum_small(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
+                               const FixedMul* rtab, MleHostRec* host_rec, uint32_t ticket, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_fold_sum_small, dim3(batch), dim3(256), 0, s, src, src_stride, dst, dst_stride, q, rtab,
+                       host_rec, ticket);
 }
 
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,
