@@ -31,6 +31,10 @@ SYMBOLS = [
     "gkr_sumcheck_layer", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove",
     "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
     "gkr_device_fill_table", "gkr_device_synchronize",
+    "gkr_layer_session_open", "gkr_layer_session_open_tables", "gkr_layer_session_dep", "gkr_layer_session_rounds",
+    "gkr_layer_session_sums", "gkr_layer_session_bind", "gkr_layer_session_tail", "gkr_layer_session_close",
+    "gkr_mle_session_open", "gkr_mle_session_sums", "gkr_mle_session_bind", "gkr_mle_session_value",
+    "gkr_mle_session_close", "gkr_device_tables_differ",
 ]
 
 
@@ -70,5 +74,8 @@ def lib():
         L.gkr_last_error.argtypes = [ctypes.c_void_p]
         L.gkr_ctx_destroy.restype = None
         L.gkr_ctx_destroy.argtypes = [ctypes.c_void_p]
+        for fn in (L.gkr_layer_session_close, L.gkr_mle_session_close):
+            fn.restype = None
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib

@@ -522,9 +522,10 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
 
 // ------------------------------------------------------------- predicate tables
 // builds canonical A, M (2^{2k} each) in device memory from device gate arrays
+// shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries
 int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
-                     const gkr_fr* z, Fr* d_A, Fr* d_M) {
-    const size_t N = (size_t)1 << (2 * k);
+                     const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0) {
+    const size_t N = (size_t)1 << (2 * k - log_p);
     hipStream_t s = ctx->stream;
     DevBuf<unsigned long long> wideA, wideM;
     DevBuf<Fr> zfac;
@@ -547,7 +548,7 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
     HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, 4, s));
     {
         Timed t(ctx, "predicate_scatter", (double)((size_t)1 << k_i) * (9.0 + 64.0));
-        gkr::launch_predicate_scatter(k_i, k, d_gt, d_l, d_r, zfac.p, wideA.p, wideM.p, bad.p, s);
+        gkr::launch_predicate_scatter(k_i, k, d_gt, d_l, d_r, zfac.p, wideA.p, wideM.p, bad.p, log_p, shard, s);
     }
     {
         Timed t(ctx, "predicate_normalise", (double)N * 2.0 * (64.0 + 32.0));
@@ -1102,6 +1103,371 @@ int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_value
         sr += 2 * k;
         q += k + 1;
     }
+    return GKR_OK;
+}
+
+// ---- step-wise sessions: one sumcheck split across GPUs ------------------------
+//
+// The hypercube is partitioned by its TRAILING log2(P) variables: rank p owns the entries whose
+// low index bits are p.  Rounds bind the LEADING variable, so both members of every pair live on
+// the same rank for the first v - log2(P) rounds; each round every rank produces partial sums, one
+// tiny all-reduce (<= 96 bytes of field elements) gives every rank the round polynomial, every
+// rank derives the same challenge and folds its shard.  The library does the table work per rank;
+// the collective and the transcript sit in the caller (gkr_amd/parallel.py: torch.distributed over
+// RCCL, or gloo in the CPU tests).  P = 1 is the whole sumcheck with an external transcript.
+
+struct gkr_layer_session {
+    int k = 0, kc = 0;          // W has 2^k entries; this shard's column index has kc = k - log2(P) bits
+    uint32_t round = 0, rounds = 0;
+    size_t cells = 0;           // current entries per table half pair (A, M each)
+    Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr;
+    gkr::LayerPartial* partials = nullptr;
+    uint32_t* d_dep = nullptr;
+    uint32_t dep[32] = {0};
+    gkr::LayerHostRec* rec = nullptr;
+    gkr::FixedMul* rtab = nullptr;   // pinned
+};
+
+struct gkr_mle_session {
+    int n = 0;                  // variables of this shard's table
+    uint32_t round = 0;
+    const Fr* input = nullptr;  // not owned
+    Fr* work = nullptr;
+    gkr::MlePartial* partials = nullptr;
+    gkr::MleHostRec* rec = nullptr;
+    gkr::FixedMul* rtab = nullptr;
+    uint32_t dep = 0;
+    bool have_sums = false;
+};
+
+static void free_layer_session(gkr_layer_session* s) {
+    if (!s) return;
+    if (s->A) (void)hipFree(s->A);
+    if (s->M) (void)hipFree(s->M);
+    if (s->Wb) (void)hipFree(s->Wb);
+    if (s->Wc) (void)hipFree(s->Wc);
+    if (s->partials) (void)hipFree(s->partials);
+    if (s->d_dep) (void)hipFree(s->d_dep);
+    if (s->rec) (void)hipHostFree(s->rec);
+    if (s->rtab) (void)hipHostFree(s->rtab);
+    delete s;
+}
+
+static int alloc_layer_session(gkr_ctx* ctx, gkr_layer_session* S, size_t cells, size_t wb, size_t wc) {
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->A), cells * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->M), cells * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->Wb), wb * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->Wc), wc * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->partials), gkr::kMaxLayerBlocks * sizeof(gkr::LayerPartial)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->d_dep), 32 * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&S->rec), sizeof(gkr::LayerHostRec), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&S->rtab), sizeof(gkr::FixedMul), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(S->rec, 0, sizeof(gkr::LayerHostRec));
+    return GKR_OK;
+}
+
+int gkr_layer_session_open(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_type, const uint32_t* left,
+                           const uint32_t* right, const gkr_fr* z, const gkr_fr* W, uint32_t nshards, uint32_t shard,
+                           gkr_layer_session** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!out || !W) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
+    if (rc) return rc;
+    uint32_t log_p = 0;
+    while ((1u << log_p) < nshards) ++log_p;
+    if (nshards == 0 || (1u << log_p) != nshards || (int)log_p > k_next || shard >= nshards)
+        return ctx->fail(GKR_ERR_INVALID, "shard count must be a power of two <= 2^k_next and shard < count");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr_layer_session* S = new gkr_layer_session();
+    S->k = k_next;
+    S->kc = k_next - (int)log_p;
+    S->rounds = (uint32_t)(2 * k_next) - log_p;
+    S->cells = (size_t)1 << (2 * k_next - log_p);
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dW;
+    rc = alloc_layer_session(ctx, S, S->cells, (size_t)1 << k_next, (size_t)1 << S->kc);
+    if (!rc) rc = upload_gates(ctx, (size_t)1 << k_i, gate_type, left, right, dgt, dl, dr);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    hipError_t e = dW.alloc((size_t)1 << k_next);
+    if (e == hipSuccess) e = hipMemcpyAsync(dW.p, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "upload W");
+    }
+    rc = build_predicates(ctx, k_i, k_next, dgt.p, dl.p, dr.p, z, S->A, S->M, log_p, shard);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    (void)hipMemsetAsync(S->d_dep, 0, 32 * sizeof(uint32_t), s);
+    gkr::launch_to_mont(dW.p, S->Wb, 1u << k_next, s);
+    gkr::launch_to_mont_strided(dW.p, S->Wc, 1u << S->kc, nshards, shard, s);
+    gkr::launch_depends(dW.p, k_next, S->d_dep, s);
+    e = hipMemcpyAsync(S->dep, S->d_dep, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "layer session setup");
+    }
+    *out = S;
+    return GKR_OK;
+}
+
+// the redundant tail after the all-gather: explicit tables of 2^kc entries (A, M, Wc) and the scalar W(b*)
+int gkr_layer_session_open_tables(gkr_ctx* ctx, int kc, const gkr_fr* A, const gkr_fr* M, const gkr_fr* wb,
+                                  const gkr_fr* Wc, gkr_layer_session** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!A || !M || !wb || !Wc || !out || kc < 1 || kc > 14) return ctx->fail(GKR_ERR_INVALID, "bad tail tables");
+    const size_t n = (size_t)1 << kc;
+    if (!all_canonical(A, n) || !all_canonical(M, n) || !all_canonical(Wc, n) || !all_canonical(wb, 1))
+        return ctx->fail(GKR_ERR_NON_CANONICAL, "tail table entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr_layer_session* S = new gkr_layer_session();
+    S->k = kc;           // only c-variables remain: phase 1 from the first round
+    S->kc = kc;
+    S->round = (uint32_t)kc;   // counts as if k = kc b-rounds were already done
+    S->rounds = (uint32_t)(2 * kc);
+    S->cells = n;
+    int rc = alloc_layer_session(ctx, S, n, 1, n);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    // W copies are kept in Montgomery form
+    std::vector<Fr> wcm(n);
+    for (size_t i = 0; i < n; ++i) wcm[i] = gkr::to_mont(to_dev(Wc[i]));
+    Fr wbm = gkr::to_mont(to_dev(*wb));
+    hipError_t e = hipMemcpyAsync(S->A, A, n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->M, M, n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->Wc, wcm.data(), n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->Wb, &wbm, sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "tail session upload");
+    }
+    *out = S;
+    return GKR_OK;
+}
+
+int gkr_layer_session_dep(gkr_ctx* ctx, const gkr_layer_session* S, uint32_t* out_dep, uint32_t count) {
+    if (!ctx || !S || !out_dep || count > 32) return GKR_ERR_INVALID;
+    for (uint32_t i = 0; i < count; ++i) out_dep[i] = S->dep[i];
+    return GKR_OK;
+}
+
+int gkr_layer_session_rounds(const gkr_layer_session* S, uint32_t* done, uint32_t* total) {
+    if (!S) return GKR_ERR_INVALID;
+    if (done) *done = S->round;
+    if (total) *total = S->rounds;
+    return GKR_OK;
+}
+
+// partial sums of the current round over this shard: out = {c0, g(1), c2}, canonical
+int gkr_layer_session_sums(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t h = (uint32_t)(S->cells / 2);
+    const uint32_t phase = S->round < (uint32_t)S->k ? 0u : 1u;
+    const uint32_t hb = phase == 0 ? (h >> S->kc) : 0u;
+    const uint32_t nblk = gkr::layer_blocks(h);
+    gkr::launch_layer_round(S->A, S->M, h, (uint32_t)S->kc, phase, hb, S->Wb, S->Wc, nblk, S->partials, s);
+    const uint32_t ticket = ++ctx->ticket;
+    gkr::launch_layer_round_reduce(S->partials, nblk, S->rec, ticket, s);
+    HIP_TRY(ctx, hipGetLastError());
+    int rc = wait_records(ctx, S->rec, 1, ticket);
+    if (rc) return rc;
+    memcpy(&out[0], &S->rec->c0, 32);
+    memcpy(&out[1], &S->rec->g1, 32);
+    memcpy(&out[2], &S->rec->c2, 32);
+    return GKR_OK;
+}
+
+// bind the current variable to r
+int gkr_layer_session_bind(gkr_ctx* ctx, gkr_layer_session* S, const gkr_fr* r) {
+    if (!ctx || !S || !r) return GKR_ERR_INVALID;
+    if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    if (!all_canonical(r, 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "r >= modulus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr::h64::F r64;
+    memcpy(&r64, r, 32);
+    gkr::h64::make_fixed_mul(r64, S->rtab->w);
+    const uint32_t h = (uint32_t)(S->cells / 2);
+    const bool bphase = S->round < (uint32_t)S->k;
+    // the W copy bound in this round: b-rounds fold Wb (2^k entries at the start), c-rounds fold Wc
+    const uint32_t idx = bphase ? S->round : S->round - (uint32_t)S->k;
+    const uint32_t hw = bphase ? (1u << (S->k - 1 - idx)) : (1u << (S->kc - 1 - idx));
+    gkr::launch_fold_small(bphase ? S->Wb : S->Wc, hw, S->rtab, s);
+    gkr::launch_layer_fold(S->A, S->M, h, S->rtab, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // rtab is reused by the next bind
+    S->cells = h;
+    S->round += 1;
+    return GKR_OK;
+}
+
+// when every local round is done: out = {A, M, Wc (canonical), W(b*) (canonical)} of this shard
+int gkr_layer_session_tail(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if (S->round != S->rounds || S->cells != 1) return ctx->fail(GKR_ERR_INVALID, "session still has rounds to run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Fr a, m, wc, wb;
+    HIP_TRY(ctx, hipMemcpyAsync(&a, S->A, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&m, S->M, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&wc, S->Wc, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&wb, S->Wb, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    out[0] = to_abi(a);
+    out[1] = to_abi(m);
+    out[2] = to_abi(gkr::from_mont(wc));
+    out[3] = to_abi(gkr::from_mont(wb));
+    return GKR_OK;
+}
+
+void gkr_layer_session_close(gkr_ctx* ctx, gkr_layer_session* S) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    free_layer_session(S);
+}
+
+// ---- plain MLE sumcheck, step-wise ----
+
+static void free_mle_session(gkr_mle_session* S) {
+    if (!S) return;
+    if (S->work) (void)hipFree(S->work);
+    if (S->partials) (void)hipFree(S->partials);
+    if (S->rec) (void)hipHostFree(S->rec);
+    if (S->rtab) (void)hipHostFree(S->rtab);
+    delete S;
+}
+
+// d_table: 2^n entries in device memory (this rank's shard, or the whole table); not modified
+int gkr_mle_session_open(gkr_ctx* ctx, const void* d_table, int n, gkr_mle_session** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!d_table || !out || n < 1 || n > 30) return ctx->fail(GKR_ERR_INVALID, "null pointer or n out of [1, 30]");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gkr_mle_session* S = new gkr_mle_session();
+    S->n = n;
+    S->input = static_cast<const Fr*>(d_table);
+    const size_t len = (size_t)1 << n;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&S->work), (len / 2 ? len / 2 : 1) * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&S->partials), gkr::kMaxBlocksPerTable * sizeof(gkr::MlePartial));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&S->rec), sizeof(gkr::MleHostRec), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&S->rtab), sizeof(gkr::FixedMul), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        free_mle_session(S);
+        return ctx->hip_fail(e, "mle session allocation");
+    }
+    memset(S->rec, 0, sizeof(gkr::MleHostRec));
+    *out = S;
+    return GKR_OK;
+}
+
+// out = {sum of the low half, sum of the high half} of the current table (canonical);
+// *out_dep (first round only, may be null): does this shard's table depend on its own last variable
+int gkr_mle_session_sums(gkr_ctx* ctx, gkr_mle_session* S, gkr_fr* out, uint32_t* out_dep) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if ((int)S->round >= S->n) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (!S->have_sums) {   // only the very first round computes sums without a fold
+        const size_t len = (size_t)1 << S->n;
+        const uint32_t h = (uint32_t)(len / 2);
+        const uint32_t nblk = gkr::mle_blocks_per_table(h, 1);
+        gkr::launch_mle_sum_first(S->input, len, h, 1, nblk, S->partials, s);
+        const uint32_t ticket = ++ctx->ticket;
+        gkr::launch_mle_round_reduce(S->partials, nblk, 1, S->rec, ticket, s);
+        HIP_TRY(ctx, hipGetLastError());
+        int rc = wait_records(ctx, S->rec, 1, ticket);
+        if (rc) return rc;
+        {
+            // a 2-entry table has no neighbour pairs inside a half: it depends on its variable iff T[1] != T[0]
+            gkr::h64::F d1;
+            memcpy(&d1, &S->rec->c1, 32);
+            S->dep = S->n == 1 ? (gkr::h64::is_zero(d1) ? 0u : 1u) : S->rec->dep;
+        }
+        S->have_sums = true;
+    }
+    gkr::h64::F c0, c1;
+    memcpy(&c0, &S->rec->c0, 32);
+    memcpy(&c1, &S->rec->c1, 32);
+    gkr::h64::F hi = gkr::h64::add(c0, c1);   // the record holds (low sum, high - low)
+    memcpy(&out[0], &c0, 32);
+    memcpy(&out[1], &hi, 32);
+    if (out_dep) *out_dep = S->dep;
+    return GKR_OK;
+}
+
+// bind the leading variable to r; the sums of the folded table are ready for the next _sums call
+int gkr_mle_session_bind(gkr_ctx* ctx, gkr_mle_session* S, const gkr_fr* r) {
+    if (!ctx || !S || !r) return GKR_ERR_INVALID;
+    if ((int)S->round >= S->n) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    if (!all_canonical(r, 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "r >= modulus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr::h64::F r64;
+    memcpy(&r64, r, 32);
+    gkr::h64::make_fixed_mul(r64, S->rtab->w);
+    const size_t len = (size_t)1 << (S->n - S->round);   // current table
+    const Fr* src = S->round == 0 ? S->input : S->work;
+    if (len == 2) {
+        gkr::launch_fold_pair(src, S->work, S->rtab, s);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    } else {
+        const uint32_t q = (uint32_t)(len / 4);
+        const uint32_t nblk = gkr::mle_blocks_per_table(q, 1);
+        gkr::launch_mle_fold_sum(src, len, S->work, len / 2, q, 1, nblk, S->rtab, 0, S->partials, s);
+        const uint32_t ticket = ++ctx->ticket;
+        gkr::launch_mle_round_reduce(S->partials, nblk, 1, S->rec, ticket, s);
+        HIP_TRY(ctx, hipGetLastError());
+        int rc = wait_records(ctx, S->rec, 1, ticket);
+        if (rc) return rc;
+    }
+    S->round += 1;
+    return GKR_OK;
+}
+
+// the single remaining entry once all n local variables are bound
+int gkr_mle_session_value(gkr_ctx* ctx, gkr_mle_session* S, gkr_fr* out) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if ((int)S->round != S->n) return ctx->fail(GKR_ERR_INVALID, "session still has rounds to run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr v;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, S->work, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = to_abi(v);
+    return GKR_OK;
+}
+
+void gkr_mle_session_close(gkr_ctx* ctx, gkr_mle_session* S) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    free_mle_session(S);
+}
+
+// *out_differ = 1 iff the two device tables differ somewhere (a table's dependence on a variable
+// that is a rank bit: compare the shards of ranks p and p ^ 1)
+int gkr_device_tables_differ(gkr_ctx* ctx, const void* d_a, const void* d_b, size_t count, uint32_t* out_differ) {
+    if (!ctx || !d_a || !d_b || !out_differ || !count) return GKR_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint32_t> flag;
+    HIP_TRY(ctx, flag.alloc(1));
+    HIP_TRY(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+    gkr::launch_tables_differ(static_cast<const Fr*>(d_a), static_cast<const Fr*>(d_b), count, flag.p, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_differ, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GKR_OK;
 }
 

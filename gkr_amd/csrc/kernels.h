@@ -61,7 +61,10 @@ void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
                               const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
-                              unsigned long long* wideM, uint32_t* bad, hipStream_t s);
+                              unsigned long long* wideM, uint32_t* bad, uint32_t log_p, uint32_t shard, hipStream_t s);
+void launch_to_mont_strided(const Fr* in, Fr* out, uint32_t count, uint32_t stride, uint32_t offset, hipStream_t s);
+void launch_tables_differ(const Fr* a, const Fr* b, size_t count, uint32_t* flag, hipStream_t s);
+void launch_fold_pair(const Fr* src, Fr* dst, const FixedMul* rtab, hipStream_t s);
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s);
 
 uint32_t layer_blocks(uint32_t h);

@@ -307,6 +307,29 @@ __global__ void k_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, uint3
         store_fr(out + i, to_mont(load_fr(in + i)));
 }
 
+// out[i] = Montgomery form of in[i * stride + offset]: the W copy a shard binds its c' variables on
+__global__ void k_to_mont_strided(const Fr* __restrict__ in, Fr* __restrict__ out, uint32_t count, uint32_t stride,
+                                  uint32_t offset) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+        store_fr(out + i, to_mont(load_fr(in + (size_t)i * stride + offset)));
+}
+
+// flag |= 1 iff a[i] != b[i] for some i (does a table depend on a variable that is a rank bit?)
+__global__ void k_tables_differ(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t count, uint32_t* __restrict__ flag) {
+    uint32_t d = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        d |= fr_eq(load_fr(a + i), load_fr(b + i)) ? 0u : 1u;
+    if (d) atomicOr(flag, 1u);
+}
+
+// the last fold of a shard: two entries -> one
+__global__ void k_fold_pair(const Fr* __restrict__ src, Fr* __restrict__ dst, const FixedMul* __restrict__ rtab) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const FixedMul T = *rtab;
+        store_fr(dst, fr_fold_fixed(load_fr(src), load_fr(src + 1), T));
+    }
+}
+
 // dep[b] = 1 iff W differs somewhere across bit (k-1-b), i.e. iff a stored
 // monomial of the MLE carries variable b+1 (length rule, poly.rs:388-420)
 __global__ void k_depends(const Fr* __restrict__ W, uint32_t k, uint32_t* __restrict__ dep) {
@@ -331,24 +354,29 @@ __global__ void k_depends(const Fr* __restrict__ W, uint32_t k, uint32_t* __rest
 // ---------------------------------------------------------------------------
 
 // zfac[2*i] = (1 - z_i) R, zfac[2*i+1] = z_i R  (Montgomery), i = 0..k_i-1
+// Shard (log_p, p): keep only gates whose right operand has low bits p (the trailing-variable
+// partition of the hypercube, one shard per GPU); cell = (l << (k_next - log_p)) | (r >> log_p).
 __global__ void k_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* __restrict__ gate_type,
                                     const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                     const Fr* __restrict__ zfac, unsigned long long* __restrict__ wideA,
-                                    unsigned long long* __restrict__ wideM, uint32_t* __restrict__ bad) {
+                                    unsigned long long* __restrict__ wideM, uint32_t* __restrict__ bad,
+                                    uint32_t log_p, uint32_t shard) {
     const uint64_t gates = 1ull << k_i;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = left[g], r = right[g];
+        if ((l >> k_next) | (r >> k_next)) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        if ((r & ((1u << log_p) - 1u)) != shard) continue;
         Fr e = fr_zero();
         e.l[0] = 1;  // canonical 1; each factor is Montgomery so the product stays canonical
         for (uint32_t i = 0; i < k_i; ++i) {
             const uint32_t bit = (uint32_t)(g >> (k_i - 1 - i)) & 1u;
             e = mont_mul(e, zfac[2 * i + bit]);
         }
-        const uint32_t l = left[g], r = right[g];
-        if ((l >> k_next) | (r >> k_next)) {
-            atomicOr(bad, 1u);
-            continue;
-        }
-        unsigned long long* cell = (gate_type[g] ? wideM : wideA) + (((size_t)l << k_next) | r) * 8;
+        unsigned long long* cell =
+            (gate_type[g] ? wideM : wideA) + (((size_t)l << (k_next - log_p)) | (r >> log_p)) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(cell + j, (unsigned long long)e.l[j]);
     }
@@ -591,15 +619,27 @@ void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s) {
     hipLaunchKernelGGL(k_to_mont, dim3(blocks_for(count, 1024)), dim3(256), 0, s, in, out, count);
 }
 
+void launch_to_mont_strided(const Fr* in, Fr* out, uint32_t count, uint32_t stride, uint32_t offset, hipStream_t s) {
+    hipLaunchKernelGGL(k_to_mont_strided, dim3(blocks_for(count, 1024)), dim3(256), 0, s, in, out, count, stride, offset);
+}
+
+void launch_tables_differ(const Fr* a, const Fr* b, size_t count, uint32_t* flag, hipStream_t s) {
+    hipLaunchKernelGGL(k_tables_differ, dim3(blocks_for(count, 2048)), dim3(256), 0, s, a, b, count, flag);
+}
+
+void launch_fold_pair(const Fr* src, Fr* dst, const FixedMul* rtab, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_pair, dim3(1), dim3(64), 0, s, src, dst, rtab);
+}
+
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s) {
     hipLaunchKernelGGL(k_depends, dim3(blocks_for(1u << k, 1024)), dim3(256), 0, s, W, k, dep);
 }
 
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
                               const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
-                              unsigned long long* wideM, uint32_t* bad, hipStream_t s) {
+                              unsigned long long* wideM, uint32_t* bad, uint32_t log_p, uint32_t shard, hipStream_t s) {
     hipLaunchKernelGGL(k_predicate_scatter, dim3(blocks_for(1ull << k_i, 4096)), dim3(256), 0, s, k_i, k_next,
-                       gate_type, left, right, zfac, wideA, wideM, bad);
+                       gate_type, left, right, zfac, wideA, wideM, bad, log_p, shard);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {

@@ -1,0 +1,392 @@
+"""One sumcheck split across GPUs: trailing-variable shards + one tiny all-reduce per round.
+
+The reference sums each round's per-assignment polynomials with a rayon map-reduce
+(rust/src/gkr/sumcheck.rs:50-63, 65-78, 97-124).  Across GPUs that reduce becomes one
+all-reduce of <= 3 field elements per round:
+
+  * rank p of P owns the hypercube entries whose index LOW bits are p (for the GKR layer: the
+    gates whose right operand % P == p; W is replicated);
+  * rounds bind the LEADING variable, so every pair (i, i + h) is rank-local for the first
+    v - log2(P) rounds: each rank computes partial sums on its shard (the library's session
+    API), the partials are all-reduced, every rank derives the same round vector and the same
+    MiMC7 challenge, and folds its shard;
+  * then every rank holds one entry per table; they are all-gathered and the last log2(P) rounds
+    run redundantly on every rank.
+
+RCCL has no modular sum: field elements travel as eight 32-bit limbs widened to int64, are summed
+with ReduceOp.SUM (exact for < 2^31 ranks) and normalised mod r by every rank.
+
+The algorithm is written once against two small interfaces -- a *shard* (sums / bind / tail) and a
+*collective* -- so that the same code runs (a) one process per GPU over torch.distributed (RCCL on
+the GPU box, gloo in the CPU tests) and (b) P logical ranks inside one process on one GPU, which is
+how bit-exactness of the sharded algorithm is checked where only one device is visible.
+"""
+
+import ctypes
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .field import MODULUS, as_limbs, from_limbs, to_limbs
+from .prover import Context, GkrError, Layer, multi_hash
+
+_M32 = 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- collectives
+
+def _to_limb_list(values: Sequence[int]) -> List[int]:
+    out = []
+    for v in values:
+        v %= MODULUS
+        out.extend((v >> (32 * i)) & _M32 for i in range(8))
+    return out
+
+
+def _from_limb_sums(limbs: Sequence[int]) -> List[int]:
+    """Eight (possibly > 32-bit) limb sums per element -> value mod r."""
+    return [sum(int(limbs[8 * e + i]) << (32 * i) for i in range(8)) % MODULUS for e in range(len(limbs) // 8)]
+
+
+class SingleProcess:
+    """World of one rank."""
+    rank, world = 0, 1
+
+    def all_reduce_fr(self, values):
+        return [v % MODULUS for v in values]
+
+    def all_gather_fr(self, values):
+        return [[v % MODULUS for v in values]]
+
+    def all_reduce_or(self, flag):
+        return bool(flag)
+
+
+class TorchCollective:
+    """torch.distributed backend: "nccl" (= RCCL over xGMI on the GPU box) or "gloo" (CPU tests)."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if device is None:
+            device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        self._device = device
+
+    def all_reduce_fr(self, values):
+        t = self._torch.tensor(_to_limb_list(values), dtype=self._torch.int64, device=self._device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        return _from_limb_sums(t.cpu().tolist())
+
+    def all_gather_fr(self, values):
+        t = self._torch.tensor(_to_limb_list(values), dtype=self._torch.int64, device=self._device)
+        outs = [self._torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t, group=self._group)
+        return [_from_limb_sums(o.cpu().tolist()) for o in outs]
+
+    def all_reduce_or(self, flag):
+        t = self._torch.tensor([1 if flag else 0], dtype=self._torch.int64, device=self._device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
+        return bool(int(t.item()))
+
+
+# ----------------------------------------------------------------------------- round vectors
+
+def layer_round_vector(tot, dep_flag):
+    """[c2, c1, c0] from the summed (c0, g(1), c2), with the reference's length 2 + dep
+    (get_univariate_coeff, rust/src/gkr/poly.rs:388-420); c1 = g(1) - c0 - c2."""
+    c0, g1, c2 = (x % MODULUS for x in tot)
+    lin = (g1 - c0 - c2) % MODULUS
+    return [c2, lin, c0] if dep_flag else [lin, c0]
+
+
+def mle_round_vector(tot, last_round, dep_last):
+    """[c1, c0] from the summed (low, high) half sums with prove_sumcheck's length rule
+    (rust/src/gkr/sumcheck.rs:158-214: add_poly drops a zero linear term except in the last round)."""
+    lo, hi = (x % MODULUS for x in tot)
+    c1 = (hi - lo) % MODULUS
+    if last_round:
+        return [c1, lo] if dep_last else [lo]
+    return [c1, lo] if c1 else [lo]
+
+
+# ----------------------------------------------------------------------------- GPU shards (library sessions)
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class LayerSession:
+    """One rank's shard of a GKR layer sumcheck (gkr_layer_session_* in include/gkr_amd.h)."""
+
+    def __init__(self, ctx: Context, handle):
+        self._ctx, self._h = ctx, handle
+
+    @classmethod
+    def open(cls, ctx: Context, layer: Layer, k_next, z, W, nshards=1, shard=0):
+        gt, l, r = layer.arrays()
+        zl = as_limbs(z) if layer.k else np.zeros((0, 4), dtype=np.uint64)
+        wl = as_limbs(W)
+        h = ctypes.c_void_p()
+        ctx._check(N.lib().gkr_layer_session_open(ctx._h, ctypes.c_int(layer.k), ctypes.c_int(k_next), _ptr(gt), _ptr(l),
+                                                  _ptr(r), _ptr(zl), _ptr(wl), ctypes.c_uint32(nshards),
+                                                  ctypes.c_uint32(shard), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def open_tables(cls, ctx: Context, kc, A, M, wb, Wc):
+        h = ctypes.c_void_p()
+        ctx._check(N.lib().gkr_layer_session_open_tables(ctx._h, ctypes.c_int(kc), _ptr(to_limbs(A)), _ptr(to_limbs(M)),
+                                                         _ptr(to_limbs([wb])), _ptr(to_limbs(Wc)), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def dep(self, k):
+        out = np.zeros(k, dtype=np.uint32)
+        self._ctx._check(N.lib().gkr_layer_session_dep(self._ctx._h, self._h, _ptr(out), ctypes.c_uint32(k)))
+        return [bool(x) for x in out]
+
+    def sums(self):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        self._ctx._check(N.lib().gkr_layer_session_sums(self._ctx._h, self._h, _ptr(out)))
+        return from_limbs(out)
+
+    def bind(self, r):
+        self._ctx._check(N.lib().gkr_layer_session_bind(self._ctx._h, self._h, _ptr(to_limbs([r]))))
+
+    def tail(self):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        self._ctx._check(N.lib().gkr_layer_session_tail(self._ctx._h, self._h, _ptr(out)))
+        return from_limbs(out)
+
+    def close(self):
+        if self._h:
+            N.lib().gkr_layer_session_close(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MleSession:
+    """One rank's shard of a plain multilinear sumcheck; the table lives in device memory."""
+
+    def __init__(self, ctx: Context, d_table, n):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        ctx._check(N.lib().gkr_mle_session_open(ctx._h, d_table, ctypes.c_int(n), ctypes.byref(self._h)))
+
+    def sums(self):
+        out = np.zeros((2, 4), dtype=np.uint64)
+        dep = ctypes.c_uint32(0)
+        self._ctx._check(N.lib().gkr_mle_session_sums(self._ctx._h, self._h, _ptr(out), ctypes.byref(dep)))
+        return from_limbs(out), bool(dep.value)
+
+    def bind(self, r):
+        self._ctx._check(N.lib().gkr_mle_session_bind(self._ctx._h, self._h, _ptr(to_limbs([r]))))
+
+    def value(self):
+        out = np.zeros((1, 4), dtype=np.uint64)
+        self._ctx._check(N.lib().gkr_mle_session_value(self._ctx._h, self._h, _ptr(out)))
+        return from_limbs(out)[0]
+
+    def close(self):
+        if self._h:
+            N.lib().gkr_mle_session_close(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------- the sharded algorithms
+
+def _log2(p):
+    lp = p.bit_length() - 1
+    if p < 1 or (1 << lp) != p:
+        raise GkrError(N.GKR_ERR_INVALID, "the number of shards must be a power of two")
+    return lp
+
+
+def layer_sumcheck_rounds(shards, reduce_fr, k, log_p, dep, hasher=multi_hash):
+    """Local rounds of the layer sumcheck over `shards` (one per logical rank held by THIS process).
+
+    reduce_fr(list_of_partial_vectors) -> summed vector over ALL ranks of the world.
+    Returns (proof, r) for the 2k - log_p rounds that are shard-local.
+    """
+    proof, rs = [], []
+    for j in range(2 * k - log_p):
+        tot = reduce_fr([s.sums() for s in shards])
+        g = layer_round_vector(tot, dep[j % k])
+        r = hasher(g, 0)
+        proof.append(g)
+        rs.append(r)
+        for s in shards:
+            s.bind(r)
+    return proof, rs
+
+
+def _finish_layer(open_tail, tails, k, log_p, dep, proof, rs, hasher):
+    """Last log_p rounds on the gathered one-entry-per-rank tables (identical on every rank)."""
+    if log_p == 0:
+        return proof, rs
+    A = [t[0] for t in tails]
+    M = [t[1] for t in tails]
+    Wc = [t[2] for t in tails]
+    wb = tails[0][3]
+    tail = open_tail(log_p, A, M, wb, Wc)
+    try:
+        for j in range(2 * k - log_p, 2 * k):
+            g = layer_round_vector(tail.sums(), dep[j % k])
+            r = hasher(g, 0)
+            proof.append(g)
+            rs.append(r)
+            tail.bind(r)
+    finally:
+        if hasattr(tail, "close"):
+            tail.close()
+    return proof, rs
+
+
+def prove_sumcheck_opt_logical(ctx: Context, layer: Layer, k_next, z, W, nshards):
+    """prove_sumcheck_opt with the hypercube cut into `nshards` logical ranks on ONE GPU: the
+    partitioned algorithm end to end (shard build, per-round reduce, gather, redundant tail), the
+    collective degenerating to an in-process sum.  Used to prove bit-exactness of the sharded
+    path on a single device."""
+    log_p = _log2(nshards)
+    shards = [LayerSession.open(ctx, layer, k_next, z, W, nshards, p) for p in range(nshards)]
+    try:
+        dep = shards[0].dep(k_next)
+
+        def reduce_fr(parts):
+            return [sum(col) % MODULUS for col in zip(*parts)]
+        proof, rs = layer_sumcheck_rounds(shards, reduce_fr, k_next, log_p, dep)
+        tails = [s.tail() for s in shards]
+    finally:
+        for s in shards:
+            s.close()
+    return _finish_layer(lambda kc, A, M, wb, Wc: LayerSession.open_tables(ctx, kc, A, M, wb, Wc), tails, k_next, log_p,
+                         dep, proof, rs, multi_hash)
+
+
+def prove_sumcheck_opt_distributed(shard, coll, k_next, dep, open_tail, hasher=multi_hash):
+    """One rank's side of the distributed layer sumcheck.  `shard` is this rank's shard object
+    (LayerSession on a GPU), `coll` a collective (TorchCollective), `open_tail(kc, A, M, wb, Wc)`
+    builds the tail object.  Every rank returns the same (proof, r)."""
+    log_p = _log2(coll.world)
+    proof, rs = layer_sumcheck_rounds([shard], lambda parts: coll.all_reduce_fr(parts[0]), k_next, log_p, dep, hasher)
+    tails = coll.all_gather_fr(shard.tail()) if log_p else []
+    return _finish_layer(open_tail, tails, k_next, log_p, dep, proof, rs, hasher)
+
+
+def mle_sumcheck_rounds(shards, reduce_fr, reduce_or, n, log_p, dep_rank_bit, hasher=multi_hash):
+    """prove_sumcheck on a table of 2^n entries cut into 2^log_p trailing-variable shards held by
+    `shards` (those of this process).  dep_rank_bit: for log_p >= 1, whether the full table depends
+    on its LAST variable (a rank bit: shards p and p ^ 1 differ) -- the last round's length rule."""
+    proof, rs = [], []
+    local = n - log_p
+    dep_local = False
+    for j in range(local):
+        parts = [s.sums() for s in shards]
+        if j == 0:
+            dep_local = reduce_or(any(d for _, d in parts))
+        tot = reduce_fr([p for p, _ in parts])
+        last = (j == n - 1)
+        g = mle_round_vector(tot, last, dep_local if log_p == 0 else dep_rank_bit)
+        r = hasher(g, 0)
+        proof.append(g)
+        rs.append(r)
+        for s in shards:
+            s.bind(r)
+    return proof, rs
+
+
+class _DeviceTail:
+    """The gathered per-rank values as a small device table (index = rank = the trailing bits)."""
+
+    def __init__(self, ctx: Context, values):
+        self._ctx = ctx
+        self._d = ctx.alloc(32 * len(values))
+        ctx.upload(self._d, to_limbs(values))
+        self._s = MleSession(ctx, self._d, _log2(len(values)))
+
+    def sums(self):
+        return self._s.sums()
+
+    def bind(self, r):
+        self._s.bind(r)
+
+    def close(self):
+        self._s.close()
+        if self._d is not None:
+            self._ctx.free(self._d)
+            self._d = None
+
+
+def _finish_mle(open_tail, values, n, log_p, dep_rank_bit, proof, rs, hasher):
+    """Last log_p rounds on the gathered one-entry-per-rank table (identical on every rank)."""
+    if log_p == 0:
+        return proof, rs
+    tail = open_tail(values)
+    try:
+        for j in range(n - log_p, n):
+            tot, _ = tail.sums()
+            g = mle_round_vector(tot, j == n - 1, dep_rank_bit)
+            r = hasher(g, 0)
+            proof.append(g)
+            rs.append(r)
+            tail.bind(r)
+    finally:
+        if hasattr(tail, "close"):
+            tail.close()
+    return proof, rs
+
+
+def prove_sumcheck_logical(ctx: Context, d_shards, n, dep_rank_bit=None):
+    """prove_sumcheck on 2^n entries held as len(d_shards) device-resident trailing-variable shards
+    (shard p = entries p, p + P, p + 2P, ...), all on one GPU."""
+    nshards = len(d_shards)
+    log_p = _log2(nshards)
+    if dep_rank_bit is None and log_p:
+        dep_rank_bit = any(tables_differ(ctx, d_shards[p], d_shards[p + 1], 1 << (n - log_p)) for p in range(0, nshards, 2))
+    sess = [MleSession(ctx, d, n - log_p) for d in d_shards]
+    try:
+        proof, rs = mle_sumcheck_rounds(sess, lambda parts: [sum(c) % MODULUS for c in zip(*parts)], bool, n, log_p,
+                                        dep_rank_bit)
+        values = [s.value() for s in sess] if log_p else []
+    finally:
+        for s in sess:
+            s.close()
+    return _finish_mle(lambda v: _DeviceTail(ctx, v), values, n, log_p, dep_rank_bit, proof, rs, multi_hash)
+
+
+def prove_sumcheck_distributed(shard, coll, n, dep_rank_bit, open_tail, hasher=multi_hash):
+    """One rank's side of the distributed plain sumcheck (shard: MleSession-like; open_tail(values)
+    builds the object that runs the last log2(P) rounds on the gathered values)."""
+    log_p = _log2(coll.world)
+    proof, rs = mle_sumcheck_rounds([shard], lambda parts: coll.all_reduce_fr(parts[0]), coll.all_reduce_or, n, log_p,
+                                    dep_rank_bit, hasher)
+    values = [v[0] for v in coll.all_gather_fr([shard.value()])] if log_p else []
+    return _finish_mle(open_tail, values, n, log_p, dep_rank_bit, proof, rs, hasher)
+
+
+def tables_differ(ctx: Context, d_a, d_b, count):
+    out = ctypes.c_uint32(0)
+    ctx._check(N.lib().gkr_device_tables_differ(ctx._h, d_a, d_b, ctypes.c_size_t(count), ctypes.byref(out)))
+    return bool(out.value)
+
+
+def shard_units(total, rank, world):
+    """Contiguous split of `total` independent units (proofs, sumchecks) over `world` ranks: the
+    no-collective sharding bench.py and proof batches use."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))

@@ -188,6 +188,45 @@ int  gkr_proof_sizes(const gkr_circuit_desc *circuit, gkr_proof_sizes_t *out);
 int  gkr_prove(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values,
                int require_zero_output, gkr_proof_buf *out);
 
+/* ---- step-wise sessions: one sumcheck split across GPUs -------------------
+ * The reference reduces each round's per-assignment polynomials with a rayon
+ * map-reduce (sumcheck.rs:50-63,65-78,97-124); across GPUs that reduce is one
+ * tiny all-reduce per round.  The hypercube is partitioned by its TRAILING
+ * log2(P) variables (rank p owns index low bits == p), so every pair of a
+ * leading-variable round is rank-local.  A session does one rank's table work;
+ * the caller owns the collective and the transcript (gkr_amd/parallel.py).
+ * P = 1 gives the whole sumcheck with an external transcript. */
+typedef struct gkr_layer_session gkr_layer_session;
+typedef struct gkr_mle_session gkr_mle_session;
+
+/* shard `shard` of `nshards` (power of two, <= 2^k_next) of the layer sumcheck:
+ * keeps the gates whose right operand % nshards == shard; runs 2 k_next - log2(nshards) rounds */
+int  gkr_layer_session_open(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_type,
+                            const uint32_t *left, const uint32_t *right, const gkr_fr *z,
+                            const gkr_fr *W, uint32_t nshards, uint32_t shard,
+                            gkr_layer_session **out);
+/* the redundant tail after the all-gather of the shards' last entries: tables of 2^kc entries */
+int  gkr_layer_session_open_tables(gkr_ctx *ctx, int kc, const gkr_fr *A, const gkr_fr *M,
+                                   const gkr_fr *wb, const gkr_fr *Wc, gkr_layer_session **out);
+int  gkr_layer_session_dep(gkr_ctx *ctx, const gkr_layer_session *s, uint32_t *out_dep, uint32_t count);
+int  gkr_layer_session_rounds(const gkr_layer_session *s, uint32_t *done, uint32_t *total);
+/* this shard's partial sums of the current round: out[0] = c0, out[1] = g(1), out[2] = c2 */
+int  gkr_layer_session_sums(gkr_ctx *ctx, gkr_layer_session *s, gkr_fr *out);
+int  gkr_layer_session_bind(gkr_ctx *ctx, gkr_layer_session *s, const gkr_fr *r);
+/* after the last local round: out = { A, M, Wc, W(b*) } of this shard */
+int  gkr_layer_session_tail(gkr_ctx *ctx, gkr_layer_session *s, gkr_fr *out);
+void gkr_layer_session_close(gkr_ctx *ctx, gkr_layer_session *s);
+
+/* plain multilinear sumcheck on a device-resident table of 2^n entries (a shard or the whole table) */
+int  gkr_mle_session_open(gkr_ctx *ctx, const void *d_table, int n, gkr_mle_session **out);
+/* out[0] = sum of the low half, out[1] = sum of the high half of the current table */
+int  gkr_mle_session_sums(gkr_ctx *ctx, gkr_mle_session *s, gkr_fr *out, uint32_t *out_dep);
+int  gkr_mle_session_bind(gkr_ctx *ctx, gkr_mle_session *s, const gkr_fr *r);
+int  gkr_mle_session_value(gkr_ctx *ctx, gkr_mle_session *s, gkr_fr *out);
+void gkr_mle_session_close(gkr_ctx *ctx, gkr_mle_session *s);
+int  gkr_device_tables_differ(gkr_ctx *ctx, const void *d_a, const void *d_b, size_t count,
+                              uint32_t *out_differ);
+
 /* ---- device memory helpers (so callers need no HIP of their own) -------- */
 int  gkr_device_alloc(gkr_ctx *ctx, size_t bytes, void **d_ptr);
 int  gkr_device_free(gkr_ctx *ctx, void *d_ptr);

@@ -1,0 +1,154 @@
+"""Worker of the world_size-2 gloo test (CPU only): drives gkr_amd.parallel's distributed
+algorithms -- the per-round all-reduce of limb-widened field elements, the all-gather, the
+redundant tail -- with shard objects computed by the CPU ORACLE (there is no GPU here; the
+product's shard object on a GPU box is the library session).  Launched by
+tests/test_distributed_gloo.py through torch.distributed.run.
+"""
+
+import json
+import os
+import random
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import torch.distributed as dist  # noqa: E402
+
+from gkr_amd import parallel  # noqa: E402
+from oracle import dense  # noqa: E402
+from oracle.field import P  # noqa: E402
+from oracle.mimc7 import multi_hash as oracle_hash  # noqa: E402
+
+
+class OracleLayerShard:
+    """Pure-Python twin of the library's layer session (sums / bind / tail) for shard p of nshards."""
+
+    def __init__(self, k_i, k, gt, l, r, z, w, nshards, shard):
+        lp = nshards.bit_length() - 1
+        self.k, self.kc, self.round = k, k - lp, 0
+        e = dense.eq_table(z) if k_i else [1]
+        n = 1 << (2 * k - lp)
+        self.a, self.m = [0] * n, [0] * n
+        for g, ty in enumerate(gt):
+            if r[g] % nshards != shard:
+                continue
+            idx = (l[g] << self.kc) | (r[g] >> lp)
+            tgt = self.m if ty else self.a
+            tgt[idx] = (tgt[idx] + e[g]) % P
+        self.wb = [x % P for x in w]
+        self.wc = [w[i * nshards + shard] % P for i in range(1 << self.kc)]
+
+    def sums(self):
+        h = len(self.a) // 2
+        c0 = g1 = c2 = 0
+        bphase = self.round < self.k
+        hb = h >> self.kc
+        for i in range(h):
+            a0, a1, m0, m1 = self.a[i], self.a[i + h], self.m[i], self.m[i + h]
+            if bphase:
+                row, col = i >> self.kc, i & ((1 << self.kc) - 1)
+                p0, p1, q0, q1 = self.wb[row], self.wb[row + hb], self.wc[col], self.wc[col]
+            else:
+                p0 = p1 = self.wb[0]
+                q0, q1 = self.wc[i], self.wc[i + h]
+            c0 += a0 * (p0 + q0) + m0 * p0 * q0
+            g1 += a1 * (p1 + q1) + m1 * p1 * q1
+            c2 += (a1 - a0) * ((p1 + q1) - (p0 + q0)) + (m1 - m0) * (p1 * q1 - p0 * q0)
+        return [c0 % P, g1 % P, c2 % P]
+
+    def bind(self, r):
+        def fold(t):
+            h = len(t) // 2
+            return [(t[i] + r * (t[i + h] - t[i])) % P for i in range(h)]
+        self.a, self.m = fold(self.a), fold(self.m)
+        if self.round < self.k:
+            self.wb = fold(self.wb)
+        else:
+            self.wc = fold(self.wc)
+        self.round += 1
+
+    def tail(self):
+        return [self.a[0], self.m[0], self.wc[0], self.wb[0]]
+
+
+class OracleLayerTail(OracleLayerShard):
+    def __init__(self, kc, A, M, wb, Wc):
+        self.k = self.kc = kc
+        self.round = kc
+        self.a, self.m, self.wb, self.wc = list(A), list(M), [wb], list(Wc)
+
+
+class OracleMleShard:
+    def __init__(self, table):
+        self.t = [x % P for x in table]
+        n = len(table)
+        self.dep = any(self.t[2 * i] != self.t[2 * i + 1] for i in range(n // 2)) if n >= 2 else False
+
+    def sums(self):
+        h = len(self.t) // 2
+        return [sum(self.t[:h]) % P, sum(self.t[h:]) % P], self.dep
+
+    def bind(self, r):
+        h = len(self.t) // 2
+        self.t = [(self.t[i] + r * (self.t[i + h] - self.t[i])) % P for i in range(h)]
+
+    def value(self):
+        return self.t[0]
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    coll = parallel.TorchCollective()
+    out = {"rank": rank, "world": world}
+
+    # independent units: contiguous split, no collective
+    out["units"] = list(parallel.shard_units(11, rank, world))
+
+    # collective plumbing: modular all-reduce through widened limbs, all-gather, or
+    vals = [(P - 1 - rank) % P, 12345 + rank, 0]
+    out["allreduce"] = [str(v) for v in coll.all_reduce_fr(vals)]
+    out["allgather"] = [[str(v) for v in row] for row in coll.all_gather_fr([rank + 7])]
+    out["or"] = coll.all_reduce_or(rank == world - 1)
+
+    # distributed GKR layer sumcheck (every rank builds the same seeded instance, keeps its shard)
+    rng = random.Random(2026)
+    k_i, k = 3, 3
+    g = 1 << k_i
+    gt = [rng.randint(0, 1) for _ in range(g)]
+    l = [rng.randrange(1 << k) for _ in range(g)]
+    r = [rng.randrange(1 << k) for _ in range(g)]
+    z = [rng.randrange(P) for _ in range(k_i)]
+    w = [rng.randrange(P) for _ in range(1 << k)]
+    shard = OracleLayerShard(k_i, k, gt, l, r, z, w, world, rank)
+    proof, rs = parallel.prove_sumcheck_opt_distributed(shard, coll, k, dense.depends_on(w, k),
+                                                        lambda kc, A, M, wb, Wc: OracleLayerTail(kc, A, M, wb, Wc),
+                                                        hasher=oracle_hash)
+    ref = dense.sumcheck_layer(k_i, k, gt, l, r, z, w)
+    out["layer_ok"] = (proof, rs) == ref
+
+    # a W that lacks a variable: short round vectors must survive the sharding
+    w2 = [(i >> (k - 1)) + 1 for i in range(1 << k)]
+    shard = OracleLayerShard(k_i, k, gt, l, r, z, w2, world, rank)
+    got = parallel.prove_sumcheck_opt_distributed(shard, coll, k, dense.depends_on(w2, k),
+                                                  lambda kc, A, M, wb, Wc: OracleLayerTail(kc, A, M, wb, Wc),
+                                                  hasher=oracle_hash)
+    out["layer_short_ok"] = got == dense.sumcheck_layer(k_i, k, gt, l, r, z, w2)
+
+    # distributed plain sumcheck
+    n = 6
+    table = [rng.randrange(P) for _ in range(1 << n)]
+    local = OracleMleShard(table[rank::world])
+    dep_rank_bit = any(table[2 * i] != table[2 * i + 1] for i in range(len(table) // 2))
+    got = parallel.prove_sumcheck_distributed(local, coll, n, dep_rank_bit, lambda v: OracleMleShard(v), hasher=oracle_hash)
+    out["mle_ok"] = got == dense.sumcheck_mle(table, n)
+
+    with open(os.path.join(os.environ["GKR_TEST_OUT"], "rank%d.json" % rank), "w") as f:
+        json.dump(out, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

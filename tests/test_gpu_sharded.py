@@ -1,0 +1,105 @@
+"""GPU parity of the multi-GPU algorithm with logical ranks on one device: the hypercube is cut
+into P trailing-variable shards, every shard is a library session, the per-round reduce is done
+in-process.  Results must equal the unsharded oracle bit for bit."""
+
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from gkr_amd import Context, Layer, parallel
+from gkr_amd.field import to_limbs
+from oracle import cdense, dense
+from oracle.field import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _layer(rng, k_i, k):
+    g = 1 << k_i
+    return Layer(k_i, [rng.randint(0, 1) for _ in range(g)], [rng.randrange(1 << k) for _ in range(g)],
+                 [rng.randrange(1 << k) for _ in range(g)])
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 4, 8])
+def test_layer_sumcheck_logical_ranks(ctx, nshards):
+    rng = random.Random(500 + nshards)
+    for k_i, k in ((4, 3), (6, 4), (0, 3)):
+        lay = _layer(rng, k_i, k)
+        z = [rng.randrange(P) for _ in range(k_i)]
+        for w in ([rng.randrange(P) for _ in range(1 << k)], [(i >> (k - 1)) + 1 for i in range(1 << k)],
+                  [(i & 1) + 5 for i in range(1 << k)]):
+            got = parallel.prove_sumcheck_opt_logical(ctx, lay, k, z, w, nshards)
+            assert got == cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w), (nshards, k_i, k)
+
+
+def test_layer_sumcheck_logical_ranks_wide(ctx):
+    rng = random.Random(77)
+    k_i, k = 12, 6
+    lay = _layer(rng, k_i, k)
+    z = [rng.randrange(P) for _ in range(k_i)]
+    w = [rng.randrange(P) for _ in range(1 << k)]
+    ref = cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w)
+    assert parallel.prove_sumcheck_opt_logical(ctx, lay, k, z, w, 8) == ref
+    assert ctx.prove_sumcheck_opt(lay, k, z, w) == ref
+
+
+def test_layer_session_as_single_rank_world(ctx):
+    rng = random.Random(78)
+    k_i, k = 5, 4
+    lay = _layer(rng, k_i, k)
+    z = [rng.randrange(P) for _ in range(k_i)]
+    w = [rng.randrange(P) for _ in range(1 << k)]
+    s = parallel.LayerSession.open(ctx, lay, k, z, w)
+    got = parallel.prove_sumcheck_opt_distributed(s, parallel.SingleProcess(), k, s.dep(k), None)
+    s.close()
+    assert got == dense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w)
+
+
+def _upload_shards(ctx, table, nshards):
+    ptrs = []
+    for p in range(nshards):
+        part = to_limbs(table[p::nshards])
+        d = ctx.alloc(part.nbytes)
+        ctx.upload(d, part)
+        ptrs.append(d)
+    return ptrs
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 4, 8])
+def test_mle_sumcheck_logical_ranks(ctx, nshards):
+    rng = random.Random(900 + nshards)
+    n = 10
+    tables = [[rng.randrange(P) for _ in range(1 << n)], [5] * (1 << n), [i >> 1 for i in range(1 << n)],
+              [rng.randrange(2) for _ in range(1 << n)]]
+    for t in tables:
+        ptrs = _upload_shards(ctx, t, nshards)
+        try:
+            assert parallel.prove_sumcheck_logical(ctx, ptrs, n) == cdense.sumcheck_mle(t, n)
+        finally:
+            for d in ptrs:
+                ctx.free(d)
+
+
+def test_tables_differ(ctx):
+    a = to_limbs(list(range(1000)))
+    b = a.copy()
+    da, db = ctx.alloc(a.nbytes), ctx.alloc(b.nbytes)
+    try:
+        ctx.upload(da, a)
+        ctx.upload(db, b)
+        assert parallel.tables_differ(ctx, da, db, 1000) is False
+        b[777, 2] = np.uint64(1)
+        ctx.upload(db, b)
+        assert parallel.tables_differ(ctx, da, db, 1000) is True
+    finally:
+        ctx.free(da)
+        ctx.free(db)
