@@ -211,6 +211,35 @@ __device__ inline __attribute__((always_inline)) void mac96_s(uint64_t& acc, uin
         : "v"(x), "s"(y_uniform));
 }
 
+// Interleaved forms: two / three INDEPENDENT accumulators advanced together.  The other chains'
+// instructions fill the two wait states a carry needs (no pad for three chains, one s_nop 0 for
+// two) and give the in-order wave independent work while a v_mad_u64_u32 result is in flight
+// (measured: a dependent mad chain issues every ~10 cycles per wave, independent ones every ~5).
+__device__ inline __attribute__((always_inline)) void mac96x2_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA,
+                                                                uint64_t& accB, uint32_t& exB, uint32_t xB, uint32_t yB) {
+    uint64_t cA, cB;
+    asm("v_mad_u64_u32 %0, %4, %6, %7, %0\n\t"
+        "v_mad_u64_u32 %2, %5, %8, %9, %2\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %4, 0, %1, %4\n\t"
+        "v_addc_co_u32_e64 %3, %5, 0, %3, %5"
+        : "+v"(accA), "+v"(exA), "+v"(accB), "+v"(exB), "=&s"(cA), "=&s"(cB)
+        : "v"(xA), "s"(yA), "v"(xB), "s"(yB));
+}
+__device__ inline __attribute__((always_inline)) void mac96x3_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA,
+                                                                uint64_t& accB, uint32_t& exB, uint32_t xB, uint32_t yB,
+                                                                uint64_t& accC, uint32_t& exC, uint32_t xC, uint32_t yC) {
+    uint64_t cA, cB, cC;
+    asm("v_mad_u64_u32 %0, %6, %9, %10, %0\n\t"
+        "v_mad_u64_u32 %2, %7, %11, %12, %2\n\t"
+        "v_mad_u64_u32 %4, %8, %13, %14, %4\n\t"
+        "v_addc_co_u32_e64 %1, %6, 0, %1, %6\n\t"
+        "v_addc_co_u32_e64 %3, %7, 0, %3, %7\n\t"
+        "v_addc_co_u32_e64 %5, %8, 0, %5, %8"
+        : "+v"(accA), "+v"(exA), "+v"(accB), "+v"(exB), "+v"(accC), "+v"(exC), "=&s"(cA), "=&s"(cB), "=&s"(cC)
+        : "v"(xA), "s"(yA), "v"(xB), "s"(yB), "v"(xC), "s"(yC));
+}
+
 // o = a + b over 256 bits (carry out dropped: callers keep sums below 2^256)
 __device__ inline __attribute__((always_inline)) void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
     asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\ts_nop 1\n\t"
@@ -257,6 +286,17 @@ GKR_HD void mac96(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
     acc = s;
 }
 GKR_HD void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) { mac96(acc, ex, x, y); }
+GKR_HD void mac96x2_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA, uint64_t& accB, uint32_t& exB, uint32_t xB,
+                      uint32_t yB) {
+    mac96(accA, exA, xA, yA);
+    mac96(accB, exB, xB, yB);
+}
+GKR_HD void mac96x3_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA, uint64_t& accB, uint32_t& exB, uint32_t xB,
+                      uint32_t yB, uint64_t& accC, uint32_t& exC, uint32_t xC, uint32_t yC) {
+    mac96(accA, exA, xA, yA);
+    mac96(accB, exB, xB, yB);
+    mac96(accC, exC, xC, yC);
+}
 GKR_HD void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
     uint64_t carry = 0;
     for (int i = 0; i < 8; ++i) {
@@ -430,6 +470,142 @@ GKR_HD Fr fr_fold_fixed(const Fr& lo, const Fr& hi, const FixedMul& T) {
     return fr_add(lo, mul_fixed(fr_sub(hi, lo), T));
 }
 
+// two fixed-multiplier products advanced together (same table, independent operands)
+GKR_HD void mul_fixed2(const Fr& dA, const Fr& dB, const FixedMul& T, Fr& outA, Fr& outB) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t sA[11], sB[11];
+    uint64_t aA = 0, aB = 0;
+    uint32_t eA = 0, eB = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mac96x2_s(aA, eA, dA.l[i], T.w[i][c], aB, eB, dB.l[i], T.w[i][c]);
+        sA[c] = (uint32_t)aA;
+        sB[c] = (uint32_t)aB;
+        aA = (aA >> 32) | ((uint64_t)eA << 32);
+        aB = (aB >> 32) | ((uint64_t)eB << 32);
+        eA = 0;
+        eB = 0;
+    }
+    sA[8] = (uint32_t)aA; sA[9] = (uint32_t)(aA >> 32); sA[10] = 0;
+    sB[8] = (uint32_t)aB; sB[9] = (uint32_t)(aB >> 32); sB[10] = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t mA = sA[k] * GKR_INV32, mB = sB[k] * GKR_INV32;
+        uint64_t xA = sA[k], xB = sB[k];
+        uint32_t fA = 0, fB = 0;
+        mac96x2_s(xA, fA, mA, p[0], xB, fB, mB, p[0]);
+        xA = (xA >> 32) | ((uint64_t)fA << 32);
+        xB = (xB >> 32) | ((uint64_t)fB << 32);
+        fA = 0;
+        fB = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            xA += sA[k + j];
+            xB += sB[k + j];
+            mac96x2_s(xA, fA, mA, p[j], xB, fB, mB, p[j]);
+            sA[k + j] = (uint32_t)xA;
+            sB[k + j] = (uint32_t)xB;
+            xA = (xA >> 32) | ((uint64_t)fA << 32);
+            xB = (xB >> 32) | ((uint64_t)fB << 32);
+            fA = 0;
+            fB = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 11; ++j) {
+            xA += sA[j]; sA[j] = (uint32_t)xA; xA >>= 32;
+            xB += sB[j]; sB[j] = (uint32_t)xB; xB >>= 32;
+        }
+    }
+    uint32_t tA[8], tB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tA[i] = sA[i + 2];
+        tB[i] = sB[i + 2];
+    }
+    outA = cond_sub_mod(tA);
+    outB = cond_sub_mod(tB);
+}
+
+// the two folds of one fold-and-sum step together
+GKR_HD void fr_fold_fixed2(const Fr& lo0, const Fr& hi0, const Fr& lo1, const Fr& hi1, const FixedMul& T, Fr& y0, Fr& y1) {
+    Fr t0, t1;
+    mul_fixed2(fr_sub(hi0, lo0), fr_sub(hi1, lo1), T, t0, t1);
+    y0 = fr_add(lo0, t0);
+    y1 = fr_add(lo1, t1);
+}
+
+// ---------------------------------------------------------------- lazy dot products
+// sum_i a_i * b_i with ONE modular reduction at the end: each product is added as a full
+// 512-bit integer into a 544-bit (17-limb) accumulator -- 64 partial products instead of the
+// 128 of a reduced Montgomery product; 2^36 products fit.  b is wave-uniform (SGPR operands).
+struct Lazy17 {
+    uint32_t l[17];
+};
+
+GKR_HD Lazy17 lazy_zero() {
+    Lazy17 z;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) z.l[i] = 0;
+    return z;
+}
+
+GKR_HD void lazy_mac_s(Lazy17& acc, const Fr& a, const Fr& b_uniform) {
+    uint64_t col = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        col += acc.l[c];   // col < 2^35 after the shift: cannot overflow
+#pragma unroll
+        for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96_s(col, ex, a.l[i], b_uniform.l[c - i]);
+        acc.l[c] = (uint32_t)col;
+        col = (col >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+    col += acc.l[15];
+    acc.l[15] = (uint32_t)col;
+    col >>= 32;
+    col += acc.l[16];
+    acc.l[16] = (uint32_t)col;
+}
+
+// three independent dot products advanced together (see mac96x3_s)
+GKR_HD void lazy_mac3_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub, Lazy17& C, const Fr& c,
+                        const Fr& uc) {
+    uint64_t cA = 0, cB = 0, cC = 0;
+    uint32_t eA = 0, eB = 0, eC = 0;
+#pragma unroll
+    for (int col = 0; col < 15; ++col) {
+        cA += A.l[col];
+        cB += B.l[col];
+        cC += C.l[col];
+#pragma unroll
+        for (int i = (col > 7 ? col - 7 : 0); i <= (col < 7 ? col : 7); ++i)
+            mac96x3_s(cA, eA, a.l[i], ua.l[col - i], cB, eB, b.l[i], ub.l[col - i], cC, eC, c.l[i], uc.l[col - i]);
+        A.l[col] = (uint32_t)cA;
+        B.l[col] = (uint32_t)cB;
+        C.l[col] = (uint32_t)cC;
+        cA = (cA >> 32) | ((uint64_t)eA << 32);
+        cB = (cB >> 32) | ((uint64_t)eB << 32);
+        cC = (cC >> 32) | ((uint64_t)eC << 32);
+        eA = 0;
+        eB = 0;
+        eC = 0;
+    }
+    cA += A.l[15]; A.l[15] = (uint32_t)cA; cA >>= 32; cA += A.l[16]; A.l[16] = (uint32_t)cA;
+    cB += B.l[15]; B.l[15] = (uint32_t)cB; cB >>= 32; cB += B.l[16]; B.l[16] = (uint32_t)cB;
+    cC += C.l[15]; C.l[15] = (uint32_t)cC; cC >>= 32; cC += C.l[16]; C.l[16] = (uint32_t)cC;
+}
+
+// X * 2^-256 mod r, canonical: eight 32-bit Montgomery steps leave (X + M p) / 2^256 < 2^288 + p
+// in ten limbs, which the wide-sum reduction below brings under r.
+template <int NL>
+struct Acc;
+template <int NL>
+GKR_HD Fr acc_reduce(const Acc<NL>& a);
+
+GKR_HD Fr lazy_reduce(const Lazy17& x);
+
 // ---------------------------------------------------------------- wide sums
 // Unreduced accumulator: NL 32-bit limbs.  Acc<9> takes 2^32 canonical addends,
 // Acc<10> takes 2^32 Acc<9> values.
@@ -509,6 +685,42 @@ GKR_HD Fr acc_reduce(const Acc<NL>& a) {
 #pragma unroll
     for (int i = 8; i < NL; ++i) hi.l[i - 8] = a.l[i];
     return fr_add(lo, mont_mul(hi, fr_r2()));
+}
+
+GKR_HD Fr lazy_reduce(const Lazy17& x) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t t[19];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = x.l[i];
+    t[17] = 0;
+    t[18] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t m = t[k] * GKR_INV32;
+        uint64_t a2 = t[k];
+        uint32_t e2 = 0;
+        mac96_s(a2, e2, m, p[0]);
+        a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+        e2 = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            a2 += t[k + j];
+            mac96_s(a2, e2, m, p[j]);
+            t[k + j] = (uint32_t)a2;
+            a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+            e2 = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 19; ++j) {
+            a2 += t[j];
+            t[j] = (uint32_t)a2;
+            a2 >>= 32;
+        }
+    }
+    Acc<10> r;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r.l[i] = t[8 + i];
+    return acc_reduce(r);
 }
 
 }  // namespace gkr

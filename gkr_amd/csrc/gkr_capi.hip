@@ -522,43 +522,79 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
 
 // ------------------------------------------------------------- predicate tables
 // builds canonical A, M (2^{2k} each) in device memory from device gate arrays
+// eq(z[lo..hi), .) over hi - lo variables, first variable most significant (host, 4x64-bit)
+static void host_eq_table(const gkr_fr* z, int lo, int hi, std::vector<gkr::h64::F>& out) {
+    using namespace gkr::h64;
+    out.assign((size_t)1 << (hi - lo), F{{0, 0, 0, 0}});
+    out[0] = F{{1, 0, 0, 0}};
+    size_t cur = 1;
+    for (int i = lo; i < hi; ++i) {
+        F zi;
+        memcpy(&zi, &z[i], 32);
+        const F zm = to_mont(zi);
+        for (size_t g = cur; g-- > 0;) {
+            const F hi_v = mont_mul(out[g], zm);   // e * z
+            const F lo_v = sub(out[g], hi_v);      // e * (1 - z)
+            out[2 * g] = lo_v;
+            out[2 * g + 1] = hi_v;
+        }
+        cur <<= 1;
+    }
+}
+
 // shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries
 int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                      const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0) {
     const size_t N = (size_t)1 << (2 * k - log_p);
     hipStream_t s = ctx->stream;
-    DevBuf<unsigned long long> wideA, wideM;
-    DevBuf<Fr> zfac;
-    DevBuf<uint32_t> bad;
-    HIP_TRY(ctx, wideA.alloc(N * 8));
-    HIP_TRY(ctx, wideM.alloc(N * 8));
-    HIP_TRY(ctx, zfac.alloc(2 * (size_t)(k_i > 0 ? k_i : 1)));
-    HIP_TRY(ctx, bad.alloc(1));
-    std::vector<Fr> hz(2 * (size_t)(k_i > 0 ? k_i : 1), gkr::fr_zero());
-    Fr one = gkr::fr_zero();
-    one.l[0] = 1;
-    for (int i = 0; i < k_i; ++i) {
-        Fr zi = to_dev(z[i]);
-        hz[2 * i] = gkr::to_mont(gkr::fr_sub(one, zi));
-        hz[2 * i + 1] = gkr::to_mont(zi);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(zfac.p, hz.data(), hz.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(wideA.p, 0, N * 64, s));
-    HIP_TRY(ctx, hipMemsetAsync(wideM.p, 0, N * 64, s));
-    HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, 4, s));
-    {
-        Timed t(ctx, "predicate_scatter", (double)((size_t)1 << k_i) * (9.0 + 64.0));
-        gkr::launch_predicate_scatter(k_i, k, d_gt, d_l, d_r, zfac.p, wideA.p, wideM.p, bad.p, log_p, shard, s);
-    }
-    {
-        Timed t(ctx, "predicate_normalise", (double)N * 2.0 * (64.0 + 32.0));
-        gkr::launch_predicate_normalise(wideA.p, d_A, N, s);
-        gkr::launch_predicate_normalise(wideM.p, d_M, N, s);
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    uint32_t* bad = nullptr;
+    const int kl = k_i / 2, kh = k_i - kl;
+    WS(ctx, "pred.ehi", Fr, (size_t)1 << kh, e_hi);
+    WS(ctx, "pred.elo", Fr, (size_t)1 << kl, e_lo);
+    WS(ctx, "pred.bad", uint32_t, 1, bad);
+    // E[g] = E_hi[g >> kl] * E_lo[g & mask]: two small tables built on the host (2^kh + 2^kl products)
+    std::vector<gkr::h64::F> hhi, hlo;
+    host_eq_table(z, 0, kh, hhi);
+    host_eq_table(z, kh, k_i, hlo);
+    for (auto& v : hlo) v = gkr::h64::to_mont(v);
+    HIP_TRY(ctx, hipMemcpyAsync(e_hi, hhi.data(), hhi.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(e_lo, hlo.data(), hlo.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+    static const bool use_atomics = getenv("GKR_PREDICATE_ATOMICS") != nullptr;
+    if (!use_atomics) {
+        // counting sort by cell, then one modular sum per cell
+        uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *bsums = nullptr, *list = nullptr;
+        WS(ctx, "pred.counts", uint32_t, 2 * N, counts);
+        WS(ctx, "pred.offsets", uint32_t, 2 * N, offsets);
+        WS(ctx, "pred.cursor", uint32_t, 2 * N, cursor);
+        WS(ctx, "pred.bsums", uint32_t, (2 * N + 2047) / 2048 + 1, bsums);
+        WS(ctx, "pred.list", uint32_t, (size_t)1 << k_i, list);
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 2 * N * sizeof(uint32_t), s));
+        Timed t(ctx, "predicate_sorted", (double)((size_t)1 << k_i) * (2 * 9.0 + 8.0) + (double)N * 2.0 * (3 * 4.0 + 32.0));
+        gkr::launch_predicate_sorted(k_i, k, d_gt, d_l, d_r, e_hi, e_lo, (uint32_t)kl, log_p, shard, N, counts, offsets, cursor,
+                                     bsums, list, bad, d_A, d_M, s);
+    } else {
+        // widened-atomic scatter (kept for comparison): 8 u64 limb atomics per gate into 64-byte cells
+        unsigned long long *wideA = nullptr, *wideM = nullptr;
+        WS(ctx, "pred.wideA", unsigned long long, N * 8, wideA);
+        WS(ctx, "pred.wideM", unsigned long long, N * 8, wideM);
+        HIP_TRY(ctx, hipMemsetAsync(wideA, 0, N * 64, s));
+        HIP_TRY(ctx, hipMemsetAsync(wideM, 0, N * 64, s));
+        {
+            Timed t(ctx, "predicate_scatter", (double)((size_t)1 << k_i) * (9.0 + 64.0));
+            gkr::launch_predicate_scatter(k_i, k, d_gt, d_l, d_r, e_hi, e_lo, (uint32_t)kl, wideA, wideM, bad, log_p, shard, s);
+        }
+        {
+            Timed t(ctx, "predicate_normalise", (double)N * 2.0 * (64.0 + 32.0));
+            gkr::launch_predicate_normalise(wideA, d_A, N, s);
+            gkr::launch_predicate_normalise(wideM, d_M, N, s);
+        }
     }
     uint32_t hbad = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad.p, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));   // also keeps hz alive until the upload is done
-    if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate operand index out of range for 2^k_next");
+    HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // also keeps the host tables alive until their upload is done
+    if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
     return GKR_OK;
 }
 
@@ -597,20 +633,33 @@ int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t*
     const gkr::h64::F* cts64 = host_mimc_constants64();
     if (host_tx) {
         HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec), reinterpret_cast<void**>(&rec)));
-        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", sizeof(gkr::FixedMul), reinterpret_cast<void**>(&h_rtab)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul), reinterpret_cast<void**>(&h_rtab)));
         HIP_TRY(ctx, hipMemcpyAsync(h_dep, dep, sizeof(uint32_t) * 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
     }
+    // The fold with r_j is deferred into the pass that computes round j+1's sums (b-phase: the
+    // fused kernel; c-phase: a separate fold of the single remaining row).
+    const gkr::FixedMul* pending = nullptr;   // challenge table not yet applied to A, M
+    static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
     for (uint32_t round = 0; round < v; ++round) {
-        const uint32_t h = (uint32_t)(N >> (round + 1));
+        const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
         const uint32_t hb = phase == 0 ? (h >> k) : 0u;
-        const uint32_t nblk = gkr::layer_blocks(h);
-        {
+        uint32_t nblk;
+        if (phase == 0 && !no_fused) {
+            Timed t(ctx, "layer_round_fused", pending ? (double)h * 2.0 * 6.0 * 32.0 : (double)h * 2.0 * 2.0 * 32.0);
+            nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, s);
+            pending = nullptr;
+        } else {
+            if (pending) {
+                Timed t(ctx, "layer_fold", (double)h * 2.0 * 6.0 * 32.0);
+                gkr::launch_layer_fold(A, M, 2 * h, pending, s);
+                pending = nullptr;
+            }
+            nblk = gkr::layer_blocks(h);
             Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0);
             gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, s);
         }
-        const gkr::FixedMul* r_ptr;
         if (host_tx) {
             const uint32_t ticket = ++ctx->ticket;
             {
@@ -635,19 +684,18 @@ int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t*
             memcpy(&oc[2], &c0, 32);
             out_len[round] = ln;
             memcpy(&out_r[round], &r, 32);
-            gkr::h64::make_fixed_mul(r, h_rtab->w);
-            r_ptr = h_rtab;
+            // two pinned tables used alternately: the deferred fold of round j reads table j % 2 while
+            // the host already writes round j+1's
+            gkr::FixedMul* slot = h_rtab + (round & 1);
+            gkr::h64::make_fixed_mul(r, slot->w);
             // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc)
-            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), r_ptr, s);
+            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, s);
+            pending = slot;
         } else {
             Timed t(ctx, "layer_round_hash", 0.0);
             gkr::launch_layer_round_hash(partials, nblk, round, k, dep, ctx->d_cts, d_coeffs, d_len, d_r_out, d_rtab, Wb,
                                          Wc, s);
-            r_ptr = d_rtab + round;
-        }
-        if (round + 1 < v) {
-            Timed t(ctx, "layer_fold", (double)h * 6.0 * 32.0);
-            gkr::launch_layer_fold(A, M, h, r_ptr, s);
+            pending = d_rtab + round;
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -857,7 +905,30 @@ int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_f
     memcpy(&r64, r, 32);
     gkr::h64::make_fixed_mul(r64, T64.w);
     if (memcmp(&T, &T64, sizeof T) != 0) return GKR_ERR_INVALID;
-    *out = to_abi(gkr::fr_fold_fixed(to_dev(*lo), to_dev(*hi), T));
+    const Fr single = gkr::fr_fold_fixed(to_dev(*lo), to_dev(*hi), T);
+    Fr y0, y1;   // the paired form the kernels use: (lo, hi) and (hi, lo) together
+    gkr::fr_fold_fixed2(to_dev(*lo), to_dev(*hi), to_dev(*hi), to_dev(*lo), T, y0, y1);
+    if (!gkr::fr_eq(y0, single) || !gkr::fr_eq(y1, gkr::fr_fold_fixed(to_dev(*hi), to_dev(*lo), T))) return GKR_ERR_INVALID;
+    *out = to_abi(single);
+    return GKR_OK;
+}
+
+int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
+    if ((!a || !b) && n) return GKR_ERR_INVALID;
+    if (!out) return GKR_ERR_INVALID;
+    if (!all_canonical(a, n) || !all_canonical(b, n)) return GKR_ERR_NON_CANONICAL;
+    // sum a_i b_i the way the fused layer kernel does: b in Montgomery form, full products
+    // accumulated unreduced, one reduction at the end
+    gkr::Lazy17 acc = gkr::lazy_zero(), t0 = gkr::lazy_zero(), t1 = gkr::lazy_zero(), t2 = gkr::lazy_zero();
+    for (size_t i = 0; i < n; ++i) {
+        const Fr x = to_dev(a[i]), y = gkr::to_mont(to_dev(b[i]));
+        gkr::lazy_mac_s(acc, x, y);
+        gkr::lazy_mac3_s(t0, x, y, t1, y, x, t2, x, y);   // the tripled form the fused layer kernel uses
+    }
+    const Fr r = gkr::lazy_reduce(acc);
+    if (!gkr::fr_eq(gkr::lazy_reduce(t0), r) || !gkr::fr_eq(gkr::lazy_reduce(t1), r) || !gkr::fr_eq(gkr::lazy_reduce(t2), r))
+        return GKR_ERR_INVALID;
+    *out = to_abi(r);
     return GKR_OK;
 }
 
@@ -924,8 +995,10 @@ static int check_layer_args(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gt
     if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
     if (k_next < 0 || k_next > 14) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, 14] (dense predicate tables)");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    // every gate is validated on the device by the scatter kernel; small layers are also checked here
+    // so that the error names the cause
     const size_t gates = (size_t)1 << k_i;
-    for (size_t g = 0; g < gates; ++g) {
+    for (size_t g = 0; g < gates && gates <= ((size_t)1 << 16); ++g) {
         if (gt[g] > 1) return ctx->fail(GKR_ERR_INVALID, "gate_type must be 0 (add) or 1 (mult)");
         if ((l[g] >> k_next) || (r[g] >> k_next)) return ctx->fail(GKR_ERR_INVALID, "gate operand index out of range");
     }

@@ -60,16 +60,23 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
-                              const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
-                              unsigned long long* wideM, uint32_t* bad, uint32_t log_p, uint32_t shard, hipStream_t s);
+                              const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
+                              unsigned long long* wideA, unsigned long long* wideM, uint32_t* bad, uint32_t log_p,
+                              uint32_t shard, hipStream_t s);
 void launch_to_mont_strided(const Fr* in, Fr* out, uint32_t count, uint32_t stride, uint32_t offset, hipStream_t s);
 void launch_tables_differ(const Fr* a, const Fr* b, size_t count, uint32_t* flag, hipStream_t s);
 void launch_fold_pair(const Fr* src, Fr* dst, const FixedMul* rtab, hipStream_t s);
+void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
+                             const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, uint32_t log_p,
+                             uint32_t shard, size_t ncells, uint32_t* counts, uint32_t* offsets, uint32_t* cursor,
+                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, hipStream_t s);
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s);
 
 uint32_t layer_blocks(uint32_t h);
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
                         const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s);
+uint32_t launch_layer_round_b(bool fold, const Fr* A_src, const Fr* M_src, Fr* A_dst, Fr* M_dst, uint32_t hb, uint32_t kc,
+                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, hipStream_t s);
 void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s);
 void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
                              const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,

@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(256) k_mle_fold_sum(const Fr* __restrict__ src
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < q; i += gridDim.x * blockDim.x) {
         Fr x0 = load_fr(s + i), x1 = load_fr(s + i + 2 * (size_t)q);
         Fr x2 = load_fr(s + i + q), x3 = load_fr(s + i + 3 * (size_t)q);
-        Fr y0 = fr_fold_fixed(x0, x1, T);
-        Fr y1 = fr_fold_fixed(x2, x3, T);
+        Fr y0, y1;
+        fr_fold_fixed2(x0, x1, x2, x3, T, y0, y1);
         store_fr(d + i, y0);
         store_fr(d + i + q, y1);
         acc_add_fr(acc[0], y0);
@@ -353,32 +353,158 @@ __global__ void k_depends(const Fr* __restrict__ W, uint32_t k, uint32_t* __rest
 // so the result is exact and order independent.
 // ---------------------------------------------------------------------------
 
-// zfac[2*i] = (1 - z_i) R, zfac[2*i+1] = z_i R  (Montgomery), i = 0..k_i-1
+// E[g] = E_hi[g >> kl] * E_lo[g & (2^kl - 1)]: the eq(z, .) weight of gate g as ONE product of two
+// small host-built tables (E_hi canonical over the leading k_i - kl bits of g, E_lo in Montgomery
+// form over the trailing kl bits; both L2-resident), instead of k_i products per gate.
 // Shard (log_p, p): keep only gates whose right operand has low bits p (the trailing-variable
 // partition of the hypercube, one shard per GPU); cell = (l << (k_next - log_p)) | (r >> log_p).
 __global__ void k_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* __restrict__ gate_type,
                                     const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                                    const Fr* __restrict__ zfac, unsigned long long* __restrict__ wideA,
-                                    unsigned long long* __restrict__ wideM, uint32_t* __restrict__ bad,
-                                    uint32_t log_p, uint32_t shard) {
+                                    const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl,
+                                    unsigned long long* __restrict__ wideA, unsigned long long* __restrict__ wideM,
+                                    uint32_t* __restrict__ bad, uint32_t log_p, uint32_t shard) {
     const uint64_t gates = 1ull << k_i;
+    const uint32_t lmask = (1u << kl) - 1u;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t l = left[g], r = right[g];
-        if ((l >> k_next) | (r >> k_next)) {
+        const uint32_t l = left[g], r = right[g], ty = gate_type[g];
+        if ((l >> k_next) | (r >> k_next) | (ty > 1u)) {
             atomicOr(bad, 1u);
             continue;
         }
         if ((r & ((1u << log_p) - 1u)) != shard) continue;
-        Fr e = fr_zero();
-        e.l[0] = 1;  // canonical 1; each factor is Montgomery so the product stays canonical
-        for (uint32_t i = 0; i < k_i; ++i) {
-            const uint32_t bit = (uint32_t)(g >> (k_i - 1 - i)) & 1u;
-            e = mont_mul(e, zfac[2 * i + bit]);
-        }
-        unsigned long long* cell =
-            (gate_type[g] ? wideM : wideA) + (((size_t)l << (k_next - log_p)) | (r >> log_p)) * 8;
+        const Fr e = mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + ((uint32_t)g & lmask)));
+        unsigned long long* cell = (ty ? wideM : wideA) + (((size_t)l << (k_next - log_p)) | (r >> log_p)) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(cell + j, (unsigned long long)e.l[j]);
+    }
+}
+
+// --- predicate build by counting sort (default): 2 u32 atomics per gate instead of 8 u64, no
+// widened tables.  cells = [A table | M table] (2 * N entries):
+//   count:  counts[cell(g)] += 1
+//   scan:   offsets = exclusive prefix sum of counts; cursor = offsets
+//   fill:   list[cursor[cell(g)]++] = g
+//   sum:    out[cell] = sum over its list segment of E[g]   (modular adds commute: any order)
+__device__ __forceinline__ bool pred_cell(uint32_t l, uint32_t r, uint32_t ty, uint32_t k_next, uint32_t log_p,
+                                          uint32_t shard, size_t ncells, size_t& cell, uint32_t* bad) {
+    if ((l >> k_next) | (r >> k_next) | (ty > 1u)) {
+        atomicOr(bad, 1u);
+        return false;
+    }
+    if ((r & ((1u << log_p) - 1u)) != shard) return false;
+    cell = (ty ? ncells : 0) + (((size_t)l << (k_next - log_p)) | (r >> log_p));
+    return true;
+}
+
+__global__ void k_pred_count(uint32_t k_i, uint32_t k_next, const uint8_t* __restrict__ gate_type,
+                             const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t log_p,
+                             uint32_t shard, size_t ncells, uint32_t* __restrict__ counts, uint32_t* __restrict__ bad) {
+    const uint64_t gates = 1ull << k_i;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        size_t cell;
+        if (pred_cell(left[g], right[g], gate_type[g], k_next, log_p, shard, ncells, cell, bad)) atomicAdd(counts + cell, 1u);
+    }
+}
+
+__global__ void k_pred_fill(uint32_t k_i, uint32_t k_next, const uint8_t* __restrict__ gate_type,
+                            const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t log_p,
+                            uint32_t shard, size_t ncells, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list,
+                            uint32_t* __restrict__ bad) {
+    const uint64_t gates = 1ull << k_i;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        size_t cell;
+        if (pred_cell(left[g], right[g], gate_type[g], k_next, log_p, shard, ncells, cell, bad))
+            list[atomicAdd(cursor + cell, 1u)] = (uint32_t)g;
+    }
+}
+
+// exclusive scan, three passes: 2048 entries per block
+constexpr uint32_t kScanPerBlock = 2048;
+__global__ void __launch_bounds__(256) k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ block_sums, size_t n) {
+    __shared__ uint32_t wave_tot[4];
+    const size_t base = (size_t)blockIdx.x * kScanPerBlock + (size_t)threadIdx.x * 8;
+    uint32_t v[8], run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0u;
+        run += v[i];
+    }
+    // inclusive scan of the per-thread totals across the block
+    uint32_t x = run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    uint32_t excl = wbase + x - run;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (base + i < n) out[base + i] = excl;
+        excl += v[i];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = wbase + x;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nblocks) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t val = i < nblocks ? block_sums[i] : 0u;
+        uint32_t x = val;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        uint32_t wbase = carry;
+        for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+        if (i < nblocks) block_sums[i] = wbase + x - val;   // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wbase + x;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                  const uint32_t* __restrict__ block_sums, size_t n) {
+    const uint32_t add = block_sums[blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * kScanPerBlock;
+    for (uint32_t t = threadIdx.x; t < kScanPerBlock; t += 256) {
+        const size_t i = base + t;
+        if (i < n) {
+            const uint32_t v = offsets[i] + add;
+            offsets[i] = v;
+            cursor[i] = v;
+        }
+    }
+}
+
+// one thread per cell: out = sum of E[g] over the cell's segment [offsets, cursor)
+__global__ void __launch_bounds__(256) k_pred_sum(size_t ncells, const uint32_t* __restrict__ offsets,
+                                                  const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ list,
+                                                  const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl,
+                                                  Fr* __restrict__ out_A, Fr* __restrict__ out_M) {
+    const uint32_t lmask = (1u << kl) - 1u;
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < 2 * ncells; c += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = offsets[c], e = cursor[c];
+        Fr acc = fr_zero();
+        for (uint32_t i = b; i < e; ++i) {
+            const uint32_t g = list[i];
+            acc = fr_add(acc, mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & lmask))));
+        }
+        store_fr(c < ncells ? out_A + c : out_M + (c - ncells), acc);
     }
 }
 
@@ -467,6 +593,99 @@ __global__ void __launch_bounds__(256) k_layer_round(const Fr* __restrict__ A, c
     block_sum<9, 3>(acc, smem);
     if (threadIdx.x == 0) {
         LayerPartial* p = partials + blockIdx.x;
+        p->c0 = acc[0];
+        p->g1 = acc[1];
+        p->c2 = acc[2];
+    }
+}
+
+// Fused b-phase round (the bandwidth-bound part of the layer sumcheck): fold the table with the
+// previous challenge while reading it, write the folded table, and accumulate this round's sums
+// in the same pass -- with the row-uniform factors pulled out so that every product has a
+// wave-uniform multiplier and no modular reduction:
+//     thread = (table T in {A, M}, column c, chunk of row pairs);  per row pair (b, b + hb):
+//         U0 += y0 * p0,  U1 += y1 * p1,  D += (y1 - y0) * (p1 - p0)      (unreduced 544-bit sums)
+//         S0 += y0,       S1 += y1                                        (T = A only)
+//     at the end, with q = W(c):
+//         T = A:  c0 += U0 + q S0,   g(1) += U1 + q S1,   c2 += D
+//         T = M:  c0 += q U0,        g(1) += q U1,        c2 += q D
+// because  a (p + q) + m p q  summed over rows = sum(a p) + q (sum(a) + sum(m p))  for a fixed
+// column.  y0, y1 are the entries of rows b, b + hb of the folded table; p0 = Wb[b], p1 = Wb[b+hb]
+// (Montgomery) are the same for the whole wave.  3 x 64 partial products per entry pair instead of
+// 8 reduced products (1024) for both tables together.
+// grid = (column blocks, row chunks, 2 tables), block = 256 columns
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_layer_round_b(const Fr* __restrict__ A_src, const Fr* __restrict__ M_src,
+                                                       Fr* __restrict__ A_dst, Fr* __restrict__ M_dst, uint32_t hb,
+                                                       uint32_t kc, uint32_t rows_per_chunk,
+                                                       const FixedMul* __restrict__ rtab, const Fr* __restrict__ Wb,
+                                                       const Fr* __restrict__ Wc, LayerPartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4 * 3];
+    const bool is_m = blockIdx.z != 0;
+    const Fr* src = is_m ? M_src : A_src;
+    Fr* dst = is_m ? M_dst : A_dst;
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ncols = 1u << kc;
+    const size_t h = (size_t)hb << kc;   // entries per half of the folded table
+    const uint32_t r0 = blockIdx.y * rows_per_chunk;
+    uint32_t r1 = r0 + rows_per_chunk;
+    if (r1 > hb) r1 = hb;
+    FixedMul T;
+    if (FOLD) T = *rtab;
+    Lazy17 U0 = lazy_zero(), U1 = lazy_zero(), D = lazy_zero();
+    Acc<9> S0 = acc_zero<9>(), S1 = acc_zero<9>();
+    const bool active = col < ncols;
+    for (uint32_t row = r0; row < r1; ++row) {
+        // row-uniform multipliers; readfirstlane makes the uniformity explicit for the SGPR operands
+        Fr p0 = Wb[row], p1 = Wb[row + hb];
+        Fr dp = fr_sub(p1, p0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            p0.l[i] = __builtin_amdgcn_readfirstlane(p0.l[i]);
+            p1.l[i] = __builtin_amdgcn_readfirstlane(p1.l[i]);
+            dp.l[i] = __builtin_amdgcn_readfirstlane(dp.l[i]);
+        }
+        if (active) {
+            const size_t idx = ((size_t)row << kc) | col;
+            Fr y0, y1;
+            if (FOLD) {
+                Fr x0 = load_fr(src + idx), x1 = load_fr(src + idx + 2 * h);
+                Fr x2 = load_fr(src + idx + h), x3 = load_fr(src + idx + 3 * h);
+                fr_fold_fixed2(x0, x1, x2, x3, T, y0, y1);
+                store_fr(dst + idx, y0);
+                store_fr(dst + idx + h, y1);
+            } else {
+                y0 = load_fr(src + idx);
+                y1 = load_fr(src + idx + h);
+            }
+            lazy_mac3_s(U0, y0, p0, U1, y1, p1, D, fr_sub(y1, y0), dp);
+            if (!is_m) {
+                acc_add_fr(S0, y0);
+                acc_add_fr(S1, y1);
+            }
+        }
+    }
+    Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
+    if (active) {
+        const Fr q = load_fr(Wc + col);
+        const Fr u0 = lazy_reduce(U0), u1 = lazy_reduce(U1), d = lazy_reduce(D);
+        Fr c0, g1, c2;
+        if (is_m) {
+            c0 = mont_mul(u0, q);
+            g1 = mont_mul(u1, q);
+            c2 = mont_mul(d, q);
+        } else {
+            c0 = fr_add(u0, mont_mul(acc_reduce(S0), q));
+            g1 = fr_add(u1, mont_mul(acc_reduce(S1), q));
+            c2 = d;
+        }
+        acc_add_fr(acc[0], c0);
+        acc_add_fr(acc[1], g1);
+        acc_add_fr(acc[2], c2);
+    }
+    block_sum<9, 3>(acc, smem);
+    if (threadIdx.x == 0) {
+        LayerPartial* p = partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         p->c0 = acc[0];
         p->g1 = acc[1];
         p->c2 = acc[2];
@@ -636,10 +855,31 @@ void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s) {
 }
 
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
-                              const uint32_t* right, const Fr* zfac, unsigned long long* wideA,
-                              unsigned long long* wideM, uint32_t* bad, uint32_t log_p, uint32_t shard, hipStream_t s) {
+                              const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
+                              unsigned long long* wideA, unsigned long long* wideM, uint32_t* bad, uint32_t log_p,
+                              uint32_t shard, hipStream_t s) {
     hipLaunchKernelGGL(k_predicate_scatter, dim3(blocks_for(1ull << k_i, 4096)), dim3(256), 0, s, k_i, k_next,
-                       gate_type, left, right, zfac, wideA, wideM, bad, log_p, shard);
+                       gate_type, left, right, e_hi, e_lo_mont, kl, wideA, wideM, bad, log_p, shard);
+}
+
+// counting-sort predicate build; counts/offsets/cursor: 2 * ncells u32 each, block_sums: ceil(2 ncells / 2048),
+// list: 2^k_i u32.  All scratch is caller-provided.
+void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
+                             const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, uint32_t log_p,
+                             uint32_t shard, size_t ncells, uint32_t* counts, uint32_t* offsets, uint32_t* cursor,
+                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, hipStream_t s) {
+    const size_t n = 2 * ncells;
+    const uint32_t gblocks = blocks_for(1ull << k_i, 4096);
+    const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
+    hipLaunchKernelGGL(k_pred_count, dim3(gblocks), dim3(256), 0, s, k_i, k_next, gate_type, left, right, log_p, shard, ncells,
+                       counts, bad);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, counts, offsets, block_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, sblocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, offsets, cursor, block_sums, n);
+    hipLaunchKernelGGL(k_pred_fill, dim3(gblocks), dim3(256), 0, s, k_i, k_next, gate_type, left, right, log_p, shard, ncells,
+                       cursor, list, bad);
+    hipLaunchKernelGGL(k_pred_sum, dim3(blocks_for(n, 8192)), dim3(256), 0, s, ncells, offsets, cursor, list, e_hi, e_lo_mont,
+                       kl, out_A, out_M);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
@@ -671,6 +911,26 @@ uint32_t layer_blocks(uint32_t h) { return blocks_for(h, kMaxLayerBlocks); }
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
                         const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s) {
     hipLaunchKernelGGL(k_layer_round, dim3(nblk), dim3(256), 0, s, A, M, h, k, phase, hb, Wb, Wc, partials);
+}
+
+// returns the number of partials written (= blocks)
+uint32_t launch_layer_round_b(bool fold, const Fr* A_src, const Fr* M_src, Fr* A_dst, Fr* M_dst, uint32_t hb, uint32_t kc,
+                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, hipStream_t s) {
+    const uint32_t col_blocks = ((1u << kc) + 255u) / 256u;
+    // ~1024 blocks per table; every block gets at least one row pair
+    uint32_t chunks = 1024u / col_blocks;
+    if (chunks < 1) chunks = 1;
+    if (chunks > hb) chunks = hb;
+    const uint32_t rows_per_chunk = (hb + chunks - 1) / chunks;
+    chunks = (hb + rows_per_chunk - 1) / rows_per_chunk;
+    dim3 grid(col_blocks, chunks, 2);
+    if (fold)
+        hipLaunchKernelGGL(k_layer_round_b<true>, grid, dim3(256), 0, s, A_src, M_src, A_dst, M_dst, hb, kc, rows_per_chunk,
+                           rtab, Wb, Wc, partials);
+    else
+        hipLaunchKernelGGL(k_layer_round_b<false>, grid, dim3(256), 0, s, A_src, M_src, A_dst, M_dst, hb, kc, rows_per_chunk,
+                           rtab, Wb, Wc, partials);
+    return col_blocks * chunks * 2;
 }
 
 void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s) {

@@ -81,6 +81,21 @@ def test_fixed_multiplier_fold_on_host_matches_bigints():
         assert from_limbs(O)[0] == (lo + r * (hi - lo)) % P
 
 
+def test_lazy_dot_product_on_host_matches_bigints():
+    lib = N.lib()
+    rng = random.Random(6)
+    for n in (0, 1, 2, 7, 300):
+        a = [rng.randrange(P) for _ in range(n)]
+        b = [rng.randrange(P) for _ in range(n)]
+        if n == 7:
+            a, b = [P - 1] * n, [P - 1] * n
+        A = to_limbs(a) if n else np.zeros((0, 4), dtype=np.uint64)
+        B = to_limbs(b) if n else np.zeros((0, 4), dtype=np.uint64)
+        O = np.zeros((1, 4), dtype=np.uint64)
+        assert lib.gkr_selftest_dot(_p(A), _p(B), ctypes.c_size_t(n), _p(O)) == 0
+        assert from_limbs(O)[0] == sum(x * y for x, y in zip(a, b)) % P
+
+
 def test_non_canonical_inputs_are_rejected():
     lib = N.lib()
     bad = np.full((1, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)

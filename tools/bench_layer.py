@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""GKR-layer sumcheck (prove_sumcheck_opt) timing at BASELINE config-5 scale on one GPU.
+
+    python tools/bench_layer.py --k-i 24 --k 12 --steps 3
+
+Random gates (type in {add, mult}, operands in [0, 2^k)), random z and W.
+Reports per-kernel HIP-event times and the canonical figures: 25 (2^{2k} - 1) field-ops,
+256 * 2^{2k} bytes for the sumcheck; the predicate build is reported separately."""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k-i", type=int, default=24)
+    ap.add_argument("--k", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--transcript", choices=["host", "device"], default="host")
+    ap.add_argument("--check", action="store_true", help="verify the sumcheck relations on the result")
+    args = ap.parse_args()
+    from gkr_amd import Context, Layer, multi_hash
+    from gkr_amd.field import MODULUS as P, from_limbs
+
+    rng = np.random.default_rng(0xC0FFEE + 5)
+    g = 1 << args.k_i
+    lay = Layer(args.k_i, rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, 1 << args.k, g, dtype=np.uint32),
+                rng.integers(0, 1 << args.k, g, dtype=np.uint32))
+
+    def rand_fr(count):
+        a = rng.integers(0, 1 << 63, (count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)
+        return a
+    z, W = rand_fr(args.k_i), rand_fr(1 << args.k)
+    ctx = Context(0)
+    ctx.set_transcript(1 if args.transcript == "host" else 0)
+    ctx.profile(True)
+    times = []
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            ctx.profile_reset()
+        t0 = time.perf_counter()
+        C, L, R = ctx.sumcheck_layer_raw(lay, args.k, z, W)
+        times.append(time.perf_counter() - t0)
+    names = ["predicate_scatter", "predicate_normalise", "predicate_sorted",
+             "layer_round_fused", "layer_round", "layer_fold", "layer_round_reduce", "layer_round_hash"]
+    prof = {n: ctx.profile_get(n) for n in names}
+    steps = args.steps
+    N = 1 << (2 * args.k)
+    sum_ms = (prof["layer_round_fused"]["total_ms"] + prof["layer_round"]["total_ms"] + prof["layer_fold"]["total_ms"]) / steps
+    out = {
+        "workload": "GKR layer sumcheck k_i=%d k=%d (2^%d-point hypercube, 2^%d gates)" % (args.k_i, args.k, 2 * args.k, args.k_i),
+        "wall_ms_per_sumcheck": 1e3 * sum(times[args.warmup:]) / steps,
+        "kernel_ms_per_sumcheck": {n: prof[n]["total_ms"] / steps for n in names},
+        "field_ops": 25 * (N - 1), "algorithmic_bytes": 256 * N,
+        "fused_kernel": {"launches_per_sumcheck": prof["layer_round_fused"]["launches"] / steps,
+                         "GBps": prof["layer_round_fused"]["bytes"] / (prof["layer_round_fused"]["total_ms"] * 1e-3) / 1e9
+                         if prof["layer_round_fused"]["total_ms"] else None},
+        "sumcheck_kernels_GBps": 256 * N / (sum_ms * 1e-3) / 1e9 if sum_ms else None,
+        "field_ops_per_s_kernels": 25 * (N - 1) / (sum_ms * 1e-3) if sum_ms else None,
+        "field_ops_per_s_wall": 25 * (N - 1) / (sum(times[args.warmup:]) / steps),
+    }
+    if args.check:
+        # verifier relations: g_j(0) + g_j(1) = g_{j-1}(r_{j-1}); r_j = MiMC(g_j)
+        claim = None
+        ok = True
+        for j in range(2 * args.k):
+            vec = from_limbs(C[j])[3 - int(L[j]):]
+            r = from_limbs(R[j])[0]
+            ev0 = vec[-1]
+            ev1 = sum(vec) % P
+            if claim is not None and (ev0 + ev1) % P != claim:
+                ok = False
+            if multi_hash(vec) != r:
+                ok = False
+            acc = 0
+            for c in vec:
+                acc = (acc * r + c) % P
+            claim = acc
+        out["verifier_relations_ok"] = ok
+    print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
