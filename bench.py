@@ -5,9 +5,12 @@ tables (BASELINE.json metric, configs[2]), one process per GPU.
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch: `--batch` independent
+A step = one pass of the hot path over one batch: `--batch` (default 256) independent
 2^n-point multilinear sumchecks (prove_sumcheck, rust/src/gkr/sumcheck.rs:158-214),
-tables resident in HBM before the timed region, MiMC7 transcript included.
+tables resident in HBM before the timed region, MiMC7 transcript included.  (One
+aggregation step of the reference proves up to 20 sub-circuits with several layers
+each, every layer one sumcheck -- aggregator.rs:350-355 -- and BASELINE configs[3]
+aggregates 64 inputs: hundreds of independent sumchecks per step are the normal load.)
 Independent sumchecks shard across ranks with no data-path collective (weak
 scaling: every rank proves its own batch).
 
@@ -36,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
-    ap.add_argument("--batch", type=int, default=64, help="independent sumchecks per rank per step")
+    ap.add_argument("--batch", type=int, default=256, help="independent sumchecks per rank per step (8 GiB of tables)")
     ap.add_argument("--transcript", choices=["host", "device"], default="host",
                     help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")

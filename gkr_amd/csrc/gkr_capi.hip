@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "keccak.h"
 #include "mimc7.h"
+#include "mimc_ifma.h"
 
 using gkr::Fr;
 
@@ -94,6 +95,25 @@ int usable_cpus() {
         if (q < hw) hw = q;
     }
     return hw;
+}
+
+// true once the eight-lane IFMA hash is initialised (CPU has avx512ifma and GKR_NO_IFMA is unset)
+bool host_ifma_ready() {
+    static int state = -1;
+    if (state < 0) {
+        state = 0;
+        if (!getenv("GKR_NO_IFMA") && gkr::gkr_ifma_available()) {
+            const gkr::h64::F* cts = host_mimc_constants64();
+            static uint64_t canon[gkr::kMimcRounds][4];
+            for (int i = 0; i < gkr::kMimcRounds; ++i) {
+                const gkr::h64::F c = gkr::h64::from_mont(cts[i]);
+                memcpy(canon[i], &c, 32);
+            }
+            gkr::gkr_ifma_init(canon);
+            state = 1;
+        }
+    }
+    return state == 1;
 }
 
 int default_host_threads() {
@@ -378,18 +398,13 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
             Timed t(ctx, "mle_round_reduce", 0.0);
             gkr::launch_mle_round_reduce(part, nblk, nb, rec + b0, G.ticket, s);
         };
-        auto hash_one = [&](int b, int round) {
-            gkr::h64::F c0, c1;
-            memcpy(&c0, &rec[b].c0, 32);
-            memcpy(&c1, &rec[b].c1, 32);
-            if (round == 0) dep_last[b] = rec[b].dep;
-            uint32_t ln;
-            if (round + 1 < n)
-                ln = gkr::h64::is_zero(c1) ? 1u : 2u;
-            else
-                ln = dep_last[b] ? 2u : 1u;
-            gkr::h64::F vec[2] = {c1, c0};
-            gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (2 - ln), (int)ln, cts, nullptr);
+        const bool ifma = host_ifma_ready();
+        // length rule + outputs of one sumcheck's round, given its challenge
+        auto round_len = [&](int b, int round, const gkr::h64::F& c1) -> uint32_t {
+            if (round + 1 < n) return gkr::h64::is_zero(c1) ? 1u : 2u;
+            return dep_last[b] ? 2u : 1u;
+        };
+        auto publish = [&](int b, int round, const gkr::h64::F& c0, const gkr::h64::F& c1, uint32_t ln, const gkr::h64::F& r) {
             gkr_fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
             memset(&oc[0], 0, 32);
             if (ln == 2) memcpy(&oc[0], &c1, 32);
@@ -398,15 +413,50 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
             memcpy(&out_r[(size_t)b * n + round], &r, 32);
             if (round + 1 < n) gkr::h64::make_fixed_mul(r, h_rtab[b].w);
         };
-        // one unit of work = one sumcheck's hash of the round its group is in
+        // up to eight sumchecks of one group: eight-lane IFMA hash when there are enough lanes to pay
+        // for it, the scalar 4x64-bit code otherwise
+        auto hash_chunk = [&](int b_first, int count, int round) {
+            gkr::h64::F c0[8], c1[8];
+            uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < count; ++i) {
+                const int b = b_first + i;
+                memcpy(&c0[i], &rec[b].c0, 32);
+                memcpy(&c1[i], &rec[b].c1, 32);
+                if (round == 0) dep_last[b] = rec[b].dep;
+                ln[i] = round_len(b, round, c1[i]);
+            }
+            if (ifma && count >= 3) {
+                uint64_t vec[8][3][4], out[8][4];
+                memset(vec, 0, sizeof vec);
+                for (int i = 0; i < count; ++i) {
+                    memcpy(vec[i][1], &c1[i], 32);
+                    memcpy(vec[i][2], &c0[i], 32);
+                }
+                gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+                for (int i = 0; i < count; ++i) {
+                    gkr::h64::F r;
+                    memcpy(&r, out[i], 32);
+                    publish(b_first + i, round, c0[i], c1[i], ln[i], r);
+                }
+            } else {
+                for (int i = 0; i < count; ++i) {
+                    gkr::h64::F vec[2] = {c1[i], c0[i]};
+                    const gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (2 - ln[i]), (int)ln[i], cts, nullptr);
+                    publish(b_first + i, round, c0[i], c1[i], ln[i], r);
+                }
+            }
+        };
+        // one unit of work = up to eight sumchecks' hashes of the round their group is in
         const std::function<bool()> try_work = [&]() -> bool {
             for (int g = 0; g < groups; ++g) {
                 Group& G = grp[g];
                 uint64_t c = G.claim.load(std::memory_order_acquire);
                 while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
-                    if (G.claim.compare_exchange_weak(c, c + 1, std::memory_order_acq_rel)) {
-                        hash_one(G.b0 + (int)(uint32_t)c, (int)(c >> 32) - 1);
-                        G.done.fetch_add(1, std::memory_order_release);
+                    const uint32_t first = (uint32_t)c;
+                    const uint32_t take = ((uint32_t)G.nb - first) < 8u ? ((uint32_t)G.nb - first) : 8u;
+                    if (G.claim.compare_exchange_weak(c, c + take, std::memory_order_acq_rel)) {
+                        hash_chunk(G.b0 + (int)first, (int)take, (int)(c >> 32) - 1);
+                        G.done.fetch_add((int)take, std::memory_order_release);
                         return true;
                     }
                 }
@@ -910,6 +960,32 @@ int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_f
     gkr::fr_fold_fixed2(to_dev(*lo), to_dev(*hi), to_dev(*hi), to_dev(*lo), T, y0, y1);
     if (!gkr::fr_eq(y0, single) || !gkr::fr_eq(y1, gkr::fr_fold_fixed(to_dev(*hi), to_dev(*lo), T))) return GKR_ERR_INVALID;
     *out = to_abi(single);
+    return GKR_OK;
+}
+
+// eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
+// host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1), else scalar
+int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int* used_ifma) {
+    if (!vecs || !len || !out) return GKR_ERR_INVALID;
+    if (!all_canonical(vecs, 24)) return GKR_ERR_NON_CANONICAL;
+    for (int k = 0; k < 8; ++k)
+        if (len[k] > 3) return GKR_ERR_INVALID;
+    const bool ifma = host_ifma_ready();
+    if (used_ifma) *used_ifma = ifma ? 1 : 0;
+    if (ifma) {
+        uint64_t v[8][3][4], o[8][4];
+        memcpy(v, vecs, sizeof v);
+        gkr::gkr_ifma_multi_hash8(v, len, 3, o);
+        memcpy(out, o, sizeof o);
+    } else {
+        const gkr::h64::F* cts = host_mimc_constants64();
+        for (int k = 0; k < 8; ++k) {
+            gkr::h64::F v[3];
+            memcpy(v, vecs + 3 * k, 96);
+            const gkr::h64::F r = gkr::h64::mimc7_multi_hash(v + (3 - len[k]), (int)len[k], cts, nullptr);
+            memcpy(&out[k], &r, 32);
+        }
+    }
     return GKR_OK;
 }
 

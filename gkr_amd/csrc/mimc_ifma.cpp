@@ -1,0 +1,266 @@
+// MiMC7 multi_hash for EIGHT transcripts at once on AVX-512 IFMA (vpmadd52luq / vpmadd52huq).
+//
+// The host transcript needs one hash per sumcheck per round; on the GPU box the process gets 16
+// CPUs (cgroup quota), so hashing throughput is what bounds a batch in its late rounds.  The
+// hashes of different sumchecks are independent: this file runs eight of them in the eight 64-bit
+// lanes of a zmm register, radix 2^52 (5 limbs, Montgomery radix 2^260), ~135 vector
+// instructions per eight modular products.  Selected at run time when the CPU has
+// avx512ifma (EPYC Zen 4/5, Xeon Ice Lake+); otherwise the scalar 4x64-bit code in fr64.h runs.
+// Same function as the reference's Mimc7::multi_hash (call sites rust/src/gkr/sumcheck.rs:84,129,152).
+//
+// Built with -mavx512f -mavx512ifma -mavx512vl for this translation unit only; nothing here is
+// executed unless gkr_ifma_available() says so.
+#include <immintrin.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "mimc_ifma.h"
+
+namespace gkr {
+namespace ifma {
+
+typedef unsigned __int128 u128;
+static const uint64_t M52 = (1ULL << 52) - 1;
+
+struct V {   // eight field elements, limb-major
+    __m512i l[5];
+};
+
+// ---- scalar helpers for constant set-up (canonical 4x64 <-> 5x52)
+static void to52(const uint64_t x[4], uint64_t o[5]) {
+    o[0] = x[0] & M52;
+    o[1] = ((x[0] >> 52) | (x[1] << 12)) & M52;
+    o[2] = ((x[1] >> 40) | (x[2] << 24)) & M52;
+    o[3] = ((x[2] >> 28) | (x[3] << 36)) & M52;
+    o[4] = x[3] >> 16;
+}
+static void from52(const uint64_t l[5], uint64_t x[4]) {
+    x[0] = l[0] | (l[1] << 52);
+    x[1] = (l[1] >> 12) | (l[2] << 40);
+    x[2] = (l[2] >> 24) | (l[3] << 28);
+    x[3] = (l[3] >> 36) | (l[4] << 16);
+}
+
+static const uint64_t kP64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+
+// small big-int helpers on 64-bit words for the one-time constants
+static int geq(const uint64_t* a, const uint64_t* b, int n) {
+    for (int i = n - 1; i >= 0; --i) {
+        if (a[i] > b[i]) return 1;
+        if (a[i] < b[i]) return 0;
+    }
+    return 1;
+}
+static void subn(uint64_t* a, const uint64_t* b, int n) {
+    uint64_t br = 0;
+    for (int i = 0; i < n; ++i) {
+        u128 d = (u128)a[i] - b[i] - br;
+        a[i] = (uint64_t)d;
+        br = (uint64_t)(d >> 64) & 1;
+    }
+}
+// x = 2 x mod p (x < p, 4 words + overflow word)
+static void dbl_mod(uint64_t x[4]) {
+    uint64_t t[5];
+    uint64_t c = 0;
+    for (int i = 0; i < 4; ++i) {
+        t[i] = (x[i] << 1) | c;
+        c = x[i] >> 63;
+    }
+    t[4] = c;
+    uint64_t p5[5] = {kP64[0], kP64[1], kP64[2], kP64[3], 0};
+    if (geq(t, p5, 5)) subn(t, p5, 5);
+    memcpy(x, t, 32);
+}
+
+static uint64_t g_p52[5], g_pinv52, g_r2_52[5], g_one52[5];
+static uint64_t g_cts52[91][5];   // MiMC constants, Montgomery (radix 2^260)
+static bool g_ready = false;
+
+static inline __m512i bc(uint64_t x) { return _mm512_set1_epi64((long long)x); }
+
+// Montgomery product of eight pairs: a b 2^-260 mod p, inputs and output < p with 52-bit limbs
+static inline V mont_mul(const V& a, const V& b) {
+    const __m512i zero = _mm512_setzero_si512(), mask = bc(M52), pinv = bc(g_pinv52);
+    __m512i t0 = zero, t1 = zero, t2 = zero, t3 = zero, t4 = zero, t5 = zero;
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+#define GKR_IFMA_ROUND(bi)                                        \
+    {                                                             \
+        t0 = _mm512_madd52lo_epu64(t0, a.l[0], bi);               \
+        t1 = _mm512_madd52hi_epu64(t1, a.l[0], bi);               \
+        t1 = _mm512_madd52lo_epu64(t1, a.l[1], bi);               \
+        t2 = _mm512_madd52hi_epu64(t2, a.l[1], bi);               \
+        t2 = _mm512_madd52lo_epu64(t2, a.l[2], bi);               \
+        t3 = _mm512_madd52hi_epu64(t3, a.l[2], bi);               \
+        t3 = _mm512_madd52lo_epu64(t3, a.l[3], bi);               \
+        t4 = _mm512_madd52hi_epu64(t4, a.l[3], bi);               \
+        t4 = _mm512_madd52lo_epu64(t4, a.l[4], bi);               \
+        t5 = _mm512_madd52hi_epu64(t5, a.l[4], bi);               \
+        const __m512i m = _mm512_and_si512(_mm512_madd52lo_epu64(zero, t0, pinv), mask); \
+        t0 = _mm512_madd52lo_epu64(t0, m, p0);                    \
+        t1 = _mm512_madd52hi_epu64(t1, m, p0);                    \
+        t1 = _mm512_madd52lo_epu64(t1, m, p1);                    \
+        t2 = _mm512_madd52hi_epu64(t2, m, p1);                    \
+        t2 = _mm512_madd52lo_epu64(t2, m, p2);                    \
+        t3 = _mm512_madd52hi_epu64(t3, m, p2);                    \
+        t3 = _mm512_madd52lo_epu64(t3, m, p3);                    \
+        t4 = _mm512_madd52hi_epu64(t4, m, p3);                    \
+        t4 = _mm512_madd52lo_epu64(t4, m, p4);                    \
+        t5 = _mm512_madd52hi_epu64(t5, m, p4);                    \
+        /* low 52 bits of t0 are now zero: shift the window down one limb */ \
+        t0 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52));     \
+        t1 = t2; t2 = t3; t3 = t4; t4 = t5; t5 = zero;            \
+    }
+    GKR_IFMA_ROUND(b.l[0]) GKR_IFMA_ROUND(b.l[1]) GKR_IFMA_ROUND(b.l[2]) GKR_IFMA_ROUND(b.l[3]) GKR_IFMA_ROUND(b.l[4])
+#undef GKR_IFMA_ROUND
+    // carry-normalise to 52-bit limbs (value < 2p < 2^255)
+    t1 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52)); t0 = _mm512_and_si512(t0, mask);
+    t2 = _mm512_add_epi64(t2, _mm512_srli_epi64(t1, 52)); t1 = _mm512_and_si512(t1, mask);
+    t3 = _mm512_add_epi64(t3, _mm512_srli_epi64(t2, 52)); t2 = _mm512_and_si512(t2, mask);
+    t4 = _mm512_add_epi64(t4, _mm512_srli_epi64(t3, 52)); t3 = _mm512_and_si512(t3, mask);
+    // conditional subtract p: d = t - p with a borrow chain; keep d where no final borrow
+    __m512i d0 = _mm512_sub_epi64(t0, p0);
+    __m512i d1 = _mm512_sub_epi64(_mm512_sub_epi64(t1, p1), _mm512_srli_epi64(d0, 63));
+    __m512i d2 = _mm512_sub_epi64(_mm512_sub_epi64(t2, p2), _mm512_srli_epi64(d1, 63));
+    __m512i d3 = _mm512_sub_epi64(_mm512_sub_epi64(t3, p3), _mm512_srli_epi64(d2, 63));
+    __m512i d4 = _mm512_sub_epi64(_mm512_sub_epi64(t4, p4), _mm512_srli_epi64(d3, 63));
+    const __mmask8 neg = _mm512_cmplt_epi64_mask(d4, _mm512_setzero_si512());   // sign bit set: t < p, keep t
+    V r;
+    r.l[0] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d0, mask), t0);
+    r.l[1] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d1, mask), t1);
+    r.l[2] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d2, mask), t2);
+    r.l[3] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d3, mask), t3);
+    r.l[4] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d4, mask), t4);
+    return r;
+}
+
+// (a + b) mod p, inputs < p with 52-bit limbs
+static inline V add_mod(const V& a, const V& b) {
+    const __m512i mask = bc(M52);
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+    __m512i t0 = _mm512_add_epi64(a.l[0], b.l[0]);
+    __m512i t1 = _mm512_add_epi64(a.l[1], b.l[1]);
+    __m512i t2 = _mm512_add_epi64(a.l[2], b.l[2]);
+    __m512i t3 = _mm512_add_epi64(a.l[3], b.l[3]);
+    __m512i t4 = _mm512_add_epi64(a.l[4], b.l[4]);
+    t1 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52)); t0 = _mm512_and_si512(t0, mask);
+    t2 = _mm512_add_epi64(t2, _mm512_srli_epi64(t1, 52)); t1 = _mm512_and_si512(t1, mask);
+    t3 = _mm512_add_epi64(t3, _mm512_srli_epi64(t2, 52)); t2 = _mm512_and_si512(t2, mask);
+    t4 = _mm512_add_epi64(t4, _mm512_srli_epi64(t3, 52)); t3 = _mm512_and_si512(t3, mask);
+    __m512i d0 = _mm512_sub_epi64(t0, p0);
+    __m512i d1 = _mm512_sub_epi64(_mm512_sub_epi64(t1, p1), _mm512_srli_epi64(d0, 63));
+    __m512i d2 = _mm512_sub_epi64(_mm512_sub_epi64(t2, p2), _mm512_srli_epi64(d1, 63));
+    __m512i d3 = _mm512_sub_epi64(_mm512_sub_epi64(t3, p3), _mm512_srli_epi64(d2, 63));
+    __m512i d4 = _mm512_sub_epi64(_mm512_sub_epi64(t4, p4), _mm512_srli_epi64(d3, 63));
+    const __mmask8 neg = _mm512_cmplt_epi64_mask(d4, _mm512_setzero_si512());
+    V r;
+    r.l[0] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d0, mask), t0);
+    r.l[1] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d1, mask), t1);
+    r.l[2] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d2, mask), t2);
+    r.l[3] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d3, mask), t3);
+    r.l[4] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d4, mask), t4);
+    return r;
+}
+
+static inline V splat(const uint64_t l[5]) {
+    V v;
+    for (int i = 0; i < 5; ++i) v.l[i] = bc(l[i]);
+    return v;
+}
+
+static inline V load8(const uint64_t (*x)[4]) {   // eight canonical 4x64 values -> limb-major 5x52
+    uint64_t t[5][8];
+    for (int k = 0; k < 8; ++k) {
+        uint64_t o[5];
+        to52(x[k], o);
+        for (int i = 0; i < 5; ++i) t[i][k] = o[i];
+    }
+    V v;
+    for (int i = 0; i < 5; ++i) v.l[i] = _mm512_loadu_si512(t[i]);
+    return v;
+}
+
+static inline void store8(const V& v, uint64_t (*x)[4]) {
+    uint64_t t[5][8];
+    for (int i = 0; i < 5; ++i) _mm512_storeu_si512(t[i], v.l[i]);
+    for (int k = 0; k < 8; ++k) {
+        uint64_t l[5] = {t[0][k], t[1][k], t[2][k], t[3][k], t[4][k]};
+        from52(l, x[k]);
+    }
+}
+
+static void init_constants(const uint64_t (*cts_canonical)[4]) {
+    to52(kP64, g_p52);
+    // -p^-1 mod 2^52 by Newton iteration on the low word
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; ++i) inv *= 2 - kP64[0] * inv;
+    g_pinv52 = (0 - inv) & M52;
+    // R^2 = 2^520 mod p by repeated doubling of 1
+    uint64_t x[4] = {1, 0, 0, 0};
+    for (int i = 0; i < 520; ++i) dbl_mod(x);
+    to52(x, g_r2_52);
+    uint64_t one[4] = {1, 0, 0, 0};
+    to52(one, g_one52);
+    g_ready = true;   // mont_mul usable from here
+    const V r2 = splat(g_r2_52);
+    for (int base = 0; base < 91; base += 8) {
+        uint64_t in[8][4];
+        memset(in, 0, sizeof in);
+        for (int k = 0; k < 8 && base + k < 91; ++k) memcpy(in[k], cts_canonical[base + k], 32);
+        V m = mont_mul(load8(in), r2);
+        uint64_t t[5][8];
+        for (int i = 0; i < 5; ++i) _mm512_storeu_si512(t[i], m.l[i]);
+        for (int k = 0; k < 8 && base + k < 91; ++k)
+            for (int i = 0; i < 5; ++i) g_cts52[base + k][i] = t[i][k];
+    }
+}
+
+// x, k Montgomery -> hash(x, k) Montgomery, eight lanes
+static inline V mimc7_hash(const V& x, const V& k) {
+    V h = x;
+    for (int i = 0; i < 91; ++i) {
+        V t = (i == 0) ? add_mod(x, k) : add_mod(add_mod(h, k), splat(g_cts52[i]));
+        V t2 = mont_mul(t, t);
+        V t4 = mont_mul(t2, t2);
+        V t6 = mont_mul(t4, t2);
+        h = mont_mul(t6, t);
+    }
+    return add_mod(h, k);
+}
+
+}  // namespace ifma
+
+bool gkr_ifma_available() {
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma");
+#else
+    return false;
+#endif
+}
+
+void gkr_ifma_init(const uint64_t (*cts_canonical)[4]) { ifma::init_constants(cts_canonical); }
+
+// Eight transcripts: lane k hashes the LAST len[k] of the `slots` elements vec[k][0..slots)
+// (round vectors are right-aligned, highest degree first); out[k] = multi_hash(.., key 0), canonical.
+void gkr_ifma_multi_hash8(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]) {
+    using namespace ifma;
+    const V r2 = splat(g_r2_52), one = splat(g_one52);
+    V r;
+    for (int i = 0; i < 5; ++i) r.l[i] = _mm512_setzero_si512();
+    for (int s = 0; s < slots; ++s) {
+        uint64_t in[8][4];
+        __mmask8 active = 0;
+        for (int k = 0; k < 8; ++k) {
+            memcpy(in[k], vec[k][s], 32);
+            if ((uint32_t)(slots - s) <= len[k]) active |= (__mmask8)(1u << k);
+        }
+        if (!active) continue;
+        const V a = mont_mul(load8(in), r2);
+        const V h = mimc7_hash(a, r);
+        const V nr = add_mod(add_mod(r, a), h);
+        for (int i = 0; i < 5; ++i) r.l[i] = _mm512_mask_blend_epi64(active, r.l[i], nr.l[i]);
+    }
+    store8(mont_mul(r, one), out);
+}
+
+}  // namespace gkr

@@ -103,6 +103,8 @@ int  gkr_mimc7_constant(int i, gkr_fr *out);     /* i in 0..90 */
 /* the device arithmetic (8x32-bit Montgomery) run on the host, for CPU-side unit tests */
 int  gkr_selftest_mul(const gkr_fr *a, const gkr_fr *b, gkr_fr *out);
 int  gkr_selftest_wide_sum(const gkr_fr *vals, size_t n, gkr_fr *out);
+/* the host transcript's batched hash: eight right-aligned 3-slot round vectors at once */
+int  gkr_selftest_hash8(const gkr_fr *vecs, const uint32_t *len, gkr_fr *out, int *used_ifma);
 /* sum_i a_i b_i through the unreduced 544-bit dot-product accumulator of the fused layer kernel */
 int  gkr_selftest_dot(const gkr_fr *a, const gkr_fr *b, size_t n, gkr_fr *out);
 /* lo + r (hi - lo) through the fixed-multiplier table the fold kernels use */
