@@ -240,6 +240,24 @@ __device__ inline __attribute__((always_inline)) void mac96x3_s(uint64_t& accA, 
         : "v"(xA), "s"(yA), "v"(xB), "s"(yB), "v"(xC), "s"(yC));
 }
 
+__device__ inline __attribute__((always_inline)) void mac96x4_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA,
+                                                                uint64_t& accB, uint32_t& exB, uint32_t xB, uint32_t yB,
+                                                                uint64_t& accC, uint32_t& exC, uint32_t xC, uint32_t yC,
+                                                                uint64_t& accD, uint32_t& exD, uint32_t xD, uint32_t yD) {
+    uint64_t cA, cB, cC, cD;
+    asm("v_mad_u64_u32 %0, %8, %12, %13, %0\n\t"
+        "v_mad_u64_u32 %2, %9, %14, %15, %2\n\t"
+        "v_mad_u64_u32 %4, %10, %16, %17, %4\n\t"
+        "v_mad_u64_u32 %6, %11, %18, %19, %6\n\t"
+        "v_addc_co_u32_e64 %1, %8, 0, %1, %8\n\t"
+        "v_addc_co_u32_e64 %3, %9, 0, %3, %9\n\t"
+        "v_addc_co_u32_e64 %5, %10, 0, %5, %10\n\t"
+        "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
+        : "+v"(accA), "+v"(exA), "+v"(accB), "+v"(exB), "+v"(accC), "+v"(exC), "+v"(accD), "+v"(exD), "=&s"(cA), "=&s"(cB),
+          "=&s"(cC), "=&s"(cD)
+        : "v"(xA), "s"(yA), "v"(xB), "s"(yB), "v"(xC), "s"(yC), "v"(xD), "s"(yD));
+}
+
 // o = a + b over 256 bits (carry out dropped: callers keep sums below 2^256)
 __device__ inline __attribute__((always_inline)) void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
     asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\ts_nop 1\n\t"
@@ -296,6 +314,14 @@ GKR_HD void mac96x3_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA, u
     mac96(accA, exA, xA, yA);
     mac96(accB, exB, xB, yB);
     mac96(accC, exC, xC, yC);
+}
+GKR_HD void mac96x4_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA, uint64_t& accB, uint32_t& exB, uint32_t xB,
+                      uint32_t yB, uint64_t& accC, uint32_t& exC, uint32_t xC, uint32_t yC, uint64_t& accD, uint32_t& exD,
+                      uint32_t xD, uint32_t yD) {
+    mac96(accA, exA, xA, yA);
+    mac96(accB, exB, xB, yB);
+    mac96(accC, exC, xC, yC);
+    mac96(accD, exD, xD, yD);
 }
 GKR_HD void add256(uint32_t (&o)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
     uint64_t carry = 0;
@@ -569,6 +595,73 @@ GKR_HD void lazy_mac_s(Lazy17& acc, const Fr& a, const Fr& b_uniform) {
     acc.l[16] = (uint32_t)col;
 }
 
+// two independent dot products advanced together (see mac96x2_s)
+GKR_HD void lazy_mac2_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub) {
+    uint64_t cA = 0, cB = 0;
+    uint32_t eA = 0, eB = 0;
+#pragma unroll
+    for (int col = 0; col < 15; ++col) {
+        cA += A.l[col];
+        cB += B.l[col];
+#pragma unroll
+        for (int i = (col > 7 ? col - 7 : 0); i <= (col < 7 ? col : 7); ++i)
+            mac96x2_s(cA, eA, a.l[i], ua.l[col - i], cB, eB, b.l[i], ub.l[col - i]);
+        A.l[col] = (uint32_t)cA;
+        B.l[col] = (uint32_t)cB;
+        cA = (cA >> 32) | ((uint64_t)eA << 32);
+        cB = (cB >> 32) | ((uint64_t)eB << 32);
+        eA = 0;
+        eB = 0;
+    }
+    cA += A.l[15]; A.l[15] = (uint32_t)cA; cA >>= 32; cA += A.l[16]; A.l[16] = (uint32_t)cA;
+    cB += B.l[15]; B.l[15] = (uint32_t)cB; cB >>= 32; cB += B.l[16]; B.l[16] = (uint32_t)cB;
+}
+
+// four independent dot products advanced together: two instructions per partial product, no pads
+GKR_HD void lazy_mac4_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub, Lazy17& C, const Fr& c,
+                        const Fr& uc, Lazy17& D, const Fr& d, const Fr& ud) {
+    uint64_t cA = 0, cB = 0, cC = 0, cD = 0;
+    uint32_t eA = 0, eB = 0, eC = 0, eD = 0;
+#pragma unroll
+    for (int col = 0; col < 15; ++col) {
+        cA += A.l[col];
+        cB += B.l[col];
+        cC += C.l[col];
+        cD += D.l[col];
+#pragma unroll
+        for (int i = (col > 7 ? col - 7 : 0); i <= (col < 7 ? col : 7); ++i)
+            mac96x4_s(cA, eA, a.l[i], ua.l[col - i], cB, eB, b.l[i], ub.l[col - i], cC, eC, c.l[i], uc.l[col - i], cD, eD,
+                      d.l[i], ud.l[col - i]);
+        A.l[col] = (uint32_t)cA;
+        B.l[col] = (uint32_t)cB;
+        C.l[col] = (uint32_t)cC;
+        D.l[col] = (uint32_t)cD;
+        cA = (cA >> 32) | ((uint64_t)eA << 32);
+        cB = (cB >> 32) | ((uint64_t)eB << 32);
+        cC = (cC >> 32) | ((uint64_t)eC << 32);
+        cD = (cD >> 32) | ((uint64_t)eD << 32);
+        eA = 0;
+        eB = 0;
+        eC = 0;
+        eD = 0;
+    }
+    cA += A.l[15]; A.l[15] = (uint32_t)cA; cA >>= 32; cA += A.l[16]; A.l[16] = (uint32_t)cA;
+    cB += B.l[15]; B.l[15] = (uint32_t)cB; cB >>= 32; cB += B.l[16]; B.l[16] = (uint32_t)cB;
+    cC += C.l[15]; C.l[15] = (uint32_t)cC; cC >>= 32; cC += C.l[16]; C.l[16] = (uint32_t)cC;
+    cD += D.l[15]; D.l[15] = (uint32_t)cD; cD >>= 32; cD += D.l[16]; D.l[16] = (uint32_t)cD;
+}
+
+// A += B (both unreduced)
+GKR_HD void lazy_add(Lazy17& A, const Lazy17& B) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        c += (uint64_t)A.l[i] + B.l[i];
+        A.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+
 // three independent dot products advanced together (see mac96x3_s)
 GKR_HD void lazy_mac3_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub, Lazy17& C, const Fr& c,
                         const Fr& uc) {
@@ -685,6 +778,44 @@ GKR_HD Fr acc_reduce(const Acc<NL>& a) {
 #pragma unroll
     for (int i = 8; i < NL; ++i) hi.l[i - 8] = a.l[i];
     return fr_add(lo, mont_mul(hi, fr_r2()));
+}
+
+// the same for a sum of at most EIGHT products of values below r: X < 8 r^2, so the eight
+// Montgomery steps leave (X + M p) / 2^256 < 8 r^2 / 2^256 + r < 2.6 r -- two conditional
+// subtractions finish the job (no wide reduction, no extra product).
+GKR_HD Fr lazy_reduce_k8(const Lazy17& x) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t t[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = x.l[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t m = t[k] * GKR_INV32;
+        uint64_t a2 = t[k];
+        uint32_t e2 = 0;
+        mac96_s(a2, e2, m, p[0]);
+        a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+        e2 = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            a2 += t[k + j];
+            mac96_s(a2, e2, m, p[j]);
+            t[k + j] = (uint32_t)a2;
+            a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+            e2 = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 17; ++j) {
+            a2 += t[j];
+            t[j] = (uint32_t)a2;
+            a2 >>= 32;
+        }
+    }
+    uint32_t r8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8[i] = t[8 + i];   // < 2.6 r < 2^256: t[16] == 0
+    const Fr once = cond_sub_mod(r8);
+    return cond_sub_mod(once.l);
 }
 
 GKR_HD Fr lazy_reduce(const Lazy17& x) {

@@ -315,6 +315,248 @@ constexpr int kMaxGroups = 16;
 #define WS(ctx, slot, type, count, ptr) \
     HIP_TRY(ctx, (ctx)->workspace(slot, (size_t)(count) * sizeof(type), reinterpret_cast<void**>(&(ptr))))
 
+// ------------------------------------------------------------- plain MLE sumcheck, multi-round passes
+// Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
+// 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 3 hashes in a row,
+// eight sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
+// variables at once.  Length rules as in run_mle_batch.
+int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,
+                         gkr_fr* out_r) {
+    using gkr::h64::F;
+    const size_t len = (size_t)1 << n;
+    hipStream_t s = ctx->stream;
+    static const int jmax = [] { const char* e = getenv("GKR_ROUNDS_PER_PASS"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
+    const int j_first = n < jmax ? n : jmax;
+    const size_t work_len = len >> j_first;   // the first folded table
+    Fr* work = nullptr;
+    gkr::MleSubPartial* partials = nullptr;
+    gkr::MleHostRec8* rec = nullptr;
+    Fr* h_w = nullptr;   // pinned: 8 Montgomery weights per sumcheck
+    WS(ctx, "mlep.work", Fr, (size_t)batch * (work_len ? work_len : 1), work);
+    WS(ctx, "mlep.partials", gkr::MleSubPartial, (size_t)batch * gkr::kMaxBlocksPerTable, partials);
+    HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRec8) * batch, reinterpret_cast<void**>(&rec)));
+    HIP_TRY(ctx, ctx->pinned_host("mlep.w", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_w)));
+    const F* cts = host_mimc_constants64();
+    const bool ifma = host_ifma_ready();
+    std::vector<uint32_t> dep_last(batch, 0);
+    gkr::SpinPool* pool = ctx->host_pool();
+
+    int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
+    if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
+    int groups = (batch + group_size - 1) / group_size;
+    if (groups > kMaxGroups) groups = kMaxGroups;
+    struct Group {
+        int b0 = 0, nb = 0;
+        int m = 0;          // variables left in the current table
+        int j = 0;          // rounds the landed sums cover (the pass in flight produces 2^j sums)
+        int round0 = 0;     // global index of the first of those rounds
+        int state = 0;      // 0 waiting for the GPU, 1 hashing, 2 finished
+        uint32_t ticket = 0;
+        std::atomic<uint64_t> claim{0};   // (generation << 32) | next sumcheck; generation = pass number + 1
+        std::atomic<int> done{0};
+        int pass = 0;
+    };
+    std::vector<Group> grp(groups);
+    for (int g = 0; g < groups; ++g) {
+        grp[g].b0 = (int)((long long)batch * g / groups);
+        grp[g].nb = (int)((long long)batch * (g + 1) / groups) - grp[g].b0;
+        grp[g].m = n;
+        grp[g].j = j_first;
+    }
+    // pass 0: sub-block sums of the input tables
+    auto launch_first = [&](Group& G) {
+        const int b0 = G.b0, nb = G.nb;
+        G.ticket = ++ctx->ticket;
+        if (len <= gkr::kSmallPassEntries) {
+            Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0);
+            gkr::launch_mle_multifold_small(0, d_tables + (size_t)b0 * len, len, nullptr, 0, (uint32_t)len, (uint32_t)G.j, nb,
+                                            h_w + (size_t)b0 * 8, rec + b0, G.ticket, s);
+            return;
+        }
+        const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)len, (uint32_t)G.j, nb);
+        gkr::MleSubPartial* part = partials + (size_t)b0 * gkr::kMaxBlocksPerTable;
+        {
+            Timed t(ctx, "mle_sub_sums", (double)nb * len * 32.0);
+            gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, s);
+        }
+        Timed t(ctx, "mle_sub_reduce", 0.0);
+        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
+    };
+    // a fold pass: bind the jin variables just hashed, produce the sums of the next jout rounds
+    auto launch_fold = [&](Group& G, int jin) {
+        const int b0 = G.b0, nb = G.nb;
+        const size_t src_len = (size_t)1 << G.m, S = src_len >> jin;
+        const bool from_input = (G.m == n);
+        const Fr* src = from_input ? d_tables + (size_t)b0 * len : work + (size_t)b0 * work_len;
+        const size_t src_stride = from_input ? len : work_len;
+        Fr* dst = work + (size_t)b0 * work_len;
+        G.m -= jin;
+        G.round0 += jin;
+        G.j = G.m < jmax ? G.m : jmax;
+        G.ticket = ++ctx->ticket;
+        const double bytes = (double)nb * ((double)src_len + (double)S) * 32.0;
+        if (S <= gkr::kSmallPassEntries) {
+            Timed t(ctx, "mle_pass_small", bytes);
+            gkr::launch_mle_multifold_small(jin, src, src_stride, dst, work_len, (uint32_t)S, (uint32_t)G.j, nb,
+                                            h_w + (size_t)b0 * 8, rec + b0, G.ticket, s);
+            return;
+        }
+        const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)S, (uint32_t)G.j, nb);
+        gkr::MleSubPartial* part = partials + (size_t)b0 * gkr::kMaxBlocksPerTable;
+        {
+            Timed t(ctx, "mle_multifold", bytes);
+            gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * 8, part, s);
+        }
+        Timed t(ctx, "mle_sub_reduce", 0.0);
+        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
+    };
+    // the J rounds of up to eight sumchecks whose sub-block sums have landed
+    auto process_chunk = [&](const Group& G, int b_first, int count) {
+        const int J = G.j;
+        F sums[8][8], rr[8][3];
+        for (int i = 0; i < count; ++i) {
+            memcpy(sums[i], rec[b_first + i].sums, sizeof(F) << J);
+            if (G.round0 == 0) dep_last[b_first + i] = rec[b_first + i].dep;
+        }
+        for (int t = 0; t < J; ++t) {
+            const int half = 1 << (J - t - 1), round = G.round0 + t;
+            F c0[8], c1[8];
+            uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < count; ++i) {
+                F lo = sums[i][0], hi = sums[i][half];
+                for (int b = 1; b < half; ++b) {
+                    lo = gkr::h64::add(lo, sums[i][b]);
+                    hi = gkr::h64::add(hi, sums[i][half + b]);
+                }
+                c0[i] = lo;
+                c1[i] = gkr::h64::sub(hi, lo);
+                if (round + 1 < n)
+                    ln[i] = gkr::h64::is_zero(c1[i]) ? 1u : 2u;
+                else
+                    ln[i] = dep_last[b_first + i] ? 2u : 1u;
+            }
+            F r[8];
+            if (ifma && count >= 3) {
+                uint64_t vec[8][3][4], out[8][4];
+                memset(vec, 0, sizeof vec);
+                for (int i = 0; i < count; ++i) {
+                    memcpy(vec[i][1], &c1[i], 32);
+                    memcpy(vec[i][2], &c0[i], 32);
+                }
+                gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+                for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
+            } else {
+                for (int i = 0; i < count; ++i) {
+                    F vec[2] = {c1[i], c0[i]};
+                    r[i] = gkr::h64::mimc7_multi_hash(vec + (2 - ln[i]), (int)ln[i], cts, nullptr);
+                }
+            }
+            for (int i = 0; i < count; ++i) {
+                const int b = b_first + i;
+                gkr_fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
+                memset(&oc[0], 0, 32);
+                if (ln[i] == 2) memcpy(&oc[0], &c1[i], 32);
+                memcpy(&oc[1], &c0[i], 32);
+                out_len[(size_t)b * n + round] = ln[i];
+                memcpy(&out_r[(size_t)b * n + round], &r[i], 32);
+                rr[i][t] = gkr::h64::to_mont(r[i]);
+                // the sub-block sums of the table with this variable bound
+                for (int bb = 0; bb < half; ++bb)
+                    sums[i][bb] = gkr::h64::add(sums[i][bb], gkr::h64::mont_mul(gkr::h64::sub(sums[i][half + bb], sums[i][bb]), rr[i][t]));
+            }
+        }
+        if (G.m - J > 0) {
+            // weights of the pass that binds these J variables: w_b = prod_t (bit_t(b) ? r_t : 1 - r_t),
+            // bit_0 = most significant; Montgomery form
+            const F one_m = gkr::h64::to_mont(F{{1, 0, 0, 0}});
+            for (int i = 0; i < count; ++i) {
+                F w[8];
+                w[0] = one_m;
+                int cur = 1;
+                for (int t = 0; t < J; ++t) {
+                    const F nr = gkr::h64::sub(one_m, rr[i][t]);
+                    for (int b = cur; b-- > 0;) {
+                        w[2 * b + 1] = gkr::h64::mont_mul(w[b], rr[i][t]);
+                        w[2 * b] = gkr::h64::mont_mul(w[b], nr);
+                    }
+                    cur <<= 1;
+                }
+                memcpy(h_w + (size_t)(b_first + i) * 8, w, sizeof(F) << J);
+            }
+        }
+    };
+    const std::function<bool()> try_work = [&]() -> bool {
+        for (int g = 0; g < groups; ++g) {
+            Group& G = grp[g];
+            uint64_t c = G.claim.load(std::memory_order_acquire);
+            while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
+                const uint32_t first = (uint32_t)c;
+                const uint32_t take = ((uint32_t)G.nb - first) < 8u ? ((uint32_t)G.nb - first) : 8u;
+                if (G.claim.compare_exchange_weak(c, c + take, std::memory_order_acq_rel)) {
+                    process_chunk(G, G.b0 + (int)first, (int)take);
+                    G.done.fetch_add((int)take, std::memory_order_release);
+                    return true;
+                }
+            }
+        }
+        return false;
+    };
+    auto records_landed = [&](const Group& G) {
+        for (int i = G.nb - 1; i >= 0; --i)
+            if (__atomic_load_n(&rec[G.b0 + i].seq, __ATOMIC_ACQUIRE) != G.ticket) return false;
+        return true;
+    };
+    pool->begin_session(&try_work);
+    int rc = GKR_OK;
+    for (int g = 0; g < groups; ++g) launch_first(grp[g]);
+    int active = groups;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t idle = 0;
+    while (active > 0 && rc == GKR_OK) {
+        bool progress = false;
+        for (int g = 0; g < groups; ++g) {
+            Group& G = grp[g];
+            if (G.state == 0 && records_landed(G)) {
+                G.done.store(0, std::memory_order_relaxed);
+                G.claim.store(((uint64_t)(++G.pass) << 32), std::memory_order_release);
+                G.state = 1;
+                progress = true;
+            } else if (G.state == 1 && G.done.load(std::memory_order_acquire) == G.nb) {
+                G.claim.store(0, std::memory_order_release);
+                if (G.m - G.j > 0) {
+                    launch_fold(G, G.j);
+                    G.state = 0;
+                } else {
+                    G.state = 2;
+                    --active;
+                }
+                progress = true;
+            }
+        }
+        if (progress) {
+            idle = 0;
+            continue;
+        }
+        if (try_work()) continue;
+        GKR_CPU_RELAX();
+        if ((++idle & 0xFFFF) == 0) {
+            hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) rc = ctx->hip_fail(q, "stream failed during a sumcheck pass");
+            else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                rc = ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a pass");
+        }
+    }
+    pool->end_session();
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->drain_events();
+    return GKR_OK;
+}
+
 // ------------------------------------------------------------- plain MLE sumcheck
 // Length rule of prove_sumcheck (sumcheck.rs:158-214): rounds 1..n-1 drop a zero
 // linear coefficient (add_poly, poly.rs:324-327); the last round has two
@@ -324,6 +566,8 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
     const size_t len = (size_t)1 << n;
     const size_t rounds = (size_t)batch * n;
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
+    static const bool per_round = getenv("GKR_MLE_PER_ROUND") != nullptr;
+    if (host_tx && !per_round) return run_mle_batch_passes(ctx, d_tables, n, batch, out_coeffs, out_len, out_r);
     Fr *work = nullptr, *d_coeffs = nullptr, *d_r = nullptr;
     uint32_t *d_len = nullptr, *d_dep = nullptr;
     gkr::MlePartial* partials = nullptr;
@@ -1004,6 +1248,20 @@ int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
     const Fr r = gkr::lazy_reduce(acc);
     if (!gkr::fr_eq(gkr::lazy_reduce(t0), r) || !gkr::fr_eq(gkr::lazy_reduce(t1), r) || !gkr::fr_eq(gkr::lazy_reduce(t2), r))
         return GKR_ERR_INVALID;
+    if (n <= 8) {   // the multi-round fold's form: four accumulators advanced together, short reduction
+        gkr::Lazy17 q[4] = {gkr::lazy_zero(), gkr::lazy_zero(), gkr::lazy_zero(), gkr::lazy_zero()};
+        Fr xs[8], ys[8];
+        for (size_t i = 0; i < 8; ++i) {
+            xs[i] = i < n ? to_dev(a[i]) : gkr::fr_zero();
+            ys[i] = i < n ? gkr::to_mont(to_dev(b[i])) : gkr::fr_zero();
+        }
+        gkr::lazy_mac4_s(q[0], xs[0], ys[0], q[1], xs[1], ys[1], q[2], xs[2], ys[2], q[3], xs[3], ys[3]);
+        gkr::lazy_mac4_s(q[0], xs[4], ys[4], q[1], xs[5], ys[5], q[2], xs[6], ys[6], q[3], xs[7], ys[7]);
+        gkr::lazy_add(q[0], q[1]);
+        gkr::lazy_add(q[2], q[3]);
+        gkr::lazy_add(q[0], q[2]);
+        if (!gkr::fr_eq(gkr::lazy_reduce_k8(q[0]), r)) return GKR_ERR_INVALID;
+    }
     *out = to_abi(r);
     return GKR_OK;
 }

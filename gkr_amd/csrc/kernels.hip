@@ -231,6 +231,164 @@ __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Multi-round passes (host transcript, default).  The sums a round needs are linear in the
+// table, so the sums of J consecutive rounds follow from the 2^J sub-block sums of the current
+// table (sub-block = the entries sharing their J leading index bits): the host derives
+// r_j .. r_{j+J-1} from them without touching the table, and ONE pass then binds all J variables,
+//     T'[i] = sum_b  w_b * T[b * S + i],     w_b = eq((r_j..r_{j+J-1}), b),   S = |T| / 2^J,
+// while accumulating the 2^J' sub-block sums of T' for the next J' rounds.  With J = 3 a 2^n
+// sumcheck reads T_1 twice and then only a geometric tail (~2.3 N elements moved instead of 4 N)
+// and needs n/3 host round trips instead of n.  Results are the same field elements: bit-exact.
+// ---------------------------------------------------------------------------
+
+// sum_b w_b * src[b * S + i] for b < 2^JIN: unreduced products in independent accumulators that
+// advance together (four at a time where there are that many), one reduction
+template <int JIN>
+__device__ __forceinline__ Fr multifold_entry(const Fr* __restrict__ s, uint32_t S, uint32_t i, const Fr* __restrict__ w) {
+    if (JIN == 1) {
+        Lazy17 a0 = lazy_zero(), a1 = lazy_zero();
+        lazy_mac2_s(a0, load_fr(s + i), w[0], a1, load_fr(s + (size_t)S + i), w[1]);
+        lazy_add(a0, a1);
+        return lazy_reduce_k8(a0);
+    }
+    Lazy17 a0 = lazy_zero(), a1 = lazy_zero(), a2 = lazy_zero(), a3 = lazy_zero();
+#pragma unroll
+    for (int b = 0; b < (1 << JIN); b += 4) {
+        const Fr x0 = load_fr(s + (size_t)b * S + i), x1 = load_fr(s + (size_t)(b + 1) * S + i);
+        const Fr x2 = load_fr(s + (size_t)(b + 2) * S + i), x3 = load_fr(s + (size_t)(b + 3) * S + i);
+        lazy_mac4_s(a0, x0, w[b], a1, x1, w[b + 1], a2, x2, w[b + 2], a3, x3, w[b + 3]);
+    }
+    lazy_add(a0, a1);
+    lazy_add(a2, a3);
+    lazy_add(a0, a2);
+    return lazy_reduce_k8(a0);
+}
+
+// pass 0: sub-block sums of the input tables.  grid = (nblk, batch), nblk = 2^J * blocks-per-sub-block,
+// every block a contiguous chunk of len / nblk entries.  dep: does the table depend on x_n
+// (entry 2m vs 2m+1; the neighbour is read through the cache the partner lane just filled).
+__global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tables, size_t table_stride, uint32_t len,
+                                                      MleSubPartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4];
+    __shared__ uint32_t s_dep;
+    const Fr* t = tables + (size_t)blockIdx.y * table_stride;
+    const uint32_t chunk = len / gridDim.x;
+    const uint32_t begin = blockIdx.x * chunk, end = begin + chunk;
+    Acc<9> acc[1] = {acc_zero<9>()};
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) s_dep = 0;
+    __syncthreads();
+    for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const Fr x = load_fr(t + i);
+        acc_add_fr(acc[0], x);
+        dep |= fr_eq(x, load_fr(t + (i ^ 1u))) ? 0u : 1u;
+    }
+    if (dep) atomicOr(&s_dep, 1u);
+    block_sum<9, 1>(acc, smem);
+    if (threadIdx.x == 0) {
+        MleSubPartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->sum = acc[0];
+        p->dep = s_dep;
+    }
+}
+
+// one pass: bind JIN variables with the weights w[0 .. 2^JIN) (Montgomery, wave-uniform), write the
+// folded table of S entries, accumulate its sub-block sums.  grid = (nblk, batch), chunk = S / nblk.
+template <int JIN>
+__global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                       size_t dst_stride, uint32_t S, const Fr* __restrict__ weights,
+                                                       MleSubPartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4];
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    const Fr* w = weights + (size_t)blockIdx.y * 8;
+    const uint32_t chunk = S / gridDim.x;
+    const uint32_t begin = blockIdx.x * chunk, end = begin + chunk;
+    Acc<9> acc[1] = {acc_zero<9>()};
+    for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const Fr y = multifold_entry<JIN>(s, S, i, w);
+        store_fr(d + i, y);
+        acc_add_fr(acc[0], y);
+    }
+    block_sum<9, 1>(acc, smem);
+    if (threadIdx.x == 0) {
+        MleSubPartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->sum = acc[0];
+        p->dep = 0;
+    }
+}
+
+// partials -> 2^jout canonical sub-block sums per table -> pinned host record.  Wave w totals
+// sub-block w.  grid = (batch), block = 512 (8 waves)
+__global__ void __launch_bounds__(512) k_mle_sub_reduce(const MleSubPartial* __restrict__ partials, uint32_t nblk,
+                                                        uint32_t jout, MleHostRec8* __restrict__ host_rec, uint32_t ticket) {
+    __shared__ uint32_t s_dep;
+    const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nsub = 1u << jout, bps = nblk >> jout;
+    if (threadIdx.x == 0) s_dep = 0;
+    __syncthreads();
+    MleHostRec8* r = host_rec + b;
+    if (wave < nsub) {
+        const MleSubPartial* p = partials + (size_t)b * nblk + (size_t)wave * bps;
+        Acc<10> tot = acc_zero<10>();
+        uint32_t dep = 0;
+        for (uint32_t i = lane; i < bps; i += 64) {
+            acc_add_acc(tot, p[i].sum);
+            dep |= p[i].dep;
+        }
+        tot = wave_sum(tot);
+        if (__any(dep) && lane == 0) atomicOr(&s_dep, 1u);
+        if (lane == 0) r->sums[wave] = acc_reduce(tot);
+    }
+    __syncthreads();   // every wave's record stores are issued and waited for before the release below
+    if (threadIdx.x == 0) {
+        r->dep = s_dep;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// small tables: one block per sumcheck does the whole pass (multifold, sub-block sums, publish)
+template <int JIN>
+__global__ void __launch_bounds__(256) k_mle_multifold_small(const Fr* __restrict__ src, size_t src_stride,
+                                                             Fr* __restrict__ dst, size_t dst_stride, uint32_t S,
+                                                             uint32_t jout, const Fr* __restrict__ weights,
+                                                             MleHostRec8* __restrict__ host_rec, uint32_t ticket) {
+    __shared__ Acc<9> smem[4];
+    const uint32_t b = blockIdx.x;
+    const Fr* s = src + (size_t)b * src_stride;
+    Fr* d = dst + (size_t)b * dst_stride;
+    const Fr* w = weights + (size_t)b * 8;
+    // JIN == 0: no fold, only the sub-block sums of the table as it stands (tiny first pass)
+    if (JIN > 0) {
+        for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
+            store_fr(d + i, multifold_entry<(JIN > 0 ? JIN : 1)>(s, S, i, w));
+        }
+        __threadfence_block();
+        __syncthreads();   // the folded table is complete and visible to the block
+    }
+    const Fr* tbl = JIN > 0 ? d : s;
+    const uint32_t sub = S >> jout;
+    MleHostRec8* r = host_rec + b;
+    uint32_t dep = 0;
+    for (uint32_t sb = 0; sb < (1u << jout); ++sb) {
+        Acc<9> acc[1] = {acc_zero<9>()};
+        for (uint32_t i = threadIdx.x; i < sub; i += blockDim.x) {
+            const Fr x = load_fr(tbl + (size_t)sb * sub + i);
+            acc_add_fr(acc[0], x);
+            if (JIN == 0) dep |= fr_eq(x, load_fr(tbl + (((size_t)sb * sub + i) ^ 1u))) ? 0u : 1u;
+        }
+        block_sum<9, 1>(acc, smem);
+        if (threadIdx.x == 0) r->sums[sb] = acc_reduce(acc[0]);
+        __syncthreads();   // smem is reused by the next sub-block
+    }
+    dep = __syncthreads_or(dep);
+    if (threadIdx.x == 0) {
+        r->dep = dep ? 1u : 0u;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Late rounds (host transcript): the table is small, so ONE block per sumcheck folds
 // it, totals the two half sums and publishes the host record itself -- one launch
 // per round instead of fold + reduce, and no partials round trip.
@@ -905,6 +1063,50 @@ void launch_mle_fold_sum_small(const Fr* src, size_t src_stride, Fr* dst, size_t
                                const FixedMul* rtab, MleHostRec* host_rec, uint32_t ticket, hipStream_t s) {
     hipLaunchKernelGGL(k_mle_fold_sum_small, dim3(batch), dim3(256), 0, s, src, src_stride, dst, dst_stride, q, rtab,
                        host_rec, ticket);
+}
+
+// blocks per table for a pass whose per-table work is `items` entries split into 2^jout sub-blocks:
+// a power of two, >= 2^jout, ~1024 items per block, enough blocks across the batch to fill the chip
+uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch) {
+    uint32_t want = mle_blocks_per_table(items, batch);
+    uint32_t b = 1u << jout;
+    while (b < want && b * 2 <= items && b * 2 <= kMaxBlocksPerTable) b <<= 1;
+    if (b > items) b = items;   // tiny tables: one entry per block at the very least
+    return b;
+}
+
+void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk,
+                         MleSubPartial* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_sub_sums, dim3(nblk, batch), dim3(256), 0, s, tables, stride, len, partials);
+}
+
+void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
+                          uint32_t nblk, const Fr* weights, MleSubPartial* partials, hipStream_t s) {
+    dim3 grid(nblk, batch);
+    if (jin == 1)
+        hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+    else if (jin == 2)
+        hipLaunchKernelGGL(k_mle_multifold<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+    else
+        hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+}
+
+void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRec8* host_rec,
+                           uint32_t ticket, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_sub_reduce, dim3(batch), dim3(512), 0, s, partials, nblk, jout, host_rec, ticket);
+}
+
+void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
+                                uint32_t batch, const Fr* weights, MleHostRec8* host_rec, uint32_t ticket, hipStream_t s) {
+    dim3 grid(batch);
+    if (jin == 0)
+        hipLaunchKernelGGL(k_mle_multifold_small<0>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+    else if (jin == 1)
+        hipLaunchKernelGGL(k_mle_multifold_small<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+    else if (jin == 2)
+        hipLaunchKernelGGL(k_mle_multifold_small<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+    else
+        hipLaunchKernelGGL(k_mle_multifold_small<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
 }
 
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,

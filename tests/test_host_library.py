@@ -84,10 +84,10 @@ def test_fixed_multiplier_fold_on_host_matches_bigints():
 def test_lazy_dot_product_on_host_matches_bigints():
     lib = N.lib()
     rng = random.Random(6)
-    for n in (0, 1, 2, 7, 300):
+    for n in (0, 1, 2, 7, 8, 5, 300):
         a = [rng.randrange(P) for _ in range(n)]
         b = [rng.randrange(P) for _ in range(n)]
-        if n == 7:
+        if n in (7, 8):
             a, b = [P - 1] * n, [P - 1] * n
         A = to_limbs(a) if n else np.zeros((0, 4), dtype=np.uint64)
         B = to_limbs(b) if n else np.zeros((0, 4), dtype=np.uint64)
