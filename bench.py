@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--transcript", choices=["host", "device"], default="host",
                     help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--proofs", type=int, default=64,
+                    help="second half of the metric: full GKR proofs of a t.circom-class layered circuit per rank (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -162,6 +164,9 @@ def main():
                     line["roofline"]["traffic_source"] = "profiles/r01/c_pmc_traffic.json (rocprofv3 --pmc passes of this command)"
             except Exception:
                 pass
+        if args.proofs > 0:
+            line["aggregated_proofs"] = proofs_per_sec(local_rank, args.proofs)
+            line["aggregated_proofs"]["proofs_per_sec_all_ranks"] = line["aggregated_proofs"]["proofs_per_sec"] * world
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(line), flush=True)
@@ -170,6 +175,40 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def proofs_per_sec(device, n_proofs):
+    """"aggregated proofs/sec": full GKR proofs (gkr_prove = prover::prove, rust/src/gkr/prover.rs:6-96) of
+    one layered circuit of the size class SURVEY appendix B.4 estimates for t.circom (4 gate layers,
+    k = [5, 6, 7, 7 | input 7]) for `n_proofs` different witnesses (BASELINE configs[3]: 64 inputs).
+    Proofs are independent (aggregator.rs:350-355 proves them from a rayon par_iter): one context per
+    host thread.  Rank 0 measures its own share; other ranks would do the same work."""
+    import numpy as np
+    from gkr_amd import Context, GKRCircuit, Layer
+    ks = [5, 6, 7, 7, 7]
+    rng = np.random.default_rng(0xC0FFEE + 3)
+    layers = [Layer(ks[i], rng.integers(0, 2, 1 << ks[i], dtype=np.uint8),
+                    rng.integers(0, 1 << ks[i + 1], 1 << ks[i], dtype=np.uint32),
+                    rng.integers(0, 1 << ks[i + 1], 1 << ks[i], dtype=np.uint32)) for i in range(4)]
+    circuit = GKRCircuit(layers, ks[-1])
+
+    def witness(i):
+        a = np.random.default_rng(1000 + i).integers(0, 1 << 63, (1 << ks[-1], 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)
+        return a
+    inputs = np.stack([witness(i) for i in range(n_proofs)])
+    ctx = Context(device)
+    ctx.prove_batch_raw(circuit, inputs[: min(8, n_proofs)])   # warm-up: code objects, workspaces
+    ctx.prove_batch_raw(circuit, inputs)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.prove_batch_raw(circuit, inputs)
+    dt = (time.perf_counter() - t0) / reps
+    ctx.close()
+    return {"proofs_per_sec": n_proofs / dt, "proofs": n_proofs, "ms_per_batch": dt * 1e3,
+            "circuit": "synthetic layered circuit, 4 gate layers, k = %s, random add/mult gates, %d witnesses" % (ks, n_proofs),
+            "how": "gkr_prove_batch: all proofs advance together, every layer sumcheck batched (one round trip per round for all)"}
 
 
 def usable_cpus():

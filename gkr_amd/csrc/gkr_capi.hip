@@ -836,28 +836,35 @@ static void host_eq_table(const gkr_fr* z, int lo, int hi, std::vector<gkr::h64:
     }
 }
 
-// shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries
+// shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries.
+// batch > 1: `batch` proofs of one circuit -- same gates (the cell lists are built once), z is batch x k_i,
+// d_A / d_M hold batch tables of N entries each.
 int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
-                     const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0) {
+                     const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0, int batch = 1) {
     const size_t N = (size_t)1 << (2 * k - log_p);
     hipStream_t s = ctx->stream;
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t* bad = nullptr;
     const int kl = k_i / 2, kh = k_i - kl;
-    WS(ctx, "pred.ehi", Fr, (size_t)1 << kh, e_hi);
-    WS(ctx, "pred.elo", Fr, (size_t)1 << kl, e_lo);
+    WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
+    WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
     WS(ctx, "pred.bad", uint32_t, 1, bad);
-    // E[g] = E_hi[g >> kl] * E_lo[g & mask]: two small tables built on the host (2^kh + 2^kl products)
-    std::vector<gkr::h64::F> hhi, hlo;
-    host_eq_table(z, 0, kh, hhi);
-    host_eq_table(z, kh, k_i, hlo);
-    for (auto& v : hlo) v = gkr::h64::to_mont(v);
+    // E[g] = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the host (2^kh + 2^kl products)
+    std::vector<gkr::h64::F> hhi((size_t)batch << kh), hlo((size_t)batch << kl), tmp;
+    for (int b = 0; b < batch; ++b) {
+        const gkr_fr* zb = z + (size_t)b * k_i;
+        host_eq_table(zb, 0, kh, tmp);
+        memcpy(hhi.data() + ((size_t)b << kh), tmp.data(), sizeof(gkr::h64::F) << kh);
+        host_eq_table(zb, kh, k_i, tmp);
+        for (auto& v : tmp) v = gkr::h64::to_mont(v);
+        memcpy(hlo.data() + ((size_t)b << kl), tmp.data(), sizeof(gkr::h64::F) << kl);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(e_hi, hhi.data(), hhi.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(e_lo, hlo.data(), hlo.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
     static const bool use_atomics = getenv("GKR_PREDICATE_ATOMICS") != nullptr;
-    if (!use_atomics) {
-        // counting sort by cell, then one modular sum per cell
+    if (!use_atomics || batch > 1) {
+        // counting sort by cell, then one modular sum per cell (per proof)
         uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *bsums = nullptr, *list = nullptr;
         WS(ctx, "pred.counts", uint32_t, 2 * N, counts);
         WS(ctx, "pred.offsets", uint32_t, 2 * N, offsets);
@@ -865,9 +872,9 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
         WS(ctx, "pred.bsums", uint32_t, (2 * N + 2047) / 2048 + 1, bsums);
         WS(ctx, "pred.list", uint32_t, (size_t)1 << k_i, list);
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, 2 * N * sizeof(uint32_t), s));
-        Timed t(ctx, "predicate_sorted", (double)((size_t)1 << k_i) * (2 * 9.0 + 8.0) + (double)N * 2.0 * (3 * 4.0 + 32.0));
+        Timed t(ctx, "predicate_sorted", (double)((size_t)1 << k_i) * (2 * 9.0 + 8.0) + (double)N * 2.0 * (3 * 4.0 + 32.0) * batch);
         gkr::launch_predicate_sorted(k_i, k, d_gt, d_l, d_r, e_hi, e_lo, (uint32_t)kl, log_p, shard, N, counts, offsets, cursor,
-                                     bsums, list, bad, d_A, d_M, s);
+                                     bsums, list, bad, d_A, d_M, (uint32_t)batch, s);
     } else {
         // widened-atomic scatter (kept for comparison): 8 u64 limb atomics per gate into 64-byte cells
         unsigned long long *wideA = nullptr, *wideM = nullptr;
@@ -893,97 +900,144 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
 }
 
 // ------------------------------------------------------------- layer sumcheck
-// d_W: canonical values of layer i+1 (2^k) in device memory
-int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
-              const gkr_fr* z, const Fr* d_W, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+// `batch` layer sumchecks that share their gates (the same layer of `batch` proofs of one circuit), or
+// one (batch = 1).  z: batch x k_i challenges (host); d_W: batch tables of 2^k canonical values;
+// outputs: per proof 2k rows (out_coeffs 3 slots per row), laid out [proof][round] with the given strides.
+int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                    const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r) {
     const size_t N = (size_t)1 << (2 * k);
+    const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
+    if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
     hipStream_t s = ctx->stream;
     Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr, *d_coeffs = nullptr, *d_r_out = nullptr;
     gkr::FixedMul* d_rtab = nullptr;
     uint32_t *d_len = nullptr, *dep = nullptr;
     gkr::LayerPartial* partials = nullptr;
-    WS(ctx, "layer.A", Fr, N, A);
-    WS(ctx, "layer.M", Fr, N, M);
-    WS(ctx, "layer.Wb", Fr, (size_t)1 << k, Wb);
-    WS(ctx, "layer.Wc", Fr, (size_t)1 << k, Wc);
+    WS(ctx, "layer.A", Fr, N * batch, A);
+    WS(ctx, "layer.M", Fr, N * batch, M);
+    WS(ctx, "layer.Wb", Fr, wlen * batch, Wb);
+    WS(ctx, "layer.Wc", Fr, wlen * batch, Wc);
     WS(ctx, "layer.coeffs", Fr, (size_t)v * 3, d_coeffs);
     WS(ctx, "layer.r", Fr, v, d_r_out);
     WS(ctx, "layer.rtab", gkr::FixedMul, v, d_rtab);
     WS(ctx, "layer.len", uint32_t, v, d_len);
-    WS(ctx, "layer.dep", uint32_t, 32, dep);
-    WS(ctx, "layer.partials", gkr::LayerPartial, gkr::kMaxLayerBlocks, partials);
-    int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M);
+    WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
+    WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
+    int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32, s));
-    gkr::launch_to_mont(d_W, Wb, 1u << k, s);
-    HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) << k, hipMemcpyDeviceToDevice, s));
-    gkr::launch_depends(d_W, k, dep, s);
+    gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, N, wlen};
+    HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
+    gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
+    HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
+    gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
 
     gkr::LayerHostRec* rec = nullptr;
-    gkr::FixedMul* h_rtab = nullptr;
-    uint32_t h_dep[32] = {0};
+    gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
+    std::vector<uint32_t> h_dep(32 * (size_t)batch, 0);
     const gkr::h64::F* cts64 = host_mimc_constants64();
+    const bool ifma = host_ifma_ready();
+    gkr::SpinPool* pool = nullptr;
     if (host_tx) {
-        HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec), reinterpret_cast<void**>(&rec)));
-        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul), reinterpret_cast<void**>(&h_rtab)));
-        HIP_TRY(ctx, hipMemcpyAsync(h_dep, dep, sizeof(uint32_t) * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
+        HIP_TRY(ctx, hipMemcpyAsync(h_dep.data(), dep, sizeof(uint32_t) * 32 * batch, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (batch >= 16) pool = ctx->host_pool();
     }
+    // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
+    // (get_univariate_coeff, poly.rs:388-420), hashed together (eight-lane IFMA where available)
+    auto hash_chunk = [&](int first, int count, uint32_t round, gkr::FixedMul* slot) {
+        gkr::h64::F c0[8], lin[8], c2[8], r[8];
+        uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < count; ++i) {
+            const int b = first + i;
+            gkr::h64::F g1;
+            memcpy(&c0[i], &rec[b].c0, 32);
+            memcpy(&g1, &rec[b].g1, 32);
+            memcpy(&c2[i], &rec[b].c2, 32);
+            lin[i] = gkr::h64::sub(gkr::h64::sub(g1, c0[i]), c2[i]);
+            ln[i] = 2u + (h_dep[(size_t)b * 32 + round % k] ? 1u : 0u);
+        }
+        if (ifma && count >= 3) {
+            uint64_t vec[8][3][4], out[8][4];
+            memset(vec, 0, sizeof vec);
+            for (int i = 0; i < count; ++i) {
+                memcpy(vec[i][0], &c2[i], 32);
+                memcpy(vec[i][1], &lin[i], 32);
+                memcpy(vec[i][2], &c0[i], 32);
+            }
+            gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+            for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
+        } else {
+            for (int i = 0; i < count; ++i) {
+                gkr::h64::F vec[3] = {c2[i], lin[i], c0[i]};
+                r[i] = gkr::h64::mimc7_multi_hash(vec + (3 - ln[i]), (int)ln[i], cts64, nullptr);
+            }
+        }
+        for (int i = 0; i < count; ++i) {
+            const int b = first + i;
+            gkr_fr* oc = out_coeffs[b] + (size_t)round * 3;
+            memset(&oc[0], 0, 32);
+            if (ln[i] == 3) memcpy(&oc[0], &c2[i], 32);
+            memcpy(&oc[1], &lin[i], 32);
+            memcpy(&oc[2], &c0[i], 32);
+            out_len[b][round] = ln[i];
+            memcpy(&out_r[b][round], &r[i], 32);
+            gkr::h64::make_fixed_mul(r[i], slot[b].w);
+        }
+    };
     // The fold with r_j is deferred into the pass that computes round j+1's sums (b-phase: the
     // fused kernel; c-phase: a separate fold of the single remaining row).
-    const gkr::FixedMul* pending = nullptr;   // challenge table not yet applied to A, M
+    const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
     static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
+    if (pool) pool->begin_session(nullptr);
     for (uint32_t round = 0; round < v; ++round) {
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
         const uint32_t hb = phase == 0 ? (h >> k) : 0u;
         uint32_t nblk;
         if (phase == 0 && !no_fused) {
-            Timed t(ctx, "layer_round_fused", pending ? (double)h * 2.0 * 6.0 * 32.0 : (double)h * 2.0 * 2.0 * 32.0);
-            nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, s);
+            Timed t(ctx, "layer_round_fused", (pending ? (double)h * 2.0 * 6.0 : (double)h * 2.0 * 2.0) * 32.0 * batch);
+            nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, lb, s);
             pending = nullptr;
         } else {
             if (pending) {
-                Timed t(ctx, "layer_fold", (double)h * 2.0 * 6.0 * 32.0);
-                gkr::launch_layer_fold(A, M, 2 * h, pending, s);
+                Timed t(ctx, "layer_fold", (double)h * 2.0 * 6.0 * 32.0 * batch);
+                gkr::launch_layer_fold(A, M, 2 * h, pending, lb, s);
                 pending = nullptr;
             }
             nblk = gkr::layer_blocks(h);
-            Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0);
-            gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, s);
+            if (nblk * (uint32_t)batch > 4096u) nblk = 4096u / batch ? 4096u / batch : 1u;
+            Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0 * batch);
+            gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, lb, s);
         }
         if (host_tx) {
             const uint32_t ticket = ++ctx->ticket;
             {
                 Timed t(ctx, "layer_round_reduce", 0.0);
-                gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, s);
+                gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, lb, s);
             }
-            rc = wait_records(ctx, rec, 1, ticket);
-            if (rc) return rc;
-            // g = [c2, c1, c0] with c1 = g(1) - c0 - c2; length 2 + dep (get_univariate_coeff, poly.rs:388-420)
-            gkr::h64::F c0, g1, c2;
-            memcpy(&c0, &rec->c0, 32);
-            memcpy(&g1, &rec->g1, 32);
-            memcpy(&c2, &rec->c2, 32);
-            gkr::h64::F lin = gkr::h64::sub(gkr::h64::sub(g1, c0), c2);
-            const uint32_t ln = 2u + (h_dep[round % k] ? 1u : 0u);
-            gkr::h64::F vec[3] = {c2, lin, c0};
-            gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (3 - ln), (int)ln, cts64, nullptr);
-            gkr_fr* oc = out_coeffs + (size_t)round * 3;
-            memset(&oc[0], 0, 32);
-            if (ln == 3) memcpy(&oc[0], &c2, 32);
-            memcpy(&oc[1], &lin, 32);
-            memcpy(&oc[2], &c0, 32);
-            out_len[round] = ln;
-            memcpy(&out_r[round], &r, 32);
-            // two pinned tables used alternately: the deferred fold of round j reads table j % 2 while
-            // the host already writes round j+1's
-            gkr::FixedMul* slot = h_rtab + (round & 1);
-            gkr::h64::make_fixed_mul(r, slot->w);
+            rc = wait_records(ctx, rec, batch, ticket);
+            if (rc) break;
+            // two sets of pinned tables used alternately: the deferred fold of round j reads set j % 2
+            // while the host already writes round j+1's
+            gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
+            if (pool) {
+                std::atomic<int> next{0};
+                const std::function<bool()> work = [&]() -> bool {
+                    const int first = next.fetch_add(8, std::memory_order_relaxed);
+                    if (first >= batch) return false;
+                    hash_chunk(first, batch - first < 8 ? batch - first : 8, round, slot);
+                    return true;
+                };
+                pool->run_now(&work);
+            } else {
+                for (int first = 0; first < batch; first += 8) hash_chunk(first, batch - first < 8 ? batch - first : 8, round, slot);
+            }
             // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc)
-            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, s);
+            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
             pending = slot;
         } else {
             Timed t(ctx, "layer_round_hash", 0.0);
@@ -992,56 +1046,71 @@ int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t*
             pending = d_rtab + round;
         }
     }
+    if (pool) pool->end_session();
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (!host_tx) {
-        HIP_TRY(ctx, hipMemcpyAsync(out_coeffs, d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(out_r, d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_coeffs[0], d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_len[0], d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_r[0], d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->drain_events();
     return GKR_OK;
 }
 
+int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z,
+              const Fr* d_W, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    return run_layer_batch(ctx, 1, k_i, k, d_gt, d_l, d_r, z, d_W, &out_coeffs, &out_len, &out_r);
+}
+
 // evaluation table -> monomial coefficients, variable 1 = most significant bit
-// (what get_multi_ext stores, poly.rs:502-536)
-void mobius_msb(std::vector<Fr>& c, int k) {
+// (what get_multi_ext stores, poly.rs:502-536); host, 4x64-bit arithmetic
+void mobius_msb(std::vector<gkr::h64::F>& c, int k) {
     const size_t n = (size_t)1 << k;
     for (int b = 0; b < k; ++b) {
         const size_t bit = (size_t)1 << (k - 1 - b);
         for (size_t i = 0; i < n; ++i)
-            if (i & bit) c[i] = gkr::fr_sub(c[i], c[i ^ bit]);
+            if (i & bit) c[i] = gkr::h64::sub(c[i], c[i ^ bit]);
     }
 }
 
 // reduce_multiple_polynomial (poly.rs:469-500): q(t) = W(b + t (c - b)).
 // coeffs: monomial coefficients of W.  out: k+1 slots right-aligned, highest first.
-void line_restriction(const std::vector<Fr>& coeffs, int k, const gkr_fr* b, const gkr_fr* c, gkr_fr* out,
+void line_restriction(const std::vector<gkr::h64::F>& coeffs, int k, const gkr_fr* b, const gkr_fr* c, gkr_fr* out,
                       uint32_t* out_len) {
-    std::vector<Fr> grad(k), cst(k), res(k + 1, gkr::fr_zero()), poly(k + 2);
+    using gkr::h64::F;
+    const F zero = {{0, 0, 0, 0}};
+    std::vector<F> grad(k), cst(k), res(k + 1, zero), poly(k + 2);
     for (int j = 0; j < k; ++j) {
-        grad[j] = gkr::to_mont(gkr::fr_sub(to_dev(c[j]), to_dev(b[j])));
-        cst[j] = gkr::to_mont(to_dev(b[j]));
+        F bj, cj;
+        memcpy(&bj, &b[j], 32);
+        memcpy(&cj, &c[j], 32);
+        grad[j] = gkr::h64::to_mont(gkr::h64::sub(cj, bj));
+        cst[j] = gkr::h64::to_mont(bj);
     }
     int maxdeg = 0;
     const size_t n = (size_t)1 << k;
     for (size_t mono = 0; mono < n; ++mono) {
-        if (gkr::fr_is_zero(coeffs[mono])) continue;
+        if (gkr::h64::is_zero(coeffs[mono])) continue;
         int deg = 0;
         poly[0] = coeffs[mono];
         for (int j = 0; j < k; ++j) {
             if (!((mono >> (k - 1 - j)) & 1)) continue;
-            poly[deg + 1] = gkr::fr_zero();
+            poly[deg + 1] = zero;
             for (int d = deg + 1; d >= 1; --d)
-                poly[d] = gkr::fr_add(gkr::mont_mul(poly[d - 1], grad[j]), gkr::mont_mul(poly[d], cst[j]));
-            poly[0] = gkr::mont_mul(poly[0], cst[j]);
+                poly[d] = gkr::h64::add(gkr::h64::mont_mul(poly[d - 1], grad[j]), gkr::h64::mont_mul(poly[d], cst[j]));
+            poly[0] = gkr::h64::mont_mul(poly[0], cst[j]);
             ++deg;
         }
         if (deg > maxdeg) maxdeg = deg;
-        for (int d = 0; d <= deg; ++d) res[d] = gkr::fr_add(res[d], poly[d]);
+        for (int d = 0; d <= deg; ++d) res[d] = gkr::h64::add(res[d], poly[d]);
     }
     *out_len = (uint32_t)(maxdeg + 1);
-    for (int d = 0; d <= k; ++d) out[k - d] = to_abi(res[d]);
+    for (int d = 0; d <= k; ++d) memcpy(&out[k - d], &res[d], 32);
 }
 
 int check_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c) {
@@ -1261,6 +1330,14 @@ int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
         gkr::lazy_add(q[2], q[3]);
         gkr::lazy_add(q[0], q[2]);
         if (!gkr::fr_eq(gkr::lazy_reduce_k8(q[0]), r)) return GKR_ERR_INVALID;
+        gkr::Lazy17 ws;   // the one-shot column form the multifold kernel uses
+        gkr::weighted_sum_s<8>(xs, ys, ws);
+        if (!gkr::fr_eq(gkr::lazy_reduce_k8(ws), r)) return GKR_ERR_INVALID;
+        if (n <= 4) {
+            Fr x4[4] = {xs[0], xs[1], xs[2], xs[3]};
+            gkr::weighted_sum_s<4>(x4, ys, ws);
+            if (!gkr::fr_eq(gkr::lazy_reduce_k8(ws), r)) return GKR_ERR_INVALID;
+        }
     }
     *out = to_abi(r);
     return GKR_OK;
@@ -1400,7 +1477,7 @@ int gkr_layer_eval(gkr_ctx* ctx, size_t gates, const uint8_t* gate_type, const u
     HIP_TRY(ctx, dprev.alloc(n_prev));
     HIP_TRY(ctx, dout.alloc(gates));
     HIP_TRY(ctx, hipMemcpyAsync(dprev.p, prev, n_prev * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    gkr::launch_layer_eval((uint32_t)gates, dgt.p, dl.p, dr.p, dprev.p, dout.p, ctx->stream);
+    gkr::launch_layer_eval((uint32_t)gates, dgt.p, dl.p, dr.p, dprev.p, dout.p, 1, 0, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, gates * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1424,14 +1501,23 @@ int gkr_proof_sizes(const gkr_circuit_desc* c, gkr_proof_sizes_t* out) {
     return GKR_OK;
 }
 
-int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int require_zero_output,
-              gkr_proof_buf* out) {
-    if (!ctx) return GKR_ERR_INVALID;
+// `batch` proofs of ONE circuit (different witnesses) advanced together: every layer's sumcheck runs as
+// one batched sumcheck (run_layer_batch), so a round costs one set of launches and one host round trip
+// for all proofs.  This is the multi-proof form of the reference's rayon par_iter over independent
+// (circuit, input) pairs (aggregator.rs:350-355) for the case where the circuits coincide
+// (BASELINE configs[3]: 64 inputs of one circom circuit).
+static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch,
+                            int require_zero_output, gkr_proof_buf* outs) {
+    using gkr::h64::F;
     int rc = check_circuit(ctx, c);
     if (rc) return rc;
-    if (!input_values || !out || !out->sumcheck_coeffs || !out->sumcheck_len || !out->sumcheck_r || !out->q ||
-        !out->q_len || !out->z || !out->r || !out->d_coeffs || !out->input_coeffs)
-        return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
+    if (!input_values || !outs || batch < 1 || batch > 4096) return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of [1, 4096]");
+    for (int b = 0; b < batch; ++b) {
+        const gkr_proof_buf* out = &outs[b];
+        if (!out->sumcheck_coeffs || !out->sumcheck_len || !out->sumcheck_r || !out->q || !out->q_len || !out->z || !out->r ||
+            !out->d_coeffs || !out->input_coeffs)
+            return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
+    }
     const uint32_t L = c->depth;
     for (uint32_t i = 0; i < L; ++i) {
         if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
@@ -1441,76 +1527,118 @@ int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_value
                 return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
     }
     const size_t n_in = (size_t)1 << c->k[L];
-    if (!all_canonical(input_values, n_in)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+    if (!all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
-    // upload the circuit; forward-evaluate every layer on the device (calculate_input, convert.rs:787-831)
+    // upload the circuit; forward-evaluate every layer of every proof on the device (calculate_input, convert.rs:787-831)
     std::vector<DevBuf<uint8_t>> dgt(L);
     std::vector<DevBuf<uint32_t>> dl(L), dr(L);
     std::vector<DevBuf<Fr>> dW(L + 1);
     for (uint32_t i = 0; i < L; ++i) {
         rc = upload_gates(ctx, (size_t)1 << c->k[i], c->gate_type[i], c->left[i], c->right[i], dgt[i], dl[i], dr[i]);
         if (rc) return rc;
-        HIP_TRY(ctx, dW[i].alloc((size_t)1 << c->k[i]));
+        HIP_TRY(ctx, dW[i].alloc((size_t)batch << c->k[i]));
     }
-    HIP_TRY(ctx, dW[L].alloc(n_in));
-    HIP_TRY(ctx, hipMemcpyAsync(dW[L].p, input_values, n_in * sizeof(Fr), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, dW[L].alloc(n_in * batch));
+    HIP_TRY(ctx, hipMemcpyAsync(dW[L].p, input_values, n_in * batch * sizeof(Fr), hipMemcpyHostToDevice, s));
     for (int i = (int)L - 1; i >= 0; --i)
-        gkr::launch_layer_eval(1u << c->k[i], dgt[i].p, dl[i].p, dr[i].p, dW[i + 1].p, dW[i].p, s);
+        gkr::launch_layer_eval(1u << c->k[i], dgt[i].p, dl[i].p, dr[i].p, dW[i + 1].p, dW[i].p, (uint32_t)batch, 1u << c->k[i + 1], s);
     HIP_TRY(ctx, hipGetLastError());
-    std::vector<std::vector<Fr>> hW(L + 1);
+    std::vector<std::vector<F>> hW(L + 1);
     for (uint32_t i = 0; i <= L; ++i) {
-        hW[i].resize((size_t)1 << c->k[i]);
-        HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i].p, sizeof(Fr) << c->k[i], hipMemcpyDeviceToHost, s));
+        hW[i].resize((size_t)batch << c->k[i]);
+        HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i].p, sizeof(Fr) * hW[i].size(), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (require_zero_output && !gkr::fr_is_zero(hW[0][0]))
-        return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
-
-    // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
-    {
-        std::vector<Fr> co = hW[0];
+    for (int b = 0; b < batch; ++b) {
+        if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
+            return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
+        // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
+        std::vector<F> co(hW[0].begin() + ((size_t)b << c->k[0]), hW[0].begin() + ((size_t)(b + 1) << c->k[0]));
         mobius_msb(co, c->k[0]);
-        memcpy(out->d_coeffs, co.data(), co.size() * sizeof(Fr));
-        co = hW[L];
+        memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
+        co.assign(hW[L].begin() + ((size_t)b << c->k[L]), hW[L].begin() + ((size_t)(b + 1) << c->k[L]));
         mobius_msb(co, c->k[L]);
-        memcpy(out->input_coeffs, co.data(), co.size() * sizeof(Fr));
+        memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
+        // z[0] = 0 (prover.rs:16-21)
+        for (uint32_t j = 0; j < c->k[0]; ++j) memset(&outs[b].z[j], 0, sizeof(gkr_fr));
     }
-
-    // z[0] = 0 (prover.rs:16-21)
-    gkr_fr* z_cur = out->z;
-    for (uint32_t j = 0; j < c->k[0]; ++j) memset(&z_cur[j], 0, sizeof(gkr_fr));
-    gkr_fr* sc = out->sumcheck_coeffs;
-    uint32_t* sl = out->sumcheck_len;
-    gkr_fr* sr = out->sumcheck_r;
-    gkr_fr* q = out->q;
+    std::vector<gkr_fr> z_cur((size_t)batch * (c->k[0] ? c->k[0] : 1));
+    memset(z_cur.data(), 0, z_cur.size() * sizeof(gkr_fr));
+    std::vector<gkr_fr*> scp(batch), srp(batch);
+    std::vector<uint32_t*> slp(batch);
+    size_t row_off = 0, q_off = 0, z_off = 0;
+    gkr::SpinPool* pool = batch >= 16 ? ctx->host_pool() : nullptr;
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = c->k[i], k = c->k[i + 1];
-        rc = run_layer(ctx, k_i, k, dgt[i].p, dl[i].p, dr[i].p, z_cur, dW[i + 1].p, sc, sl, sr);
+        for (int b = 0; b < batch; ++b) {
+            scp[b] = outs[b].sumcheck_coeffs + row_off * 3;
+            slp[b] = outs[b].sumcheck_len + row_off;
+            srp[b] = outs[b].sumcheck_r + row_off;
+        }
+        rc = run_layer_batch(ctx, batch, k_i, k, dgt[i].p, dl[i].p, dr[i].p, z_cur.data(), dW[i + 1].p, scp.data(), slp.data(),
+                             srp.data());
         if (rc) return rc;
-        const gkr_fr* b_star = sr;
-        const gkr_fr* c_star = sr + k;
-        // q_i = W_{i+1} restricted to the line b* -> c* (prover.rs:70)
-        std::vector<Fr> co = hW[i + 1];
-        mobius_msb(co, k);
-        line_restriction(co, k, b_star, c_star, q, &out->q_len[i]);
-        // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector
-        // and key as the sumcheck's last challenge, so it is that challenge
-        const gkr_fr r_star = sr[2 * k - 1];
-        out->r[i] = r_star;
-        // z_{i+1} = b* + r* (c* - b*) (l_function, poly.rs:538-551)
-        gkr_fr* z_next = z_cur + k_i;
-        const Fr rs = gkr::to_mont(to_dev(r_star));
-        for (int j = 0; j < k; ++j)
-            z_next[j] = to_abi(gkr::fr_fold(to_dev(b_star[j]), to_dev(c_star[j]), rs));
-        z_cur = z_next;
-        sc += (size_t)2 * k * 3;
-        sl += 2 * k;
-        sr += 2 * k;
-        q += k + 1;
+        std::vector<gkr_fr> z_next((size_t)batch * k);
+        auto finish = [&](int b) {
+            const gkr_fr* sr = srp[b];
+            const gkr_fr* b_star = sr;
+            const gkr_fr* c_star = sr + k;
+            // q_i = W_{i+1} restricted to the line b* -> c* (prover.rs:70)
+            std::vector<F> co(hW[i + 1].begin() + ((size_t)b << k), hW[i + 1].begin() + ((size_t)(b + 1) << k));
+            mobius_msb(co, k);
+            line_restriction(co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
+            // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector and key as the
+            // sumcheck's last challenge, so it is that challenge
+            const gkr_fr r_star = sr[2 * k - 1];
+            outs[b].r[i] = r_star;
+            // z_{i+1} = b* + r* (c* - b*) (l_function, poly.rs:538-551)
+            F rs;
+            memcpy(&rs, &r_star, 32);
+            rs = gkr::h64::to_mont(rs);
+            gkr_fr* zn = outs[b].z + z_off + k_i;
+            for (int j = 0; j < k; ++j) {
+                F bj, cj;
+                memcpy(&bj, &b_star[j], 32);
+                memcpy(&cj, &c_star[j], 32);
+                const F v = gkr::h64::add(bj, gkr::h64::mont_mul(gkr::h64::sub(cj, bj), rs));
+                memcpy(&zn[j], &v, 32);
+                memcpy(&z_next[(size_t)b * k + j], &v, 32);
+            }
+        };
+        if (pool) {
+            std::atomic<int> next{0};
+            const std::function<bool()> work = [&]() -> bool {
+                const int b = next.fetch_add(1, std::memory_order_relaxed);
+                if (b >= batch) return false;
+                finish(b);
+                return true;
+            };
+            pool->begin_session(nullptr);
+            pool->run_now(&work);
+            pool->end_session();
+        } else {
+            for (int b = 0; b < batch; ++b) finish(b);
+        }
+        z_cur.swap(z_next);
+        row_off += (size_t)2 * k;
+        q_off += (size_t)k + 1;
+        z_off += (size_t)k_i;
     }
     return GKR_OK;
+}
+
+int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int require_zero_output,
+              gkr_proof_buf* out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    return prove_batch_impl(ctx, c, input_values, 1, require_zero_output, out);
+}
+
+int gkr_prove_batch(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch, int require_zero_output,
+                    gkr_proof_buf* outs) {
+    if (!ctx) return GKR_ERR_INVALID;
+    return prove_batch_impl(ctx, c, input_values, batch, require_zero_output, outs);
 }
 
 // ---- step-wise sessions: one sumcheck split across GPUs ------------------------
@@ -1616,7 +1744,7 @@ int gkr_layer_session_open(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gat
     (void)hipMemsetAsync(S->d_dep, 0, 32 * sizeof(uint32_t), s);
     gkr::launch_to_mont(dW.p, S->Wb, 1u << k_next, s);
     gkr::launch_to_mont_strided(dW.p, S->Wc, 1u << S->kc, nshards, shard, s);
-    gkr::launch_depends(dW.p, k_next, S->d_dep, s);
+    gkr::launch_depends(dW.p, k_next, S->d_dep, 1, s);
     e = hipMemcpyAsync(S->dep, S->d_dep, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
@@ -1688,9 +1816,9 @@ int gkr_layer_session_sums(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
     const uint32_t phase = S->round < (uint32_t)S->k ? 0u : 1u;
     const uint32_t hb = phase == 0 ? (h >> S->kc) : 0u;
     const uint32_t nblk = gkr::layer_blocks(h);
-    gkr::launch_layer_round(S->A, S->M, h, (uint32_t)S->kc, phase, hb, S->Wb, S->Wc, nblk, S->partials, s);
+    gkr::launch_layer_round(S->A, S->M, h, (uint32_t)S->kc, phase, hb, S->Wb, S->Wc, nblk, S->partials, gkr::single_layer(), s);
     const uint32_t ticket = ++ctx->ticket;
-    gkr::launch_layer_round_reduce(S->partials, nblk, S->rec, ticket, s);
+    gkr::launch_layer_round_reduce(S->partials, nblk, S->rec, ticket, gkr::single_layer(), s);
     HIP_TRY(ctx, hipGetLastError());
     int rc = wait_records(ctx, S->rec, 1, ticket);
     if (rc) return rc;
@@ -1715,8 +1843,8 @@ int gkr_layer_session_bind(gkr_ctx* ctx, gkr_layer_session* S, const gkr_fr* r) 
     // the W copy bound in this round: b-rounds fold Wb (2^k entries at the start), c-rounds fold Wc
     const uint32_t idx = bphase ? S->round : S->round - (uint32_t)S->k;
     const uint32_t hw = bphase ? (1u << (S->k - 1 - idx)) : (1u << (S->kc - 1 - idx));
-    gkr::launch_fold_small(bphase ? S->Wb : S->Wc, hw, S->rtab, s);
-    gkr::launch_layer_fold(S->A, S->M, h, S->rtab, s);
+    gkr::launch_fold_small(bphase ? S->Wb : S->Wc, hw, S->rtab, gkr::single_layer(), s);
+    gkr::launch_layer_fold(S->A, S->M, h, S->rtab, gkr::single_layer(), s);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));   // rtab is reused by the next bind
     S->cells = h;

@@ -48,6 +48,18 @@ class SpinPool {
         }
         cv_.notify_all();
     }
+    // Within an open session: run `work` on the workers and the caller until it reports no work left,
+    // then return once every participant has left it.  (A session opened with a null function idles
+    // between run_now calls.)
+    void run_now(const std::function<bool()>* work) {
+        // job_busy_ is a balanced in/out count of workers inside the probe window: never reset it
+        job_.store(work, std::memory_order_release);
+        while ((*work)()) {
+        }
+        job_.store(nullptr, std::memory_order_release);
+        while (job_busy_.load(std::memory_order_acquire) != 0) GKR_CPU_RELAX();
+    }
+
     // returns once no worker is inside try_work any more
     void end_session() {
         session_.fetch_add(1, std::memory_order_release);       // even = closed
@@ -70,7 +82,16 @@ class SpinPool {
                 const std::function<bool()>* fn = fn_;
                 unsigned idle = 0;
                 while (session_.load(std::memory_order_acquire) == s) {
-                    if ((*fn)()) {
+                    bool did = false;
+                    if (fn) {
+                        did = (*fn)();
+                    } else {
+                        job_busy_.fetch_add(1, std::memory_order_acq_rel);
+                        const std::function<bool()>* job = job_.load(std::memory_order_acquire);
+                        if (job) did = (*job)();
+                        job_busy_.fetch_sub(1, std::memory_order_acq_rel);
+                    }
+                    if (did) {
                         idle = 0;
                     } else {
                         GKR_CPU_RELAX();
@@ -91,6 +112,8 @@ class SpinPool {
     std::atomic<int> inside_{0};
     std::atomic<bool> stop_{false};
     const std::function<bool()>* fn_ = nullptr;
+    std::atomic<const std::function<bool()>*> job_{nullptr};
+    std::atomic<int> job_busy_{0};
 };
 
 }  // namespace gkr

@@ -17,6 +17,15 @@ struct MlePartial {
     uint32_t dep, pad;
 };
 
+// a batch of layer sumchecks that share their gates (proofs of one circuit): per-proof strides of the
+// predicate tables, the W copies and the partials; batch = 1 with zero strides is the single sumcheck
+struct LayerBatch {
+    uint32_t batch;
+    uint32_t pstride;
+    size_t tstride, wstride;
+};
+inline LayerBatch single_layer() { return LayerBatch{1u, 0u, 0, 0}; }
+
 struct LayerPartial {
     Acc<9> c0, g1, c2;
     uint32_t pad;
@@ -63,8 +72,8 @@ void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
                                 uint32_t batch, const Fr* weights, MleHostRec8* host_rec, uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
-                               hipStream_t s);
-void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, hipStream_t s);
+                               LayerBatch lb, hipStream_t s);
+void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s);
 
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
 
@@ -78,9 +87,9 @@ void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t r
                            uint32_t* dep_last, hipStream_t s);
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
-                       const Fr* prev, Fr* out, hipStream_t s);
+                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s);
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
-void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s);
+void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, uint32_t batch, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
                               const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
                               unsigned long long* wideA, unsigned long long* wideM, uint32_t* bad, uint32_t log_p,
@@ -91,15 +100,17 @@ void launch_fold_pair(const Fr* src, Fr* dst, const FixedMul* rtab, hipStream_t 
 void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
                              const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, uint32_t log_p,
                              uint32_t shard, size_t ncells, uint32_t* counts, uint32_t* offsets, uint32_t* cursor,
-                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, hipStream_t s);
+                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, uint32_t batch,
+                             hipStream_t s);
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s);
 
 uint32_t layer_blocks(uint32_t h);
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
-                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s);
+                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, LayerBatch lb, hipStream_t s);
 uint32_t launch_layer_round_b(bool fold, const Fr* A_src, const Fr* M_src, Fr* A_dst, Fr* M_dst, uint32_t hb, uint32_t kc,
-                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, hipStream_t s);
-void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s);
+                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, LayerBatch lb,
+                              hipStream_t s);
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, LayerBatch lb, hipStream_t s);
 void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,
                              const uint32_t* dep, const Fr* cts, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
                              FixedMul* rtab, Fr* Wb, Fr* Wc, hipStream_t s);

@@ -246,23 +246,19 @@ __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restr
 // advance together (four at a time where there are that many), one reduction
 template <int JIN>
 __device__ __forceinline__ Fr multifold_entry(const Fr* __restrict__ s, uint32_t S, uint32_t i, const Fr* __restrict__ w) {
-    if (JIN == 1) {
+    if constexpr (JIN == 1) {
         Lazy17 a0 = lazy_zero(), a1 = lazy_zero();
         lazy_mac2_s(a0, load_fr(s + i), w[0], a1, load_fr(s + (size_t)S + i), w[1]);
         lazy_add(a0, a1);
         return lazy_reduce_k8(a0);
-    }
-    Lazy17 a0 = lazy_zero(), a1 = lazy_zero(), a2 = lazy_zero(), a3 = lazy_zero();
+    } else {
+        Fr x[1 << JIN];
 #pragma unroll
-    for (int b = 0; b < (1 << JIN); b += 4) {
-        const Fr x0 = load_fr(s + (size_t)b * S + i), x1 = load_fr(s + (size_t)(b + 1) * S + i);
-        const Fr x2 = load_fr(s + (size_t)(b + 2) * S + i), x3 = load_fr(s + (size_t)(b + 3) * S + i);
-        lazy_mac4_s(a0, x0, w[b], a1, x1, w[b + 1], a2, x2, w[b + 2], a3, x3, w[b + 3]);
+        for (int b = 0; b < (1 << JIN); ++b) x[b] = load_fr(s + (size_t)b * S + i);
+        Lazy17 t;
+        weighted_sum_s<(1 << JIN)>(x, w, t);
+        return lazy_reduce_k8(t);
     }
-    lazy_add(a0, a1);
-    lazy_add(a2, a3);
-    lazy_add(a0, a2);
-    return lazy_reduce_k8(a0);
 }
 
 // pass 0: sub-block sums of the input tables.  grid = (nblk, batch), nblk = 2^J * blocks-per-sub-block,
@@ -462,7 +458,9 @@ __global__ void __launch_bounds__(64) k_mle_round_reduce(const MlePartial* __res
 
 __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_type,
                              const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                             const Fr* __restrict__ prev, Fr* __restrict__ out) {
+                             const Fr* __restrict__ prev, Fr* __restrict__ out, uint32_t prev_stride) {
+    prev += (size_t)blockIdx.y * prev_stride;   // grid.y = proof of a batch (same gates, its own values)
+    out += (size_t)blockIdx.y * gates;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < gates; g += gridDim.x * blockDim.x) {
         Fr a = load_fr(prev + left[g]), b = load_fr(prev + right[g]);
         store_fr(out + g, gate_type[g] ? fr_mul(a, b) : fr_add(a, b));
@@ -502,6 +500,8 @@ __global__ void k_fold_pair(const Fr* __restrict__ src, Fr* __restrict__ dst, co
 // monomial of the MLE carries variable b+1 (length rule, poly.rs:388-420)
 __global__ void k_depends(const Fr* __restrict__ W, uint32_t k, uint32_t* __restrict__ dep) {
     const uint32_t n = 1u << k;
+    W += (size_t)blockIdx.y << k;   // grid.y = proof of a batch: its own W, its own 32 flags
+    dep += (size_t)blockIdx.y * 32;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Fr a = load_fr(W + i);
         for (uint32_t b = 0; b < k; ++b) {
@@ -663,8 +663,13 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offsets
 __global__ void __launch_bounds__(256) k_pred_sum(size_t ncells, const uint32_t* __restrict__ offsets,
                                                   const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ list,
                                                   const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl,
-                                                  Fr* __restrict__ out_A, Fr* __restrict__ out_M) {
+                                                  uint32_t kh, Fr* __restrict__ out_A, Fr* __restrict__ out_M) {
     const uint32_t lmask = (1u << kl) - 1u;
+    // grid.y = proof of a batch: same gates (same cell lists), its own eq tables and output tables
+    e_hi += (size_t)blockIdx.y << kh;
+    e_lo_mont += (size_t)blockIdx.y << kl;
+    out_A += (size_t)blockIdx.y * ncells;
+    out_M += (size_t)blockIdx.y * ncells;
     for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < 2 * ncells; c += (size_t)gridDim.x * blockDim.x) {
         const uint32_t b = offsets[c], e = cursor[c];
         Fr acc = fr_zero();
@@ -733,9 +738,14 @@ __device__ __forceinline__ PairTerms layer_pair(const Fr& a0, const Fr& a1, cons
 __global__ void __launch_bounds__(256) k_layer_round(const Fr* __restrict__ A, const Fr* __restrict__ M, uint32_t h,
                                                      uint32_t k, uint32_t phase, uint32_t hb,
                                                      const Fr* __restrict__ Wb, const Fr* __restrict__ Wc,
-                                                     LayerPartial* __restrict__ partials) {
+                                                     LayerPartial* __restrict__ partials, LayerBatch lb) {
     __shared__ Acc<9> smem[4 * 3];
     Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
+    A += blockIdx.y * lb.tstride;   // grid.y = proof of a batch
+    M += blockIdx.y * lb.tstride;
+    Wb += blockIdx.y * lb.wstride;
+    Wc += blockIdx.y * lb.wstride;
+    partials += blockIdx.y * lb.pstride;
     const uint32_t cmask = (1u << k) - 1;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
         Fr a0 = load_fr(A + i), a1 = load_fr(A + i + h);
@@ -787,15 +797,21 @@ __global__ void __launch_bounds__(256) k_layer_round_b(const Fr* __restrict__ A_
                                                        Fr* __restrict__ A_dst, Fr* __restrict__ M_dst, uint32_t hb,
                                                        uint32_t kc, uint32_t rows_per_chunk,
                                                        const FixedMul* __restrict__ rtab, const Fr* __restrict__ Wb,
-                                                       const Fr* __restrict__ Wc, LayerPartial* __restrict__ partials) {
+                                                       const Fr* __restrict__ Wc, LayerPartial* __restrict__ partials,
+                                                       LayerBatch lb, uint32_t chunks) {
     __shared__ Acc<9> smem[4 * 3];
     const bool is_m = blockIdx.z != 0;
-    const Fr* src = is_m ? M_src : A_src;
-    Fr* dst = is_m ? M_dst : A_dst;
+    const uint32_t proof = blockIdx.y / chunks, chunk_id = blockIdx.y % chunks;   // grid.y = (proof, row chunk)
+    const Fr* src = (is_m ? M_src : A_src) + proof * lb.tstride;
+    Fr* dst = (is_m ? M_dst : A_dst) + proof * lb.tstride;
+    Wb += proof * lb.wstride;
+    Wc += proof * lb.wstride;
+    rtab += proof;
+    partials += proof * lb.pstride;
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ncols = 1u << kc;
     const size_t h = (size_t)hb << kc;   // entries per half of the folded table
-    const uint32_t r0 = blockIdx.y * rows_per_chunk;
+    const uint32_t r0 = chunk_id * rows_per_chunk;
     uint32_t r1 = r0 + rows_per_chunk;
     if (r1 > hb) r1 = hb;
     FixedMul T;
@@ -853,7 +869,7 @@ __global__ void __launch_bounds__(256) k_layer_round_b(const Fr* __restrict__ A_
     }
     block_sum<9, 3>(acc, smem);
     if (threadIdx.x == 0) {
-        LayerPartial* p = partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        LayerPartial* p = partials + ((size_t)blockIdx.z * chunks + chunk_id) * gridDim.x + blockIdx.x;
         p->c0 = acc[0];
         p->g1 = acc[1];
         p->c2 = acc[2];
@@ -862,8 +878,10 @@ __global__ void __launch_bounds__(256) k_layer_round_b(const Fr* __restrict__ A_
 
 // fold A and M in place with the challenge of the round just hashed: T[i] += r (T[i+h] - T[i])
 __global__ void __launch_bounds__(256) k_layer_fold(Fr* __restrict__ A, Fr* __restrict__ M, uint32_t h,
-                                                    const FixedMul* __restrict__ rtab) {
-    const FixedMul T = *rtab;
+                                                    const FixedMul* __restrict__ rtab, LayerBatch lb) {
+    A += blockIdx.y * lb.tstride;   // grid.y = proof of a batch
+    M += blockIdx.y * lb.tstride;
+    const FixedMul T = rtab[blockIdx.y];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
         store_fr(A + i, fr_fold_fixed(load_fr(A + i), load_fr(A + i + h), T));
         store_fr(M + i, fr_fold_fixed(load_fr(M + i), load_fr(M + i + h), T));
@@ -922,7 +940,10 @@ __global__ void __launch_bounds__(64) k_layer_round_hash(const LayerPartial* __r
 
 // Host-transcript tail of a layer round: totals -> pinned host record.
 __global__ void __launch_bounds__(64) k_layer_round_reduce(const LayerPartial* __restrict__ partials, uint32_t nblk,
-                                                           LayerHostRec* __restrict__ host_rec, uint32_t ticket) {
+                                                           LayerHostRec* __restrict__ host_rec, uint32_t ticket,
+                                                           uint32_t pstride) {
+    partials += (size_t)blockIdx.x * pstride;   // grid.x = proof of a batch
+    host_rec += blockIdx.x;
     Acc<10> c0 = acc_zero<10>(), g1 = acc_zero<10>(), c2 = acc_zero<10>();
     for (uint32_t i = threadIdx.x; i < nblk; i += 64) {
         acc_add_acc(c0, partials[i].c0);
@@ -943,8 +964,10 @@ __global__ void __launch_bounds__(64) k_layer_round_reduce(const LayerPartial* _
 // In-place fold of a small Montgomery table (the W copy bound in this round):
 // W[i] += r (W[i + hw] - W[i]).  One block; see k_layer_round_hash for why the
 // strided in-place loop is safe.
-__global__ void __launch_bounds__(256) k_fold_small(Fr* __restrict__ W, uint32_t hw, const FixedMul* __restrict__ rtab) {
-    const FixedMul T = *rtab;
+__global__ void __launch_bounds__(256) k_fold_small(Fr* __restrict__ W, uint32_t hw, const FixedMul* __restrict__ rtab,
+                                                    uint32_t wstride) {
+    W += (size_t)blockIdx.x * wstride;   // grid.x = proof of a batch
+    const FixedMul T = rtab[blockIdx.x];
     for (uint32_t base = 0; base < hw; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         Fr v = fr_zero();
@@ -1002,9 +1025,9 @@ void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t r
 }
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
-                       const Fr* prev, Fr* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096)), dim3(256), 0, s, gates, gate_type, left, right,
-                       prev, out);
+                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096), batch), dim3(256), 0, s, gates, gate_type, left, right,
+                       prev, out, prev_stride);
 }
 
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s) {
@@ -1023,8 +1046,8 @@ void launch_fold_pair(const Fr* src, Fr* dst, const FixedMul* rtab, hipStream_t 
     hipLaunchKernelGGL(k_fold_pair, dim3(1), dim3(64), 0, s, src, dst, rtab);
 }
 
-void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, hipStream_t s) {
-    hipLaunchKernelGGL(k_depends, dim3(blocks_for(1u << k, 1024)), dim3(256), 0, s, W, k, dep);
+void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, uint32_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_depends, dim3(blocks_for(1u << k, 1024), batch), dim3(256), 0, s, W, k, dep);
 }
 
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
@@ -1040,7 +1063,8 @@ void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate
 void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,
                              const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, uint32_t log_p,
                              uint32_t shard, size_t ncells, uint32_t* counts, uint32_t* offsets, uint32_t* cursor,
-                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, hipStream_t s) {
+                             uint32_t* block_sums, uint32_t* list, uint32_t* bad, Fr* out_A, Fr* out_M, uint32_t batch,
+                             hipStream_t s) {
     const size_t n = 2 * ncells;
     const uint32_t gblocks = blocks_for(1ull << k_i, 4096);
     const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
@@ -1051,8 +1075,8 @@ void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_
     hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, offsets, cursor, block_sums, n);
     hipLaunchKernelGGL(k_pred_fill, dim3(gblocks), dim3(256), 0, s, k_i, k_next, gate_type, left, right, log_p, shard, ncells,
                        cursor, list, bad);
-    hipLaunchKernelGGL(k_pred_sum, dim3(blocks_for(n, 8192)), dim3(256), 0, s, ncells, offsets, cursor, list, e_hi, e_lo_mont,
-                       kl, out_A, out_M);
+    hipLaunchKernelGGL(k_pred_sum, dim3(blocks_for(n, 8192), batch), dim3(256), 0, s, ncells, offsets, cursor, list, e_hi,
+                       e_lo_mont, kl, k_i - kl, out_A, out_M);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
@@ -1115,43 +1139,44 @@ void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t
 }
 
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(k_layer_round_reduce, dim3(1), dim3(64), 0, s, partials, nblk, host_rec, ticket);
+                               LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_round_reduce, dim3(lb.batch), dim3(64), 0, s, partials, nblk, host_rec, ticket, lb.pstride);
 }
 
-void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, hipStream_t s) {
-    hipLaunchKernelGGL(k_fold_small, dim3(1), dim3(256), 0, s, W, hw, rtab);
+void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_small, dim3(lb.batch), dim3(256), 0, s, W, hw, rtab, (uint32_t)lb.wstride);
 }
 
 uint32_t layer_blocks(uint32_t h) { return blocks_for(h, kMaxLayerBlocks); }
 
 void launch_layer_round(const Fr* A, const Fr* M, uint32_t h, uint32_t k, uint32_t phase, uint32_t hb, const Fr* Wb,
-                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, hipStream_t s) {
-    hipLaunchKernelGGL(k_layer_round, dim3(nblk), dim3(256), 0, s, A, M, h, k, phase, hb, Wb, Wc, partials);
+                        const Fr* Wc, uint32_t nblk, LayerPartial* partials, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_round, dim3(nblk, lb.batch), dim3(256), 0, s, A, M, h, k, phase, hb, Wb, Wc, partials, lb);
 }
 
 // returns the number of partials written (= blocks)
 uint32_t launch_layer_round_b(bool fold, const Fr* A_src, const Fr* M_src, Fr* A_dst, Fr* M_dst, uint32_t hb, uint32_t kc,
-                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, hipStream_t s) {
+                              const FixedMul* rtab, const Fr* Wb, const Fr* Wc, LayerPartial* partials, LayerBatch lb,
+                              hipStream_t s) {
     const uint32_t col_blocks = ((1u << kc) + 255u) / 256u;
-    // ~1024 blocks per table; every block gets at least one row pair
-    uint32_t chunks = 1024u / col_blocks;
+    // ~1024 blocks per table over the whole batch; every block gets at least one row pair
+    uint32_t chunks = 1024u / (col_blocks * lb.batch);
     if (chunks < 1) chunks = 1;
     if (chunks > hb) chunks = hb;
     const uint32_t rows_per_chunk = (hb + chunks - 1) / chunks;
     chunks = (hb + rows_per_chunk - 1) / rows_per_chunk;
-    dim3 grid(col_blocks, chunks, 2);
+    dim3 grid(col_blocks, chunks * lb.batch, 2);
     if (fold)
         hipLaunchKernelGGL(k_layer_round_b<true>, grid, dim3(256), 0, s, A_src, M_src, A_dst, M_dst, hb, kc, rows_per_chunk,
-                           rtab, Wb, Wc, partials);
+                           rtab, Wb, Wc, partials, lb, chunks);
     else
         hipLaunchKernelGGL(k_layer_round_b<false>, grid, dim3(256), 0, s, A_src, M_src, A_dst, M_dst, hb, kc, rows_per_chunk,
-                           rtab, Wb, Wc, partials);
-    return col_blocks * chunks * 2;
+                           rtab, Wb, Wc, partials, lb, chunks);
+    return col_blocks * chunks * 2;   // partials per proof
 }
 
-void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, hipStream_t s) {
-    hipLaunchKernelGGL(k_layer_fold, dim3(blocks_for(h, 4096)), dim3(256), 0, s, A, M, h, rtab);
+void launch_layer_fold(Fr* A, Fr* M, uint32_t h, const FixedMul* rtab, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_fold, dim3(blocks_for(h, 4096 / lb.batch + 1), lb.batch), dim3(256), 0, s, A, M, h, rtab, lb);
 }
 
 void launch_layer_round_hash(const LayerPartial* partials, uint32_t nblk, uint32_t round, uint32_t k,

@@ -247,7 +247,12 @@ class Context:
 
     # -- full proof (prover::prove, prover.rs:6-96)
     def prove(self, circuit: GKRCircuit, input_values, require_zero_output=False) -> Proof:
+        return self.prove_batch(circuit, [input_values], require_zero_output)[0]
+
+    def prove_batch(self, circuit: GKRCircuit, inputs, require_zero_output=False) -> List[Proof]:
+        """Proofs of one circuit for several witnesses, advanced together on the GPU (gkr_prove_batch)."""
         L = circuit.depth()
+        B = len(inputs)
         ks = circuit.get_k_list()
         karr = np.asarray(ks, dtype=np.uint32)
         gates = [lay.arrays() for lay in circuit.layer]
@@ -259,36 +264,68 @@ class Context:
         rc = N.lib().gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(sizes))
         if rc:
             raise GkrError(rc, "gkr_proof_sizes")
-        inp = as_limbs(input_values)
-        if inp.shape[0] != 1 << ks[-1]:
-            raise GkrError(N.GKR_ERR_INVALID, "input layer needs 2^input_k values")
-        sc = np.zeros((sizes.rounds, 3, 4), dtype=np.uint64)
-        sl = np.zeros(sizes.rounds, dtype=np.uint32)
-        sr = np.zeros((sizes.rounds, 4), dtype=np.uint64)
-        q = np.zeros((sizes.q_slots, 4), dtype=np.uint64)
-        ql = np.zeros(L, dtype=np.uint32)
-        z = np.zeros((max(sizes.z_values, 1), 4), dtype=np.uint64)
-        rr = np.zeros((L, 4), dtype=np.uint64)
-        dco = np.zeros((sizes.d_coeffs, 4), dtype=np.uint64)
-        ico = np.zeros((sizes.input_coeffs, 4), dtype=np.uint64)
-        buf = N.ProofBuf(*[a.ctypes.data for a in (sc, sl, sr, q, ql, z, rr, dco, ico)])
-        self._check(N.lib().gkr_prove(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(1 if require_zero_output else 0),
-                                      ctypes.byref(buf)))
-        proofs, rs, qs, zs = [], [], [], []
-        ro = qo = 0
-        for i in range(L):
-            k = ks[i + 1]
-            proofs.append([from_limbs(sc[ro + j])[3 - int(sl[ro + j]):] for j in range(2 * k)])
-            rs.append(from_limbs(sr[ro:ro + 2 * k]))
-            qs.append(from_limbs(q[qo:qo + k + 1])[k + 1 - int(ql[i]):])
-            ro += 2 * k
-            qo += k + 1
-        zo = 0
-        for i in range(L + 1):
-            zs.append(from_limbs(z[zo:zo + ks[i]]) if ks[i] else [])
-            zo += ks[i]
-        return Proof(sumcheck_proofs=proofs, sumcheck_r=rs, d=_terms_from_coeffs(dco, ks[0]), q=qs, z=zs,
-                     r=from_limbs(rr), depth=L + 1, input_func=_terms_from_coeffs(ico, ks[-1]), k=ks)
+        n_in = 1 << ks[-1]
+        inp = np.empty((B, n_in, 4), dtype=np.uint64)
+        for b, vals in enumerate(inputs):
+            a = as_limbs(vals)
+            if a.shape[0] != n_in:
+                raise GkrError(N.GKR_ERR_INVALID, "input layer needs 2^input_k values")
+            inp[b] = a
+        sc = np.zeros((B, sizes.rounds, 3, 4), dtype=np.uint64)
+        sl = np.zeros((B, sizes.rounds), dtype=np.uint32)
+        sr = np.zeros((B, sizes.rounds, 4), dtype=np.uint64)
+        q = np.zeros((B, sizes.q_slots, 4), dtype=np.uint64)
+        ql = np.zeros((B, L), dtype=np.uint32)
+        z = np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64)
+        rr = np.zeros((B, L, 4), dtype=np.uint64)
+        dco = np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64)
+        ico = np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)
+        bufs = (N.ProofBuf * B)(*[N.ProofBuf(*[a[b].ctypes.data for a in (sc, sl, sr, q, ql, z, rr, dco, ico)])
+                                  for b in range(B)])
+        self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B),
+                                            ctypes.c_int(1 if require_zero_output else 0), bufs))
+        out = []
+        for b in range(B):
+            proofs, rs, qs, zs = [], [], [], []
+            ro = qo = 0
+            for i in range(L):
+                k = ks[i + 1]
+                proofs.append([from_limbs(sc[b, ro + j])[3 - int(sl[b, ro + j]):] for j in range(2 * k)])
+                rs.append(from_limbs(sr[b, ro:ro + 2 * k]))
+                qs.append(from_limbs(q[b, qo:qo + k + 1])[k + 1 - int(ql[b, i]):])
+                ro += 2 * k
+                qo += k + 1
+            zo = 0
+            for i in range(L + 1):
+                zs.append(from_limbs(z[b, zo:zo + ks[i]]) if ks[i] else [])
+                zo += ks[i]
+            out.append(Proof(sumcheck_proofs=proofs, sumcheck_r=rs, d=_terms_from_coeffs(dco[b], ks[0]), q=qs, z=zs,
+                             r=from_limbs(rr[b]), depth=L + 1, input_func=_terms_from_coeffs(ico[b], ks[-1]), k=ks))
+        return out
+
+    def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs):
+        """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg).
+        inputs_limbs: (B, 2^input_k, 4) uint64.  Returns the challenge arrays (B, rounds, 4)."""
+        L = circuit.depth()
+        B = inputs_limbs.shape[0]
+        ks = circuit.get_k_list()
+        karr = np.asarray(ks, dtype=np.uint32)
+        gates = [lay.arrays() for lay in circuit.layer]
+        gt_p = (ctypes.c_void_p * L)(*[g[0].ctypes.data for g in gates])
+        l_p = (ctypes.c_void_p * L)(*[g[1].ctypes.data for g in gates])
+        r_p = (ctypes.c_void_p * L)(*[g[2].ctypes.data for g in gates])
+        desc = N.CircuitDesc(L, karr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), gt_p, l_p, r_p)
+        sizes = N.ProofSizes()
+        self._check(N.lib().gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(sizes)))
+        inp = np.ascontiguousarray(inputs_limbs, dtype=np.uint64)
+        arrs = [np.zeros((B, sizes.rounds, 3, 4), dtype=np.uint64), np.zeros((B, sizes.rounds), dtype=np.uint32),
+                np.zeros((B, sizes.rounds, 4), dtype=np.uint64), np.zeros((B, sizes.q_slots, 4), dtype=np.uint64),
+                np.zeros((B, L), dtype=np.uint32), np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64),
+                np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
+                np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
+        bufs = (N.ProofBuf * B)(*[N.ProofBuf(*[a[b].ctypes.data for a in arrs]) for b in range(B)])
+        self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B), ctypes.c_int(0), bufs))
+        return arrs[2]
 
 
 _default_ctx = None

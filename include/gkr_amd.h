@@ -192,6 +192,13 @@ int  gkr_proof_sizes(const gkr_circuit_desc *circuit, gkr_proof_sizes_t *out);
 int  gkr_prove(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values,
                int require_zero_output, gkr_proof_buf *out);
 
+/* `batch` proofs of ONE circuit for `batch` witnesses, advanced together (every layer's sumcheck runs
+ * batched: one set of launches and one host round trip per round for all proofs) -- the reference proves
+ * independent (circuit, input) pairs from a rayon par_iter (aggregator.rs:350-355).  input_values:
+ * batch x 2^k[L] values; outs: `batch` caller-allocated proof buffers.  Needs the host transcript. */
+int  gkr_prove_batch(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values, int batch,
+                     int require_zero_output, gkr_proof_buf *outs);
+
 /* ---- step-wise sessions: one sumcheck split across GPUs -------------------
  * The reference reduces each round's per-assignment polynomials with a rayon
  * map-reduce (sumcheck.rs:50-63,65-78,97-124); across GPUs that reduce is one

@@ -248,6 +248,37 @@ def test_prove_random_circuits_match_oracle(ctx, seed):
     assert terms_as_set(pr.input_func) == terms_as_set(dense.monomial_terms(inputs, ks[-1]))
 
 
+def test_prove_batch_equals_single_proofs_and_oracle(ctx):
+    """gkr_prove_batch: proofs of one circuit for many witnesses advanced together (host transcript)."""
+    if ctx.device_name() and getattr(ctx, "_mode", None) == "device":
+        pytest.skip("batched proving needs the host transcript")
+    rng = random.Random(4242)
+    ks = [3, 4, 5, 4]
+    layers = []
+    for i in range(len(ks) - 1):
+        g, n = 1 << ks[i], 1 << ks[i + 1]
+        layers.append(([rng.randint(0, 1) for _ in range(g)], [rng.randrange(n) for _ in range(g)],
+                       [rng.randrange(n) for _ in range(g)]))
+    circ = _circuit(layers, 1 << ks[-1])
+    B = 19   # not a multiple of the eight hash lanes
+    inputs = [[rng.randrange(P) for _ in range(1 << ks[-1])] for _ in range(B)]
+    inputs[3] = [7] * (1 << ks[-1])                       # constant inputs: short round vectors
+    inputs[5] = [i & 1 for i in range(1 << ks[-1])]       # depends on the last variable only
+    try:
+        got = ctx.prove_batch(circ, inputs)
+    except GkrError as e:
+        if "host transcript" in str(e):
+            pytest.skip("batched proving needs the host transcript")
+        raise
+    for b in (0, 3, 5, 11, 18):
+        ref = cdense.prove(layers, inputs[b])
+        pr = got[b]
+        assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"], b
+        assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"], b
+    one = ctx.prove(circ, inputs[7])
+    assert one == got[7]
+
+
 def test_prove_zero_output_check(ctx):
     # convert.rs:838: the reference asserts output 0 == 0 on a satisfying witness
     circ = _circuit([([0, 1], [0, 1], [1, 1])], 2)
