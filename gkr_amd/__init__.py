@@ -9,5 +9,7 @@ from .field import MODULUS, from_limbs, to_limbs
 from .prover import (Context, GKRCircuit, GkrError, Layer, Proof, default_context, multi_hash, prove,
                      prove_sumcheck, prove_sumcheck_opt)
 
-__all__ = ["MODULUS", "from_limbs", "to_limbs", "Context", "GKRCircuit", "GkrError", "Layer", "Proof",
+from .verifier import verify
+
+__all__ = ["verify", "MODULUS", "from_limbs", "to_limbs", "Context", "GKRCircuit", "GkrError", "Layer", "Proof",
            "default_context", "multi_hash", "prove", "prove_sumcheck", "prove_sumcheck_opt"]

@@ -279,6 +279,23 @@ def test_prove_batch_equals_single_proofs_and_oracle(ctx):
     assert one == got[7]
 
 
+def test_product_proofs_pass_the_verifier(ctx):
+    """every proof the GPU prover makes satisfies the reference verifier's relations (python/gkr.py:202-231)"""
+    from gkr_amd import verify
+    rng = random.Random(777)
+    ks = [2, 4, 5, 5]
+    layers = []
+    for i in range(len(ks) - 1):
+        g, n = 1 << ks[i], 1 << ks[i + 1]
+        layers.append(([rng.randint(0, 1) for _ in range(g)], [rng.randrange(n) for _ in range(g)],
+                       [rng.randrange(n) for _ in range(g)]))
+    circ = _circuit(layers, 1 << ks[-1])
+    pr = ctx.prove(circ, [rng.randrange(P) for _ in range(1 << ks[-1])])
+    assert verify(pr, circ)
+    pr.sumcheck_proofs[1][2][-1] = (pr.sumcheck_proofs[1][2][-1] + 1) % P
+    assert not verify(pr, circ)
+
+
 def test_prove_zero_output_check(ctx):
     # convert.rs:838: the reference asserts output 0 == 0 on a satisfying witness
     circ = _circuit([([0, 1], [0, 1], [1, 1])], 2)
