@@ -55,11 +55,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (single-GPU boxes): run several ranks on one device over gloo to exercise the N > 1 code path
+    backend = os.environ.get("GKR_BENCH_BACKEND", "nccl")
+    if "GKR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["GKR_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
 
@@ -100,7 +107,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
