@@ -7,7 +7,7 @@ which carries no `f` field: the last sumcheck claim is compared with
 add(z, b*, c*) (q(0) + q(1)) + mult(z, b*, c*) q(0) q(1) directly.
 
 Verification is O(gates * k) per layer of cheap arithmetic; it is not on the accelerated path.  It gives an
-end-to-end check of a proof that needs neither the oracle nor the reference.
+end-to-end check of a proof that needs neither the CPU checker under tests/ nor the reference.
 """
 
 from typing import List
