@@ -116,6 +116,28 @@ bool host_ifma_ready() {
     return state == 1;
 }
 
+// up to sixteen transcripts on the IFMA code: two interleaved groups of eight fill the FMA pipes (one group is
+// a dependent chain), so chunks of sixteen cost ~1.3x a chunk of eight
+constexpr int kHashChunkMax = 16;
+inline void ifma_hash_chunk(const uint64_t (*vec)[3][4], const uint32_t* ln, int count, uint64_t (*out)[4]) {
+    if (count > 8)
+        gkr::gkr_ifma_multi_hash16(vec, ln, 3, out);
+    else
+        gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+}
+// chunk of sumchecks one host thread hashes at a time: sixteen when the host threads are the scarce resource
+// (throughput: MI355X + 2 threads, 256 x 2^20: 7.1 ms per step against 8.5), eight otherwise (latency: with 15
+// threads 5.04 ms against 5.19)
+inline int hash_chunk_size(int tables, int threads) {
+    static const int forced = [] {
+        const char* e = getenv("GKR_HASH_CHUNK");
+        const int v = e ? atoi(e) : 0;
+        return v == 8 || v == 16 ? v : 0;
+    }();
+    if (forced) return forced;
+    return tables >= 32 * threads ? 16 : 8;
+}
+
 int default_host_threads() {
     if (const char* e = getenv("GKR_HOST_THREADS")) {
         int v = atoi(e);
@@ -318,7 +340,7 @@ constexpr int kMaxGroups = 16;
 // ------------------------------------------------------------- plain MLE sumcheck, multi-round passes
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 3 hashes in a row,
-// eight sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
+// eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
 // variables at once.  Length rules as in run_mle_batch.
 int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,
                          gkr_fr* out_r) {
@@ -340,6 +362,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     const bool ifma = host_ifma_ready();
     std::vector<uint32_t> dep_last(batch, 0);
     gkr::SpinPool* pool = ctx->host_pool();
+    const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
     int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
@@ -413,15 +436,15 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // the J rounds of up to eight sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
         const int J = G.j;
-        F sums[8][8], rr[8][3];
+        F sums[kHashChunkMax][8], rr[kHashChunkMax][3];
         for (int i = 0; i < count; ++i) {
             memcpy(sums[i], rec[b_first + i].sums, sizeof(F) << J);
             if (G.round0 == 0) dep_last[b_first + i] = rec[b_first + i].dep;
         }
         for (int t = 0; t < J; ++t) {
             const int half = 1 << (J - t - 1), round = G.round0 + t;
-            F c0[8], c1[8];
-            uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            F c0[kHashChunkMax], c1[kHashChunkMax];
+            uint32_t ln[kHashChunkMax] = {};
             for (int i = 0; i < count; ++i) {
                 F lo = sums[i][0], hi = sums[i][half];
                 for (int b = 1; b < half; ++b) {
@@ -435,15 +458,15 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                 else
                     ln[i] = dep_last[b_first + i] ? 2u : 1u;
             }
-            F r[8];
+            F r[kHashChunkMax];
             if (ifma && count >= 3) {
-                uint64_t vec[8][3][4], out[8][4];
+                uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
                 memset(vec, 0, sizeof vec);
                 for (int i = 0; i < count; ++i) {
                     memcpy(vec[i][1], &c1[i], 32);
                     memcpy(vec[i][2], &c0[i], 32);
                 }
-                gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+                ifma_hash_chunk(vec, ln, count, out);
                 for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
             } else {
                 for (int i = 0; i < count; ++i) {
@@ -491,7 +514,8 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             uint64_t c = G.claim.load(std::memory_order_acquire);
             while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
                 const uint32_t first = (uint32_t)c;
-                const uint32_t take = ((uint32_t)G.nb - first) < 8u ? ((uint32_t)G.nb - first) : 8u;
+                const uint32_t left = (uint32_t)G.nb - first;
+                const uint32_t take = left < chunk_tables ? left : chunk_tables;
                 if (G.claim.compare_exchange_weak(c, c + take, std::memory_order_acq_rel)) {
                     process_chunk(G, G.b0 + (int)first, (int)take);
                     G.done.fetch_add((int)take, std::memory_order_release);
@@ -585,6 +609,7 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
         const gkr::h64::F* cts = host_mimc_constants64();
         std::vector<uint32_t> dep_last(batch, 0);
         gkr::SpinPool* pool = ctx->host_pool();
+        const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
         // The batch is cut into groups that advance through their rounds independently:
         //   GPU (one in-order stream):  sums/fold of group g, round j  ->  reduce -> pinned records
@@ -660,8 +685,8 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
         // up to eight sumchecks of one group: eight-lane IFMA hash when there are enough lanes to pay
         // for it, the scalar 4x64-bit code otherwise
         auto hash_chunk = [&](int b_first, int count, int round) {
-            gkr::h64::F c0[8], c1[8];
-            uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            gkr::h64::F c0[kHashChunkMax], c1[kHashChunkMax];
+            uint32_t ln[kHashChunkMax] = {};
             for (int i = 0; i < count; ++i) {
                 const int b = b_first + i;
                 memcpy(&c0[i], &rec[b].c0, 32);
@@ -670,13 +695,13 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
                 ln[i] = round_len(b, round, c1[i]);
             }
             if (ifma && count >= 3) {
-                uint64_t vec[8][3][4], out[8][4];
+                uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
                 memset(vec, 0, sizeof vec);
                 for (int i = 0; i < count; ++i) {
                     memcpy(vec[i][1], &c1[i], 32);
                     memcpy(vec[i][2], &c0[i], 32);
                 }
-                gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+                ifma_hash_chunk(vec, ln, count, out);
                 for (int i = 0; i < count; ++i) {
                     gkr::h64::F r;
                     memcpy(&r, out[i], 32);
@@ -697,7 +722,8 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
                 uint64_t c = G.claim.load(std::memory_order_acquire);
                 while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
                     const uint32_t first = (uint32_t)c;
-                    const uint32_t take = ((uint32_t)G.nb - first) < 8u ? ((uint32_t)G.nb - first) : 8u;
+                    const uint32_t left = (uint32_t)G.nb - first;
+                const uint32_t take = left < chunk_tables ? left : chunk_tables;
                     if (G.claim.compare_exchange_weak(c, c + take, std::memory_order_acq_rel)) {
                         hash_chunk(G.b0 + (int)first, (int)take, (int)(c >> 32) - 1);
                         G.done.fetch_add((int)take, std::memory_order_release);
@@ -949,8 +975,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
     // (get_univariate_coeff, poly.rs:388-420), hashed together (eight-lane IFMA where available)
     auto hash_chunk = [&](int first, int count, uint32_t round, gkr::FixedMul* slot) {
-        gkr::h64::F c0[8], lin[8], c2[8], r[8];
-        uint32_t ln[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
+        uint32_t ln[kHashChunkMax] = {};
         for (int i = 0; i < count; ++i) {
             const int b = first + i;
             gkr::h64::F g1;
@@ -961,14 +987,14 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             ln[i] = 2u + (h_dep[(size_t)b * 32 + round % k] ? 1u : 0u);
         }
         if (ifma && count >= 3) {
-            uint64_t vec[8][3][4], out[8][4];
+            uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
             memset(vec, 0, sizeof vec);
             for (int i = 0; i < count; ++i) {
                 memcpy(vec[i][0], &c2[i], 32);
                 memcpy(vec[i][1], &lin[i], 32);
                 memcpy(vec[i][2], &c0[i], 32);
             }
-            gkr::gkr_ifma_multi_hash8(vec, ln, 3, out);
+            ifma_hash_chunk(vec, ln, count, out);
             for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
         } else {
             for (int i = 0; i < count; ++i) {
@@ -1024,17 +1050,19 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             // two sets of pinned tables used alternately: the deferred fold of round j reads set j % 2
             // while the host already writes round j+1's
             gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
+            const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
             if (pool) {
                 std::atomic<int> next{0};
                 const std::function<bool()> work = [&]() -> bool {
-                    const int first = next.fetch_add(8, std::memory_order_relaxed);
+                    const int first = next.fetch_add(chunk, std::memory_order_relaxed);
                     if (first >= batch) return false;
-                    hash_chunk(first, batch - first < 8 ? batch - first : 8, round, slot);
+                    hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
                     return true;
                 };
                 pool->run_now(&work);
             } else {
-                for (int first = 0; first < batch; first += 8) hash_chunk(first, batch - first < 8 ? batch - first : 8, round, slot);
+                for (int first = 0; first < batch; first += chunk)
+                    hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
             }
             // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc)
             gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
@@ -1277,7 +1305,8 @@ int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_f
 }
 
 // eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
-// host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1), else scalar
+// host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1; its sixteen-lane
+// form is cross-checked on the way), else scalar
 int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int* used_ifma) {
     if (!vecs || !len || !out) return GKR_ERR_INVALID;
     if (!all_canonical(vecs, 24)) return GKR_ERR_NON_CANONICAL;
@@ -1290,6 +1319,17 @@ int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int
         memcpy(v, vecs, sizeof v);
         gkr::gkr_ifma_multi_hash8(v, len, 3, o);
         memcpy(out, o, sizeof o);
+        // the sixteen-lane interleaved form on the same vectors (second half in reverse order) must agree
+        uint64_t v16[16][3][4], o16[16][4];
+        uint32_t len16[16];
+        for (int k = 0; k < 8; ++k) {
+            memcpy(v16[k], v[k], sizeof v[k]);
+            memcpy(v16[15 - k], v[k], sizeof v[k]);
+            len16[k] = len16[15 - k] = len[k];
+        }
+        gkr::gkr_ifma_multi_hash16(v16, len16, 3, o16);
+        for (int k = 0; k < 8; ++k)
+            if (memcmp(o16[k], o[k], 32) != 0 || memcmp(o16[15 - k], o[k], 32) != 0) return GKR_ERR_INVALID;
     } else {
         const gkr::h64::F* cts = host_mimc_constants64();
         for (int k = 0; k < 8; ++k) {

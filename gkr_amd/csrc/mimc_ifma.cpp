@@ -162,6 +162,86 @@ static inline V add_mod(const V& a, const V& b) {
     return r;
 }
 
+// Lazy forms for the inside of the MiMC7 round chain: no conditional subtraction.  With R = 2^260 and
+// p < 2^254 a Montgomery product of operands below 2^257 is below 2^254 + p < 2^255, and a sum of three
+// such values stays below 2^257, so the chain never needs a canonical value until the very end.
+static inline V mont_mul_lazy(const V& a, const V& b) {
+    const __m512i zero = _mm512_setzero_si512(), mask = bc(M52), pinv = bc(g_pinv52);
+    __m512i t0 = zero, t1 = zero, t2 = zero, t3 = zero, t4 = zero, t5 = zero;
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+#define GKR_IFMA_ROUND(bi)                                        \
+    {                                                             \
+        t0 = _mm512_madd52lo_epu64(t0, a.l[0], bi);               \
+        t1 = _mm512_madd52hi_epu64(t1, a.l[0], bi);               \
+        t1 = _mm512_madd52lo_epu64(t1, a.l[1], bi);               \
+        t2 = _mm512_madd52hi_epu64(t2, a.l[1], bi);               \
+        t2 = _mm512_madd52lo_epu64(t2, a.l[2], bi);               \
+        t3 = _mm512_madd52hi_epu64(t3, a.l[2], bi);               \
+        t3 = _mm512_madd52lo_epu64(t3, a.l[3], bi);               \
+        t4 = _mm512_madd52hi_epu64(t4, a.l[3], bi);               \
+        t4 = _mm512_madd52lo_epu64(t4, a.l[4], bi);               \
+        t5 = _mm512_madd52hi_epu64(t5, a.l[4], bi);               \
+        const __m512i m = _mm512_and_si512(_mm512_madd52lo_epu64(zero, t0, pinv), mask); \
+        t0 = _mm512_madd52lo_epu64(t0, m, p0);                    \
+        t1 = _mm512_madd52hi_epu64(t1, m, p0);                    \
+        t1 = _mm512_madd52lo_epu64(t1, m, p1);                    \
+        t2 = _mm512_madd52hi_epu64(t2, m, p1);                    \
+        t2 = _mm512_madd52lo_epu64(t2, m, p2);                    \
+        t3 = _mm512_madd52hi_epu64(t3, m, p2);                    \
+        t3 = _mm512_madd52lo_epu64(t3, m, p3);                    \
+        t4 = _mm512_madd52hi_epu64(t4, m, p3);                    \
+        t4 = _mm512_madd52lo_epu64(t4, m, p4);                    \
+        t5 = _mm512_madd52hi_epu64(t5, m, p4);                    \
+        t0 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52));     \
+        t1 = t2; t2 = t3; t3 = t4; t4 = t5; t5 = zero;            \
+    }
+    GKR_IFMA_ROUND(b.l[0]) GKR_IFMA_ROUND(b.l[1]) GKR_IFMA_ROUND(b.l[2]) GKR_IFMA_ROUND(b.l[3]) GKR_IFMA_ROUND(b.l[4])
+#undef GKR_IFMA_ROUND
+    V r;
+    t1 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52)); r.l[0] = _mm512_and_si512(t0, mask);
+    t2 = _mm512_add_epi64(t2, _mm512_srli_epi64(t1, 52)); r.l[1] = _mm512_and_si512(t1, mask);
+    t3 = _mm512_add_epi64(t3, _mm512_srli_epi64(t2, 52)); r.l[2] = _mm512_and_si512(t2, mask);
+    t4 = _mm512_add_epi64(t4, _mm512_srli_epi64(t3, 52)); r.l[3] = _mm512_and_si512(t3, mask);
+    r.l[4] = t4;
+    return r;
+}
+
+// a + b + c with carry normalisation only (limbs back to 52 bits; value may exceed p)
+static inline V add3_lazy(const V& a, const V& b, const V& c) {
+    const __m512i mask = bc(M52);
+    __m512i t0 = _mm512_add_epi64(_mm512_add_epi64(a.l[0], b.l[0]), c.l[0]);
+    __m512i t1 = _mm512_add_epi64(_mm512_add_epi64(a.l[1], b.l[1]), c.l[1]);
+    __m512i t2 = _mm512_add_epi64(_mm512_add_epi64(a.l[2], b.l[2]), c.l[2]);
+    __m512i t3 = _mm512_add_epi64(_mm512_add_epi64(a.l[3], b.l[3]), c.l[3]);
+    __m512i t4 = _mm512_add_epi64(_mm512_add_epi64(a.l[4], b.l[4]), c.l[4]);
+    V r;
+    t1 = _mm512_add_epi64(t1, _mm512_srli_epi64(t0, 52)); r.l[0] = _mm512_and_si512(t0, mask);
+    t2 = _mm512_add_epi64(t2, _mm512_srli_epi64(t1, 52)); r.l[1] = _mm512_and_si512(t1, mask);
+    t3 = _mm512_add_epi64(t3, _mm512_srli_epi64(t2, 52)); r.l[2] = _mm512_and_si512(t2, mask);
+    t4 = _mm512_add_epi64(t4, _mm512_srli_epi64(t3, 52)); r.l[3] = _mm512_and_si512(t3, mask);
+    r.l[4] = t4;
+    return r;
+}
+
+// subtract p where the value is >= p (limbs normalised, value < 2^260)
+static inline V cond_sub(const V& t) {
+    const __m512i mask = bc(M52);
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+    __m512i d0 = _mm512_sub_epi64(t.l[0], p0);
+    __m512i d1 = _mm512_sub_epi64(_mm512_sub_epi64(t.l[1], p1), _mm512_srli_epi64(d0, 63));
+    __m512i d2 = _mm512_sub_epi64(_mm512_sub_epi64(t.l[2], p2), _mm512_srli_epi64(d1, 63));
+    __m512i d3 = _mm512_sub_epi64(_mm512_sub_epi64(t.l[3], p3), _mm512_srli_epi64(d2, 63));
+    __m512i d4 = _mm512_sub_epi64(_mm512_sub_epi64(t.l[4], p4), _mm512_srli_epi64(d3, 63));
+    const __mmask8 neg = _mm512_cmplt_epi64_mask(d4, _mm512_setzero_si512());
+    V r;
+    r.l[0] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d0, mask), t.l[0]);
+    r.l[1] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d1, mask), t.l[1]);
+    r.l[2] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d2, mask), t.l[2]);
+    r.l[3] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d3, mask), t.l[3]);
+    r.l[4] = _mm512_mask_blend_epi64(neg, _mm512_and_si512(d4, mask), t.l[4]);
+    return r;
+}
+
 static inline V splat(const uint64_t l[5]) {
     V v;
     for (int i = 0; i < 5; ++i) v.l[i] = bc(l[i]);
@@ -215,17 +295,126 @@ static void init_constants(const uint64_t (*cts_canonical)[4]) {
     }
 }
 
-// x, k Montgomery -> hash(x, k) Montgomery, eight lanes
+// x, k Montgomery and canonical -> hash(x, k) Montgomery and canonical, eight lanes.  Inside the chain the
+// values are only kept below 2^257 (see mont_mul_lazy); the last sum is canonicalised.
 static inline V mimc7_hash(const V& x, const V& k) {
-    V h = x;
+    V zero;
+    for (int i = 0; i < 5; ++i) zero.l[i] = _mm512_setzero_si512();
+    V h = zero;
     for (int i = 0; i < 91; ++i) {
-        V t = (i == 0) ? add_mod(x, k) : add_mod(add_mod(h, k), splat(g_cts52[i]));
-        V t2 = mont_mul(t, t);
-        V t4 = mont_mul(t2, t2);
-        V t6 = mont_mul(t4, t2);
-        h = mont_mul(t6, t);
+        const V t = (i == 0) ? add3_lazy(x, k, zero) : add3_lazy(h, k, splat(g_cts52[i]));
+        const V t2 = mont_mul_lazy(t, t);
+        const V t4 = mont_mul_lazy(t2, t2);
+        const V t6 = mont_mul_lazy(t4, t2);
+        h = mont_mul_lazy(t6, t);
     }
-    return add_mod(h, k);
+    // h < 2^255, k < p: the sum is below 6p
+    V s = add3_lazy(h, k, zero);
+    for (int i = 0; i < 5; ++i) s = cond_sub(s);
+    return s;
+}
+
+// W independent eight-lane products advanced together: one product is a chain of dependent madd52
+// (4-cycle latency each), two fill the FMA pipes.
+template <int W>
+static inline void mont_mul_lazy_w(const V (&a)[W], const V (&b)[W], V (&r)[W]) {
+    const __m512i zero = _mm512_setzero_si512(), mask = bc(M52), pinv = bc(g_pinv52);
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+    __m512i t[W][6];
+#pragma GCC unroll 8
+    for (int w = 0; w < W; ++w)
+        for (int i = 0; i < 6; ++i) t[w][i] = zero;
+#pragma GCC unroll 8
+    for (int j = 0; j < 5; ++j) {
+#pragma GCC unroll 8
+        for (int w = 0; w < W; ++w) {
+            const __m512i bi = b[w].l[j];
+            t[w][0] = _mm512_madd52lo_epu64(t[w][0], a[w].l[0], bi);
+            t[w][1] = _mm512_madd52hi_epu64(t[w][1], a[w].l[0], bi);
+            t[w][1] = _mm512_madd52lo_epu64(t[w][1], a[w].l[1], bi);
+            t[w][2] = _mm512_madd52hi_epu64(t[w][2], a[w].l[1], bi);
+            t[w][2] = _mm512_madd52lo_epu64(t[w][2], a[w].l[2], bi);
+            t[w][3] = _mm512_madd52hi_epu64(t[w][3], a[w].l[2], bi);
+            t[w][3] = _mm512_madd52lo_epu64(t[w][3], a[w].l[3], bi);
+            t[w][4] = _mm512_madd52hi_epu64(t[w][4], a[w].l[3], bi);
+            t[w][4] = _mm512_madd52lo_epu64(t[w][4], a[w].l[4], bi);
+            t[w][5] = _mm512_madd52hi_epu64(t[w][5], a[w].l[4], bi);
+        }
+#pragma GCC unroll 8
+        for (int w = 0; w < W; ++w) {
+            const __m512i m = _mm512_and_si512(_mm512_madd52lo_epu64(zero, t[w][0], pinv), mask);
+            t[w][0] = _mm512_madd52lo_epu64(t[w][0], m, p0);
+            t[w][1] = _mm512_madd52hi_epu64(t[w][1], m, p0);
+            t[w][1] = _mm512_madd52lo_epu64(t[w][1], m, p1);
+            t[w][2] = _mm512_madd52hi_epu64(t[w][2], m, p1);
+            t[w][2] = _mm512_madd52lo_epu64(t[w][2], m, p2);
+            t[w][3] = _mm512_madd52hi_epu64(t[w][3], m, p2);
+            t[w][3] = _mm512_madd52lo_epu64(t[w][3], m, p3);
+            t[w][4] = _mm512_madd52hi_epu64(t[w][4], m, p3);
+            t[w][4] = _mm512_madd52lo_epu64(t[w][4], m, p4);
+            t[w][5] = _mm512_madd52hi_epu64(t[w][5], m, p4);
+            t[w][0] = _mm512_add_epi64(t[w][1], _mm512_srli_epi64(t[w][0], 52));
+            t[w][1] = t[w][2]; t[w][2] = t[w][3]; t[w][3] = t[w][4]; t[w][4] = t[w][5]; t[w][5] = zero;
+        }
+    }
+#pragma GCC unroll 8
+    for (int w = 0; w < W; ++w) {
+        t[w][1] = _mm512_add_epi64(t[w][1], _mm512_srli_epi64(t[w][0], 52)); r[w].l[0] = _mm512_and_si512(t[w][0], mask);
+        t[w][2] = _mm512_add_epi64(t[w][2], _mm512_srli_epi64(t[w][1], 52)); r[w].l[1] = _mm512_and_si512(t[w][1], mask);
+        t[w][3] = _mm512_add_epi64(t[w][3], _mm512_srli_epi64(t[w][2], 52)); r[w].l[2] = _mm512_and_si512(t[w][2], mask);
+        t[w][4] = _mm512_add_epi64(t[w][4], _mm512_srli_epi64(t[w][3], 52)); r[w].l[3] = _mm512_and_si512(t[w][3], mask);
+        r[w].l[4] = t[w][4];
+    }
+}
+
+template <int W>
+static inline void mimc7_hash_w(const V (&x)[W], const V (&k)[W], V (&out)[W]) {
+    V zero;
+    for (int i = 0; i < 5; ++i) zero.l[i] = _mm512_setzero_si512();
+    V h[W], t[W], t2[W], t4[W], t6[W];
+    for (int w = 0; w < W; ++w) h[w] = zero;
+    for (int i = 0; i < 91; ++i) {
+        const V c = (i == 0) ? zero : splat(g_cts52[i]);
+        for (int w = 0; w < W; ++w) t[w] = (i == 0) ? add3_lazy(x[w], k[w], zero) : add3_lazy(h[w], k[w], c);
+        mont_mul_lazy_w<W>(t, t, t2);
+        mont_mul_lazy_w<W>(t2, t2, t4);
+        mont_mul_lazy_w<W>(t4, t2, t6);
+        mont_mul_lazy_w<W>(t6, t, h);
+    }
+    for (int w = 0; w < W; ++w) {
+        V s = add3_lazy(h[w], k[w], zero);
+        for (int i = 0; i < 5; ++i) s = cond_sub(s);
+        out[w] = s;
+    }
+}
+
+template <int W>
+static void multi_hash_w(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]) {
+    const V r2 = splat(g_r2_52), one = splat(g_one52);
+    V r[W], a[W], h[W];
+    __mmask8 active[W];
+    for (int w = 0; w < W; ++w)
+        for (int i = 0; i < 5; ++i) r[w].l[i] = _mm512_setzero_si512();
+    for (int s = 0; s < slots; ++s) {
+        unsigned any = 0;
+        for (int w = 0; w < W; ++w) {
+            uint64_t in[8][4];
+            active[w] = 0;
+            for (int k = 0; k < 8; ++k) {
+                memcpy(in[k], vec[8 * w + k][s], 32);
+                if ((uint32_t)(slots - s) <= len[8 * w + k]) active[w] |= (__mmask8)(1u << k);
+            }
+            any |= active[w];
+            a[w] = mont_mul(load8(in), r2);
+        }
+        if (!any) continue;
+        mimc7_hash_w<W>(a, r, h);
+        for (int w = 0; w < W; ++w) {
+            const V nr = add_mod(add_mod(r[w], a[w]), h[w]);
+            for (int i = 0; i < 5; ++i) r[w].l[i] = _mm512_mask_blend_epi64(active[w], r[w].l[i], nr.l[i]);
+        }
+    }
+    for (int w = 0; w < W; ++w) store8(mont_mul(r[w], one), out + 8 * w);
 }
 
 }  // namespace ifma
@@ -261,6 +450,11 @@ void gkr_ifma_multi_hash8(const uint64_t (*vec)[3][4], const uint32_t* len, int 
         for (int i = 0; i < 5; ++i) r.l[i] = _mm512_mask_blend_epi64(active, r.l[i], nr.l[i]);
     }
     store8(mont_mul(r, one), out);
+}
+
+// Sixteen transcripts, as two interleaved groups of eight (same conventions; vec, len, out hold 16 entries).
+void gkr_ifma_multi_hash16(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]) {
+    ifma::multi_hash_w<2>(vec, len, slots, out);
 }
 
 }  // namespace gkr

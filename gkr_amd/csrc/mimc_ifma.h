@@ -8,4 +8,5 @@ bool gkr_ifma_available();
 void gkr_ifma_init(const uint64_t (*cts_canonical)[4]);
 // vec[k][s]: slot s of lane k (right-aligned round vector, `slots` <= 3 slots); len[k] trailing slots are hashed
 void gkr_ifma_multi_hash8(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]);
+void gkr_ifma_multi_hash16(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]);
 }  // namespace gkr

@@ -1,0 +1,51 @@
+// Host transcript hash cost: eight- and sixteen-lane AVX-512 IFMA MiMC7 against the scalar 4x64-bit code.
+//   g++ -O3 -std=c++17 -Igkr_amd/csrc tools/hash_timing.cpp gkr_amd/csrc/mimc_ifma.o gkr_amd/csrc/keccak.o -o /tmp/hash_timing
+#include "fr64.h"
+#include "keccak.h"
+#include "mimc7.h"
+#include "mimc_ifma.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+using namespace gkr;
+
+int main() {
+    Fr cts32[91];
+    mimc7_make_constants(cts32);
+    h64::F cts64[91];
+    memcpy(cts64, cts32, sizeof cts64);
+    static uint64_t vec[16][3][4], out[16][4];
+    uint32_t len[16];
+    for (int k = 0; k < 16; ++k)
+        for (int s = 0; s < 3; ++s)
+            for (int j = 0; j < 4; ++j) vec[k][s][j] = (uint64_t)(k * 7 + s * 3 + j + 1) * 0x9e3779b97f4a7c15ull >> (j == 3 ? 4 : 0);
+    const int N = 2000;
+    uint64_t acc = 0;
+    for (uint32_t l = 2; l <= 3; ++l) {
+        for (int k = 0; k < 16; ++k) len[k] = l;
+        if (gkr_ifma_available()) {
+            uint64_t canon[91][4];
+            for (int i = 0; i < 91; ++i) {
+                h64::F c = h64::from_mont(cts64[i]);
+                memcpy(canon[i], &c, 32);
+            }
+            gkr_ifma_init(canon);
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < N; ++i) { vec[0][1][0] = i; gkr_ifma_multi_hash8(vec, len, 3, out); acc ^= out[0][0]; }
+            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+            printf("len %u  ifma8 : %6.2f us per call = %.2f us per hash\n", l, us, us / 8);
+            t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < N; ++i) { vec[0][1][0] = i; gkr_ifma_multi_hash16(vec, len, 3, out); acc ^= out[0][0]; }
+            us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+            printf("len %u  ifma16: %6.2f us per call = %.2f us per hash\n", l, us, us / 16);
+        }
+        h64::F v[3];
+        memcpy(v, vec[0], sizeof v);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < N; ++i) { v[1].l[0] = i; h64::F r = h64::mimc7_multi_hash(v + (3 - l), (int)l, cts64, nullptr); acc ^= r.l[0]; }
+        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+        printf("len %u  scalar: %6.2f us per hash\n", l, us);
+    }
+    printf("(%llx)\n", (unsigned long long)acc);
+    return 0;
+}
