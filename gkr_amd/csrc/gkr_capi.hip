@@ -175,6 +175,8 @@ bool all_canonical(const gkr_fr* v, size_t n) {
 struct gkr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
+    std::vector<hipEvent_t> aux_events;        // one per group of a batch: "the side kernel of this group is done"
     Fr* d_cts = nullptr;
     int transcript = GKR_TRANSCRIPT_HOST;
     std::string err;
@@ -228,6 +230,19 @@ struct gkr_ctx {
         if (!pool) pool.reset(new gkr::SpinPool(default_host_threads() - 1));
         return pool.get();
     }
+    hipError_t aux_stream(int events) {
+        if (!aux) {
+            hipError_t rc = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+            if (rc != hipSuccess) return rc;
+        }
+        while ((int)aux_events.size() < events) {
+            hipEvent_t e;
+            hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (rc != hipSuccess) return rc;
+            aux_events.push_back(e);
+        }
+        return hipSuccess;
+    }
 
     int fail(int status, const std::string& what) {
         err = what;
@@ -268,18 +283,20 @@ struct Timed {
     gkr_ctx* c;
     PendingEvent ev;
     bool on;
-    Timed(gkr_ctx* ctx, const char* name, double bytes) : c(ctx), on(ctx->profile) {
+    hipStream_t st;
+    Timed(gkr_ctx* ctx, const char* name, double bytes, hipStream_t stream = nullptr)
+        : c(ctx), on(ctx->profile), st(stream ? stream : ctx->stream) {
         if (on) {
             ev.start = c->get_event();
             ev.stop = c->get_event();
             ev.name = name;
             ev.bytes = bytes;
-            hipEventRecord(ev.start, c->stream);
+            hipEventRecord(ev.start, st);
         }
     }
     ~Timed() {
         if (on) {
-            hipEventRecord(ev.stop, c->stream);
+            hipEventRecord(ev.stop, st);
             c->pending.push_back(ev);
         }
     }
@@ -345,19 +362,39 @@ constexpr int kMaxGroups = 16;
 int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,
                          gkr_fr* out_r) {
     using gkr::h64::F;
+    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+    double dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_d = 0, dbg_e = 0;
     const size_t len = (size_t)1 << n;
     hipStream_t s = ctx->stream;
-    static const int jmax = [] { const char* e = getenv("GKR_ROUNDS_PER_PASS"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
-    const int j_first = n < jmax ? n : jmax;
+    // rounds per pass: up to 5 with the matrix-core fold (fewer passes, ~2.07 N elements moved instead of 2.29 N),
+    // up to 3 with the v_mad_u64_u32 fold (GKR_NO_MFMA_FOLD)
+    static const int jmax = [] {
+        const int cap = getenv("GKR_NO_MFMA_FOLD") ? 3 : gkr::kMlePassMaxRounds;
+        const char* e = getenv("GKR_ROUNDS_PER_PASS");
+        const int v = e ? atoi(e) : cap;
+        return v < 1 ? 1 : (v > cap ? cap : v);
+    }();
+    // rounds the sums of a table of 2^m entries may cover: a fold pass over more than kSmallPassEntries outputs
+    // splits each sub-block over whole 64-entry chunks
+    auto rounds_for = [&](int m) {
+        int j = m < jmax ? m : jmax;
+        if (((size_t)1 << m) > gkr::kSmallPassEntries && m != n && j > m - 6) j = m - 6;
+        return j < 1 ? 1 : j;
+    };
+    const int j_first = rounds_for(n);
     const size_t work_len = len >> j_first;   // the first folded table
     Fr* work = nullptr;
     gkr::MleSubPartial* partials = nullptr;
-    gkr::MleHostRec8* rec = nullptr;
-    Fr* h_w = nullptr;   // pinned: 8 Montgomery weights per sumcheck
+    gkr::MleHostRecSub* rec = nullptr;
+    Fr* h_w = nullptr;   // pinned: up to 32 Montgomery weights per sumcheck
     WS(ctx, "mlep.work", Fr, (size_t)batch * (work_len ? work_len : 1), work);
     WS(ctx, "mlep.partials", gkr::MleSubPartial, (size_t)batch * gkr::kMaxBlocksPerTable, partials);
-    HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRec8) * batch, reinterpret_cast<void**>(&rec)));
-    HIP_TRY(ctx, ctx->pinned_host("mlep.w", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_w)));
+    unsigned char* plans = nullptr;   // per sumcheck: the digit matrix of the matrix-core fold pass
+    WS(ctx, "mlep.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
+    HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
+    HIP_TRY(ctx, ctx->pinned_host("mlep.w", sizeof(Fr) * gkr::kMleMaxSub * batch, reinterpret_cast<void**>(&h_w)));
     const F* cts = host_mimc_constants64();
     const bool ifma = host_ifma_ready();
     std::vector<uint32_t> dep_last(batch, 0);
@@ -378,9 +415,12 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         std::atomic<uint64_t> claim{0};   // (generation << 32) | next sumcheck; generation = pass number + 1
         std::atomic<int> done{0};
         int pass = 0;
+        int index = 0;
     };
     std::vector<Group> grp(groups);
+    HIP_TRY(ctx, ctx->aux_stream(groups));
     for (int g = 0; g < groups; ++g) {
+        grp[g].index = g;
         grp[g].b0 = (int)((long long)batch * g / groups);
         grp[g].nb = (int)((long long)batch * (g + 1) / groups) - grp[g].b0;
         grp[g].m = n;
@@ -393,7 +433,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         if (len <= gkr::kSmallPassEntries) {
             Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0);
             gkr::launch_mle_multifold_small(0, d_tables + (size_t)b0 * len, len, nullptr, 0, (uint32_t)len, (uint32_t)G.j, nb,
-                                            h_w + (size_t)b0 * 8, rec + b0, G.ticket, s);
+                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
             return;
         }
         const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)len, (uint32_t)G.j, nb);
@@ -415,20 +455,32 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         Fr* dst = work + (size_t)b0 * work_len;
         G.m -= jin;
         G.round0 += jin;
-        G.j = G.m < jmax ? G.m : jmax;
+        G.j = rounds_for(G.m);
         G.ticket = ++ctx->ticket;
         const double bytes = (double)nb * ((double)src_len + (double)S) * 32.0;
         if (S <= gkr::kSmallPassEntries) {
             Timed t(ctx, "mle_pass_small", bytes);
             gkr::launch_mle_multifold_small(jin, src, src_stride, dst, work_len, (uint32_t)S, (uint32_t)G.j, nb,
-                                            h_w + (size_t)b0 * 8, rec + b0, G.ticket, s);
+                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
             return;
         }
-        const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)S, (uint32_t)G.j, nb);
+        const uint32_t nblk = gkr::mle_multifold_blocks((uint32_t)S, (uint32_t)G.j, nb);
         gkr::MleSubPartial* part = partials + (size_t)b0 * gkr::kMaxBlocksPerTable;
+        unsigned char* plan = plans + (size_t)b0 * gkr::mle_fold_plan_bytes();
+        if (gkr::mle_multifold_uses_mfma((uint32_t)S, nblk)) {
+            // the digit matrices only depend on the weights the host just wrote: built on the side stream, so the
+            // main stream (busy with another group's pass) pays one event wait, not a launch round trip
+            {
+                Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux);
+                gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, ctx->aux);
+            }
+            (void)hipEventRecord(ctx->aux_events[G.index], ctx->aux);
+            (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
+        }
         {
             Timed t(ctx, "mle_multifold", bytes);
-            gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * 8, part, s);
+            gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub, plan,
+                                      part, s);
         }
         Timed t(ctx, "mle_sub_reduce", 0.0);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
@@ -436,7 +488,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // the J rounds of up to eight sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
         const int J = G.j;
-        F sums[kHashChunkMax][8], rr[kHashChunkMax][3];
+        F sums[kHashChunkMax][gkr::kMleMaxSub], rr[kHashChunkMax][gkr::kMlePassMaxRounds];
         for (int i = 0; i < count; ++i) {
             memcpy(sums[i], rec[b_first + i].sums, sizeof(F) << J);
             if (G.round0 == 0) dep_last[b_first + i] = rec[b_first + i].dep;
@@ -493,7 +545,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             // bit_0 = most significant; Montgomery form
             const F one_m = gkr::h64::to_mont(F{{1, 0, 0, 0}});
             for (int i = 0; i < count; ++i) {
-                F w[8];
+                F w[gkr::kMleMaxSub];
                 w[0] = one_m;
                 int cur = 1;
                 for (int t = 0; t < J; ++t) {
@@ -504,7 +556,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                     }
                     cur <<= 1;
                 }
-                memcpy(h_w + (size_t)(b_first + i) * 8, w, sizeof(F) << J);
+                memcpy(h_w + (size_t)(b_first + i) * gkr::kMleMaxSub, w, sizeof(F) << J);
             }
         }
     };
@@ -530,9 +582,11 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             if (__atomic_load_n(&rec[G.b0 + i].seq, __ATOMIC_ACQUIRE) != G.ticket) return false;
         return true;
     };
+    dbg_a = dbg_us();
     pool->begin_session(&try_work);
     int rc = GKR_OK;
     for (int g = 0; g < groups; ++g) launch_first(grp[g]);
+    dbg_b = dbg_us();
     int active = groups;
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t idle = 0;
@@ -570,14 +624,20 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                 rc = ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a pass");
         }
     }
+    dbg_c = dbg_us();
     pool->end_session();
     if (rc) {
         (void)hipStreamSynchronize(s);
         return rc;
     }
+    dbg_d = dbg_us();
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    dbg_e = dbg_us();
     ctx->drain_events();
+    if (dbg)
+        fprintf(stderr, "[gkr timing] setup %.0f us, first launches %.0f, loop %.0f, end_session %.0f, sync %.0f, drain %.0f\n", dbg_a,
+                dbg_b - dbg_a, dbg_c - dbg_b, dbg_d - dbg_c, dbg_e - dbg_d, dbg_us() - dbg_e);
     return GKR_OK;
 }
 
@@ -1207,6 +1267,8 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     ctx->release_buffers();
     if (ctx->d_cts) hipFree(ctx->d_cts);
+    for (hipEvent_t e : ctx->aux_events) hipEventDestroy(e);
+    if (ctx->aux) hipStreamDestroy(ctx->aux);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

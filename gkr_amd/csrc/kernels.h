@@ -55,22 +55,28 @@ struct MleSubPartial {
     Acc<9> sum;
     uint32_t dep, pad[2];
 };
-struct MleHostRec8 {     // pinned hand-off record: up to 8 sub-block sums, seq written last
-    Fr sums[8];
+constexpr int kMlePassMaxRounds = 5;                   // rounds one pass can cover (matrix-core fold: mfma_fold.h)
+constexpr int kMleMaxSub = 1 << kMlePassMaxRounds;     // sub-block sums / fold weights per sumcheck and pass
+struct MleHostRecSub {   // pinned hand-off record: up to 32 sub-block sums, seq written last
+    Fr sums[kMleMaxSub];
     uint32_t dep, seq;
     uint32_t pad[14];
 };
-static_assert(sizeof(MleHostRec8) == 320, "hand-off record layout");
+static_assert(sizeof(MleHostRecSub) == 1088, "hand-off record layout");
 constexpr uint32_t kSmallPassEntries = 512;   // passes whose output has <= this many entries run as one block per sumcheck
 uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch);
+uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch);
+bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk);
 void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk,
                          MleSubPartial* partials, hipStream_t s);
+size_t mle_fold_plan_bytes();
+void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batch, hipStream_t s);
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, const Fr* weights, MleSubPartial* partials, hipStream_t s);
-void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRec8* host_rec,
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s);
+void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRecSub* host_rec,
                            uint32_t ticket, hipStream_t s);
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
-                                uint32_t batch, const Fr* weights, MleHostRec8* host_rec, uint32_t ticket, hipStream_t s);
+                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
                                LayerBatch lb, hipStream_t s);
 void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s);

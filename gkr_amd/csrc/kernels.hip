@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "mfma_fold.h"
 #include "mimc7.h"
 
 namespace gkr {
@@ -251,13 +252,25 @@ __device__ __forceinline__ Fr multifold_entry(const Fr* __restrict__ s, uint32_t
         lazy_mac2_s(a0, load_fr(s + i), w[0], a1, load_fr(s + (size_t)S + i), w[1]);
         lazy_add(a0, a1);
         return lazy_reduce_k8(a0);
-    } else {
+    } else if constexpr (JIN <= 3) {
         Fr x[1 << JIN];
 #pragma unroll
         for (int b = 0; b < (1 << JIN); ++b) x[b] = load_fr(s + (size_t)b * S + i);
         Lazy17 t;
         weighted_sum_s<(1 << JIN)>(x, w, t);
         return lazy_reduce_k8(t);
+    } else {
+        // 16 or 32 inputs (small tables only): eight at a time, reduced sums added
+        Fr y = fr_zero();
+        for (int q = 0; q < (1 << (JIN - 3)); ++q) {
+            Fr x[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) x[b] = load_fr(s + (size_t)(q * 8 + b) * S + i);
+            Lazy17 t;
+            weighted_sum_s<8>(x, w + q * 8, t);
+            y = fr_add(y, lazy_reduce_k8(t));
+        }
+        return y;
     }
 }
 
@@ -298,7 +311,7 @@ __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ sr
     __shared__ Acc<9> smem[4];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
     Fr* d = dst + (size_t)blockIdx.y * dst_stride;
-    const Fr* w = weights + (size_t)blockIdx.y * 8;
+    const Fr* w = weights + (size_t)blockIdx.y * kMleMaxSub;
     const uint32_t chunk = S / gridDim.x;
     const uint32_t begin = blockIdx.x * chunk, end = begin + chunk;
     Acc<9> acc[1] = {acc_zero<9>()};
@@ -315,18 +328,49 @@ __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ sr
     }
 }
 
-// partials -> 2^jout canonical sub-block sums per table -> pinned host record.  Wave w totals
-// sub-block w.  grid = (batch), block = 512 (8 waves)
+// the same pass with the products on the matrix cores (mfma_fold.h): k_mle_fold_plan turns each sumcheck's
+// weights into its digit matrix (grid = batch), k_mle_multifold_mfma streams the tables through it
+// (chunk = S / nblk a multiple of 64)
+template <int JIN>
+__global__ void __launch_bounds__(256) k_mle_fold_plan(const Fr* __restrict__ weights, MfmaFoldPlan* __restrict__ plans) {
+    __shared__ __attribute__((aligned(16))) unsigned char digits[32 * 32 * (1 << JIN)];
+    mfma_plan_block<JIN>(weights + (size_t)blockIdx.x * kMleMaxSub, plans + blockIdx.x, digits);
+}
+
+template <int JIN>
+__global__ void __launch_bounds__(256) k_mle_multifold_mfma(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                            size_t dst_stride, uint32_t S, const MfmaFoldPlan* __restrict__ plans,
+                                                            MleSubPartial* __restrict__ partials) {
+    __shared__ Acc<9> smem[4];
+    __shared__ __attribute__((aligned(16))) unsigned char digits[JIN > 2 ? 32 * 32 * (1 << JIN) : 16];
+    const Fr* s = src + (size_t)blockIdx.y * src_stride;
+    Fr* d = dst + (size_t)blockIdx.y * dst_stride;
+    const uint32_t chunk = S / gridDim.x;
+    const uint32_t begin = blockIdx.x * chunk;
+    Acc<9> acc[1] = {acc_zero<9>()};
+    mfma_multifold_block<JIN>(s, d, S, plans + blockIdx.y, begin, begin + chunk, blockIdx.x * 5u + blockIdx.y * 3u, acc[0], digits);
+    block_sum<9, 1>(acc, smem);
+    if (threadIdx.x == 0) {
+        MleSubPartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->sum = acc[0];
+        p->dep = 0;
+    }
+}
+
+// partials -> 2^jout canonical sub-block sums per table -> pinned host record.  The eight waves total the
+// sub-blocks (wave w: sub-blocks w, w + 8, ...), then one thread per sub-block reduces its total mod p.
+// grid = (batch), block = 512
 __global__ void __launch_bounds__(512) k_mle_sub_reduce(const MleSubPartial* __restrict__ partials, uint32_t nblk,
-                                                        uint32_t jout, MleHostRec8* __restrict__ host_rec, uint32_t ticket) {
+                                                        uint32_t jout, MleHostRecSub* __restrict__ host_rec, uint32_t ticket) {
     __shared__ uint32_t s_dep;
+    __shared__ Acc<10> s_tot[kMleMaxSub];
     const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nsub = 1u << jout, bps = nblk >> jout;
     if (threadIdx.x == 0) s_dep = 0;
     __syncthreads();
-    MleHostRec8* r = host_rec + b;
-    if (wave < nsub) {
-        const MleSubPartial* p = partials + (size_t)b * nblk + (size_t)wave * bps;
+    MleHostRecSub* r = host_rec + b;
+    for (uint32_t sb = wave; sb < nsub; sb += 8u) {
+        const MleSubPartial* p = partials + (size_t)b * nblk + (size_t)sb * bps;
         Acc<10> tot = acc_zero<10>();
         uint32_t dep = 0;
         for (uint32_t i = lane; i < bps; i += 64) {
@@ -335,9 +379,11 @@ __global__ void __launch_bounds__(512) k_mle_sub_reduce(const MleSubPartial* __r
         }
         tot = wave_sum(tot);
         if (__any(dep) && lane == 0) atomicOr(&s_dep, 1u);
-        if (lane == 0) r->sums[wave] = acc_reduce(tot);
+        if (lane == 0) s_tot[sb] = tot;
     }
-    __syncthreads();   // every wave's record stores are issued and waited for before the release below
+    __syncthreads();
+    if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_tot[threadIdx.x]);
+    __syncthreads();   // every record store is issued and waited for before the release below
     if (threadIdx.x == 0) {
         r->dep = s_dep;
         __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -349,12 +395,11 @@ template <int JIN>
 __global__ void __launch_bounds__(256) k_mle_multifold_small(const Fr* __restrict__ src, size_t src_stride,
                                                              Fr* __restrict__ dst, size_t dst_stride, uint32_t S,
                                                              uint32_t jout, const Fr* __restrict__ weights,
-                                                             MleHostRec8* __restrict__ host_rec, uint32_t ticket) {
-    __shared__ Acc<9> smem[4];
+                                                             MleHostRecSub* __restrict__ host_rec, uint32_t ticket) {
     const uint32_t b = blockIdx.x;
     const Fr* s = src + (size_t)b * src_stride;
     Fr* d = dst + (size_t)b * dst_stride;
-    const Fr* w = weights + (size_t)b * 8;
+    const Fr* w = weights + (size_t)b * kMleMaxSub;
     // JIN == 0: no fold, only the sub-block sums of the table as it stands (tiny first pass)
     if (JIN > 0) {
         for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
@@ -364,19 +409,32 @@ __global__ void __launch_bounds__(256) k_mle_multifold_small(const Fr* __restric
         __syncthreads();   // the folded table is complete and visible to the block
     }
     const Fr* tbl = JIN > 0 ? d : s;
-    const uint32_t sub = S >> jout;
-    MleHostRec8* r = host_rec + b;
+    const uint32_t sub = S >> jout, nsub = 1u << jout;
+    MleHostRecSub* r = host_rec + b;
     uint32_t dep = 0;
-    for (uint32_t sb = 0; sb < (1u << jout); ++sb) {
-        Acc<9> acc[1] = {acc_zero<9>()};
-        for (uint32_t i = threadIdx.x; i < sub; i += blockDim.x) {
+    // 256 / nsub threads per sub-block (nsub <= 32): partial sums, totals through LDS, then one thread per
+    // sub-block reduces its total mod p
+    {
+        __shared__ Acc<9> s_part[256];
+        const uint32_t tps = 256u >> jout, sb = threadIdx.x / tps, rr = threadIdx.x % tps;
+        Acc<9> acc = acc_zero<9>();
+        for (uint32_t i = rr; i < sub; i += tps) {
             const Fr x = load_fr(tbl + (size_t)sb * sub + i);
-            acc_add_fr(acc[0], x);
+            acc_add_fr(acc, x);
             if (JIN == 0) dep |= fr_eq(x, load_fr(tbl + (((size_t)sb * sub + i) ^ 1u))) ? 0u : 1u;
         }
-        block_sum<9, 1>(acc, smem);
-        if (threadIdx.x == 0) r->sums[sb] = acc_reduce(acc[0]);
-        __syncthreads();   // smem is reused by the next sub-block
+        s_part[threadIdx.x] = acc;
+        __syncthreads();
+        // tree over the tps partials of each sub-block (tps is a power of two)
+        for (uint32_t step = tps >> 1; step >= 1u; step >>= 1) {
+            if (rr < step) {
+                Acc<9> mine = s_part[threadIdx.x];
+                acc_add_acc(mine, s_part[threadIdx.x + step]);
+                s_part[threadIdx.x] = mine;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_part[threadIdx.x * tps]);
     }
     dep = __syncthreads_or(dep);
     if (threadIdx.x == 0) {
@@ -1104,9 +1162,48 @@ void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t
     hipLaunchKernelGGL(k_mle_sub_sums, dim3(nblk, batch), dim3(256), 0, s, tables, stride, len, partials);
 }
 
+// matrix-core form unless GKR_NO_MFMA_FOLD is set or the chunk is not a whole number of 64-entry wave tiles
+bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk) {
+    static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
+    return !off && nblk > 0 && S % nblk == 0 && (S / nblk) % 64u == 0;
+}
+
+size_t mle_fold_plan_bytes() { return sizeof(MfmaFoldPlan); }
+
+// the plans of `batch` sumchecks (batch * mle_fold_plan_bytes() of device memory) from their weights; only needed
+// when mle_multifold_uses_mfma says so
+void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batch, hipStream_t s) {
+    MfmaFoldPlan* pl = static_cast<MfmaFoldPlan*>(plans);
+    if (jin == 1)
+        hipLaunchKernelGGL(k_mle_fold_plan<1>, dim3(batch), dim3(256), 0, s, weights, pl);
+    else if (jin == 2)
+        hipLaunchKernelGGL(k_mle_fold_plan<2>, dim3(batch), dim3(256), 0, s, weights, pl);
+    else if (jin == 3)
+        hipLaunchKernelGGL(k_mle_fold_plan<3>, dim3(batch), dim3(256), 0, s, weights, pl);
+    else if (jin == 4)
+        hipLaunchKernelGGL(k_mle_fold_plan<4>, dim3(batch), dim3(256), 0, s, weights, pl);
+    else
+        hipLaunchKernelGGL(k_mle_fold_plan<5>, dim3(batch), dim3(256), 0, s, weights, pl);
+}
+
+// plans: what launch_mle_fold_plan built for this pass (matrix-core form), unused otherwise
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, const Fr* weights, MleSubPartial* partials, hipStream_t s) {
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s) {
     dim3 grid(nblk, batch);
+    if (mle_multifold_uses_mfma(S, nblk)) {
+        const MfmaFoldPlan* pl = static_cast<const MfmaFoldPlan*>(plans);
+        if (jin == 1)
+            hipLaunchKernelGGL(k_mle_multifold_mfma<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+        else if (jin == 2)
+            hipLaunchKernelGGL(k_mle_multifold_mfma<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+        else if (jin == 3)
+            hipLaunchKernelGGL(k_mle_multifold_mfma<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+        else if (jin == 4)
+            hipLaunchKernelGGL(k_mle_multifold_mfma<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+        else
+            hipLaunchKernelGGL(k_mle_multifold_mfma<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+        return;
+    }
     if (jin == 1)
         hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
     else if (jin == 2)
@@ -1115,13 +1212,26 @@ void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, si
         hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
 }
 
-void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRec8* host_rec,
+// blocks per table for a multifold pass of S output entries split into 2^jout sub-blocks.  The matrix-core
+// kernel pays a per-block set-up (digit matrix of the sumcheck), so it wants few, long chunks: a power of two
+// >= 2^jout, ~1024 blocks over the batch (two resident per CU), chunks of at least 256 entries (MI355X,
+// 64 x 2^17: 16 blocks per table 5.7 TB/s, 128 blocks 5.3).
+uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch) {
+    static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
+    if (off) return mle_pass_blocks(S, jout, batch);
+    uint32_t b = 1u << jout;
+    while ((uint64_t)b * batch < 1024u && S / (2u * b) >= 256u && 2u * b <= kMaxBlocksPerTable) b <<= 1;
+    if (b > S) b = S;
+    return b;
+}
+
+void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRecSub* host_rec,
                            uint32_t ticket, hipStream_t s) {
     hipLaunchKernelGGL(k_mle_sub_reduce, dim3(batch), dim3(512), 0, s, partials, nblk, jout, host_rec, ticket);
 }
 
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
-                                uint32_t batch, const Fr* weights, MleHostRec8* host_rec, uint32_t ticket, hipStream_t s) {
+                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s) {
     dim3 grid(batch);
     if (jin == 0)
         hipLaunchKernelGGL(k_mle_multifold_small<0>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
@@ -1129,8 +1239,12 @@ void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* d
         hipLaunchKernelGGL(k_mle_multifold_small<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
     else if (jin == 2)
         hipLaunchKernelGGL(k_mle_multifold_small<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
-    else
+    else if (jin == 3)
         hipLaunchKernelGGL(k_mle_multifold_small<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+    else if (jin == 4)
+        hipLaunchKernelGGL(k_mle_multifold_small<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+    else
+        hipLaunchKernelGGL(k_mle_multifold_small<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
 }
 
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,

@@ -81,6 +81,26 @@ def test_mle_baseline_sizes_match_oracle(ctx, n, seed):
         ctx.free(d)
 
 
+@pytest.mark.parametrize("n", [13, 14, 16])
+def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
+    """The fold pass multiplies on the matrix cores over signed bytes (mfma_fold.h): tables made of the byte
+    patterns that sit on its sign and carry boundaries (0x00, 0x7f, 0x80, 0xff runs, p - 1, small values) must
+    come out as the same field elements."""
+    rng = random.Random(4000 + n)
+    specials = [0, 1, P - 1, P - 2, (1 << 253) - 1, int.from_bytes(b"\x80" * 31 + b"\x20", "little"),
+                int.from_bytes(b"\x7f" * 31 + b"\x2f", "little"), int.from_bytes(b"\xff" * 31 + b"\x2f", "little"),
+                int.from_bytes(b"\x00\xff" * 15 + b"\x00\x30", "little"), 0x80, 0xff, 1 << 128]
+    assert all(x < P for x in specials)
+    for mode in ("all_max", "specials", "mixed"):
+        if mode == "all_max":
+            t = [P - 1] * (1 << n)
+        elif mode == "specials":
+            t = [specials[rng.randrange(len(specials))] for _ in range(1 << n)]
+        else:
+            t = [specials[rng.randrange(len(specials))] if rng.random() < 0.5 else rng.randrange(P) for _ in range(1 << n)]
+        assert ctx.prove_sumcheck(t, n) == cdense.sumcheck_mle(t, n), mode
+
+
 def test_mle_batch_is_independent_sumchecks(ctx):
     n, batch = 12, 5
     count = 1 << n
