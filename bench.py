@@ -5,7 +5,7 @@ tables (BASELINE.json metric, configs[2]), one process per GPU.
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch: `--batch` (default 256) independent
+A step = one pass of the hot path over one batch: `--batch` (default 1024, 32 GiB of tables) independent
 2^n-point multilinear sumchecks (prove_sumcheck, rust/src/gkr/sumcheck.rs:158-214),
 tables resident in HBM before the timed region, MiMC7 transcript included.  (One
 aggregation step of the reference proves up to 20 sub-circuits with several layers
@@ -16,8 +16,9 @@ scaling: every rank proves its own batch).
 
 field-ops: 5 (2^n - 1) per sumcheck; algorithmic bytes 128 * 2^n per sumcheck
 (SURVEY.md section 8d).  The JSON line also carries
-  roofline      the dominant kernel (mle_fold_sum) timed with HIP events on the
-                library's stream during the timed steps
+  roofline      the dominant kernel (k_mle_multifold_mfma, the fold pass) timed with HIP events on
+                the library's stream during the timed steps (profile level 2: only the bandwidth-
+                bound kernels carry events, the small round-trip kernels are left alone)
   cpu_baseline  the plain-C oracle (oracle/c, OpenMP over the host cores) on a
                 bounded sample of the same workload; rank 0, N = 1 only
 """
@@ -39,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
-    ap.add_argument("--batch", type=int, default=256, help="independent sumchecks per rank per step (8 GiB of tables)")
+    ap.add_argument("--batch", type=int, default=1024, help="independent sumchecks per rank per step (32 GiB of tables)")
     ap.add_argument("--transcript", choices=["host", "device"], default="host",
                     help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
@@ -95,7 +96,7 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    ctx.profile(not args.no_profile)        # on during warm-up too: the event pool is created lazily
+    ctx.profile(0 if args.no_profile else 2)   # on during warm-up too: the event pool is created lazily
     for _ in range(args.warmup):
         step()
     ctx.profile_reset()
@@ -116,7 +117,7 @@ def main():
     value = total_ops / elapsed
 
     if rank == 0:
-        names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small",            # multi-round passes (default)
+        names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",            # multi-round passes (default)
                  "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]   # per-round paths
         prof = {k: ctx.profile_get(k) for k in names}
         dom_name = "mle_multifold" if prof["mle_multifold"]["launches"] else "mle_fold_sum"
@@ -145,14 +146,14 @@ def main():
             "sumchecks_per_sec": batch * args.steps * world / elapsed,
             "step_ms_each": [round(x * 1e3, 3) for x in step_times[args.warmup:]],
             "roofline": {
-                "bound": "hbm", "kernel": "k_" + dom_name,
+                "bound": "hbm", "kernel": "k_mle_multifold_mfma" if dom_name == "mle_multifold" else "k_" + dom_name,
                 "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                 "traffic": None,
                 "launches": dom["launches"],
                 "avg_launch_us": (dom["total_ms"] * 1e3 / dom["launches"]) if dom["launches"] else None,
                 "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
-                "bytes_rule": "k_mle_multifold: (2^J + 1) * 32 B per output entry (reads 2^J source entries, writes one); "
-                              "k_mle_fold_sum: 192 B per output pair" ,
+                "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
+                              "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair",
             },
             "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
             # SURVEY 8d's per-round accounting (128 * 2^n bytes per sumcheck) over ALL kernel time of the step:
@@ -167,7 +168,7 @@ def main():
             try:
                 tj = json.load(open(traffic_file))
                 if tj.get("batch") == batch and tj.get("n") == n:
-                    line["roofline"]["traffic"] = tj["k_mle_multifold"]["per_launch_mean_bytes"]
+                    line["roofline"]["traffic"] = tj["k_mle_multifold_mfma"]["per_launch_mean_bytes"]
                     line["roofline"]["traffic_source"] = "profiles/r01/c_pmc_traffic.json (rocprofv3 --pmc passes of this command)"
             except Exception:
                 pass

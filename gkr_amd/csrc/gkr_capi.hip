@@ -180,7 +180,7 @@ struct gkr_ctx {
     Fr* d_cts = nullptr;
     int transcript = GKR_TRANSCRIPT_HOST;
     std::string err;
-    bool profile = false;
+    int profile = 0;                           // 0 off, 1 every kernel, 2 the bandwidth-bound kernels only
     std::map<std::string, ProfileRow> prof;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -284,8 +284,10 @@ struct Timed {
     PendingEvent ev;
     bool on;
     hipStream_t st;
-    Timed(gkr_ctx* ctx, const char* name, double bytes, hipStream_t stream = nullptr)
-        : c(ctx), on(ctx->profile), st(stream ? stream : ctx->stream) {
+    // minor: a small latency-bound kernel on the round-trip path (left out at profile level 2, where the event
+    // records themselves would show in the wall time)
+    Timed(gkr_ctx* ctx, const char* name, double bytes, hipStream_t stream = nullptr, bool minor = false)
+        : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && !minor)), st(stream ? stream : ctx->stream) {
         if (on) {
             ev.start = c->get_event();
             ev.stop = c->get_event();
@@ -391,6 +393,12 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     Fr* h_w = nullptr;   // pinned: up to 32 Montgomery weights per sumcheck
     WS(ctx, "mlep.work", Fr, (size_t)batch * (work_len ? work_len : 1), work);
     WS(ctx, "mlep.partials", gkr::MleSubPartial, (size_t)batch * gkr::kMaxBlocksPerTable, partials);
+    uint32_t* counters = nullptr;     // per sumcheck: blocks of the pass in flight that have delivered their partial
+    {
+        const size_t had = ctx->ws["mlep.counters"].second;
+        WS(ctx, "mlep.counters", uint32_t, (size_t)batch, counters);
+        if (ctx->ws["mlep.counters"].second != had) HIP_TRY(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t) * batch, ctx->stream));
+    }
     unsigned char* plans = nullptr;   // per sumcheck: the digit matrix of the matrix-core fold pass
     WS(ctx, "mlep.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
     HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
@@ -401,7 +409,9 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     gkr::SpinPool* pool = ctx->host_pool();
     const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
-    int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
+    // groups of 64 sumchecks (2 GiB of 2^20-point tables): large enough to fill the chip, small enough that a
+    // group's latency-bound late passes hide behind other groups' bandwidth-bound ones
+    int group_size = batch >= 128 ? 64 : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
     if (groups > kMaxGroups) groups = kMaxGroups;
@@ -431,7 +441,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         const int b0 = G.b0, nb = G.nb;
         G.ticket = ++ctx->ticket;
         if (len <= gkr::kSmallPassEntries) {
-            Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0);
+            Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0, nullptr, true);
             gkr::launch_mle_multifold_small(0, d_tables + (size_t)b0 * len, len, nullptr, 0, (uint32_t)len, (uint32_t)G.j, nb,
                                             h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
             return;
@@ -442,7 +452,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             Timed t(ctx, "mle_sub_sums", (double)nb * len * 32.0);
             gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, s);
         }
-        Timed t(ctx, "mle_sub_reduce", 0.0);
+        Timed t(ctx, "mle_sub_reduce", 0.0, nullptr, true);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
     };
     // a fold pass: bind the jin variables just hashed, produce the sums of the next jout rounds
@@ -459,7 +469,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         G.ticket = ++ctx->ticket;
         const double bytes = (double)nb * ((double)src_len + (double)S) * 32.0;
         if (S <= gkr::kSmallPassEntries) {
-            Timed t(ctx, "mle_pass_small", bytes);
+            Timed t(ctx, "mle_pass_small", bytes, nullptr, true);
             gkr::launch_mle_multifold_small(jin, src, src_stride, dst, work_len, (uint32_t)S, (uint32_t)G.j, nb,
                                             h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
             return;
@@ -471,19 +481,15 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             // the digit matrices only depend on the weights the host just wrote: built on the side stream, so the
             // main stream (busy with another group's pass) pays one event wait, not a launch round trip
             {
-                Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux);
+                Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux, true);
                 gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, ctx->aux);
             }
             (void)hipEventRecord(ctx->aux_events[G.index], ctx->aux);
             (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
         }
-        {
-            Timed t(ctx, "mle_multifold", bytes);
-            gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub, plan,
-                                      part, s);
-        }
-        Timed t(ctx, "mle_sub_reduce", 0.0);
-        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
+        Timed t(ctx, "mle_multifold", bytes);
+        gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, (uint32_t)G.j,
+                                  h_w + (size_t)b0 * gkr::kMleMaxSub, plan, part, counters + b0, rec + b0, G.ticket, s);
     };
     // the J rounds of up to eight sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
@@ -634,7 +640,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
     dbg_e = dbg_us();
-    ctx->drain_events();
+    if (ctx->pending.size() > 8192) ctx->drain_events();   // otherwise when the profile is read
     if (dbg)
         fprintf(stderr, "[gkr timing] setup %.0f us, first launches %.0f, loop %.0f, end_session %.0f, sync %.0f, drain %.0f\n", dbg_a,
                 dbg_b - dbg_a, dbg_c - dbg_b, dbg_d - dbg_c, dbg_e - dbg_d, dbg_us() - dbg_e);
@@ -1263,6 +1269,8 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) hipStreamSynchronize(ctx->aux);
+    ctx->drain_events();
     ctx->drain_events();
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     ctx->release_buffers();
@@ -1289,7 +1297,7 @@ int gkr_ctx_device_name(const gkr_ctx* ctx, char* buf, size_t len) {
 
 int gkr_ctx_profile(gkr_ctx* ctx, int enable) {
     if (!ctx) return GKR_ERR_INVALID;
-    ctx->profile = enable != 0;
+    ctx->profile = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return GKR_OK;
 }
 

@@ -148,7 +148,8 @@ class Context:
         self._check(N.lib().gkr_ctx_set_transcript(self._h, ctypes.c_int(mode)))
 
     def profile(self, enable=True):
-        self._check(N.lib().gkr_ctx_profile(self._h, ctypes.c_int(1 if enable else 0)))
+        """0/False off, 1/True every kernel, 2 the bandwidth-bound kernels only (see gkr_amd.h)."""
+        self._check(N.lib().gkr_ctx_profile(self._h, ctypes.c_int(int(enable))))
 
     def profile_reset(self):
         self._check(N.lib().gkr_ctx_profile_reset(self._h))

@@ -87,9 +87,12 @@ const char *gkr_last_error(const gkr_ctx *ctx);
 int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
 int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
 
-/* Per-kernel timing with HIP events on the context's stream (bench.py's
- * roofline leg).  kernel: "mle_fold_sum", "mle_sum_first", "mle_round_hash",
- * "layer_round", "layer_fold", "layer_round_hash". */
+/* Per-kernel timing with HIP events on the stream each kernel is launched on (bench.py's
+ * roofline leg).  enable: 0 off, 1 every kernel, 2 only the bandwidth-bound kernels ("mle_multifold",
+ * "mle_sub_sums", "mle_fold_sum", "layer_round", ...): the small kernels on the round-trip path are
+ * left alone so that the event records do not show in the wall time being measured.
+ * kernel: "mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",
+ * "mle_fold_sum", "mle_sum_first", "mle_round_hash", "layer_round", "layer_fold", "layer_round_hash". */
 int  gkr_ctx_profile(gkr_ctx *ctx, int enable);
 int  gkr_ctx_profile_get(gkr_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms,
                          double *algorithmic_bytes);
