@@ -163,23 +163,27 @@ def main():
         first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
         if first["total_ms"] > 0:
             line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
-        traffic_file = os.path.join(REPO, "profiles", "r01", "c_pmc_traffic.json")
+        traffic_file = os.path.join(REPO, "profiles", "r01", "d_pmc_traffic.json")
         if os.path.exists(traffic_file) and dom_name == "mle_multifold":
             try:
                 tj = json.load(open(traffic_file))
                 if tj.get("batch") == batch and tj.get("n") == n:
                     line["roofline"]["traffic"] = tj["k_mle_multifold_mfma"]["per_launch_mean_bytes"]
-                    line["roofline"]["traffic_source"] = "profiles/r01/c_pmc_traffic.json (rocprofv3 --pmc passes of this command)"
+                    line["roofline"]["traffic_source"] = "profiles/r01/d_pmc_traffic.json (rocprofv3 --pmc passes of this command)"
             except Exception:
                 pass
         if args.proofs > 0:
+            # second half of the metric, on its own context, once the sumcheck workload's 32 GiB are released
+            ctx.free(tables)
+            tables = None
             line["aggregated_proofs"] = proofs_per_sec(local_rank, args.proofs)
             line["aggregated_proofs"]["proofs_per_sec_all_ranks"] = line["aggregated_proofs"]["proofs_per_sec"] * world
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
-    ctx.free(tables)
+    if tables is not None:
+        ctx.free(tables)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

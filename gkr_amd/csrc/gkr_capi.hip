@@ -383,6 +383,9 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     auto rounds_for = [&](int m) {
         int j = m < jmax ? m : jmax;
         if (((size_t)1 << m) > gkr::kSmallPassEntries && m != n && j > m - 6) j = m - 6;
+        // the fold these rounds lead to leaves 2^(m-j) entries: 1024 or 2048 is too many for the one-block kernel and
+        // too few to fill the chip with 64-entry wave tiles -- stop at 4096 and take the rest in the pass after
+        if (jmax > 3 && (m - j == 10 || m - j == 11) && m - 12 >= 1) j = m - 12;
         return j < 1 ? 1 : j;
     };
     const int j_first = rounds_for(n);
@@ -480,12 +483,17 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         if (gkr::mle_multifold_uses_mfma((uint32_t)S, nblk)) {
             // the digit matrices only depend on the weights the host just wrote: built on the side stream, so the
             // main stream (busy with another group's pass) pays one event wait, not a launch round trip
-            {
-                Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux, true);
-                gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, ctx->aux);
+            static const bool plan_inline = getenv("GKR_PLAN_MAIN") != nullptr;
+            if (plan_inline) {
+                gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, s);
+            } else {
+                {
+                    Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux, true);
+                    gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, ctx->aux);
+                }
+                (void)hipEventRecord(ctx->aux_events[G.index], ctx->aux);
+                (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
             }
-            (void)hipEventRecord(ctx->aux_events[G.index], ctx->aux);
-            (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
         }
         Timed t(ctx, "mle_multifold", bytes);
         gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, (uint32_t)G.j,

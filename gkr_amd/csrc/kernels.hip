@@ -1292,8 +1292,9 @@ void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, si
 uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch) {
     static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
     if (off) return mle_pass_blocks(S, jout, batch);
+    static const uint32_t target = [] { const char* e = getenv("GKR_FOLD_BLOCKS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1024u; }();
     uint32_t b = 1u << jout;
-    while ((uint64_t)b * batch < 1024u && S / (2u * b) >= 256u && 2u * b <= kMaxBlocksPerTable) b <<= 1;
+    while ((uint64_t)b * batch < target && S / (2u * b) >= 256u && 2u * b <= kMaxBlocksPerTable) b <<= 1;
     if (b > S) b = S;
     return b;
 }

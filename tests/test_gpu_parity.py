@@ -101,6 +101,25 @@ def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
         assert ctx.prove_sumcheck(t, n) == cdense.sumcheck_mle(t, n), mode
 
 
+@pytest.mark.parametrize("env", [{"GKR_NO_MFMA_FOLD": "1"}, {"GKR_ROUNDS_PER_PASS": "1"}, {"GKR_ROUNDS_PER_PASS": "3"},
+                                 {"GKR_ROUNDS_PER_PASS": "4"}, {"GKR_HASH_CHUNK": "16", "GKR_HOST_THREADS": "2"},
+                                 {"GKR_NO_IFMA": "1"}, {"GKR_PLAN_MAIN": "1", "GKR_FOLD_BLOCKS": "8192"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_fold_pass_variants_match_oracle(env):
+    """Every schedule of the host-transcript sumcheck gives the same transcript: the v_mad_u64_u32 fold instead
+    of the matrix-core one, 1 / 3 / 4 rounds per pass instead of 5, sixteen-lane and scalar host hashing, other
+    block counts.  The knobs are read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sizes = ((14, 20), (17, 3)) if "GKR_ROUNDS_PER_PASS" in env or "GKR_NO_MFMA_FOLD" in env else ((14, 20),)
+    for n, batch in sizes:
+        out = subprocess.run([sys.executable, os.path.join(here, "fold_variants_worker.py"), str(n), str(batch)],
+                             env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_mle_batch_is_independent_sumchecks(ctx):
     n, batch = 12, 5
     count = 1 << n
