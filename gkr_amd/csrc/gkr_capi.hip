@@ -138,6 +138,13 @@ inline int hash_chunk_size(int tables, int threads) {
     return tables >= 32 * threads ? 16 : 8;
 }
 
+// device allocations of the library: optionally physically contiguous (experiment knob GKR_ALLOC_CONTIGUOUS)
+inline hipError_t device_malloc(void** p, size_t bytes) {
+    static const bool contiguous = getenv("GKR_ALLOC_CONTIGUOUS") != nullptr;
+    if (contiguous) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    return hipMalloc(p, bytes);
+}
+
 int default_host_threads() {
     if (const char* e = getenv("GKR_HOST_THREADS")) {
         int v = atoi(e);
@@ -197,7 +204,7 @@ struct gkr_ctx {
             if (e.first) (void)hipFree(e.first);
             e.first = nullptr;
             e.second = 0;
-            hipError_t rc = hipMalloc(&e.first, bytes);
+            hipError_t rc = device_malloc(&e.first, bytes);
             if (rc != hipSuccess) return rc;
             e.second = bytes;
         }
@@ -396,12 +403,6 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     Fr* h_w = nullptr;   // pinned: up to 32 Montgomery weights per sumcheck
     WS(ctx, "mlep.work", Fr, (size_t)batch * (work_len ? work_len : 1), work);
     WS(ctx, "mlep.partials", gkr::MleSubPartial, (size_t)batch * gkr::kMaxBlocksPerTable, partials);
-    uint32_t* counters = nullptr;     // per sumcheck: blocks of the pass in flight that have delivered their partial
-    {
-        const size_t had = ctx->ws["mlep.counters"].second;
-        WS(ctx, "mlep.counters", uint32_t, (size_t)batch, counters);
-        if (ctx->ws["mlep.counters"].second != had) HIP_TRY(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t) * batch, ctx->stream));
-    }
     unsigned char* plans = nullptr;   // per sumcheck: the digit matrix of the matrix-core fold pass
     WS(ctx, "mlep.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
     HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
@@ -412,9 +413,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     gkr::SpinPool* pool = ctx->host_pool();
     const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
-    // groups of 64 sumchecks (2 GiB of 2^20-point tables): large enough to fill the chip, small enough that a
-    // group's latency-bound late passes hide behind other groups' bandwidth-bound ones
-    int group_size = batch >= 128 ? 64 : (batch >= 16 ? (batch + 1) / 2 : batch);
+    // four groups (measured on MI355X at batch 1024, same box: groups of 256 4.13e11 field-ops/s, of 128 4.00e11, of
+    // 64 3.75e11 -- larger launches stream better, and four groups are enough for one group's latency-bound late
+    // passes to hide behind the others' bandwidth-bound early ones)
+    int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
     if (groups > kMaxGroups) groups = kMaxGroups;
@@ -495,9 +497,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                 (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
             }
         }
-        Timed t(ctx, "mle_multifold", bytes);
-        gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, (uint32_t)G.j,
-                                  h_w + (size_t)b0 * gkr::kMleMaxSub, plan, part, counters + b0, rec + b0, G.ticket, s);
+        {
+            Timed t(ctx, "mle_multifold", bytes);
+            gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub,
+                                      plan, part, s);
+        }
+        Timed t(ctx, "mle_sub_reduce", 0.0, nullptr, true);
+        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
     };
     // the J rounds of up to eight sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
@@ -2129,7 +2135,7 @@ int gkr_device_tables_differ(gkr_ctx* ctx, const void* d_a, const void* d_b, siz
 int gkr_device_alloc(gkr_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr || !bytes) return GKR_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(d_ptr, bytes);
+    hipError_t e = device_malloc(d_ptr, bytes);
     if (e == hipErrorOutOfMemory) return ctx->fail(GKR_ERR_NOMEM, "hipMalloc: out of memory");
     HIP_TRY(ctx, e);
     return GKR_OK;

@@ -67,9 +67,7 @@ constexpr uint32_t kSmallPassEntries = 512;   // passes whose output has <= this
 uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch);
 uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch);
 bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk);
-// Pass 0: partial sums, then a reduce kernel.  Fold passes publish their own sums: counters = one zeroed uint32
-// per sumcheck (the kernels leave them zero), host_rec / ticket = where and with which sequence number the
-// 2^jout sums of each sumcheck land.
+// Every pass: per-block partial sums, then a reduce kernel that writes the pinned host record.
 void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk, MleSubPartial* partials,
                          hipStream_t s);
 void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRecSub* host_rec,
@@ -77,8 +75,7 @@ void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_
 size_t mle_fold_plan_bytes();
 void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batch, hipStream_t s);
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, uint32_t jout, const Fr* weights, const void* plans, MleSubPartial* partials,
-                          uint32_t* counters, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s);
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
                                 uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,

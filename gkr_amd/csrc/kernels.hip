@@ -274,66 +274,6 @@ __device__ __forceinline__ Fr multifold_entry(const Fr* __restrict__ s, uint32_t
     }
 }
 
-// A pass publishes its own sums: every block stores its partial, and the block that arrives LAST at the
-// table's counter totals the partials per sub-block and writes the pinned host record (no separate reduce
-// launch on the round-trip path).  Per-XCD L2s are not coherent with each other, so the handed-off bytes go
-// around them: agent-scope (sc1) stores drained before the counter increment, agent-scope loads in the
-// reader.  `pass`: blockIdx.x, gridDim.x = nblk = 2^jout * blocks-per-sub-block.  Thread 0 holds `total`.
-struct PassPublish {
-    MleSubPartial* partials;   // nblk per sumcheck
-    uint32_t* counters;        // one per sumcheck, zero between passes
-    MleHostRecSub* host_rec;
-    uint32_t jout, ticket;
-};
-
-__device__ __forceinline__ void publish_pass_sums(const PassPublish& pp, const Acc<9>& total, uint32_t dep_block) {
-    __shared__ uint32_t s_last;
-    __shared__ Acc<10> s_tot[256];
-    const uint32_t nblk = gridDim.x, table = blockIdx.y;
-    MleSubPartial* tp = pp.partials + (size_t)table * nblk;
-    if (threadIdx.x == 0) {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(tp + blockIdx.x);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) __hip_atomic_store(dst + i, total.l[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 9, dep_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores are acknowledged before the count
-        const uint32_t old = __hip_atomic_fetch_add(pp.counters + table, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old + 1u == nblk) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const uint32_t nsub = 1u << pp.jout, bps = nblk >> pp.jout;
-    const uint32_t tps = 256u >> pp.jout, sb = threadIdx.x / tps, rr = threadIdx.x % tps;
-    Acc<10> tot = acc_zero<10>();
-    uint32_t dep = 0;
-    for (uint32_t i = rr; i < bps; i += tps) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(tp + (size_t)sb * bps + i);
-        Acc<9> part;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) part.l[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dep |= __hip_atomic_load(src + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        acc_add_acc(tot, part);
-    }
-    s_tot[threadIdx.x] = tot;
-    __syncthreads();
-    for (uint32_t step = tps >> 1; step >= 1u; step >>= 1) {   // tree over the tps partial totals of a sub-block
-        if (rr < step) {
-            Acc<10> mine = s_tot[threadIdx.x];
-            acc_add_acc(mine, s_tot[threadIdx.x + step]);
-            s_tot[threadIdx.x] = mine;
-        }
-        __syncthreads();
-    }
-    MleHostRecSub* r = pp.host_rec + table;
-    if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_tot[threadIdx.x * tps]);
-    dep = __syncthreads_or(dep);   // also: every record store is issued and waited for before the release below
-    if (threadIdx.x == 0) {
-        r->dep = dep ? 1u : 0u;
-        __hip_atomic_store(pp.counters + table, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&r->seq, pp.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // pass 0: sub-block sums of the input tables.  grid = (nblk, batch), nblk = 2^J * blocks-per-sub-block,
 // every block a contiguous chunk of len / nblk entries.  dep: does the table depend on x_n
 // (entry 2m vs 2m+1; the neighbour is read through the cache the partner lane just filled).
@@ -367,7 +307,7 @@ __global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tab
 template <int JIN>
 __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                        size_t dst_stride, uint32_t S, const Fr* __restrict__ weights,
-                                                       PassPublish pp) {
+                                                       MleSubPartial* __restrict__ partials) {
     __shared__ Acc<9> smem[4];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
     Fr* d = dst + (size_t)blockIdx.y * dst_stride;
@@ -381,7 +321,11 @@ __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ sr
         acc_add_fr(acc[0], y);
     }
     block_sum<9, 1>(acc, smem);
-    publish_pass_sums(pp, acc[0], 0u);
+    if (threadIdx.x == 0) {
+        MleSubPartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->sum = acc[0];
+        p->dep = 0;
+    }
 }
 
 // the same pass with the products on the matrix cores (mfma_fold.h): k_mle_fold_plan turns each sumcheck's
@@ -396,7 +340,7 @@ __global__ void __launch_bounds__(256) k_mle_fold_plan(const Fr* __restrict__ we
 template <int JIN>
 __global__ void __launch_bounds__(256) k_mle_multifold_mfma(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                             size_t dst_stride, uint32_t S, const MfmaFoldPlan* __restrict__ plans,
-                                                            PassPublish pp) {
+                                                            MleSubPartial* __restrict__ partials) {
     __shared__ Acc<9> smem[4];
     __shared__ __attribute__((aligned(16))) unsigned char digits[JIN > 2 ? 32 * 32 * (1 << JIN) : 16];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
@@ -406,11 +350,16 @@ __global__ void __launch_bounds__(256) k_mle_multifold_mfma(const Fr* __restrict
     Acc<9> acc[1] = {acc_zero<9>()};
     mfma_multifold_block<JIN>(s, d, S, plans + blockIdx.y, begin, begin + chunk, blockIdx.x * 5u + blockIdx.y * 3u, acc[0], digits);
     block_sum<9, 1>(acc, smem);
-    publish_pass_sums(pp, acc[0], 0u);
+    if (threadIdx.x == 0) {
+        MleSubPartial* p = partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        p->sum = acc[0];
+        p->dep = 0;
+    }
 }
 
-// pass 0 only (its blocks are many and short, see k_mle_sub_sums): partials -> 2^jout canonical sub-block sums per
-// table -> pinned host record.  The eight waves total the
+// partials of a pass -> 2^jout canonical sub-block sums per table -> pinned host record.  (Fusing this into the
+// passes -- the last block to arrive at a per-sumcheck counter reduces -- was measured: the write-through partial
+// stores and the counter round trip cost the fold pass 15 % of its bandwidth, three times what the launch saves.)  The eight waves total the
 // sub-blocks (wave w: sub-blocks w, w + 8, ...), then one thread per sub-block reduces its total mod p.
 // grid = (batch), block = 512
 __global__ void __launch_bounds__(512) k_mle_sub_reduce(const MleSubPartial* __restrict__ partials, uint32_t nblk,
@@ -1210,19 +1159,6 @@ uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch) {
     return b;
 }
 
-// publish = where the pass's last-arriving block of each sumcheck writes the 2^jout sub-block sums
-static PassPublish make_publish(MleSubPartial* partials, uint32_t* counters, MleHostRecSub* host_rec, uint32_t jout, uint32_t ticket) {
-    PassPublish pp;
-    pp.partials = partials;
-    pp.counters = counters;
-    pp.host_rec = host_rec;
-    pp.jout = jout;
-    pp.ticket = ticket;
-    return pp;
-}
-
-// pass 0 streams best as many short blocks (~1024 entries each), too short to carry the publishing hand-shake:
-// a separate reduce kernel totals its partials
 void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk, MleSubPartial* partials,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_mle_sub_sums, dim3(nblk, batch), dim3(256), 0, s, tables, stride, len, partials);
@@ -1259,30 +1195,28 @@ void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batc
 
 // plans: what launch_mle_fold_plan built for this pass (matrix-core form), unused otherwise
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, uint32_t jout, const Fr* weights, const void* plans, MleSubPartial* partials,
-                          uint32_t* counters, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s) {
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s) {
     dim3 grid(nblk, batch);
-    const PassPublish pp = make_publish(partials, counters, host_rec, jout, ticket);
     if (mle_multifold_uses_mfma(S, nblk)) {
         const MfmaFoldPlan* pl = static_cast<const MfmaFoldPlan*>(plans);
         if (jin == 1)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, pp);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
         else if (jin == 2)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, pp);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
         else if (jin == 3)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, pp);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
         else if (jin == 4)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, pp);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
         else
-            hipLaunchKernelGGL(k_mle_multifold_mfma<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, pp);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
         return;
     }
     if (jin == 1)
-        hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, pp);
+        hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
     else if (jin == 2)
-        hipLaunchKernelGGL(k_mle_multifold<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, pp);
+        hipLaunchKernelGGL(k_mle_multifold<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
     else
-        hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, pp);
+        hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
 }
 
 // blocks per table for a multifold pass of S output entries split into 2^jout sub-blocks.  The matrix-core

@@ -60,6 +60,19 @@ def test_mle_length_rule_edge_cases(ctx):
         assert ctx.prove_sumcheck(t, n) == dense.sumcheck_mle(t, n)
 
 
+def test_mle_last_variable_dependence_on_streamed_tables(ctx):
+    """The "does the table depend on x_n" bit of tables large enough for the streaming first pass (neighbour
+    entries compared across lanes): independent of x_n, dependent through one single pair, constant."""
+    n = 13
+    pairs = [(i >> 1) * 7919 + 3 for i in range(1 << n)]
+    one_pair = list(pairs)
+    one_pair[5431] += 1
+    last = list(pairs)
+    last[-1] = 12345
+    for t in (pairs, one_pair, last, [9] * (1 << n)):
+        assert ctx.prove_sumcheck(t, n) == cdense.sumcheck_mle(t, n)
+
+
 @pytest.mark.parametrize("n,seed", [(16, 0xC0FFEE + 1), (20, 0xC0FFEE + 2)])
 def test_mle_baseline_sizes_match_oracle(ctx, n, seed):
     """configs 2/3 of BASELINE.json: 2^16 and 2^20 point tables, generated on the
