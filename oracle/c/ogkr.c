@@ -107,6 +107,14 @@ void ogkr_fr_sub(const ogkr_fr *a, const ogkr_fr *b, ogkr_fr *out) { fr_sub(a->l
 void ogkr_fr_mul(const ogkr_fr *a, const ogkr_fr *b, ogkr_fr *out) { fr_mul(a->l, b->l, out->l); }
 int ogkr_fr_is_canonical(const ogkr_fr *a) { return !geq_mod(a->l); }
 
+void ogkr_set_threads(int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+}
+
 int ogkr_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

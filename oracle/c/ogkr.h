@@ -75,6 +75,8 @@ int ogkr_line_restriction(int k, const ogkr_fr *b, const ogkr_fr *c, const ogkr_
 /* evaluation table -> monomial coefficients (MSB-first Moebius transform), in place */
 void ogkr_mobius(ogkr_fr *vals, int k);
 
+/* default thread count of every parallel loop below (OpenMP's own default is one per visible CPU) */
+void ogkr_set_threads(int threads);
 int ogkr_max_threads(void);
 
 #ifdef __cplusplus

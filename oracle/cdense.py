@@ -30,7 +30,22 @@ def lib():
         build()
         _lib = ctypes.CDLL(_SO)
         _lib.ogkr_max_threads.restype = ctypes.c_int
+        # OpenMP's default is one thread per visible CPU; a container whose cgroup quota is smaller (the GPU box
+        # shows 256 CPUs under a 16-CPU quota) then spends its time throttled
+        if hasattr(_lib, "ogkr_set_threads"):
+            _lib.ogkr_set_threads(ctypes.c_int(_quota_cpus()))
     return _lib
+
+
+def _quota_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def _p(a):
@@ -54,6 +69,11 @@ def from_limbs(arr):
 
 def max_threads():
     return lib().ogkr_max_threads()
+
+
+def usable_threads():
+    """Threads the process can really run (affinity and cgroup quota), what the library's loops default to."""
+    return max(1, min(_quota_cpus(), max_threads()))
 
 
 def fr_mul(a, b):
@@ -90,7 +110,7 @@ def sumcheck_mle_raw(table_limbs, n, threads=0):
     C = np.zeros((n, 2, 4), dtype=np.uint64)
     L = np.zeros(n, dtype=np.uint32)
     R = np.zeros((n, 4), dtype=np.uint64)
-    rc = lib().ogkr_sumcheck_mle(_p(table_limbs), ctypes.c_int(n), _p(C), _p(L), _p(R), ctypes.c_int(threads))
+    rc = lib().ogkr_sumcheck_mle(_p(table_limbs), ctypes.c_int(n), _p(C), _p(L), _p(R), ctypes.c_int(threads if threads > 0 else usable_threads()))
     if rc:
         raise ValueError("ogkr_sumcheck_mle rc=%d" % rc)
     return C, L, R
@@ -116,7 +136,7 @@ def sumcheck_layer_raw(k_i, k_next, gate_type, left, right, z_limbs, w_limbs, th
     z_limbs = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
     w_limbs = np.ascontiguousarray(w_limbs, dtype=np.uint64)
     rc = lib().ogkr_sumcheck_layer(ctypes.c_int(k_i), ctypes.c_int(k_next), _p(gt), _p(l), _p(r), _p(z_limbs),
-                                   _p(w_limbs), _p(C), _p(L), _p(R), ctypes.c_int(threads))
+                                   _p(w_limbs), _p(C), _p(L), _p(R), ctypes.c_int(threads if threads > 0 else usable_threads()))
     if rc:
         raise ValueError("ogkr_sumcheck_layer rc=%d" % rc)
     return C, L, R
