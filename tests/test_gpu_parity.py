@@ -133,6 +133,23 @@ def test_fold_pass_variants_match_oracle(env):
         assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("n,batch", [(6, 40), (9, 33), (10, 17), (11, 9), (12, 130), (15, 7), (17, 5), (18, 3), (19, 2), (21, 1)])
+def test_mle_every_pass_schedule_matches_oracle(ctx, n, batch):
+    """Table sizes on both sides of every switch in the pass schedule (one-block passes up to 2^9 entries, fold
+    passes that stop at 2^12, 3/4/5 rounds per pass, one to four groups per batch), ragged batch sizes."""
+    count = 1 << n
+    d = ctx.alloc(batch * count * 32)
+    try:
+        for b in range(batch):
+            ctx.fill_table(N.ctypes.c_void_p(d.value + b * count * 32), count, 31337 + 97 * n + b)
+        C, L, R = ctx.sumcheck_mle_batch_device(d, n, batch)
+    finally:
+        ctx.free(d)
+    for b in range(batch):
+        c2, l2, r2 = cdense.sumcheck_mle_raw(cdense.fill_table(count, 31337 + 97 * n + b), n)
+        assert np.array_equal(C[b], c2) and np.array_equal(L[b], l2) and np.array_equal(R[b], r2), (n, b)
+
+
 def test_mle_batch_is_independent_sumchecks(ctx):
     n, batch = 12, 5
     count = 1 << n
