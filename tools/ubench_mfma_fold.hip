@@ -62,7 +62,8 @@ static int run(uint32_t S, uint32_t batch, uint32_t nblk, int reps, bool check) 
     Acc<9>* d_part;
     MfmaFoldPlan* d_plan;
     CK(hipMalloc(&d_plan, sizeof(MfmaFoldPlan) * batch));
-    CK(hipMalloc(&d_src, sizeof(Fr) * h_src.size()));
+    if (getenv("UB_CONTIG")) CK(hipExtMallocWithFlags((void**)&d_src, sizeof(Fr) * h_src.size(), hipDeviceMallocContiguous));
+    else CK(hipMalloc(&d_src, sizeof(Fr) * h_src.size()));
     CK(hipMalloc(&d_dst, sizeof(Fr) * (size_t)S * batch));
     CK(hipMalloc(&d_w, sizeof(Fr) * h_wm.size()));
     CK(hipMalloc(&d_part, sizeof(Acc<9>) * 256 * (size_t)nblk * batch));
