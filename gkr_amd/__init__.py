@@ -10,6 +10,7 @@ from .prover import (Context, GKRCircuit, GkrError, Layer, Proof, default_contex
                      prove_sumcheck, prove_sumcheck_opt)
 
 from .verifier import verify
+from .aggregate import aggregated_input, circom_input, circom_meta
 
-__all__ = ["verify", "MODULUS", "from_limbs", "to_limbs", "Context", "GKRCircuit", "GkrError", "Layer", "Proof",
+__all__ = ["verify", "aggregated_input", "circom_input", "circom_meta", "MODULUS", "from_limbs", "to_limbs", "Context", "GKRCircuit", "GkrError", "Layer", "Proof",
            "default_context", "multi_hash", "prove", "prove_sumcheck", "prove_sumcheck_opt"]

@@ -1,0 +1,109 @@
+"""The proof as input signals of verifier.circom -- the artefact right after the hot path.
+
+Mirror of the reference's `get_meta` (aggregator.rs:92-146), `modify_proof_for_circom` (:148-213),
+`CircomInputProof::new_from_proof` (:20-82) and `write_aggregated_input` (file_utils.rs:49-67).  The
+formatting itself is done by the library (`gkr_circom_meta`, `gkr_circom_input_json`, host-only C++ in
+csrc/circom_input.cpp); this module re-encodes a `Proof` into the ABI's flat buffers and parses the result.
+"""
+
+import ctypes
+import json
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .field import MODULUS, to_limbs
+from .prover import GkrError, Proof
+
+
+def _limbs(values):
+    return to_limbs([v % MODULUS for v in values]) if len(values) else np.zeros((0, 4), dtype=np.uint64)
+
+
+class _Encoded:
+    """A Proof in the C ABI's layout (gkr_proof_buf, include/gkr_amd.h); keeps the arrays alive."""
+
+    def __init__(self, proof: Proof):
+        ks = list(proof.k)
+        L = proof.depth - 1
+        if len(ks) != L + 1 or len(proof.sumcheck_proofs) != L:
+            raise GkrError(N.GKR_ERR_INVALID, "proof shape does not match its k list")
+        rounds = sum(2 * ks[i + 1] for i in range(L))
+        self.coeffs = np.zeros((max(rounds, 1), 3, 4), dtype=np.uint64)
+        self.lens = np.zeros(max(rounds, 1), dtype=np.uint32)
+        self.rs = np.zeros((max(rounds, 1), 4), dtype=np.uint64)
+        self.q = np.zeros((max(sum(ks[i + 1] + 1 for i in range(L)), 1), 4), dtype=np.uint64)
+        self.q_len = np.zeros(max(L, 1), dtype=np.uint32)
+        self.z = np.zeros((max(sum(ks), 1), 4), dtype=np.uint64)
+        self.r = _limbs(proof.r) if L else np.zeros((1, 4), dtype=np.uint64)
+        row = qo = 0
+        for i in range(L):
+            k = ks[i + 1]
+            for j, vec in enumerate(proof.sumcheck_proofs[i]):
+                self.coeffs[row + j, 3 - len(vec):] = _limbs(vec)
+                self.lens[row + j] = len(vec)
+            self.rs[row:row + 2 * k] = _limbs(proof.sumcheck_r[i])
+            qv = proof.q[i]
+            self.q[qo + k + 1 - len(qv):qo + k + 1] = _limbs(qv)
+            self.q_len[i] = len(qv)
+            row += 2 * k
+            qo += k + 1
+        zo = 0
+        for i in range(L + 1):
+            if ks[i]:
+                self.z[zo:zo + ks[i]] = _limbs(proof.z[i])
+            zo += ks[i]
+        self.d = self._coeff_table(proof.d, ks[0])
+        self.inp = self._coeff_table(proof.input_func, ks[L])
+        self.karr = np.asarray(ks, dtype=np.uint32)
+        self.desc = N.CircuitDesc(L, self.karr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), None, None, None)
+        self.buf = N.ProofBuf(*[a.ctypes.data for a in (self.coeffs, self.lens, self.rs, self.q, self.q_len, self.z, self.r,
+                                                        self.d, self.inp)])
+
+    @staticmethod
+    def _coeff_table(terms, k):
+        """term list [coeff, e_1..e_k] -> 2^k monomial coefficients (variable 1 = most significant index bit)."""
+        vals = [0] * (1 << k)
+        for t in terms:
+            m = 0
+            for e in t[1:]:
+                m = (m << 1) | (int(e) & 1)
+            vals[m] = (vals[m] + t[0]) % MODULUS
+        return _limbs(vals)
+
+
+def circom_meta(proof: Proof) -> List[int]:
+    """get_meta (aggregator.rs:92-146): the VerifyGKR template arguments of one proof."""
+    e = _Encoded(proof)
+    out = np.zeros(8 + len(proof.k), dtype=np.uint32)
+    count = ctypes.c_size_t()
+    rc = N.lib().gkr_circom_meta(ctypes.byref(e.desc), ctypes.byref(e.buf), out.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_size_t(len(out)), ctypes.byref(count))
+    if rc:
+        raise GkrError(rc, "gkr_circom_meta")
+    return [int(x) for x in out[:count.value]]
+
+
+def circom_input(proof: Proof, index: int) -> Dict[str, list]:
+    """The seven padded arrays of decimal strings, keys suffixed with the proof's index."""
+    e = _Encoded(proof)
+    need = ctypes.c_size_t()
+    rc = N.lib().gkr_circom_input_json(ctypes.byref(e.desc), ctypes.byref(e.buf), ctypes.c_int(index), None, ctypes.c_size_t(0),
+                                       ctypes.byref(need))
+    if rc:
+        raise GkrError(rc, "gkr_circom_input_json")
+    text = ctypes.create_string_buffer(need.value)
+    rc = N.lib().gkr_circom_input_json(ctypes.byref(e.desc), ctypes.byref(e.buf), ctypes.c_int(index), text,
+                                       ctypes.c_size_t(need.value), ctypes.byref(need))
+    if rc:
+        raise GkrError(rc, "gkr_circom_input_json")
+    return json.loads(text.value.decode())
+
+
+def aggregated_input(circuit_input: Dict[str, object], proofs: Sequence[Proof]) -> Dict[str, object]:
+    """write_aggregated_input (file_utils.rs:49-67): the circuit's own inputs plus every proof's signals."""
+    out = dict(circuit_input)
+    for i, p in enumerate(proofs):
+        out.update(circom_input(p, i))
+    return out

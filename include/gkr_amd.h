@@ -202,6 +202,23 @@ int  gkr_prove(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *inpu
 int  gkr_prove_batch(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values, int batch,
                      int require_zero_output, gkr_proof_buf *outs);
 
+/* ---- the proof as input signals of verifier.circom (host only) -----------
+ * What the reference does with a Proof right after the path: pad its ragged vectors to the dimensions of
+ * the generated verifier component (get_meta aggregator.rs:92-146, modify_proof_for_circom :148-213), print
+ * field elements as decimal strings (file_utils.rs:20-28) and merge them into the circuit's input JSON
+ * under keys suffixed with the proof's index (CircomInputProof aggregator.rs:20-82, file_utils.rs:49-67).
+ * circuit: only depth and k are read.
+ * gkr_circom_meta: [depth, largest k, k[0], #terms of D, longest round vector, longest q, #terms of the
+ *   input function, k[L], k[0..L]] -- the VerifyGKR template arguments; *count = 8 + L + 1.
+ * gkr_circom_input_json: one JSON object with the keys sumcheckProof<i>, sumcheckr<i>, q<i>, D<i>, z<i>,
+ *   r<i>, inputFunc<i> (NUL-terminated).  *needed = bytes including the terminator; with out == NULL only
+ *   the size is returned; GKR_ERR_NOMEM if capacity is too small.  Term order of D / inputFunc: ascending
+ *   monomial index (the reference's order is HashMap order, i.e. unspecified). */
+int  gkr_circom_meta(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof, uint32_t *meta, size_t capacity,
+                     size_t *count);
+int  gkr_circom_input_json(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof, int proof_index, char *out,
+                           size_t capacity, size_t *needed);
+
 /* ---- step-wise sessions: one sumcheck split across GPUs -------------------
  * The reference reduces each round's per-assignment polynomials with a rayon
  * map-reduce (sumcheck.rs:50-63,65-78,97-124); across GPUs that reduce is one

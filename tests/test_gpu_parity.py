@@ -365,6 +365,21 @@ def test_product_proofs_pass_the_verifier(ctx):
     assert not verify(pr, circ)
 
 
+def test_proofs_format_as_verifier_circom_inputs(ctx, gkr_cases):
+    """The artefact after the path (aggregator.rs:92-213, file_utils.rs:49-67) from the GPU prover's own proofs."""
+    from gkr_amd.aggregate import aggregated_input, circom_input, circom_meta
+    from helpers import canon_circom, expected_circom_input, expected_circom_meta
+    proofs = []
+    for case in gkr_cases[:4]:
+        layers = layers_of(case)
+        p = ctx.prove(_circuit(layers, len(case["inputs"])), ints(case["inputs"]))
+        assert circom_meta(p) == expected_circom_meta(p)
+        assert canon_circom(circom_input(p, len(proofs))) == canon_circom(expected_circom_input(p, len(proofs)))
+        proofs.append(p)
+    merged = aggregated_input({"a": "1"}, proofs)
+    assert len(merged) == 1 + 7 * len(proofs)
+
+
 def test_prove_zero_output_check(ctx):
     # convert.rs:838: the reference asserts output 0 == 0 on a satisfying witness
     circ = _circuit([([0, 1], [0, 1], [1, 1])], 2)
