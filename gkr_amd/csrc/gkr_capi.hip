@@ -365,7 +365,7 @@ constexpr int kMaxGroups = 16;
 
 // ------------------------------------------------------------- plain MLE sumcheck, multi-round passes
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
-// 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 3 hashes in a row,
+// 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
 // eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
 // variables at once.  Length rules as in run_mle_batch.
 int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,

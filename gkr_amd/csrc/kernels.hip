@@ -238,9 +238,10 @@ __global__ void __launch_bounds__(64) k_mle_round_hash(const MlePartial* __restr
 // table (sub-block = the entries sharing their J leading index bits): the host derives
 // r_j .. r_{j+J-1} from them without touching the table, and ONE pass then binds all J variables,
 //     T'[i] = sum_b  w_b * T[b * S + i],     w_b = eq((r_j..r_{j+J-1}), b),   S = |T| / 2^J,
-// while accumulating the 2^J' sub-block sums of T' for the next J' rounds.  With J = 3 a 2^n
-// sumcheck reads T_1 twice and then only a geometric tail (~2.3 N elements moved instead of 4 N)
-// and needs n/3 host round trips instead of n.  Results are the same field elements: bit-exact.
+// while accumulating the 2^J' sub-block sums of T' for the next J' rounds.  With J = 5 (matrix-core
+// fold, mfma_fold.h; J <= 3 for the v_mad_u64_u32 fold below) a 2^n sumcheck reads T_1 twice and then
+// only a tail 32x smaller (~2.07 N elements moved instead of 4 N) and needs ~n/5 host round trips
+// instead of n.  Results are the same field elements: bit-exact.
 // ---------------------------------------------------------------------------
 
 // sum_b w_b * src[b * S + i] for b < 2^JIN: unreduced products in independent accumulators that
