@@ -94,7 +94,7 @@ def test_mle_baseline_sizes_match_oracle(ctx, n, seed):
         ctx.free(d)
 
 
-@pytest.mark.parametrize("n", [13, 14, 16])
+@pytest.mark.parametrize("n", [13, 14, 16, 17])
 def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
     """The fold pass multiplies on the matrix cores over signed bytes (mfma_fold.h): tables made of the byte
     patterns that sit on its sign and carry boundaries (0x00, 0x7f, 0x80, 0xff runs, p - 1, small values) must
@@ -126,7 +126,7 @@ def test_fold_pass_variants_match_oracle(env):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sizes = ((14, 20), (17, 3)) if "GKR_ROUNDS_PER_PASS" in env or "GKR_NO_MFMA_FOLD" in env else ((14, 20),)
+    sizes = ((14, 20), (17, 3), (18, 2)) if "GKR_ROUNDS_PER_PASS" in env or "GKR_NO_MFMA_FOLD" in env else ((14, 20), (17, 3))
     for n, batch in sizes:
         out = subprocess.run([sys.executable, os.path.join(here, "fold_variants_worker.py"), str(n), str(batch)],
                              env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
