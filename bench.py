@@ -84,11 +84,13 @@ def main():
 
     step_times = []
 
+    outputs = [None]   # the proof arrays of the previous step are reused (no fresh pages inside the timed call)
+
     def step():
         t = time.perf_counter()
-        r = ctx.sumcheck_mle_batch_device(tables, n, batch)
+        outputs[0] = ctx.sumcheck_mle_batch_device(tables, n, batch, out=outputs[0])
         step_times.append(time.perf_counter() - t)
-        return r
+        return outputs[0]
 
     def barrier():
         if world > 1:

@@ -196,10 +196,17 @@ class Context:
         self._check(N.lib().gkr_sumcheck_mle(self._h, _ptr(table_limbs), ctypes.c_int(n), _ptr(C), _ptr(L), _ptr(R)))
         return C, L, R
 
-    def sumcheck_mle_batch_device(self, d_tables, n, batch):
-        C = np.zeros((batch, n, 2, 4), dtype=np.uint64)
-        L = np.zeros((batch, n), dtype=np.uint32)
-        R = np.zeros((batch, n, 4), dtype=np.uint64)
+    def sumcheck_mle_batch_device(self, d_tables, n, batch, out=None):
+        """out: (C, L, R) arrays of an earlier call to write into (a caller that proves batch after batch saves the
+        page faults of fresh output arrays, which otherwise land inside the hash workers)."""
+        if out is not None:
+            C, L, R = out
+            if C.shape != (batch, n, 2, 4) or L.shape != (batch, n) or R.shape != (batch, n, 4):
+                raise GkrError(N.GKR_ERR_INVALID, "output arrays do not match (batch, n)")
+        else:
+            C = np.zeros((batch, n, 2, 4), dtype=np.uint64)
+            L = np.zeros((batch, n), dtype=np.uint32)
+            R = np.zeros((batch, n, 4), dtype=np.uint64)
         self._check(N.lib().gkr_sumcheck_mle_batch_device(self._h, d_tables, ctypes.c_int(n), ctypes.c_int(batch),
                                                           _ptr(C), _ptr(L), _ptr(R)))
         return C, L, R
