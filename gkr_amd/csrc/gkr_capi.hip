@@ -266,14 +266,14 @@ struct gkr_ctx {
             return e;
         }
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         return e;
     }
     void drain_events() {
         for (auto& p : pending) {
-            hipEventSynchronize(p.stop);
+            (void)hipEventSynchronize(p.stop);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, p.start, p.stop);
+            (void)hipEventElapsedTime(&ms, p.start, p.stop);
             ProfileRow& r = prof[p.name];
             r.launches += 1;
             r.total_ms += ms;
@@ -300,12 +300,12 @@ struct Timed {
             ev.stop = c->get_event();
             ev.name = name;
             ev.bytes = bytes;
-            hipEventRecord(ev.start, st);
+            (void)hipEventRecord(ev.start, st);
         }
     }
     ~Timed() {
         if (on) {
-            hipEventRecord(ev.stop, st);
+            (void)hipEventRecord(ev.stop, st);
             c->pending.push_back(ev);
         }
     }
@@ -324,7 +324,7 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     ~DevBuf() {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     }
     hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)); }
 };
@@ -1281,17 +1281,17 @@ int gkr_ctx_create(int device_id, gkr_ctx** out) {
 
 void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->aux) hipStreamSynchronize(ctx->aux);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     ctx->drain_events();
     ctx->drain_events();
-    for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->release_buffers();
-    if (ctx->d_cts) hipFree(ctx->d_cts);
-    for (hipEvent_t e : ctx->aux_events) hipEventDestroy(e);
-    if (ctx->aux) hipStreamDestroy(ctx->aux);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->d_cts) (void)hipFree(ctx->d_cts);
+    for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
