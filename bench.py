@@ -139,7 +139,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (BN254 Fr, 254-bit modular integers)",
+            "dtype": "u32x8 (BN254 Fr, 254-bit modular integers; the fold pass's constant-by-table products as exact i8 MFMA with i32 sums)",
             "data": "synthetic",
             "config": {"workload": "plain MLE sumcheck (prove_sumcheck), 2^%d points per table, BASELINE configs[2]" % n,
                        "log2_points": n, "batch_per_gpu": batch, "sumchecks_per_step": batch * world,
