@@ -595,6 +595,26 @@ GKR_HD void lazy_mac_s(Lazy17& acc, const Fr& a, const Fr& b_uniform) {
     acc.l[16] = (uint32_t)col;
 }
 
+// the same with a per-lane multiplier (both operands in vector registers)
+GKR_HD void lazy_mac_v(Lazy17& acc, const Fr& a, const Fr& b) {
+    uint64_t col = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        col += acc.l[c];
+#pragma unroll
+        for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96(col, ex, a.l[i], b.l[c - i]);
+        acc.l[c] = (uint32_t)col;
+        col = (col >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+    col += acc.l[15];
+    acc.l[15] = (uint32_t)col;
+    col >>= 32;
+    col += acc.l[16];
+    acc.l[16] = (uint32_t)col;
+}
+
 // two independent dot products advanced together (see mac96x2_s)
 GKR_HD void lazy_mac2_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub) {
     uint64_t cA = 0, cB = 0;

@@ -1031,6 +1031,19 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     WS(ctx, "layer.len", uint32_t, v, d_len);
     WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
     WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
+    // b-phase in linear time (kernels.hip, k_layer_uv): host transcript only; GKR_LAYER_DENSE_B keeps the k passes
+    // over the dense predicate tables
+    static const bool dense_b = getenv("GKR_LAYER_DENSE_B") != nullptr;
+    const bool lin_b = host_tx && !dense_b && k >= 1;
+    Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
+    Fr* h_eq = nullptr;   // pinned: eq(u, .) of every proof, Montgomery
+    if (lin_b) {
+        WS(ctx, "layer.U", Fr, wlen * batch, U);
+        WS(ctx, "layer.V", Fr, wlen * batch, V);
+        WS(ctx, "layer.eq", Fr, wlen * batch, d_eq);
+        WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
+        HIP_TRY(ctx, ctx->pinned_host("layer.heq", sizeof(Fr) * wlen * batch, reinterpret_cast<void**>(&h_eq)));
+    }
     int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
     if (rc) return rc;
     gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, N, wlen};
@@ -1038,6 +1051,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
     HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
     gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
+    if (lin_b) {
+        Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
+        gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
+    }
 
     gkr::LayerHostRec* rec = nullptr;
     gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
@@ -1098,13 +1115,59 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     // fused kernel; c-phase: a separate fold of the single remaining row).
     const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
     static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
+    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    double t_launch = 0, t_wait = 0, t_hash = 0;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now_us();
+    auto lap = [&](double& bucket) {
+        const double t = now_us();
+        bucket += t - t_mark;
+        t_mark = t;
+    };
     if (pool) pool->begin_session(nullptr);
     for (uint32_t round = 0; round < v; ++round) {
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
         const uint32_t hb = phase == 0 ? (h >> k) : 0u;
-        uint32_t nblk;
-        if (phase == 0 && !no_fused) {
+        uint32_t nblk = 0;
+        bool published = false;   // the round's kernel wrote the host record itself
+        if (lin_b && round == (uint32_t)k) {
+            // all of b is bound: collapse the rows of A, M at u = (r_1 .. r_k) into the single row the c-phase works on
+            std::vector<gkr::h64::F> tmp;
+            for (int b = 0; b < batch; ++b) {
+                host_eq_table(out_r[b], 0, k, tmp);
+                for (size_t i = 0; i < wlen; ++i) {
+                    const gkr::h64::F m = gkr::h64::to_mont(tmp[i]);
+                    memcpy(&h_eq[(size_t)b * wlen + i], &m, 32);
+                }
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(d_eq, h_eq, sizeof(Fr) * wlen * batch, hipMemcpyHostToDevice, s));
+            Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
+            gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
+            pending = nullptr;   // U, V are done with; the row is already taken at u
+        }
+        if (phase == 0 && lin_b) {
+            const uint32_t ticket = ++ctx->ticket;
+            Timed t(ctx, "layer_uv_round", 0.0);
+            gkr::launch_uv_round(pending != nullptr, Wb, U, V, 1u << (k - 1 - (int)round), pending, rec, ticket, lb, s);
+            pending = nullptr;
+            published = true;
+            lap(t_launch);
+            rc = wait_records(ctx, rec, batch, ticket);
+            lap(t_wait);
+            if (rc) break;
+        } else if (phase == 1 && lin_b && k <= 13) {
+            // the single remaining row: one small block per proof folds it and publishes the round's sums
+            const uint32_t ticket = ++ctx->ticket;
+            Timed t(ctx, "layer_c_round", 0.0);
+            gkr::launch_c_round(pending != nullptr, A, M, Wc, Wb, h, pending, rec, ticket, lb, s);
+            pending = nullptr;
+            published = true;
+            lap(t_launch);
+            rc = wait_records(ctx, rec, batch, ticket);
+            lap(t_wait);
+            if (rc) break;
+        } else if (phase == 0 && !no_fused) {
             Timed t(ctx, "layer_round_fused", (pending ? (double)h * 2.0 * 6.0 : (double)h * 2.0 * 2.0) * 32.0 * batch);
             nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, lb, s);
             pending = nullptr;
@@ -1120,13 +1183,17 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, lb, s);
         }
         if (host_tx) {
-            const uint32_t ticket = ++ctx->ticket;
-            {
-                Timed t(ctx, "layer_round_reduce", 0.0);
-                gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, lb, s);
+            if (!published) {
+                const uint32_t ticket = ++ctx->ticket;
+                {
+                    Timed t(ctx, "layer_round_reduce", 0.0);
+                    gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, lb, s);
+                }
+                lap(t_launch);
+                rc = wait_records(ctx, rec, batch, ticket);
+                lap(t_wait);
+                if (rc) break;
             }
-            rc = wait_records(ctx, rec, batch, ticket);
-            if (rc) break;
             // two sets of pinned tables used alternately: the deferred fold of round j reads set j % 2
             // while the host already writes round j+1's
             gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
@@ -1144,8 +1211,12 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 for (int first = 0; first < batch; first += chunk)
                     hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
             }
-            // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc)
-            gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
+            lap(t_hash);
+            // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc); the linear-time
+            // round kernels fold W themselves with the pending challenge, except for the last b round, whose
+            // fold leaves the scalar W(u) the c-phase multiplies with
+            const bool fused_w = lin_b && (phase == 0 ? round + 1 < (uint32_t)k : k <= 13);
+            if (!fused_w) gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
             pending = slot;
         } else {
             Timed t(ctx, "layer_round_hash", 0.0);
@@ -1155,6 +1226,9 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         }
     }
     if (pool) pool->end_session();
+    if (dbg)
+        fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us\n", k, batch, v, t_launch,
+                t_wait, t_hash);
     if (rc) {
         (void)hipStreamSynchronize(s);
         return rc;

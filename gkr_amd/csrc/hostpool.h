@@ -52,18 +52,23 @@ class SpinPool {
     // then return once every participant has left it.  (A session opened with a null function idles
     // between run_now calls.)
     void run_now(const std::function<bool()>* work) {
-        // job_busy_ is a balanced in/out count of workers inside the probe window: never reset it
-        job_.store(work, std::memory_order_release);
+        // job_busy_ is a balanced in/out count of workers inside the probe window: never reset it.
+        // Retiring the job is a store followed by a load of ANOTHER variable, and a worker does the mirror
+        // image (count up, then read the job): both sides must be sequentially consistent, or the caller can
+        // read "no worker inside" before its own store is visible while a worker still picks up the old job and
+        // calls it after the caller's stack frame is gone (seen as a crash with one worker and short rounds).
+        job_.store(work, std::memory_order_seq_cst);
         while ((*work)()) {
         }
-        job_.store(nullptr, std::memory_order_release);
-        while (job_busy_.load(std::memory_order_acquire) != 0) GKR_CPU_RELAX();
+        job_.store(nullptr, std::memory_order_seq_cst);
+        while (job_busy_.load(std::memory_order_seq_cst) != 0) GKR_CPU_RELAX();
     }
 
     // returns once no worker is inside try_work any more
     void end_session() {
-        session_.fetch_add(1, std::memory_order_release);       // even = closed
-        while (inside_.load(std::memory_order_acquire) != 0) GKR_CPU_RELAX();
+        // same store-then-load-another-variable shape as run_now: sequentially consistent on both sides
+        session_.fetch_add(1, std::memory_order_seq_cst);       // even = closed
+        while (inside_.load(std::memory_order_seq_cst) != 0) GKR_CPU_RELAX();
     }
 
    private:
@@ -76,9 +81,9 @@ class SpinPool {
                 if (stop_.load()) return;
                 continue;
             }
-            inside_.fetch_add(1, std::memory_order_acq_rel);
+            inside_.fetch_add(1, std::memory_order_seq_cst);
             // re-check after announcing: end_session() may have closed in between
-            if (session_.load(std::memory_order_acquire) == s) {
+            if (session_.load(std::memory_order_seq_cst) == s) {
                 const std::function<bool()>* fn = fn_;
                 unsigned idle = 0;
                 while (session_.load(std::memory_order_acquire) == s) {
@@ -86,10 +91,10 @@ class SpinPool {
                     if (fn) {
                         did = (*fn)();
                     } else {
-                        job_busy_.fetch_add(1, std::memory_order_acq_rel);
-                        const std::function<bool()>* job = job_.load(std::memory_order_acquire);
+                        job_busy_.fetch_add(1, std::memory_order_seq_cst);
+                        const std::function<bool()>* job = job_.load(std::memory_order_seq_cst);
                         if (job) did = (*job)();
-                        job_busy_.fetch_sub(1, std::memory_order_acq_rel);
+                        job_busy_.fetch_sub(1, std::memory_order_seq_cst);
                     }
                     if (did) {
                         idle = 0;

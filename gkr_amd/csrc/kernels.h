@@ -81,6 +81,14 @@ void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* d
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
                                LayerBatch lb, hipStream_t s);
 void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s);
+// b-phase in linear time (kernels.hip): U, V tables of 2^k entries per proof, their rounds, the row collapse
+void launch_layer_uv(const Fr* A, const Fr* M, const Fr* W, Fr* U, Fr* V, uint32_t k, LayerBatch lb, hipStream_t s);
+void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,
+                     LayerBatch lb, hipStream_t s);
+void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec,
+                    uint32_t ticket, LayerBatch lb, hipStream_t s);
+uint32_t layer_collapse_chunks(uint32_t k, uint32_t batch);
+void launch_layer_collapse(Fr* A, Fr* M, const Fr* eq, Fr* scratch, uint32_t k, LayerBatch lb, hipStream_t s);
 
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
 

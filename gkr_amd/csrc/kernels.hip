@@ -1022,6 +1022,176 @@ __global__ void __launch_bounds__(64) k_layer_round_reduce(const LayerPartial* _
     }
 }
 
+// ---------------------------------------------------------------------------
+// b-phase in linear time (host transcript).  Summed over c, the layer polynomial is
+//     h(b) = sum_c f(b, c) = W(b) U(b) + V(b),   U(b) = sum_c [a(b,c) + m(b,c) W(c)],   V(b) = sum_c a(b,c) W(c)
+// with U, V multilinear in b -- so the k rounds that bind b are a sumcheck over three tables of 2^k entries
+// (W, U, V) instead of k passes over the 2^{2k}-entry predicate tables: ONE pass over A, M builds U, V
+// (k_layer_uv), the rounds run in one small block per proof (k_uv_round, which also publishes the host record:
+// no reduce launch), and ONE more pass collapses the rows at the bound point u = (r_1..r_k),
+//     a_u(c) = sum_b eq(u, b) a(b, c)   (k_layer_collapse_*),
+// which is the single remaining row the c-phase kernels expect.  Same round polynomials: bit-exact.
+// ---------------------------------------------------------------------------
+
+// grid = (2^k rows, batch), block = 256: U[row], V[row] of one proof.  W: the Montgomery copy over columns.
+__global__ void __launch_bounds__(256) k_layer_uv(const Fr* __restrict__ A, const Fr* __restrict__ M, const Fr* __restrict__ W,
+                                                  Fr* __restrict__ U, Fr* __restrict__ V, uint32_t k, LayerBatch lb) {
+    __shared__ Acc<9> smem[4 * 2];
+    const uint32_t row = blockIdx.x, cols = 1u << k;
+    const Fr* a = A + blockIdx.y * lb.tstride + (size_t)row * cols;
+    const Fr* m = M + blockIdx.y * lb.tstride + (size_t)row * cols;
+    const Fr* w = W + blockIdx.y * lb.wstride;
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    Lazy17 mw = lazy_zero(), aw = lazy_zero();
+    bool any = false;
+    for (uint32_t c = threadIdx.x; c < cols; c += blockDim.x) {
+        const Fr av = load_fr(a + c), mv = load_fr(m + c), q = load_fr(w + c);
+        acc_add_fr(acc[0], av);
+        lazy_mac_v(mw, mv, q);
+        lazy_mac_v(aw, av, q);
+        any = true;
+    }
+    if (any) {
+        acc_add_fr(acc[0], lazy_reduce(mw));
+        acc_add_fr(acc[1], lazy_reduce(aw));
+    }
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        store_fr(U + blockIdx.y * lb.wstride + row, acc_reduce(acc[0]));
+        store_fr(V + blockIdx.y * lb.wstride + row, acc_reduce(acc[1]));
+    }
+}
+
+// One b-round of one proof: (FOLD) bind the previous variable in U, V with that round's challenge, then
+//     c0 = sum W_lo U_lo + V_lo,   g(1) = sum W_hi U_hi + V_hi,   c2 = sum (W_hi - W_lo)(U_hi - U_lo)
+// over the h pairs (i, i + h); W (Montgomery) is folded along with U, V.  grid = (batch), block = 256.
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_uv_round(Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t h,
+                                                  const FixedMul* __restrict__ rtab, LayerHostRec* __restrict__ host_rec,
+                                                  uint32_t ticket, uint32_t wstride) {
+    __shared__ Acc<9> smem[4 * 3];
+    W += (size_t)blockIdx.x * wstride;
+    U += (size_t)blockIdx.x * wstride;
+    V += (size_t)blockIdx.x * wstride;
+    if (FOLD) {
+        const FixedMul T = rtab[blockIdx.x];
+        const uint32_t hw = 2u * h;   // size of the tables after this fold
+        for (uint32_t base = 0; base < hw; base += blockDim.x) {
+            const uint32_t i = base + threadIdx.x;
+            Fr u = fr_zero(), v = fr_zero(), w = fr_zero();
+            if (i < hw) {
+                u = fr_fold_fixed(load_fr(U + i), load_fr(U + i + hw), T);
+                v = fr_fold_fixed(load_fr(V + i), load_fr(V + i + hw), T);
+                w = fr_fold_fixed(load_fr(W + i), load_fr(W + i + hw), T);
+            }
+            __syncthreads();   // all reads of this stripe done before any write lands in [0, hw)
+            if (i < hw) {
+                store_fr(U + i, u);
+                store_fr(V + i, v);
+                store_fr(W + i, w);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+        const Fr wl = load_fr(W + i), wh = load_fr(W + i + h);
+        const Fr ul = load_fr(U + i), uh = load_fr(U + i + h);
+        acc_add_fr(acc[0], mont_mul(ul, wl));
+        acc_add_fr(acc[0], load_fr(V + i));
+        acc_add_fr(acc[1], mont_mul(uh, wh));
+        acc_add_fr(acc[1], load_fr(V + i + h));
+        acc_add_fr(acc[2], mont_mul(fr_sub(uh, ul), fr_sub(wh, wl)));
+    }
+    block_sum<9, 3>(acc, smem);
+    if (threadIdx.x == 0) {
+        LayerHostRec* r = host_rec + blockIdx.x;
+        r->c0 = acc_reduce(acc[0]);
+        r->g1 = acc_reduce(acc[1]);
+        r->c2 = acc_reduce(acc[2]);
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// One c-round of one proof on the single remaining row (2h entries of A, M; W over c in Montgomery form;
+// p = W(u), Montgomery): (FOLD) bind the previous variable in A, M, Wc, then the round's sums, published to
+// the host record -- one launch per round instead of fold + fold + round + reduce.  grid = (batch), block = 256.
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_c_round(Fr* __restrict__ A, Fr* __restrict__ M, Fr* __restrict__ Wc,
+                                                 const Fr* __restrict__ Wb, uint32_t h, const FixedMul* __restrict__ rtab,
+                                                 LayerHostRec* __restrict__ host_rec, uint32_t ticket, LayerBatch lb) {
+    __shared__ Acc<9> smem[4 * 3];
+    A += blockIdx.x * lb.tstride;
+    M += blockIdx.x * lb.tstride;
+    Wc += blockIdx.x * lb.wstride;
+    const Fr p = load_fr(Wb + blockIdx.x * lb.wstride);
+    if (FOLD) {
+        const FixedMul T = rtab[blockIdx.x];
+        const uint32_t hw = 2u * h;
+        for (uint32_t base = 0; base < hw; base += blockDim.x) {
+            const uint32_t i = base + threadIdx.x;
+            Fr a = fr_zero(), m = fr_zero(), w = fr_zero();
+            if (i < hw) {
+                a = fr_fold_fixed(load_fr(A + i), load_fr(A + i + hw), T);
+                m = fr_fold_fixed(load_fr(M + i), load_fr(M + i + hw), T);
+                w = fr_fold_fixed(load_fr(Wc + i), load_fr(Wc + i + hw), T);
+            }
+            __syncthreads();   // all reads of this stripe done before any write lands in [0, hw)
+            if (i < hw) {
+                store_fr(A + i, a);
+                store_fr(M + i, m);
+                store_fr(Wc + i, w);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+        const PairTerms t = layer_pair(load_fr(A + i), load_fr(A + i + h), load_fr(M + i), load_fr(M + i + h), p, p,
+                                       load_fr(Wc + i), load_fr(Wc + i + h));
+        acc_add_fr(acc[0], t.c0);
+        acc_add_fr(acc[1], t.g1);
+        acc_add_fr(acc[2], t.c2);
+    }
+    block_sum<9, 3>(acc, smem);
+    if (threadIdx.x == 0) {
+        LayerHostRec* r = host_rec + blockIdx.x;
+        r->c0 = acc_reduce(acc[0]);
+        r->g1 = acc_reduce(acc[1]);
+        r->c2 = acc_reduce(acc[2]);
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Row collapse, stage 1: partial[chunk][c] = sum over the chunk's rows of eq[row] * T[row][c] for T = A (z = 0)
+// and M (z = 1).  eq: Montgomery, the same value for the whole wave.  grid = (column blocks, chunks, 2 * batch).
+__global__ void __launch_bounds__(256) k_layer_collapse_rows(const Fr* __restrict__ A, const Fr* __restrict__ M,
+                                                             const Fr* __restrict__ eq, Fr* __restrict__ partial, uint32_t k,
+                                                             uint32_t rows_per_chunk, LayerBatch lb) {
+    const uint32_t cols = 1u << k, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t proof = blockIdx.z >> 1, table = blockIdx.z & 1u, chunks = gridDim.y;
+    if (c >= cols) return;
+    const Fr* t = (table ? M : A) + proof * lb.tstride;
+    const Fr* e = eq + (size_t)proof * cols;
+    const uint32_t r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, cols);
+    Lazy17 acc = lazy_zero();
+    for (uint32_t r = r0; r < r1; ++r) lazy_mac_s(acc, load_fr(t + (size_t)r * cols + c), e[r]);
+    store_fr(partial + (((size_t)blockIdx.z * chunks + blockIdx.y) << k) + c, lazy_reduce(acc));
+}
+
+// stage 2: row 0 of A / M = sum of the chunk partials.  grid = (column blocks, 2 * batch)
+__global__ void __launch_bounds__(256) k_layer_collapse_sum(const Fr* __restrict__ partial, Fr* __restrict__ A, Fr* __restrict__ M,
+                                                            uint32_t k, uint32_t chunks, LayerBatch lb) {
+    const uint32_t cols = 1u << k, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t proof = blockIdx.y >> 1, table = blockIdx.y & 1u;
+    if (c >= cols) return;
+    Acc<9> acc = acc_zero<9>();
+    for (uint32_t ch = 0; ch < chunks; ++ch) acc_add_fr(acc, load_fr(partial + (((size_t)blockIdx.y * chunks + ch) << k) + c));
+    store_fr((table ? M : A) + proof * lb.tstride + c, acc_reduce(acc));
+}
+
 // In-place fold of a small Montgomery table (the W copy bound in this round):
 // W[i] += r (W[i + hw] - W[i]).  One block; see k_layer_round_hash for why the
 // strided in-place loop is safe.
@@ -1263,6 +1433,45 @@ void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, Laye
 
 void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s) {
     hipLaunchKernelGGL(k_fold_small, dim3(lb.batch), dim3(256), 0, s, W, hw, rtab, (uint32_t)lb.wstride);
+}
+
+void launch_layer_uv(const Fr* A, const Fr* M, const Fr* W, Fr* U, Fr* V, uint32_t k, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_uv, dim3(1u << k, lb.batch), dim3(256), 0, s, A, M, W, U, V, k, lb);
+}
+
+void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec,
+                    uint32_t ticket, LayerBatch lb, hipStream_t s) {
+    if (fold)
+        hipLaunchKernelGGL(k_c_round<true>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
+    else
+        hipLaunchKernelGGL(k_c_round<false>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
+}
+
+void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,
+                     LayerBatch lb, hipStream_t s) {
+    if (fold)
+        hipLaunchKernelGGL(k_uv_round<true>, dim3(lb.batch), dim3(256), 0, s, W, U, V, h, rtab, host_rec, ticket, (uint32_t)lb.wstride);
+    else
+        hipLaunchKernelGGL(k_uv_round<false>, dim3(lb.batch), dim3(256), 0, s, W, U, V, h, rtab, host_rec, ticket, (uint32_t)lb.wstride);
+}
+
+// chunks of rows the collapse is split into (enough blocks to fill the chip); scratch = 2 * batch * chunks * 2^k elements
+uint32_t layer_collapse_chunks(uint32_t k, uint32_t batch) {
+    const uint32_t rows = 1u << k, col_blocks = (rows + 255u) / 256u;
+    uint32_t chunks = 2048u / (col_blocks * 2u * batch);
+    if (chunks < 1) chunks = 1;
+    if (chunks > rows) chunks = rows;
+    return chunks;
+}
+
+void launch_layer_collapse(Fr* A, Fr* M, const Fr* eq, Fr* scratch, uint32_t k, LayerBatch lb, hipStream_t s) {
+    const uint32_t rows = 1u << k, col_blocks = (rows + 255u) / 256u;
+    uint32_t chunks = layer_collapse_chunks(k, lb.batch);
+    const uint32_t rows_per_chunk = (rows + chunks - 1) / chunks;
+    chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+    hipLaunchKernelGGL(k_layer_collapse_rows, dim3(col_blocks, chunks, 2 * lb.batch), dim3(256), 0, s, A, M, eq, scratch, k,
+                       rows_per_chunk, lb);
+    hipLaunchKernelGGL(k_layer_collapse_sum, dim3(col_blocks, 2 * lb.batch), dim3(256), 0, s, scratch, A, M, k, chunks, lb);
 }
 
 uint32_t layer_blocks(uint32_t h) { return blocks_for(h, kMaxLayerBlocks); }

@@ -1,0 +1,42 @@
+// Stress of SpinPool::run_now (gkr_amd/csrc/hostpool.h): many very short jobs whose state lives in the caller's
+// stack frame.  A worker that still calls a job after run_now has returned (the retire-then-check race) finds the
+// frame re-used: the job then sees a poisoned tag and the run fails.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+
+#include "hostpool.h"
+
+static std::atomic<long> bad{0};
+
+static void one_round(gkr::SpinPool& pool, int items, unsigned tag_value) {
+    struct Frame {
+        std::atomic<int> next{0};
+        std::atomic<unsigned> tag{0};
+        std::atomic<int> done{0};
+    } f;
+    f.tag.store(tag_value);
+    const int n = items;
+    const std::function<bool()> work = [&]() -> bool {
+        if (f.tag.load(std::memory_order_relaxed) != tag_value) bad.fetch_add(1);
+        const int i = f.next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= n) return false;
+        f.done.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    };
+    pool.run_now(&work);
+    if (f.done.load() != n) bad.fetch_add(1);
+    f.tag.store(0xDEADBEEFu);   // the frame is dead from here on
+}
+
+int main(int argc, char** argv) {
+    const int workers = argc > 1 ? atoi(argv[1]) : 1;
+    const long rounds = argc > 2 ? atol(argv[2]) : 300000;
+    gkr::SpinPool pool(workers);
+    pool.begin_session(nullptr);
+    for (long r = 0; r < rounds; ++r) one_round(pool, 2 + (int)(r % 3), 0x1000u + (unsigned)(r & 0xFFF));
+    pool.end_session();
+    printf("workers=%d rounds=%ld bad=%ld\n", workers, rounds, bad.load());
+    return bad.load() ? 1 : 0;
+}

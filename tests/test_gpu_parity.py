@@ -237,6 +237,22 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
     assert ctx.prove_sumcheck_opt(lay, k, z, w) == cdense.sumcheck_layer(k_i, k, gt, lay.left, lay.right, z, w)
 
 
+@pytest.mark.parametrize("env", [{}, {"GKR_LAYER_DENSE_B": "1"}, {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
+                                 {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_layer_path_variants_match_oracle(env):
+    """The layer sumcheck's b-phase has two forms -- linear time over the (W, U, V) tables of 2^k entries (default),
+    and k passes over the dense 2^{2k}-entry predicate tables (fused or round + fold kernels): the same transcript
+    from each, single layers and a batch of proofs.  The knobs are read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "layer_variants_worker.py")], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_layer_sumcheck_length_rule_edges(ctx):
     gates = Layer(2, [0, 1, 0, 1], [0, 1, 2, 3], [3, 2, 1, 0])
     for w in ([1, 2, 1, 2], [1, 1, 2, 2], [7, 7, 7, 7], [0, 0, 0, 0]):
