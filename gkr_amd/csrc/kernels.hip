@@ -1042,18 +1042,25 @@ __global__ void __launch_bounds__(256) k_layer_uv(const Fr* __restrict__ A, cons
     const Fr* m = M + blockIdx.y * lb.tstride + (size_t)row * cols;
     const Fr* w = W + blockIdx.y * lb.wstride;
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
-    Lazy17 mw = lazy_zero(), aw = lazy_zero();
-    bool any = false;
-    for (uint32_t c = threadIdx.x; c < cols; c += blockDim.x) {
-        const Fr av = load_fr(a + c), mv = load_fr(m + c), q = load_fr(w + c);
-        acc_add_fr(acc[0], av);
-        lazy_mac_v(mw, mv, q);
-        lazy_mac_v(aw, av, q);
-        any = true;
-    }
-    if (any) {
+    if (cols >= 4u * blockDim.x) {
+        // several entries per thread: unreduced dot products, one reduction each at the end
+        Lazy17 mw = lazy_zero(), aw = lazy_zero();
+        for (uint32_t c = threadIdx.x; c < cols; c += blockDim.x) {
+            const Fr av = load_fr(a + c), mv = load_fr(m + c), q = load_fr(w + c);
+            acc_add_fr(acc[0], av);
+            lazy_mac_v(mw, mv, q);
+            lazy_mac_v(aw, av, q);
+        }
         acc_add_fr(acc[0], lazy_reduce(mw));
         acc_add_fr(acc[1], lazy_reduce(aw));
+    } else {
+        // short rows: a reduction per thread would cost more than the products it saves
+        for (uint32_t c = threadIdx.x; c < cols; c += blockDim.x) {
+            const Fr av = load_fr(a + c), mv = load_fr(m + c), q = load_fr(w + c);
+            acc_add_fr(acc[0], av);
+            acc_add_fr(acc[0], mont_mul(mv, q));
+            acc_add_fr(acc[1], mont_mul(av, q));
+        }
     }
     block_sum<9, 2>(acc, smem);
     if (threadIdx.x == 0) {
