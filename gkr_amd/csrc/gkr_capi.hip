@@ -945,28 +945,45 @@ static void host_eq_table(const gkr_fr* z, int lo, int hi, std::vector<gkr::h64:
 // shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries.
 // batch > 1: `batch` proofs of one circuit -- same gates (the cell lists are built once), z is batch x k_i,
 // d_A / d_M hold batch tables of N entries each.
+// E[g] = eq(z, g) = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the host (2^kh + 2^kl
+// products), E_lo in Montgomery form so that the product of the two is canonical.  The uploads are asynchronous on
+// the context's stream from pinned buffers.
+static int upload_eq_tables(gkr_ctx* ctx, int k_i, const gkr_fr* z, int batch, Fr** e_hi_out, Fr** e_lo_out) {
+    const int kl = k_i / 2, kh = k_i - kl;
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
+    WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
+    gkr::h64::F *hhi = nullptr, *hlo = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("pred.hhi", sizeof(gkr::h64::F) * ((size_t)batch << kh), reinterpret_cast<void**>(&hhi)));
+    HIP_TRY(ctx, ctx->pinned_host("pred.hlo", sizeof(gkr::h64::F) * ((size_t)batch << kl), reinterpret_cast<void**>(&hlo)));
+    std::vector<gkr::h64::F> tmp;
+    for (int b = 0; b < batch; ++b) {
+        const gkr_fr* zb = z + (size_t)b * k_i;
+        host_eq_table(zb, 0, kh, tmp);
+        memcpy(hhi + ((size_t)b << kh), tmp.data(), sizeof(gkr::h64::F) << kh);
+        host_eq_table(zb, kh, k_i, tmp);
+        for (auto& v : tmp) v = gkr::h64::to_mont(v);
+        memcpy(hlo + ((size_t)b << kl), tmp.data(), sizeof(gkr::h64::F) << kl);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(e_hi, hhi, sizeof(Fr) * ((size_t)batch << kh), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e_lo, hlo, sizeof(Fr) * ((size_t)batch << kl), hipMemcpyHostToDevice, ctx->stream));
+    *e_hi_out = e_hi;
+    *e_lo_out = e_lo;
+    return GKR_OK;
+}
+
 int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                      const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0, int batch = 1) {
     const size_t N = (size_t)1 << (2 * k - log_p);
     hipStream_t s = ctx->stream;
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t* bad = nullptr;
-    const int kl = k_i / 2, kh = k_i - kl;
-    WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
-    WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
+    const int kl = k_i / 2;
     WS(ctx, "pred.bad", uint32_t, 1, bad);
-    // E[g] = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the host (2^kh + 2^kl products)
-    std::vector<gkr::h64::F> hhi((size_t)batch << kh), hlo((size_t)batch << kl), tmp;
-    for (int b = 0; b < batch; ++b) {
-        const gkr_fr* zb = z + (size_t)b * k_i;
-        host_eq_table(zb, 0, kh, tmp);
-        memcpy(hhi.data() + ((size_t)b << kh), tmp.data(), sizeof(gkr::h64::F) << kh);
-        host_eq_table(zb, kh, k_i, tmp);
-        for (auto& v : tmp) v = gkr::h64::to_mont(v);
-        memcpy(hlo.data() + ((size_t)b << kl), tmp.data(), sizeof(gkr::h64::F) << kl);
+    {
+        const int rc_eq = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
+        if (rc_eq) return rc_eq;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(e_hi, hhi.data(), hhi.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(e_lo, hlo.data(), hlo.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
     static const bool use_atomics = getenv("GKR_PREDICATE_ATOMICS") != nullptr;
     if (!use_atomics || batch > 1) {
@@ -1021,8 +1038,22 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     gkr::FixedMul* d_rtab = nullptr;
     uint32_t *d_len = nullptr, *dep = nullptr;
     gkr::LayerPartial* partials = nullptr;
-    WS(ctx, "layer.A", Fr, N * batch, A);
-    WS(ctx, "layer.M", Fr, N * batch, M);
+    // Three forms of the b-phase (all the same transcript):
+    //   gate lists (default with the host transcript, k <= 13): no 2^{2k}-entry tables at all -- U, V and the
+    //     c-phase row are summed straight from the gates grouped by left / right operand (kernels.hip, k_gate_*);
+    //   dense predicate tables, U, V and the row from two passes over them (layers with more than 2^{2k-2} gates;
+    //     GKR_LAYER_DENSE_TABLES forces it, GKR_LAYER_GATE_LISTS forces the gate lists);
+    //   GKR_LAYER_DENSE_B (and the device transcript): k passes over the dense tables.
+    static const bool dense_b = getenv("GKR_LAYER_DENSE_B") != nullptr;
+    static const bool dense_tables = getenv("GKR_LAYER_DENSE_TABLES") != nullptr;
+    const bool lin_b = host_tx && !dense_b && k >= 1;
+    // gate lists pay when the layer is sparse in its 2^{2k} cells (every circom layer is); for a layer with a gate in
+    // (nearly) every cell the dense tables' counting sort is the cheaper grouping (k_i = 24, k = 12: 8.9 ms against 9.1)
+    static const bool gate_lists_always = getenv("GKR_LAYER_GATE_LISTS") != nullptr;
+    const bool sparse = lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k);
+    const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
+    WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
+    WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
     WS(ctx, "layer.Wb", Fr, wlen * batch, Wb);
     WS(ctx, "layer.Wc", Fr, wlen * batch, Wc);
     WS(ctx, "layer.coeffs", Fr, (size_t)v * 3, d_coeffs);
@@ -1031,27 +1062,49 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     WS(ctx, "layer.len", uint32_t, v, d_len);
     WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
     WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
-    // b-phase in linear time (kernels.hip, k_layer_uv): host transcript only; GKR_LAYER_DENSE_B keeps the k passes
-    // over the dense predicate tables
-    static const bool dense_b = getenv("GKR_LAYER_DENSE_B") != nullptr;
-    const bool lin_b = host_tx && !dense_b && k >= 1;
     Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
     Fr* h_eq = nullptr;   // pinned: eq(u, .) of every proof, Montgomery
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr;
+    const uint32_t kl = (uint32_t)(k_i / 2);
     if (lin_b) {
         WS(ctx, "layer.U", Fr, wlen * batch, U);
         WS(ctx, "layer.V", Fr, wlen * batch, V);
         WS(ctx, "layer.eq", Fr, wlen * batch, d_eq);
-        WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
+        if (!sparse)
+            WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
         HIP_TRY(ctx, ctx->pinned_host("layer.heq", sizeof(Fr) * wlen * batch, reinterpret_cast<void**>(&h_eq)));
     }
-    int rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
-    if (rc) return rc;
-    gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, N, wlen};
+    int rc = GKR_OK;
+    uint32_t* bad = nullptr;
+    if (sparse) {
+        uint32_t *g_counts = nullptr, *g_bsums = nullptr;
+        const size_t nb2 = (size_t)2 << k;
+        WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
+        WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
+        WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
+        WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
+        WS(ctx, "gates.list", uint32_t, (size_t)2 << k_i, g_list);
+        WS(ctx, "pred.bad", uint32_t, 1, bad);
+        rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
+        Timed t(ctx, "gate_lists", (double)((size_t)1 << k_i) * (9.0 + 4 * 4.0));
+        gkr::launch_gate_lists((uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
+    } else {
+        rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
+        if (rc) return rc;
+    }
+    gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, tlen, wlen};
     HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
     gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
     HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
     gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
-    if (lin_b) {
+    if (sparse) {
+        Timed t(ctx, "gate_uv", (double)((size_t)1 << k_i) * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+        gkr::launch_gate_uv((uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_r, e_hi, e_lo, kl, Wc, U, V, lb, s);
+    } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
     }
@@ -1066,7 +1119,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
         HIP_TRY(ctx, hipMemcpyAsync(h_dep.data(), dep, sizeof(uint32_t) * 32 * batch, hipMemcpyDeviceToHost, s));
+        uint32_t hbad = 0;
+        if (sparse) HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
         if (batch >= 16) pool = ctx->host_pool();
     }
     // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
@@ -1142,8 +1198,14 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 }
             }
             HIP_TRY(ctx, hipMemcpyAsync(d_eq, h_eq, sizeof(Fr) * wlen * batch, hipMemcpyHostToDevice, s));
-            Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
-            gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
+            if (sparse) {
+                Timed t(ctx, "gate_rows", (double)((size_t)1 << k_i) * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+                gkr::launch_gate_rows((uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq, A, M,
+                                      lb, s);
+            } else {
+                Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
+                gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
+            }
             pending = nullptr;   // U, V are done with; the row is already taken at u
         }
         if (phase == 0 && lin_b) {

@@ -742,6 +742,98 @@ __global__ void __launch_bounds__(256) k_pred_sum(size_t ncells, const uint32_t*
     }
 }
 
+// ---------------------------------------------------------------------------
+// Gate lists for the linear-time layer sumcheck (no 2^{2k}-entry predicate tables at all): the gates grouped by
+// their LEFT operand (what U, V of the b-phase sum over) and by their RIGHT operand (what the rows a_u, m_u of the
+// c-phase sum over).  One counting sort over 2 * 2^k buckets -- bucket b = left operand b, bucket 2^k + c = right
+// operand c -- into one list of 2 G entries; shared by all proofs of a batch (same gates).
+// ---------------------------------------------------------------------------
+__global__ void k_gate_count(uint32_t k_i, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+                             const uint32_t* __restrict__ right, uint32_t* __restrict__ counts, uint32_t* __restrict__ bad) {
+    const uint64_t gates = 1ull << k_i;
+    const uint32_t n = 1u << k;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = left[g], r = right[g];
+        if (l >= n || r >= n || gate_type[g] > 1) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        atomicAdd(counts + l, 1u);
+        atomicAdd(counts + n + r, 1u);
+    }
+}
+
+__global__ void k_gate_fill(uint32_t k_i, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+                            const uint32_t* __restrict__ right, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
+    const uint64_t gates = 1ull << k_i;
+    const uint32_t n = 1u << k;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = left[g], r = right[g];
+        if (l >= n || r >= n || gate_type[g] > 1) continue;
+        list[atomicAdd(cursor + l, 1u)] = (uint32_t)g;
+        list[atomicAdd(cursor + n + r, 1u)] = (uint32_t)g;
+    }
+}
+
+// U[b] = sum over the gates with left operand b of E[g] * (add ? 1 : W[right]),  V[b] = sum over its add gates of
+// E[g] * W[right];  E[g] = e_hi[g >> kl] * e_lo[g & mask] (e_lo and W in Montgomery form, so products are canonical).
+// grid = (2^k buckets, batch); any block size that is a multiple of 64.
+__global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
+                                                 const uint32_t* __restrict__ list, const uint8_t* __restrict__ gate_type,
+                                                 const uint32_t* __restrict__ right, const Fr* __restrict__ e_hi,
+                                                 const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
+                                                 const Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t wstride) {
+    __shared__ Acc<9> smem[4 * 2];
+    const uint32_t b = blockIdx.x, lmask = (1u << kl) - 1u;
+    e_hi += (size_t)blockIdx.y << kh;
+    e_lo_mont += (size_t)blockIdx.y << kl;
+    W += (size_t)blockIdx.y * wstride;
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = offsets[b] + threadIdx.x; i < cursor[b]; i += blockDim.x) {
+        const uint32_t g = list[i];
+        const Fr e = mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & lmask)));
+        const Fr ew = mont_mul(e, load_fr(W + right[g]));
+        if (gate_type[g]) {
+            acc_add_fr(acc[0], ew);
+        } else {
+            acc_add_fr(acc[0], e);
+            acc_add_fr(acc[1], ew);
+        }
+    }
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        store_fr(U + (size_t)blockIdx.y * wstride + b, acc_reduce(acc[0]));
+        store_fr(V + (size_t)blockIdx.y * wstride + b, acc_reduce(acc[1]));
+    }
+}
+
+// a_u[c] = sum over the add gates with right operand c of E[g] * eq(u, left[g]),  m_u[c] the same over its mult gates
+// (eq in Montgomery form).  grid = (2^k buckets, batch).
+__global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
+                                                   const uint32_t* __restrict__ list, const uint8_t* __restrict__ gate_type,
+                                                   const uint32_t* __restrict__ left, const Fr* __restrict__ e_hi,
+                                                   const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
+                                                   const Fr* __restrict__ eq_mont, Fr* __restrict__ A_row, Fr* __restrict__ M_row,
+                                                   uint32_t k, uint32_t wstride) {
+    __shared__ Acc<9> smem[4 * 2];
+    const uint32_t c = blockIdx.x, lmask = (1u << kl) - 1u, bucket = (1u << k) + c;
+    e_hi += (size_t)blockIdx.y << kh;
+    e_lo_mont += (size_t)blockIdx.y << kl;
+    eq_mont += (size_t)blockIdx.y * wstride;
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    for (uint32_t i = offsets[bucket] + threadIdx.x; i < cursor[bucket]; i += blockDim.x) {
+        const uint32_t g = list[i];
+        const Fr e = mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & lmask)));
+        const Fr t = mont_mul(e, load_fr(eq_mont + left[g]));
+        acc_add_fr(acc[gate_type[g] ? 1 : 0], t);
+    }
+    block_sum<9, 2>(acc, smem);
+    if (threadIdx.x == 0) {
+        store_fr(A_row + (size_t)blockIdx.y * wstride + c, acc_reduce(acc[0]));
+        store_fr(M_row + (size_t)blockIdx.y * wstride + c, acc_reduce(acc[1]));
+    }
+}
+
 // widened cell -> canonical Fr.  limb sums < 2^32 * 2^32; value < 2^32 r.
 __global__ void k_predicate_normalise(const unsigned long long* __restrict__ wide, Fr* __restrict__ out, size_t cells) {
     for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
@@ -1315,6 +1407,37 @@ void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_
                        cursor, list, bad);
     hipLaunchKernelGGL(k_pred_sum, dim3(blocks_for(n, 8192), batch), dim3(256), 0, s, ncells, offsets, cursor, list, e_hi,
                        e_lo_mont, kl, k_i - kl, out_A, out_M);
+}
+
+// gate lists by left and by right operand: counts / offsets / cursor 2 * 2^k u32 each (counts zeroed by the caller),
+// block_sums ceil(2 * 2^k / 2048) + 1, list 2 * 2^k_i u32
+void launch_gate_lists(uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                       uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
+                       hipStream_t s) {
+    const size_t n = (size_t)2 << k;
+    const uint32_t gblocks = blocks_for(1ull << k_i, 4096);
+    const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
+    hipLaunchKernelGGL(k_gate_count, dim3(gblocks), dim3(256), 0, s, k_i, k, gate_type, left, right, counts, bad);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, counts, offsets, block_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, sblocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, offsets, cursor, block_sums, n);
+    hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, k_i, k, gate_type, left, right, cursor, list);
+}
+
+static uint32_t bucket_threads(uint32_t k_i, uint32_t k) { return (k_i > k + 6) ? 256u : 64u; }   // gates per bucket on average
+
+void launch_gate_uv(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+                    const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
+                    Fr* U, Fr* V, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(k_i, k)), 0, s, offsets, cursor, list, gate_type, right,
+                       e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride);
+}
+
+void launch_gate_rows(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+                      const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
+                      const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(k_i, k)), 0, s, offsets, cursor, list, gate_type, left,
+                       e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {

@@ -237,13 +237,15 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
     assert ctx.prove_sumcheck_opt(lay, k, z, w) == cdense.sumcheck_layer(k_i, k, gt, lay.left, lay.right, z, w)
 
 
-@pytest.mark.parametrize("env", [{}, {"GKR_LAYER_DENSE_B": "1"}, {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
+@pytest.mark.parametrize("env", [{}, {"GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"}, {"GKR_LAYER_DENSE_B": "1"},
+                                 {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
                                  {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
-    """The layer sumcheck's b-phase has two forms -- linear time over the (W, U, V) tables of 2^k entries (default),
-    and k passes over the dense 2^{2k}-entry predicate tables (fused or round + fold kernels): the same transcript
-    from each, single layers and a batch of proofs.  The knobs are read once per process, hence the child."""
+    """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from
+    the gate lists (default), the same with U, V taken from dense predicate tables, and k passes over the dense
+    2^{2k}-entry tables (fused or round + fold kernels): the same transcript from each, single layers and a batch of
+    proofs.  The knobs are read once per process, hence the child."""
     import os
     import subprocess
     import sys

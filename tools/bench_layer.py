@@ -52,12 +52,12 @@ def main():
         times.append(time.perf_counter() - t0)
     names = ["predicate_scatter", "predicate_normalise", "predicate_sorted",
              "layer_round_fused", "layer_round", "layer_fold", "layer_round_reduce", "layer_round_hash",
-             "layer_uv", "layer_uv_round", "layer_collapse", "layer_c_round"]
+             "layer_uv", "layer_uv_round", "layer_collapse", "layer_c_round", "gate_lists", "gate_uv", "gate_rows"]
     prof = {n: ctx.profile_get(n) for n in names}
     steps = args.steps
     N = 1 << (2 * args.k)
     sum_ms = sum(prof[n]["total_ms"] for n in ("layer_round_fused", "layer_round", "layer_fold", "layer_uv", "layer_uv_round",
-                                               "layer_collapse", "layer_c_round")) / steps
+                                               "layer_collapse", "layer_c_round", "gate_uv", "gate_rows")) / steps
     out = {
         "workload": "GKR layer sumcheck k_i=%d k=%d (2^%d-point hypercube, 2^%d gates)" % (args.k_i, args.k, 2 * args.k, args.k_i),
         "wall_ms_per_sumcheck": 1e3 * sum(times[args.warmup:]) / steps,

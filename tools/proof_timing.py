@@ -30,7 +30,7 @@ t0 = time.perf_counter()
 ctx.prove_batch_raw(circuit, inputs)
 wall_p = time.perf_counter() - t0
 tot = 0.0
-for name in ("layer_round", "layer_round_fused", "layer_uv", "layer_uv_round", "layer_collapse", "layer_fold", "layer_round_reduce",
+for name in ("gate_lists", "gate_uv", "gate_rows", "layer_c_round", "layer_round", "layer_round_fused", "layer_uv", "layer_uv_round", "layer_collapse", "layer_fold", "layer_round_reduce",
              "layer_round_hash", "predicate_sorted",
              "predicate_scatter", "predicate_normalise"):
     p = ctx.profile_get(name)
