@@ -1125,6 +1125,24 @@ __global__ void __launch_bounds__(64) k_layer_round_reduce(const LayerPartial* _
 // which is the single remaining row the c-phase kernels expect.  Same round polynomials: bit-exact.
 // ---------------------------------------------------------------------------
 
+// The three round sums of one proof (thread 0 holds them after block_sum) -> canonical values in the pinned host
+// record.  The three reductions run side by side in lanes 0..2 of the first wave; lane 0's release store of the
+// sequence number follows the wave's record stores in program order.
+__device__ __forceinline__ void publish_round(const Acc<9> (&acc)[3], Acc<9>* tot /* shared, 3 */, LayerHostRec* r, uint32_t ticket) {
+    if (threadIdx.x == 0) {
+        tot[0] = acc[0];
+        tot[1] = acc[1];
+        tot[2] = acc[2];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const Fr v = acc_reduce(tot[threadIdx.x]);
+        Fr* dst = threadIdx.x == 0 ? &r->c0 : (threadIdx.x == 1 ? &r->g1 : &r->c2);
+        *dst = v;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // grid = (2^k rows, batch), block = 256: U[row], V[row] of one proof.  W: the Montgomery copy over columns.
 __global__ void __launch_bounds__(256) k_layer_uv(const Fr* __restrict__ A, const Fr* __restrict__ M, const Fr* __restrict__ W,
                                                   Fr* __restrict__ U, Fr* __restrict__ V, uint32_t k, LayerBatch lb) {
@@ -1204,13 +1222,8 @@ __global__ void __launch_bounds__(256) k_uv_round(Fr* __restrict__ W, Fr* __rest
         acc_add_fr(acc[2], mont_mul(fr_sub(uh, ul), fr_sub(wh, wl)));
     }
     block_sum<9, 3>(acc, smem);
-    if (threadIdx.x == 0) {
-        LayerHostRec* r = host_rec + blockIdx.x;
-        r->c0 = acc_reduce(acc[0]);
-        r->g1 = acc_reduce(acc[1]);
-        r->c2 = acc_reduce(acc[2]);
-        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    __syncthreads();   // smem is reused for the totals
+    publish_round(acc, smem, host_rec + blockIdx.x, ticket);
 }
 
 // One c-round of one proof on the single remaining row (2h entries of A, M; W over c in Montgomery form;
@@ -1255,13 +1268,8 @@ __global__ void __launch_bounds__(256) k_c_round(Fr* __restrict__ A, Fr* __restr
         acc_add_fr(acc[2], t.c2);
     }
     block_sum<9, 3>(acc, smem);
-    if (threadIdx.x == 0) {
-        LayerHostRec* r = host_rec + blockIdx.x;
-        r->c0 = acc_reduce(acc[0]);
-        r->g1 = acc_reduce(acc[1]);
-        r->c2 = acc_reduce(acc[2]);
-        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    __syncthreads();   // smem is reused for the totals
+    publish_round(acc, smem, host_rec + blockIdx.x, ticket);
 }
 
 // Row collapse, stage 1: partial[chunk][c] = sum over the chunk's rows of eq[row] * T[row][c] for T = A (z = 0)
