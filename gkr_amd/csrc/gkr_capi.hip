@@ -1210,8 +1210,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         }
         if (phase == 0 && lin_b) {
             const uint32_t ticket = ++ctx->ticket;
-            Timed t(ctx, "layer_uv_round", 0.0);
-            gkr::launch_uv_round(pending != nullptr, Wb, U, V, 1u << (k - 1 - (int)round), pending, rec, ticket, lb, s);
+            {
+                Timed t(ctx, "layer_uv_round", 0.0);
+                gkr::launch_uv_round(pending != nullptr, Wb, U, V, 1u << (k - 1 - (int)round), pending, rec, ticket, lb, s);
+            }
             pending = nullptr;
             published = true;
             lap(t_launch);
@@ -1221,8 +1223,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         } else if (phase == 1 && lin_b && k <= 13) {
             // the single remaining row: one small block per proof folds it and publishes the round's sums
             const uint32_t ticket = ++ctx->ticket;
-            Timed t(ctx, "layer_c_round", 0.0);
-            gkr::launch_c_round(pending != nullptr, A, M, Wc, Wb, h, pending, rec, ticket, lb, s);
+            {
+                Timed t(ctx, "layer_c_round", 0.0);
+                gkr::launch_c_round(pending != nullptr, A, M, Wc, Wb, h, pending, rec, ticket, lb, s);
+            }
             pending = nullptr;
             published = true;
             lap(t_launch);
