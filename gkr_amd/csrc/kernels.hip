@@ -1212,14 +1212,30 @@ __global__ void __launch_bounds__(256) k_uv_round(Fr* __restrict__ W, Fr* __rest
         __syncthreads();
     }
     Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
-    for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-        const Fr wl = load_fr(W + i), wh = load_fr(W + i + h);
-        const Fr ul = load_fr(U + i), uh = load_fr(U + i + h);
-        acc_add_fr(acc[0], mont_mul(ul, wl));
-        acc_add_fr(acc[0], load_fr(V + i));
-        acc_add_fr(acc[1], mont_mul(uh, wh));
-        acc_add_fr(acc[1], load_fr(V + i + h));
-        acc_add_fr(acc[2], mont_mul(fr_sub(uh, ul), fr_sub(wh, wl)));
+    if (h * 4u <= blockDim.x) {
+        // few pairs: one product per thread
+        const uint32_t i = threadIdx.x >> 2, part = threadIdx.x & 3u;
+        if (i < h && part < 3u) {
+            if (part == 0) {
+                acc_add_fr(acc[0], mont_mul(load_fr(U + i), load_fr(W + i)));
+                acc_add_fr(acc[0], load_fr(V + i));
+            } else if (part == 1) {
+                acc_add_fr(acc[1], mont_mul(load_fr(U + i + h), load_fr(W + i + h)));
+                acc_add_fr(acc[1], load_fr(V + i + h));
+            } else {
+                acc_add_fr(acc[2], mont_mul(fr_sub(load_fr(U + i + h), load_fr(U + i)), fr_sub(load_fr(W + i + h), load_fr(W + i))));
+            }
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+            const Fr wl = load_fr(W + i), wh = load_fr(W + i + h);
+            const Fr ul = load_fr(U + i), uh = load_fr(U + i + h);
+            acc_add_fr(acc[0], mont_mul(ul, wl));
+            acc_add_fr(acc[0], load_fr(V + i));
+            acc_add_fr(acc[1], mont_mul(uh, wh));
+            acc_add_fr(acc[1], load_fr(V + i + h));
+            acc_add_fr(acc[2], mont_mul(fr_sub(uh, ul), fr_sub(wh, wl)));
+        }
     }
     block_sum<9, 3>(acc, smem);
     __syncthreads();   // smem is reused for the totals
@@ -1260,12 +1276,31 @@ __global__ void __launch_bounds__(256) k_c_round(Fr* __restrict__ A, Fr* __restr
         __syncthreads();
     }
     Acc<9> acc[3] = {acc_zero<9>(), acc_zero<9>(), acc_zero<9>()};
-    for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
-        const PairTerms t = layer_pair(load_fr(A + i), load_fr(A + i + h), load_fr(M + i), load_fr(M + i + h), p, p,
-                                       load_fr(Wc + i), load_fr(Wc + i + h));
-        acc_add_fr(acc[0], t.c0);
-        acc_add_fr(acc[1], t.g1);
-        acc_add_fr(acc[2], t.c2);
+    if (h * 4u <= blockDim.x) {
+        // few pairs: the three sums of a pair go to three different threads (a pair is ~8 dependent-free products,
+        // and with one thread per pair most of the block would idle through them)
+        const uint32_t i = threadIdx.x >> 2, part = threadIdx.x & 3u;
+        if (i < h && part < 3u) {
+            const Fr q0 = load_fr(Wc + i), q1 = load_fr(Wc + i + h);
+            const Fr s0 = fr_add(p, q0), s1 = fr_add(p, q1);
+            const Fr pq0 = mont_mul(p, q0), pq1 = mont_mul(p, q1);
+            if (part == 0) {
+                acc_add_fr(acc[0], fr_add(mont_mul(load_fr(A + i), s0), mont_mul(load_fr(M + i), pq0)));
+            } else if (part == 1) {
+                acc_add_fr(acc[1], fr_add(mont_mul(load_fr(A + i + h), s1), mont_mul(load_fr(M + i + h), pq1)));
+            } else {
+                const Fr da = fr_sub(load_fr(A + i + h), load_fr(A + i)), dm = fr_sub(load_fr(M + i + h), load_fr(M + i));
+                acc_add_fr(acc[2], fr_add(mont_mul(da, fr_sub(s1, s0)), mont_mul(dm, fr_sub(pq1, pq0))));
+            }
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < h; i += blockDim.x) {
+            const PairTerms t = layer_pair(load_fr(A + i), load_fr(A + i + h), load_fr(M + i), load_fr(M + i + h), p, p,
+                                           load_fr(Wc + i), load_fr(Wc + i + h));
+            acc_add_fr(acc[0], t.c0);
+            acc_add_fr(acc[1], t.g1);
+            acc_add_fr(acc[2], t.c2);
+        }
     }
     block_sum<9, 3>(acc, smem);
     __syncthreads();   // smem is reused for the totals
