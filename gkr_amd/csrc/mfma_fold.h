@@ -201,7 +201,11 @@ __device__ __forceinline__ void mfma_multifold_block(const Fr* __restrict__ s, F
         const uint32_t voff = (e0 + c) * 32u + 16u * h;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
+#if defined(MF_STREAM_PAD)   // experiment (tools/ubench_mfma_fold.hip): streams MF_STREAM_PAD entries further apart
+            const char* base = reinterpret_cast<const char*>(s + (size_t)(stage * KS + k) * (S + MF_STREAM_PAD));
+#else
             const char* base = reinterpret_cast<const char*>(s + (size_t)(stage * KS + k) * S);
+#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 x[t][k] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(base + voff + 1024u * t));

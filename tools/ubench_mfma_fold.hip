@@ -8,6 +8,10 @@
 #include <vector>
 #include "fr32.h"
 #include "mfma_fold.h"
+#ifndef MF_STREAM_PAD
+#define MF_STREAM_PAD 0
+#define MF_NO_PAD 1
+#endif
 #ifndef ROT
 #define ROT (blockIdx.x * 5u + blockIdx.y * 3u)
 #endif
@@ -51,7 +55,7 @@ static Fr rand_fr(int kind) {
 template <int JIN>
 static int run(uint32_t S, uint32_t batch, uint32_t nblk, int reps, bool check) {
     constexpr int NB = 1 << JIN;
-    const size_t src_len = (size_t)S * NB;
+    const size_t src_len = ((size_t)S + MF_STREAM_PAD) * NB;   // MF_STREAM_PAD: the stride experiment (0 = the real layout)
     std::vector<Fr> h_src(src_len * batch), h_w(32 * (size_t)batch), h_wm(32 * (size_t)batch);
     for (size_t i = 0; i < h_src.size(); ++i) h_src[i] = rand_fr(i < 64 ? (int)(i % 5) : (rnd() % 64 == 0 ? (int)(rnd() % 5) : 0));
     for (size_t i = 0; i < h_w.size(); ++i) {
@@ -80,7 +84,7 @@ static int run(uint32_t S, uint32_t batch, uint32_t nblk, int reps, bool check) 
         for (uint32_t t = 0; t < batch; ++t)
             for (uint32_t i = 0; i < S; ++i) {
                 Fr y = fr_zero();
-                for (int b = 0; b < NB; ++b) y = fr_add(y, mont_mul(h_src[(size_t)t * src_len + (size_t)b * S + i], h_wm[(size_t)t * 32 + b]));
+                for (int b = 0; b < NB; ++b) y = fr_add(y, mont_mul(h_src[(size_t)t * src_len + (size_t)b * (S + MF_STREAM_PAD) + i], h_wm[(size_t)t * 32 + b]));
                 if (!fr_eq(y, h_dst[(size_t)t * S + i])) {
                     if (bad < 4) {
                         printf("  mismatch table %u entry %u: got", t, i);
