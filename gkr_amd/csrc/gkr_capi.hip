@@ -363,6 +363,18 @@ constexpr int kMaxGroups = 16;
 #define WS(ctx, slot, type, count, ptr) \
     HIP_TRY(ctx, (ctx)->workspace(slot, (size_t)(count) * sizeof(type), reinterpret_cast<void**>(&(ptr))))
 
+// Rounds the sub-block sums of a table of 2^m entries cover (= variables the next fold pass binds) in a sumcheck over
+// 2^n points with at most jmax rounds per pass.  A fold pass over more than kSmallPassEntries outputs splits each
+// sub-block over whole 64-entry chunks (so at most m - 6 rounds from its sums); and a fold should not leave 1024 or
+// 2048 entries -- too many for the one-block kernel, too few to fill the chip with 64-entry wave tiles: stop at 4096
+// and take the rest in the pass after.
+static int mle_pass_rounds(int m, int n, int jmax) {
+    int j = m < jmax ? m : jmax;
+    if (((size_t)1 << m) > gkr::kSmallPassEntries && m != n && j > m - 6) j = m - 6;
+    if (jmax > 3 && (m - j == 10 || m - j == 11) && m - 12 >= 1) j = m - 12;
+    return j < 1 ? 1 : j;
+}
+
 // ------------------------------------------------------------- plain MLE sumcheck, multi-round passes
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
@@ -385,16 +397,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         const int v = e ? atoi(e) : cap;
         return v < 1 ? 1 : (v > cap ? cap : v);
     }();
-    // rounds the sums of a table of 2^m entries may cover: a fold pass over more than kSmallPassEntries outputs
-    // splits each sub-block over whole 64-entry chunks
-    auto rounds_for = [&](int m) {
-        int j = m < jmax ? m : jmax;
-        if (((size_t)1 << m) > gkr::kSmallPassEntries && m != n && j > m - 6) j = m - 6;
-        // the fold these rounds lead to leaves 2^(m-j) entries: 1024 or 2048 is too many for the one-block kernel and
-        // too few to fill the chip with 64-entry wave tiles -- stop at 4096 and take the rest in the pass after
-        if (jmax > 3 && (m - j == 10 || m - j == 11) && m - 12 >= 1) j = m - 12;
-        return j < 1 ? 1 : j;
-    };
+    auto rounds_for = [&](int m) { return mle_pass_rounds(m, n, jmax); };
     const int j_first = rounds_for(n);
     const size_t work_len = len >> j_first;   // the first folded table
     Fr* work = nullptr;
@@ -1531,6 +1534,22 @@ int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_f
 // eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
 // host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1; its sixteen-lane
 // form is cross-checked on the way), else scalar
+// the pass schedule of a 2^n-point sumcheck (host logic only): rounds[i] = rounds covered by pass i, *passes = how many.
+// mfma != 0: the default schedule (up to 5 rounds per pass), 0: the v_mad_u64_u32 fold's (up to 3).
+int gkr_selftest_pass_schedule(int n, int mfma, uint32_t* rounds, size_t capacity, size_t* passes) {
+    if (n < 1 || n > 40 || !passes) return GKR_ERR_INVALID;
+    const int jmax = mfma ? gkr::kMlePassMaxRounds : 3;
+    size_t count = 0;
+    for (int m = n; m > 0;) {
+        const int j = mle_pass_rounds(m, n, jmax);
+        if (rounds && count < capacity) rounds[count] = (uint32_t)j;
+        ++count;
+        m -= j;
+    }
+    *passes = count;
+    return (rounds && count > capacity) ? GKR_ERR_NOMEM : GKR_OK;
+}
+
 int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int* used_ifma) {
     if (!vecs || !len || !out) return GKR_ERR_INVALID;
     if (!all_canonical(vecs, 24)) return GKR_ERR_NON_CANONICAL;

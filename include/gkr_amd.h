@@ -110,6 +110,9 @@ int  gkr_selftest_wide_sum(const gkr_fr *vals, size_t n, gkr_fr *out);
 int  gkr_selftest_hash8(const gkr_fr *vecs, const uint32_t *len, gkr_fr *out, int *used_ifma);
 /* sum_i a_i b_i through the unreduced 544-bit dot-product accumulator of the fused layer kernel */
 int  gkr_selftest_dot(const gkr_fr *a, const gkr_fr *b, size_t n, gkr_fr *out);
+/* the pass schedule of a 2^n-point plain sumcheck (host logic): rounds covered by each pass; mfma = 1 default
+ * (up to 5 rounds per pass), 0 the v_mad_u64_u32 fold's (up to 3).  *passes = number of passes. */
+int  gkr_selftest_pass_schedule(int n, int mfma, uint32_t *rounds, size_t capacity, size_t *passes);
 /* lo + r (hi - lo) through the fixed-multiplier table the fold kernels use */
 int  gkr_selftest_fold(const gkr_fr *lo, const gkr_fr *hi, const gkr_fr *r, gkr_fr *out);
 

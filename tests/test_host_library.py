@@ -158,3 +158,41 @@ def test_proof_sizes_host_only():
     k0 = np.asarray([1, 0], dtype=np.uint32)
     desc = N.CircuitDesc(1, k0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), dummy, dummy, dummy)
     assert lib.gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(s)) == N.GKR_ERR_DEGENERATE
+
+
+def test_pass_schedule_of_the_plain_sumcheck():
+    """Host logic of the multi-round passes: the rounds of the passes add up to n; a fold pass over more than 512
+    outputs leaves at least 64 entries per sub-block of its sums (whole wave tiles) and never 1024 or 2048 entries;
+    the first pass of a large table covers five rounds (three with the v_mad_u64_u32 fold)."""
+    import ctypes
+    import numpy as np
+    from gkr_amd import _native as N
+    L = N.lib()
+    for mfma in (1, 0):
+        for n in range(1, 33):
+            rounds = np.zeros(64, dtype=np.uint32)
+            count = ctypes.c_size_t()
+            assert L.gkr_selftest_pass_schedule(ctypes.c_int(n), ctypes.c_int(mfma), rounds.ctypes.data_as(ctypes.c_void_p),
+                                                ctypes.c_size_t(64), ctypes.byref(count)) == 0
+            r = [int(x) for x in rounds[:count.value]]
+            assert sum(r) == n and all(1 <= j <= (5 if mfma else 3) for j in r)
+            m = n
+            for i, j in enumerate(r):
+                if i > 0 and (1 << m) > 512:          # this table came out of a fold pass whose sums have 2^j sub-blocks
+                    assert m - j >= 6
+                m -= j
+                if mfma and m > 9:
+                    assert m not in (10, 11)          # a fold leaves <= 512 entries (one-block kernel) or >= 4096
+            if n >= 17:
+                assert r[0] == (5 if mfma else 3)
+    assert [int(x) for x in _schedule(L, 20, 1)] == [5, 3, 5, 5, 2]
+
+
+def _schedule(L, n, mfma):
+    import ctypes
+    import numpy as np
+    rounds = np.zeros(64, dtype=np.uint32)
+    count = ctypes.c_size_t()
+    assert L.gkr_selftest_pass_schedule(ctypes.c_int(n), ctypes.c_int(mfma), rounds.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(64),
+                                        ctypes.byref(count)) == 0
+    return rounds[:count.value]
