@@ -197,20 +197,10 @@ def proofs_per_sec(device, n_proofs):
     k = [5, 6, 7, 7 | input 7]) for `n_proofs` different witnesses (BASELINE configs[3]: 64 inputs).
     Proofs are independent (aggregator.rs:350-355 proves them from a rayon par_iter): one context per
     host thread.  Rank 0 measures its own share; other ranks would do the same work."""
-    import numpy as np
-    from gkr_amd import Context, GKRCircuit, Layer
-    ks = [5, 6, 7, 7, 7]
-    rng = np.random.default_rng(0xC0FFEE + 3)
-    layers = [Layer(ks[i], rng.integers(0, 2, 1 << ks[i], dtype=np.uint8),
-                    rng.integers(0, 1 << ks[i + 1], 1 << ks[i], dtype=np.uint32),
-                    rng.integers(0, 1 << ks[i + 1], 1 << ks[i], dtype=np.uint32)) for i in range(4)]
-    circuit = GKRCircuit(layers, ks[-1])
-
-    def witness(i):
-        a = np.random.default_rng(1000 + i).integers(0, 1 << 63, (1 << ks[-1], 4), dtype=np.uint64)
-        a[:, 3] &= np.uint64((1 << 61) - 1)
-        return a
-    inputs = np.stack([witness(i) for i in range(n_proofs)])
+    from gkr_amd import Context, synth
+    ks = synth.PROOF_BATCH_KS
+    circuit = synth.proof_batch_circuit()
+    inputs = synth.proof_batch_witnesses(n_proofs)   # what tests/test_gpu_config_scale.py checks against the oracle
     ctx = Context(device)
     ctx.prove_batch_raw(circuit, inputs[: min(8, n_proofs)])   # warm-up: code objects, workspaces
     ctx.prove_batch_raw(circuit, inputs)

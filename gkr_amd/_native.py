@@ -18,6 +18,7 @@ GKR_ERR_NO_DEVICE = 3
 GKR_ERR_HIP = 4
 GKR_ERR_NOMEM = 5
 GKR_ERR_DEGENERATE = 6
+GKR_ERR_UNSUPPORTED = 7
 
 GKR_TRANSCRIPT_DEVICE = 0
 GKR_TRANSCRIPT_HOST = 1
@@ -28,8 +29,11 @@ SYMBOLS = [
     "gkr_ctx_set_transcript", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get",
     "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
     "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_pass_schedule", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
-    "gkr_sumcheck_layer", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
+    "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
     "gkr_circom_meta", "gkr_circom_input_json",
+    "gkr_r1cs_parse", "gkr_r1cs_build", "gkr_r1cs_info", "gkr_r1cs_export", "gkr_r1cs_serialize", "gkr_r1cs_free",
+    "gkr_wtns_parse", "gkr_wtns_serialize", "gkr_r1cs_compile", "gkr_layered_count", "gkr_layered_circuit",
+    "gkr_layered_input_layer", "gkr_layered_input_values", "gkr_layered_free",
     "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
     "gkr_device_fill_table", "gkr_device_synchronize",
     "gkr_layer_session_open", "gkr_layer_session_open_tables", "gkr_layer_session_dep", "gkr_layer_session_rounds",
@@ -52,6 +56,12 @@ class CircuitDesc(ctypes.Structure):
 class ProofBuf(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in
                 ("sumcheck_coeffs", "sumcheck_len", "sumcheck_r", "q", "q_len", "z", "r", "d_coeffs", "input_coeffs")]
+
+
+class R1csInfo(ctypes.Structure):
+    _fields_ = [("n_wires", ctypes.c_uint32), ("n_pub_out", ctypes.c_uint32), ("n_pub_in", ctypes.c_uint32),
+                ("n_prv_in", ctypes.c_uint32), ("n_labels", ctypes.c_uint64), ("n_constraints", ctypes.c_size_t),
+                ("n_terms", ctypes.c_size_t)]
 
 
 class ProofSizes(ctypes.Structure):
@@ -78,5 +88,8 @@ def lib():
         for fn in (L.gkr_layer_session_close, L.gkr_mle_session_close):
             fn.restype = None
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        for fn in (L.gkr_r1cs_free, L.gkr_layered_free):
+            fn.restype = None
+            fn.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib

@@ -6,6 +6,7 @@
 // hash runs on the device by default, so a whole sumcheck is one uninterrupted
 // stream of launches with a single copy-back at the end.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,6 +70,9 @@ const gkr::h64::F* host_mimc_constants64() {
 // quota allows gets the whole process throttled for the rest of a 100 ms period.
 int usable_cpus() {
     int hw = (int)std::thread::hardware_concurrency();
+    cpu_set_t mask;   // a process pinned to a few cores (taskset, per-rank core binding) must not spin on more threads
+    CPU_ZERO(&mask);
+    if (sched_getaffinity(0, sizeof mask, &mask) == 0 && CPU_COUNT(&mask) > 0) hw = CPU_COUNT(&mask);
     if (hw < 1) hw = 1;
     double quota = -1, period = -1;
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -606,12 +610,12 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         return true;
     };
     dbg_a = dbg_us();
-    pool->begin_session(&try_work);
+    gkr::SpinPool::Session session(pool, &try_work);
     int rc = GKR_OK;
     for (int g = 0; g < groups; ++g) launch_first(grp[g]);
     dbg_b = dbg_us();
     int active = groups;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     uint32_t idle = 0;
     while (active > 0 && rc == GKR_OK) {
         bool progress = false;
@@ -636,6 +640,8 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         }
         if (progress) {
             idle = 0;
+            t0 = std::chrono::steady_clock::now();   // the limit is on time without progress, not on the whole call
+            if (hipError_t le = hipGetLastError(); le != hipSuccess) rc = ctx->hip_fail(le, "launch of a sumcheck pass");
             continue;
         }
         if (try_work()) continue;
@@ -648,7 +654,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         }
     }
     dbg_c = dbg_us();
-    pool->end_session();
+    session.close();
     if (rc) {
         (void)hipStreamSynchronize(s);
         return rc;
@@ -821,12 +827,12 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
                 if (__atomic_load_n(&rec[G.b0 + i].seq, __ATOMIC_ACQUIRE) != G.ticket) return false;
             return true;
         };
-        pool->begin_session(&try_work);
+        gkr::SpinPool::Session session(pool, &try_work);
         int rc = GKR_OK;
         int started = 1;
         launch_round(grp[0], 0);
         int active = groups;
-        const auto t0 = std::chrono::steady_clock::now();
+        auto t0 = std::chrono::steady_clock::now();
         uint32_t idle = 0;
         while (active > 0 && rc == GKR_OK) {
             bool progress = false;
@@ -856,6 +862,8 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
             }
             if (progress) {
                 idle = 0;
+                t0 = std::chrono::steady_clock::now();   // the limit is on time without progress
+                if (hipError_t le = hipGetLastError(); le != hipSuccess) rc = ctx->hip_fail(le, "launch of a sumcheck round");
                 continue;
             }
             if (try_work()) continue;   // nothing to schedule: help with the hashing
@@ -867,7 +875,7 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
                     rc = ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a round");
             }
         }
-        pool->end_session();
+        session.close();
         if (rc) {
             (void)hipStreamSynchronize(s);
             return rc;
@@ -1029,13 +1037,26 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
 // `batch` layer sumchecks that share their gates (the same layer of `batch` proofs of one circuit), or
 // one (batch = 1).  z: batch x k_i challenges (host); d_W: batch tables of 2^k canonical values;
 // outputs: per proof 2k rows (out_coeffs 3 slots per row), laid out [proof][round] with the given strides.
+// One rank's share of a layer split across GPUs by GATES (gkr_sumcheck_layer_sharded): the device gate arrays hold
+// gates gate_base .. gate_base + gate_count - 1, and the two tables that are sums over gates -- (U, V) before the
+// b-rounds, the row (a_u, m_u) before the c-rounds -- are completed by the caller's sum-over-ranks hook.
+struct LayerShardArgs {
+    uint64_t gate_base = 0, gate_count = 0;
+    gkr_allreduce_fn allreduce = nullptr;
+    void* user = nullptr;
+};
+
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
-                    const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r) {
+                    const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                    const LayerShardArgs* shard = nullptr) {
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
+    if (shard && (!host_tx || batch != 1 || k > 13))
+        return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript, one proof and k_next <= 13");
+    const gkr::GateSpan span{shard ? shard->gate_base : 0, shard ? shard->gate_count : (uint64_t)1 << k_i};
     hipStream_t s = ctx->stream;
     Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr, *d_coeffs = nullptr, *d_r_out = nullptr;
     gkr::FixedMul* d_rtab = nullptr;
@@ -1053,7 +1074,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     // gate lists pay when the layer is sparse in its 2^{2k} cells (every circom layer is); for a layer with a gate in
     // (nearly) every cell the dense tables' counting sort is the cheaper grouping (k_i = 24, k = 12: 8.9 ms against 9.1)
     static const bool gate_lists_always = getenv("GKR_LAYER_GATE_LISTS") != nullptr;
-    const bool sparse = lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k);
+    const bool sparse = shard || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k));
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -1087,14 +1108,14 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
         WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
         WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
-        WS(ctx, "gates.list", uint32_t, (size_t)2 << k_i, g_list);
+        WS(ctx, "gates.list", uint32_t, 2 * span.count + 1, g_list);
         WS(ctx, "pred.bad", uint32_t, 1, bad);
         rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
         HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
-        Timed t(ctx, "gate_lists", (double)((size_t)1 << k_i) * (9.0 + 4 * 4.0));
-        gkr::launch_gate_lists((uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
+        Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
+        gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
     } else {
         rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
         if (rc) return rc;
@@ -1105,11 +1126,37 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
     gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
     if (sparse) {
-        Timed t(ctx, "gate_uv", (double)((size_t)1 << k_i) * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
-        gkr::launch_gate_uv((uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_r, e_hi, e_lo, kl, Wc, U, V, lb, s);
+        Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_r, e_hi, e_lo, kl, Wc, U, V, lb, s);
     } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
+    }
+
+    // `count` field elements at d_vals (device) := their sums over all ranks; `flag` travels along as one more element
+    // so that every rank learns of a rank that found a bad gate (and all of them leave before the next collective)
+    auto sum_over_ranks = [&](Fr* d_a, Fr* d_b, size_t each, uint32_t* flag) -> int {
+        std::vector<gkr_fr> buf(2 * each + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(buf.data(), d_a, each * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(buf.data() + each, d_b, each * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        buf[2 * each] = gkr_fr{{flag ? (uint64_t)(*flag != 0) : 0, 0, 0, 0}};
+        if (const int arc = shard->allreduce(shard->user, buf.data(), buf.size()))
+            return ctx->fail(GKR_ERR_INVALID, "the sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+        if (!all_canonical(buf.data(), buf.size())) return ctx->fail(GKR_ERR_NON_CANONICAL, "the sum-over-ranks hook returned a value >= r");
+        if (flag) *flag = (buf[2 * each].l[0] | buf[2 * each].l[1] | buf[2 * each].l[2] | buf[2 * each].l[3]) ? 1u : 0u;
+        HIP_TRY(ctx, hipMemcpyAsync(d_a, buf.data(), each * sizeof(Fr), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_b, buf.data() + each, each * sizeof(Fr), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));   // buf goes out of scope
+        return GKR_OK;
+    };
+    if (shard) {
+        uint32_t hbad = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        rc = sum_over_ranks(U, V, wlen, &hbad);
+        if (rc) return rc;
+        if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range (on some rank)");
     }
 
     gkr::LayerHostRec* rec = nullptr;
@@ -1183,7 +1230,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         bucket += t - t_mark;
         t_mark = t;
     };
-    if (pool) pool->begin_session(nullptr);
+    gkr::SpinPool::Session session(pool, nullptr);   // closed on every path out of the round loop
     for (uint32_t round = 0; round < v; ++round) {
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
@@ -1200,11 +1247,20 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     memcpy(&h_eq[(size_t)b * wlen + i], &m, 32);
                 }
             }
-            HIP_TRY(ctx, hipMemcpyAsync(d_eq, h_eq, sizeof(Fr) * wlen * batch, hipMemcpyHostToDevice, s));
+            if (hipError_t ce = hipMemcpyAsync(d_eq, h_eq, sizeof(Fr) * wlen * batch, hipMemcpyHostToDevice, s); ce != hipSuccess) {
+                rc = ctx->hip_fail(ce, "upload of eq(u, .)");
+                break;
+            }
             if (sparse) {
-                Timed t(ctx, "gate_rows", (double)((size_t)1 << k_i) * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
-                gkr::launch_gate_rows((uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq, A, M,
-                                      lb, s);
+                {
+                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq,
+                                          A, M, lb, s);
+                }
+                if (shard) {
+                    rc = sum_over_ranks(A, M, wlen, nullptr);
+                    if (rc) break;
+                }
             } else {
                 Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
                 gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
@@ -1294,7 +1350,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             pending = d_rtab + round;
         }
     }
-    if (pool) pool->end_session();
+    session.close();
     if (dbg)
         fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us\n", k, batch, v, t_launch,
                 t_wait, t_hash);
@@ -1391,6 +1447,7 @@ const char* gkr_strerror(int status) {
         case GKR_ERR_HIP: return "HIP runtime error";
         case GKR_ERR_NOMEM: return "out of memory";
         case GKR_ERR_DEGENERATE: return "degenerate sumcheck (v == 0)";
+        case GKR_ERR_UNSUPPORTED: return "R1CS shape the reference's compiler does not support";
         default: return "unknown status";
     }
 }
@@ -1718,6 +1775,72 @@ int gkr_sumcheck_layer(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_ty
     return run_layer(ctx, k_i, k_next, dgt.p, dl.p, dr.p, z, dW.p, out_coeffs, out_len, out_r);
 }
 
+int gkr_sumcheck_layer_sharded(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
+                               const uint8_t* gate_type, const uint32_t* left, const uint32_t* right, const gkr_fr* z,
+                               const gkr_fr* W, gkr_allreduce_fn allreduce, void* user, gkr_fr* out_coeffs, uint32_t* out_len,
+                               gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!W || !out_coeffs || !out_len || !out_r || !allreduce || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (gate_count && (!gate_type || !left || !right)) return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > 13) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, 13] for a gate-sharded layer");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    // gates are validated on the device (k_gate_count); a bad one fails every rank through the first exchange
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dW;
+    const size_t n_alloc = gate_count ? (size_t)gate_count : 1;
+    HIP_TRY(ctx, dgt.alloc(n_alloc));
+    HIP_TRY(ctx, dl.alloc(n_alloc));
+    HIP_TRY(ctx, dr.alloc(n_alloc));
+    if (gate_count) {
+        HIP_TRY(ctx, hipMemcpyAsync(dgt.p, gate_type, gate_count, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dl.p, left, gate_count * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dr.p, right, gate_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, dW.alloc((size_t)1 << k_next));
+    HIP_TRY(ctx, hipMemcpyAsync(dW.p, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
+    LayerShardArgs sh;
+    sh.gate_base = gate_first;
+    sh.gate_count = gate_count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    return run_layer_batch(ctx, 1, k_i, k_next, dgt.p, dl.p, dr.p, z, dW.p, &out_coeffs, &out_len, &out_r, &sh);
+}
+
+int gkr_fr_widen(const gkr_fr* values, size_t count, int64_t* limbs) {
+    if ((!values || !limbs) && count) return GKR_ERR_INVALID;
+    for (size_t i = 0; i < count; ++i)
+        for (int j = 0; j < 4; ++j) {
+            limbs[8 * i + 2 * j] = (int64_t)(values[i].l[j] & 0xffffffffull);
+            limbs[8 * i + 2 * j + 1] = (int64_t)(values[i].l[j] >> 32);
+        }
+    return GKR_OK;
+}
+
+int gkr_fr_narrow(const int64_t* limbs, size_t count, gkr_fr* values) {
+    if ((!values || !limbs) && count) return GKR_ERR_INVALID;
+    for (size_t i = 0; i < count; ++i) {
+        gkr::Acc<10> a = gkr::acc_zero<10>();
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; ++j) {
+            if (limbs[8 * i + j] < 0) return GKR_ERR_INVALID;
+            const uint64_t w = (uint64_t)limbs[8 * i + j];
+            const uint64_t lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            a.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        a.l[8] = (uint32_t)carry;
+        a.l[9] = (uint32_t)(carry >> 32);
+        values[i] = to_abi(gkr::acc_reduce(a));
+    }
+    return GKR_OK;
+}
+
 int gkr_predicate_tables(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_type, const uint32_t* left,
                          const uint32_t* right, const gkr_fr* z, gkr_fr* out_A, gkr_fr* out_M) {
     if (!ctx) return GKR_ERR_INVALID;
@@ -1898,9 +2021,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
                 finish(b);
                 return true;
             };
-            pool->begin_session(nullptr);
+            gkr::SpinPool::Session session(pool, nullptr);
             pool->run_now(&work);
-            pool->end_session();
         } else {
             for (int b = 0; b < batch; ++b) finish(b);
         }

@@ -71,6 +71,25 @@ class SpinPool {
         while (inside_.load(std::memory_order_seq_cst) != 0) GKR_CPU_RELAX();
     }
 
+    // Scope guard for a session: whatever path leaves the scope (an early error return included), the
+    // session is closed and no worker is left spinning on a function object of a dead stack frame.
+    class Session {
+       public:
+        Session(SpinPool* pool, const std::function<bool()>* try_work) : pool_(pool) {
+            if (pool_) pool_->begin_session(try_work);
+        }
+        ~Session() { close(); }
+        Session(const Session&) = delete;
+        Session& operator=(const Session&) = delete;
+        void close() {
+            if (pool_) pool_->end_session();
+            pool_ = nullptr;
+        }
+
+       private:
+        SpinPool* pool_;
+    };
+
    private:
     void worker() {
         for (;;) {

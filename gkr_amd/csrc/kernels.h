@@ -81,14 +81,18 @@ void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* d
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
                                LayerBatch lb, hipStream_t s);
 void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s);
-// gate lists by left / right operand and the 2^k-entry tables summed straight from them (no dense predicate tables)
-void launch_gate_lists(uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+// gate lists by left / right operand and the 2^k-entry tables summed straight from them (no dense predicate tables).
+// GateSpan: the gate arrays hold gates base .. base + count - 1 of the layer (the whole layer, or one rank's shard).
+struct GateSpan {
+    uint64_t base, count;
+};
+void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
                        hipStream_t s);
-void launch_gate_uv(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
                     Fr* U, Fr* V, LayerBatch lb, hipStream_t s);
-void launch_gate_rows(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
                       const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s);
 // b-phase in linear time (kernels.hip): U, V tables of 2^k entries per proof, their rounds, the row collapse

@@ -7,8 +7,9 @@
 // perfectly coalesced streams.  One lane owns one 32-byte element
 // (2 x global_load_dwordx4).
 //
-// Data parallel work only -- no MFMA: this is 254-bit modular integer arithmetic
-// (v_mad_u64_u32 chains); the roofline is HBM bandwidth.
+// 254-bit modular integer arithmetic on v_mad_u64_u32 carry chains (fr32.h); the one exception is the multi-round
+// fold pass, whose fixed-weight products run as int8 digit products on the matrix cores (mfma_fold.h) because the
+// VALU form was instruction-issue bound.  Every roofline here is HBM bandwidth.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -292,7 +293,12 @@ __global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tab
     for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
         const Fr x = load_fr(t + i);
         acc_add_fr(acc[0], x);
-        dep |= fr_eq(x, load_fr(t + (i ^ 1u))) ? 0u : 1u;
+        // entry 2m against 2m+1: the partner sits in the neighbour lane (chunks are multiples of 256 entries, so lanes
+        // i and i^1 are in one wave and both active); DPP quad_perm [1,0,3,2] swaps neighbours, no second load
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d |= x.l[k] ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[k], 0xB1, 0xF, 0xF, true);
+        dep |= d;
     }
     if (dep) atomicOr(&s_dep, 1u);
     block_sum<9, 1>(acc, smem);
@@ -748,9 +754,8 @@ __global__ void __launch_bounds__(256) k_pred_sum(size_t ncells, const uint32_t*
 // c-phase sum over).  One counting sort over 2 * 2^k buckets -- bucket b = left operand b, bucket 2^k + c = right
 // operand c -- into one list of 2 G entries; shared by all proofs of a batch (same gates).
 // ---------------------------------------------------------------------------
-__global__ void k_gate_count(uint32_t k_i, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+__global__ void k_gate_count(uint64_t gates, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
                              const uint32_t* __restrict__ right, uint32_t* __restrict__ counts, uint32_t* __restrict__ bad) {
-    const uint64_t gates = 1ull << k_i;
     const uint32_t n = 1u << k;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t l = left[g], r = right[g];
@@ -763,9 +768,8 @@ __global__ void k_gate_count(uint32_t k_i, uint32_t k, const uint8_t* __restrict
     }
 }
 
-__global__ void k_gate_fill(uint32_t k_i, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+__global__ void k_gate_fill(uint64_t gates, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
                             const uint32_t* __restrict__ right, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
-    const uint64_t gates = 1ull << k_i;
     const uint32_t n = 1u << k;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t l = left[g], r = right[g];
@@ -778,11 +782,15 @@ __global__ void k_gate_fill(uint32_t k_i, uint32_t k, const uint8_t* __restrict_
 // U[b] = sum over the gates with left operand b of E[g] * (add ? 1 : W[right]),  V[b] = sum over its add gates of
 // E[g] * W[right];  E[g] = e_hi[g >> kl] * e_lo[g & mask] (e_lo and W in Montgomery form, so products are canonical).
 // grid = (2^k buckets, batch); any block size that is a multiple of 64.
+// The gate arrays may hold a contiguous SHARD of the layer (one rank's gates when a layer is split across GPUs):
+// list entries index the shard's arrays, and gate_base + entry is the gate's index in the layer, which is what E
+// depends on.
 __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
                                                  const uint32_t* __restrict__ list, const uint8_t* __restrict__ gate_type,
                                                  const uint32_t* __restrict__ right, const Fr* __restrict__ e_hi,
                                                  const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
-                                                 const Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t wstride) {
+                                                 const Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t wstride,
+                                                 uint32_t gate_base) {
     __shared__ Acc<9> smem[4 * 2];
     const uint32_t b = blockIdx.x, lmask = (1u << kl) - 1u;
     e_hi += (size_t)blockIdx.y << kh;
@@ -790,8 +798,8 @@ __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ of
     W += (size_t)blockIdx.y * wstride;
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
     for (uint32_t i = offsets[b] + threadIdx.x; i < cursor[b]; i += blockDim.x) {
-        const uint32_t g = list[i];
-        const Fr e = mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & lmask)));
+        const uint32_t g = list[i], gg = g + gate_base;
+        const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
         const Fr ew = mont_mul(e, load_fr(W + right[g]));
         if (gate_type[g]) {
             acc_add_fr(acc[0], ew);
@@ -814,7 +822,7 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ left, const Fr* __restrict__ e_hi,
                                                    const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                    const Fr* __restrict__ eq_mont, Fr* __restrict__ A_row, Fr* __restrict__ M_row,
-                                                   uint32_t k, uint32_t wstride) {
+                                                   uint32_t k, uint32_t wstride, uint32_t gate_base) {
     __shared__ Acc<9> smem[4 * 2];
     const uint32_t c = blockIdx.x, lmask = (1u << kl) - 1u, bucket = (1u << k) + c;
     e_hi += (size_t)blockIdx.y << kh;
@@ -822,8 +830,8 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
     eq_mont += (size_t)blockIdx.y * wstride;
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
     for (uint32_t i = offsets[bucket] + threadIdx.x; i < cursor[bucket]; i += blockDim.x) {
-        const uint32_t g = list[i];
-        const Fr e = mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & lmask)));
+        const uint32_t g = list[i], gg = g + gate_base;
+        const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
         const Fr t = mont_mul(e, load_fr(eq_mont + left[g]));
         acc_add_fr(acc[gate_type[g] ? 1 : 0], t);
     }
@@ -1139,7 +1147,11 @@ __device__ __forceinline__ void publish_round(const Acc<9> (&acc)[3], Acc<9>* to
         const Fr v = acc_reduce(tot[threadIdx.x]);
         Fr* dst = threadIdx.x == 0 ? &r->c0 : (threadIdx.x == 1 ? &r->g1 : &r->c2);
         *dst = v;
+        // lanes 1 and 2 order their own stores to host memory ahead of the barrier below; lane 0's release store of
+        // the sequence number then follows all three in every memory model, not only because they share a wave
+        __threadfence_system();
     }
+    __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1454,33 +1466,33 @@ void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_
 
 // gate lists by left and by right operand: counts / offsets / cursor 2 * 2^k u32 each (counts zeroed by the caller),
 // block_sums ceil(2 * 2^k / 2048) + 1, list 2 * 2^k_i u32
-void launch_gate_lists(uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
                        hipStream_t s) {
     const size_t n = (size_t)2 << k;
-    const uint32_t gblocks = blocks_for(1ull << k_i, 4096);
+    const uint32_t gblocks = blocks_for(gates, 4096);
     const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
-    hipLaunchKernelGGL(k_gate_count, dim3(gblocks), dim3(256), 0, s, k_i, k, gate_type, left, right, counts, bad);
+    hipLaunchKernelGGL(k_gate_count, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, counts, bad);
     hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, counts, offsets, block_sums, n);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, sblocks);
     hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, offsets, cursor, block_sums, n);
-    hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, k_i, k, gate_type, left, right, cursor, list);
+    hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, cursor, list);
 }
 
-static uint32_t bucket_threads(uint32_t k_i, uint32_t k) { return (k_i > k + 6) ? 256u : 64u; }   // gates per bucket on average
+static uint32_t bucket_threads(uint64_t gates, uint32_t k) { return (gates >> k) > 64u ? 256u : 64u; }   // gates per bucket on average
 
-void launch_gate_uv(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
                     Fr* U, Fr* V, LayerBatch lb, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(k_i, k)), 0, s, offsets, cursor, list, gate_type, right,
-                       e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride);
+    hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list, gate_type,
+                       right, e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
 }
 
-void launch_gate_rows(uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
                       const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(k_i, k)), 0, s, offsets, cursor, list, gate_type, left,
-                       e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride);
+    hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list, gate_type,
+                       left, e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride, (uint32_t)span.base);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {

@@ -1,4 +1,14 @@
-"""One sumcheck split across GPUs: trailing-variable shards + one tiny all-reduce per round.
+"""One sumcheck split across GPUs.
+
+GKR layer (the default form, `prove_sumcheck_opt_gate_sharded`): the layer's GATES are partitioned over the
+ranks -- any partition works, contiguous ranges are used -- because every table the linear-time layer sumcheck
+works on is a sum over gates: U(b), V(b) before the rounds that bind b, the row a_u(c), m_u(c) before the rounds
+that bind c.  Two sum-over-ranks exchanges of 2 * 2^k field elements per layer, then every rank runs the 2k rounds
+on the completed tables and holds the whole transcript (gkr_sumcheck_layer_sharded in include/gkr_amd.h; the
+reference's counterpart is the rayon map-reduce over the gate list, sumcheck.rs:50-63, 97-124).
+
+Plain multilinear sumcheck, and the older dense form of the layer: trailing-variable shards + one tiny all-reduce
+per round, described next.
 
 The reference sums each round's per-assignment polynomials with a rayon map-reduce
 (rust/src/gkr/sumcheck.rs:50-63, 65-78, 97-124).  Across GPUs that reduce becomes one
@@ -91,6 +101,137 @@ class TorchCollective:
         t = self._torch.tensor([1 if flag else 0], dtype=self._torch.int64, device=self._device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
         return bool(int(t.item()))
+
+    def sum_limbs(self, limbs):
+        """SUM all-reduce of an int64 limb array (the transport of make_allreduce_hook)."""
+        t = self._torch.from_numpy(np.ascontiguousarray(limbs, dtype=np.int64)).to(self._device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        return t.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- gate-sharded layer sumcheck
+
+def gate_range(k_i, rank, world):
+    """Contiguous share of the layer's 2^k_i gates held by `rank` of `world` (any partition would do)."""
+    r = shard_units(1 << k_i, rank, world)
+    return r.start, len(r)
+
+
+def widen(values_limbs):
+    """(n, 4) uint64 canonical field elements -> (n, 8) int64 32-bit limbs (gkr_fr_widen)."""
+    v = np.ascontiguousarray(values_limbs, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty((v.shape[0], 8), dtype=np.int64)
+    rc = N.lib().gkr_fr_widen(_ptr(v), ctypes.c_size_t(v.shape[0]), _ptr(out))
+    if rc:
+        raise GkrError(rc, "gkr_fr_widen")
+    return out
+
+
+def narrow(limb_sums):
+    """(n, 8) int64 limb sums (< 2^31 addends) -> (n, 4) uint64 canonical values mod r (gkr_fr_narrow)."""
+    w = np.ascontiguousarray(limb_sums, dtype=np.int64).reshape(-1, 8)
+    out = np.empty((w.shape[0], 4), dtype=np.uint64)
+    rc = N.lib().gkr_fr_narrow(_ptr(w), ctypes.c_size_t(w.shape[0]), _ptr(out))
+    if rc:
+        raise GkrError(rc, "gkr_fr_narrow")
+    return out
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+def make_allreduce_hook(sum_limbs):
+    """The gkr_allreduce_fn the library calls back: `sum_limbs(int64 array (n, 8)) -> summed array` is the
+    transport (torch.distributed SUM all-reduce, or an in-process sum for logical ranks).  Returns the ctypes
+    function object (keep it alive for the duration of the call) and a list that collects exceptions."""
+    errors = []
+
+    def hook(_user, values, count):
+        try:
+            buf = np.ctypeslib.as_array(ctypes.cast(values, ctypes.POINTER(ctypes.c_uint64)), shape=(count, 4))
+            buf[:] = narrow(sum_limbs(widen(buf)))
+            return 0
+        except Exception as e:   # never unwind through the C frame
+            errors.append(e)
+            return 1
+    return ALLREDUCE_FN(hook), errors
+
+
+def prove_sumcheck_opt_gate_sharded(ctx: Context, k_i, k_next, gate_first, gate_type, left, right, z, W, sum_limbs):
+    """One rank's side of a layer sumcheck split by gates: this rank holds gates gate_first .. of the layer.
+    Every rank returns the same (proof, r) as the unsharded prove_sumcheck_opt."""
+    gt = np.ascontiguousarray(gate_type, dtype=np.uint8)
+    l = np.ascontiguousarray(left, dtype=np.uint32)
+    r = np.ascontiguousarray(right, dtype=np.uint32)
+    if not (len(gt) == len(l) == len(r)):
+        raise GkrError(N.GKR_ERR_INVALID, "gate arrays of different lengths")
+    zl = as_limbs(z) if k_i else np.zeros((0, 4), dtype=np.uint64)
+    wl = as_limbs(W)
+    v = 2 * max(k_next, 0)
+    C = np.zeros((max(v, 1), 3, 4), dtype=np.uint64)
+    L = np.zeros(max(v, 1), dtype=np.uint32)
+    R = np.zeros((max(v, 1), 4), dtype=np.uint64)
+    hook, errors = make_allreduce_hook(sum_limbs)
+    rc = N.lib().gkr_sumcheck_layer_sharded(ctx._h, ctypes.c_int(k_i), ctypes.c_int(k_next), ctypes.c_uint64(gate_first),
+                                            ctypes.c_uint64(len(gt)), _ptr(gt), _ptr(l), _ptr(r), _ptr(zl), _ptr(wl), hook, None,
+                                            _ptr(C), _ptr(L), _ptr(R))
+    if errors:
+        raise errors[0]
+    ctx._check(rc)
+    return [from_limbs(C[j])[3 - int(L[j]):] for j in range(v)], from_limbs(R[:v])
+
+
+class ThreadedSum:
+    """Sum-over-ranks for P logical ranks that are P threads of one process (one GPU): every rank deposits its
+    limbs, the last one in adds them up, all leave with the total."""
+
+    def __init__(self, world):
+        import threading
+        self._barrier = threading.Barrier(world)
+        self._parts = [None] * world
+        self._total = None
+
+    def for_rank(self, rank):
+        def sum_limbs(limbs):
+            self._parts[rank] = limbs
+            if self._barrier.wait() == 0:
+                self._total = np.sum(np.stack(self._parts), axis=0)
+            self._barrier.wait()
+            return self._total
+        return sum_limbs
+
+    def abort(self):
+        self._barrier.abort()
+
+
+def prove_sumcheck_opt_logical_gates(device, layer: Layer, k_next, z, W, nshards):
+    """prove_sumcheck_opt with the gates cut into `nshards` logical ranks on ONE GPU (one thread and one context
+    per rank, as one process per GPU would have): the gate-sharded algorithm end to end, the collective being an
+    in-process sum.  Returns the list of every rank's (proof, r) -- they must all be equal."""
+    import threading
+    gt, l, r = layer.arrays()
+    coll = ThreadedSum(nshards)
+    out, errs = [None] * nshards, []
+
+    def run(rank):
+        try:
+            first, count = gate_range(layer.k, rank, nshards)
+            with Context(device) as ctx:
+                out[rank] = prove_sumcheck_opt_gate_sharded(ctx, layer.k, k_next, first, gt[first:first + count],
+                                                            l[first:first + count], r[first:first + count], z, W,
+                                                            coll.for_rank(rank))
+        except Exception as e:
+            errs.append(e)
+            coll.abort()
+    threads = [threading.Thread(target=run, args=(p,)) for p in range(nshards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
+        raise (real or errs)[0]
+    return out
 
 
 # ----------------------------------------------------------------------------- round vectors

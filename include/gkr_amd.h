@@ -65,7 +65,9 @@ enum {
     GKR_ERR_NO_DEVICE = 3,
     GKR_ERR_HIP = 4,          /* a HIP runtime call failed; see gkr_last_error */
     GKR_ERR_NOMEM = 5,
-    GKR_ERR_DEGENERATE = 6    /* v == 0: the reference underflows (sumcheck.rs:49) */
+    GKR_ERR_DEGENERATE = 6,   /* v == 0: the reference underflows (sumcheck.rs:49) */
+    GKR_ERR_UNSUPPORTED = 7   /* an R1CS shape the reference's compiler cannot handle either (it panics or recurses
+                                 without end: a constraint with an empty A, B or C, convert.rs:619-622) */
 };
 
 /* Transcript placement: where the per-round MiMC7 hash runs.  The hash is a
@@ -135,6 +137,35 @@ int  gkr_sumcheck_mle_batch_device(gkr_ctx *ctx, const void *d_tables, int n, in
 int  gkr_sumcheck_layer(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_type,
                         const uint32_t *left, const uint32_t *right, const gkr_fr *z,
                         const gkr_fr *W, gkr_fr *out_coeffs, uint32_t *out_len, gkr_fr *out_r);
+
+/* ---- one layer sumcheck split across GPUs by GATES ------------------------------------------------------
+ * The reference sums the per-gate terms of a round with a rayon map-reduce over the gate list
+ * (sumcheck.rs:50-63 b-rounds, :97-124 c-rounds).  In the linear-time form of the layer sumcheck every table the
+ * rounds work on is a SUM OVER GATES: U(b), V(b) (2^k_next entries each) for the k_next rounds that bind b, then
+ * the row a_u(c), m_u(c) for the k_next rounds that bind c.  So ANY partition of the gates over ranks works: each
+ * rank sums its own gates, two sum-over-ranks exchanges per layer (2 * 2^k_next field elements each) complete the
+ * tables, and the 2 k_next rounds run on the completed (tiny) tables identically on every rank -- every rank gets
+ * the whole transcript, no broadcast.  Bit-exact: modular sums commute.
+ *
+ * This rank holds gates gate_first .. gate_first + gate_count - 1 of the layer's 2^k_i (the three arrays have
+ * gate_count entries; gate_count may be 0).  z, W and the outputs are as for gkr_sumcheck_layer and identical on
+ * all ranks.  Needs the host transcript and k_next <= 13.
+ *
+ * allreduce: called twice per layer (three times never), each time with `count` canonical field elements in host
+ * memory that it must replace by their sums over all ranks mod r (the same on every rank); 0 = success.  RCCL has
+ * no modular sum: gkr_fr_widen / gkr_fr_narrow turn field elements into eight 32-bit limbs held in int64 (an
+ * ordinary integer SUM all-reduce of those is exact for < 2^31 ranks) and back (gkr_amd/parallel.py does exactly
+ * that over torch.distributed).  One extra element travels with the first exchange: "some rank saw a bad gate", so
+ * that all ranks fail together instead of one leaving the others inside a collective. */
+typedef int (*gkr_allreduce_fn)(void *user, gkr_fr *values, size_t count);
+int  gkr_sumcheck_layer_sharded(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
+                                const uint8_t *gate_type, const uint32_t *left, const uint32_t *right, const gkr_fr *z,
+                                const gkr_fr *W, gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs,
+                                uint32_t *out_len, gkr_fr *out_r);
+/* host only: count field elements <-> count x 8 int64 (32-bit limbs, least significant first); narrow reduces
+ * limb sums of up to 2^31 addends mod r */
+int  gkr_fr_widen(const gkr_fr *values, size_t count, int64_t *limbs);
+int  gkr_fr_narrow(const int64_t *limbs, size_t count, gkr_fr *values);
 
 /* dense predicate tables A, M (2^{2 k_next} each) = add_i / mult_i restricted to z */
 int  gkr_predicate_tables(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_type,
@@ -221,6 +252,52 @@ int  gkr_circom_meta(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof
                      size_t *count);
 int  gkr_circom_input_json(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof, int proof_index, char *out,
                            size_t capacity, size_t *needed);
+
+/* ---- in front of the path: R1CS + witness -> layered circuits (host only) ------------------------------
+ * What the reference does between circom's output files and prover::prove: read the iden3 `.r1cs` and `.wtns`
+ * containers (third-party r1cs-file / wtns-file crates; aggregator.rs:341,345,399,404), turn every constraint
+ * <A,w> * <B,w> - <C,w> = 0 into an expression tree (convert_constraints_to_nodes, convert.rs:360-632), and
+ * compile the trees into at most 20 layered circuits whose every layer has 2^k add / mult gates over the next
+ * one (compile, convert.rs:154-358; get_k :140-152).  gkr_layered_circuit hands out the gkr_circuit_desc that
+ * gkr_prove / gkr_prove_batch take; gkr_layered_input_values gathers a witness into the input layer's values
+ * (calculate_input, convert.rs:796-810) -- the forward evaluation and the "output 0 is zero" assertion
+ * (:812-838) happen inside gkr_prove (require_zero_output).
+ * Formats: `.r1cs` = magic "r1cs", version 1, sections (type u32, size u64): 1 header {field size 32, prime,
+ * nWires, nPubOut, nPubIn, nPrvIn, nLabels u64, nConstraints}, 2 constraints {per constraint three linear
+ * combinations: nTerms, then (wire u32, coefficient 32 B LE) per term}, 3 wire2label; `.wtns` = magic "wtns",
+ * version 2, sections 1 {field size, prime, nWitness} and 2 {values, 32 B LE}.  Only BN254 Fr is accepted.
+ * The writers exist because there is no circom in the build image: test fixtures have to be written. */
+typedef struct gkr_r1cs gkr_r1cs;
+typedef struct gkr_layered gkr_layered;
+typedef struct {
+    uint32_t n_wires, n_pub_out, n_pub_in, n_prv_in;
+    uint64_t n_labels;
+    size_t n_constraints, n_terms;   /* n_terms: over all A, B, C of all constraints */
+} gkr_r1cs_info_t;
+
+int  gkr_r1cs_parse(const void *bytes, size_t len, gkr_r1cs **out);
+/* flat form: term_counts has 3 entries per constraint (A, B, C), wires / coeffs list all terms in that order */
+int  gkr_r1cs_build(uint32_t n_wires, uint32_t n_pub_out, uint32_t n_pub_in, uint32_t n_prv_in, size_t n_constraints,
+                    const uint32_t *term_counts, const uint32_t *wires, const gkr_fr *coeffs, gkr_r1cs **out);
+int  gkr_r1cs_info(const gkr_r1cs *r1cs, gkr_r1cs_info_t *out);
+int  gkr_r1cs_export(const gkr_r1cs *r1cs, uint32_t *term_counts, uint32_t *wires, gkr_fr *coeffs);
+/* *needed = size of the file image; with out == NULL only the size is returned; GKR_ERR_NOMEM if too small */
+int  gkr_r1cs_serialize(const gkr_r1cs *r1cs, void *out, size_t capacity, size_t *needed);
+void gkr_r1cs_free(gkr_r1cs *r1cs);
+int  gkr_wtns_parse(const void *bytes, size_t len, gkr_fr *out, size_t capacity, size_t *count);
+int  gkr_wtns_serialize(const gkr_fr *values, size_t count, void *out, size_t capacity, size_t *needed);
+
+/* bad_constraint (may be NULL): index of the constraint behind GKR_ERR_UNSUPPORTED */
+int  gkr_r1cs_compile(const gkr_r1cs *r1cs, gkr_layered **out, size_t *bad_constraint);
+int  gkr_layered_count(const gkr_layered *layered, uint32_t *circuits);
+/* the arrays *out points to stay owned by `layered` */
+int  gkr_layered_circuit(const gkr_layered *layered, uint32_t index, gkr_circuit_desc *out);
+/* input layer of circuit `index`: slot s holds witness[wire[s]], or constant[s] where wire[s] == UINT32_MAX */
+int  gkr_layered_input_layer(const gkr_layered *layered, uint32_t index, const uint32_t **wire, const gkr_fr **constant,
+                             size_t *slots);
+int  gkr_layered_input_values(const gkr_layered *layered, uint32_t index, const gkr_fr *witness, size_t n_witness,
+                              gkr_fr *out_values);
+void gkr_layered_free(gkr_layered *layered);
 
 /* ---- step-wise sessions: one sumcheck split across GPUs -------------------
  * The reference reduces each round's per-assignment polynomials with a rayon

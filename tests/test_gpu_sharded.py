@@ -41,6 +41,32 @@ def test_layer_sumcheck_logical_ranks(ctx, nshards):
             assert got == cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w), (nshards, k_i, k)
 
 
+@pytest.mark.parametrize("nshards", [1, 2, 3, 4, 8])
+def test_layer_sumcheck_gate_sharded_logical_ranks(nshards):
+    """The gate-sharded form (gkr_sumcheck_layer_sharded): any partition of the gates, also a world that is not a
+    power of two; every rank ends with the unsharded oracle's transcript, short round vectors included."""
+    rng = random.Random(1500 + nshards)
+    for k_i, k in ((4, 3), (7, 4), (0, 3), (2, 5), (10, 6)):
+        lay = _layer(rng, k_i, k)
+        z = [rng.randrange(P) for _ in range(k_i)]
+        for w in ([rng.randrange(P) for _ in range(1 << k)], [(i >> (k - 1)) + 1 for i in range(1 << k)],
+                  [(i & 1) + 5 for i in range(1 << k)]):
+            want = cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w)
+            got = parallel.prove_sumcheck_opt_logical_gates(0, lay, k, z, w, nshards)
+            assert len(got) == nshards and all(g == want for g in got), (nshards, k_i, k)
+
+
+def test_gate_sharded_bad_gate_fails_every_rank():
+    """A bad gate on ONE rank: every rank must come back with an error (none may stay inside the collective)."""
+    from gkr_amd import GkrError
+    rng = random.Random(1600)
+    lay = _layer(rng, 6, 4)
+    lay.left[-1] = 1 << 4   # operand out of range, in the last rank's share
+    with pytest.raises(GkrError):
+        parallel.prove_sumcheck_opt_logical_gates(0, lay, 4, [rng.randrange(P) for _ in range(6)],
+                                                  [rng.randrange(P) for _ in range(16)], 4)
+
+
 def test_layer_sumcheck_logical_ranks_wide(ctx):
     rng = random.Random(77)
     k_i, k = 12, 6

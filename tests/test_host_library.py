@@ -196,3 +196,56 @@ def _schedule(L, n, mfma):
     assert L.gkr_selftest_pass_schedule(ctypes.c_int(n), ctypes.c_int(mfma), rounds.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(64),
                                         ctypes.byref(count)) == 0
     return rounds[:count.value]
+
+
+def test_limb_widening_for_the_modular_all_reduce():
+    """gkr_fr_widen / gkr_fr_narrow (host only): field elements as eight 32-bit limbs in int64, so that an ordinary
+    integer SUM all-reduce followed by narrow is the modular sum over ranks (RCCL has no modular sum)."""
+    import random
+    from gkr_amd import parallel
+    from gkr_amd.field import from_limbs, to_limbs
+    rng = random.Random(31)
+    vals = [P - 1, P - 2, 0, 1, (1 << 253) + 12345] + [rng.randrange(P) for _ in range(40)]
+    w = parallel.widen(to_limbs(vals))
+    assert w.shape == (len(vals), 8) and w.dtype == np.int64 and int(w.max()) < (1 << 32) and int(w.min()) >= 0
+    assert from_limbs(parallel.narrow(w)) == vals
+    for ranks in (2, 8, 1000, (1 << 31) - 1):
+        assert from_limbs(parallel.narrow(w * ranks)) == [(v * ranks) % P for v in vals]
+    other = parallel.widen(to_limbs(list(reversed(vals))))
+    assert from_limbs(parallel.narrow(w + other)) == [(a + b) % P for a, b in zip(vals, reversed(vals))]
+    bad = w.copy()
+    bad[3, 2] = -1
+    with pytest.raises(parallel.GkrError):
+        parallel.narrow(bad)
+
+
+def test_all_reduce_hook_round_trip_in_process():
+    """The ctypes callback the library calls for a sum over ranks, driven here directly (no GPU): three logical
+    ranks, in-process sum."""
+    import ctypes
+    import threading
+    from gkr_amd import parallel
+    from gkr_amd.field import from_limbs, to_limbs
+    world = 3
+    coll = parallel.ThreadedSum(world)
+    parts = [[(P - 1 - 7 * r) % P, 1000 + r, 0] for r in range(world)]
+    outs = [None] * world
+
+    def run(r):
+        hook, errors = parallel.make_allreduce_hook(coll.for_rank(r))
+        buf = to_limbs(parts[r])
+        assert hook(None, buf.ctypes.data_as(ctypes.c_void_p), len(parts[r])) == 0 and not errors
+        outs[r] = from_limbs(buf)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    want = [sum(col) % P for col in zip(*parts)]
+    assert outs == [want] * world
+
+
+def test_gate_ranges_partition_the_layer():
+    from gkr_amd import parallel
+    for k_i, world in ((0, 1), (0, 4), (5, 3), (10, 8), (3, 16)):
+        spans = [parallel.gate_range(k_i, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == 1 << k_i
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))

@@ -3,17 +3,19 @@
 
     python tools/bench_layer.py --k-i 24 --k 12 --steps 3
 
-Random gates (type in {add, mult}, operands in [0, 2^k)), random z and W.
+Random gates (type in {add, mult}, operands in [0, 2^k)), random z and W (the inputs are
+gkr_amd.synth.config5_layer, what tests/test_gpu_config_scale.py checks against the oracle).
 Reports per-kernel HIP-event times and the canonical figures: 25 (2^{2k} - 1) field-ops,
-256 * 2^{2k} bytes for the sumcheck; the predicate build is reported separately."""
+256 * 2^{2k} bytes for the sumcheck; the predicate build is reported separately.
+No time is printed for a wrong transcript: the sumcheck relations are always checked (g_j(0) + g_j(1) =
+g_{j-1}(r_{j-1}), r_j = MiMC7(g_j)), and where tests/golden/config_hashes.json holds the digest of the reference
+semantics' transcript for this size, the GPU's transcript must have it."""
 
 import argparse
 import json
 import os
 import sys
 import time
-
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -25,21 +27,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--transcript", choices=["host", "device"], default="host")
-    ap.add_argument("--check", action="store_true", help="verify the sumcheck relations on the result")
     args = ap.parse_args()
-    from gkr_amd import Context, Layer, multi_hash
+    from gkr_amd import Context, multi_hash, synth
     from gkr_amd.field import MODULUS as P, from_limbs
 
-    rng = np.random.default_rng(0xC0FFEE + 5)
-    g = 1 << args.k_i
-    lay = Layer(args.k_i, rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, 1 << args.k, g, dtype=np.uint32),
-                rng.integers(0, 1 << args.k, g, dtype=np.uint32))
-
-    def rand_fr(count):
-        a = rng.integers(0, 1 << 63, (count, 4), dtype=np.uint64)
-        a[:, 3] &= np.uint64((1 << 61) - 1)
-        return a
-    z, W = rand_fr(args.k_i), rand_fr(1 << args.k)
+    lay, z, W = synth.config5_layer(args.k_i, args.k)
     ctx = Context(0)
     ctx.set_transcript(1 if args.transcript == "host" else 0)
     ctx.profile(True)
@@ -70,26 +62,29 @@ def main():
         "field_ops_per_s_kernels": 25 * (N - 1) / (sum_ms * 1e-3) if sum_ms else None,
         "field_ops_per_s_wall": 25 * (N - 1) / (sum(times[args.warmup:]) / steps),
     }
-    if args.check:
-        # verifier relations: g_j(0) + g_j(1) = g_{j-1}(r_{j-1}); r_j = MiMC(g_j)
-        claim = None
-        ok = True
-        for j in range(2 * args.k):
-            vec = from_limbs(C[j])[3 - int(L[j]):]
-            r = from_limbs(R[j])[0]
-            ev0 = vec[-1]
-            ev1 = sum(vec) % P
-            if claim is not None and (ev0 + ev1) % P != claim:
-                ok = False
-            if multi_hash(vec) != r:
-                ok = False
-            acc = 0
-            for c in vec:
-                acc = (acc * r + c) % P
-            claim = acc
-        out["verifier_relations_ok"] = ok
-    print(json.dumps(out))
+    # verifier relations: g_j(0) + g_j(1) = g_{j-1}(r_{j-1}); r_j = MiMC(g_j)
+    claim = None
+    ok = True
+    for j in range(2 * args.k):
+        vec = from_limbs(C[j])[3 - int(L[j]):]
+        r = from_limbs(R[j])[0]
+        if claim is not None and (vec[-1] + sum(vec)) % P != claim:
+            ok = False
+        if multi_hash(vec) != r:
+            ok = False
+        acc = 0
+        for c in vec:
+            acc = (acc * r + c) % P
+        claim = acc
+    out["verifier_relations_ok"] = ok
+    want = synth.golden_digest("layer", "k_i=%d,k=%d" % (args.k_i, args.k))
+    out["transcript_sha256"] = synth.transcript_digest(C, L, R)
+    out["matches_golden_digest"] = None if want is None else (out["transcript_sha256"] == want)
     ctx.close()
+    if not out["verifier_relations_ok"] or out["matches_golden_digest"] is False:
+        raise SystemExit("WRONG TRANSCRIPT (relations ok: %s, golden digest match: %s) -- no timing reported"
+                         % (out["verifier_relations_ok"], out["matches_golden_digest"]))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
