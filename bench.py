@@ -1,223 +1,49 @@
 #!/usr/bin/env python3
-"""Headline benchmark: BN254-Fr sumcheck field-ops/sec on 2^20-point multilinear
-tables (BASELINE.json metric, configs[2]), one process per GPU.
+"""Headline benchmark: BN254-Fr sumcheck field-ops/sec on 2^20-point multilinear tables (BASELINE.json metric,
+configs[2]) and aggregated proofs/sec (configs[0] / configs[3]), one process per GPU.
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W [--mode mle|proofs|layer-split]
 
-A step = one pass of the hot path over one batch: `--batch` (default 1024, 32 GiB of tables) independent
-2^n-point multilinear sumchecks (prove_sumcheck, rust/src/gkr/sumcheck.rs:158-214),
-tables resident in HBM before the timed region, MiMC7 transcript included.  (One
-aggregation step of the reference proves up to 20 sub-circuits with several layers
-each, every layer one sumcheck -- aggregator.rs:350-355 -- and BASELINE configs[3]
-aggregates 64 inputs: hundreds of independent sumchecks per step are the normal load.)
-Independent sumchecks shard across ranks with no data-path collective (weak
-scaling: every rank proves its own batch).
+--mode mle (default): a step = one pass of the hot path over one batch: `--batch` (default 1024, 32 GiB of tables)
+    independent 2^n-point multilinear sumchecks (prove_sumcheck, rust/src/gkr/sumcheck.rs:158-214), tables resident
+    in HBM before the timed region, MiMC7 transcript included.  Independent sumchecks shard across ranks with no
+    data-path collective (weak scaling: every rank proves its own batch).  The same line carries, on every rank's
+    own share and MAX-reduced over ranks, `aggregated_proofs`: the R1CS of rust/t.circom (hand-written equivalent)
+    compiled to its 12 layered circuits and proven for 3 and for 64 inputs (configs[0], configs[3]).
+--mode proofs: configs[3] as its own timed workload: `--proofs` inputs of the demo circuit split over the ranks
+    (strong scaling; no collective), a step = every rank proving its share of the inputs, all 12 sub-circuits.
+--mode layer-split: configs[4]: ONE GKR layer (k_i = 24, k = 12: 2^24 gates, 2^24-point hypercube) split over the
+    ranks by gates, two sum-over-ranks exchanges (RCCL all-reduce of limb-widened field elements) per sumcheck
+    (gkr_sumcheck_layer_sharded); a step = one layer sumcheck; strong scaling.
 
-field-ops: 5 (2^n - 1) per sumcheck; algorithmic bytes 128 * 2^n per sumcheck
+field-ops: 5 (2^n - 1) per plain sumcheck, 25 (2^{2k} - 1) per layer sumcheck; algorithmic bytes 128 * 2^n
 (SURVEY.md section 8d).  The JSON line also carries
-  roofline      the dominant kernel (k_mle_multifold_mfma, the fold pass) timed with HIP events on
-                the library's stream during the timed steps (profile level 2: only the bandwidth-
-                bound kernels carry events, the small round-trip kernels are left alone)
-  cpu_baseline  the plain-C oracle (oracle/c, OpenMP over the host cores) on a
-                bounded sample of the same workload; rank 0, N = 1 only
+  roofline       the dominant kernel (k_mle_multifold_mfma, the fold pass) timed with HIP events on the library's
+                 stream during the timed steps (profile level 2: only the bandwidth-bound kernels carry events)
+  cpu_baseline   the plain-C oracle (oracle/c), one sumcheck per host core, on a bounded sample of the same
+                 workload; rank 0, N = 1 only; plus cpu_ref_algo (the reference's term-list algorithm restated,
+                 largest size under its time cap) and cpu_pipeline (the oracle proving the demo circuit)
 """
 
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
-    ap.add_argument("--batch", type=int, default=1024, help="independent sumchecks per rank per step (32 GiB of tables)")
-    ap.add_argument("--transcript", choices=["host", "device"], default="host",
-                    help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
-    ap.add_argument("--proofs", type=int, default=64,
-                    help="second half of the metric: full GKR proofs of a t.circom-class layered circuit per rank (0 = skip)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (single-GPU boxes): run several ranks on one device over gloo to exercise the N > 1 code path
-    backend = os.environ.get("GKR_BENCH_BACKEND", "nccl")
-    if "GKR_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["GKR_BENCH_DEVICE"])
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
-
-    from gkr_amd import Context
-
-    n, batch = args.n, args.batch
-    count = 1 << n
-    ctx = Context(local_rank)
-    ctx.set_transcript(1 if args.transcript == "host" else 0)
-    tables = ctx.alloc(batch * count * 32)
-    for b in range(batch):
-        ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, 0xC0FFEE + 2 + 1000 * rank + b)
-    ctx.synchronize()
-
-    step_times = []
-
-    outputs = [None]   # the proof arrays of the previous step are reused (no fresh pages inside the timed call)
-
-    def step():
-        t = time.perf_counter()
-        outputs[0] = ctx.sumcheck_mle_batch_device(tables, n, batch, out=outputs[0])
-        step_times.append(time.perf_counter() - t)
-        return outputs[0]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.synchronize()
-
-    ctx.profile(0 if args.no_profile else 2)   # on during warm-up too: the event pool is created lazily
-    for _ in range(args.warmup):
-        step()
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ops_per_sumcheck = 5 * (count - 1)
-    total_ops = ops_per_sumcheck * batch * args.steps * world
-    value = total_ops / elapsed
-
-    if rank == 0:
-        names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",            # multi-round passes (default)
-                 "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]   # per-round paths
-        prof = {k: ctx.profile_get(k) for k in names}
-        dom_name = "mle_multifold" if prof["mle_multifold"]["launches"] else "mle_fold_sum"
-        dom = prof[dom_name]
-        achieved = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
-        peak = 8000.0
-        kernel_ms_total = sum(v["total_ms"] for v in prof.values())
-        sumchecks = batch * args.steps
-        line = {
-            "metric": "BN254-Fr sumcheck field-ops/sec @ 2^20 vars",
-            "value": value,
-            "unit": "field-ops/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32x8 (BN254 Fr, 254-bit modular integers; the fold pass's constant-by-table products as exact i8 MFMA with i32 sums)",
-            "data": "synthetic",
-            "config": {"workload": "plain MLE sumcheck (prove_sumcheck), 2^%d points per table, BASELINE configs[2]" % n,
-                       "log2_points": n, "batch_per_gpu": batch, "sumchecks_per_step": batch * world,
-                       "transcript": "MiMC7-91 on %s, included in the timed region" % args.transcript,
-                       "parallelism": "independent sumchecks per rank, no collective"},
-            "sumchecks_per_sec": batch * args.steps * world / elapsed,
-            "step_ms_each": [round(x * 1e3, 3) for x in step_times[args.warmup:]],
-            "roofline": {
-                "bound": "hbm", "kernel": "k_mle_multifold_mfma" if dom_name == "mle_multifold" else "k_" + dom_name,
-                "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                "traffic": None,
-                "launches": dom["launches"],
-                "avg_launch_us": (dom["total_ms"] * 1e3 / dom["launches"]) if dom["launches"] else None,
-                "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
-                "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
-                              "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair",
-            },
-            "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
-            # SURVEY 8d's per-round accounting (128 * 2^n bytes per sumcheck) over ALL kernel time of the step:
-            # the multi-round schedule moves fewer bytes than that figure, so this can exceed what HBM delivers
-            "survey_accounting_GBps": (128.0 * count * sumchecks) / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total else None,
-        }
-        first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
-        if first["total_ms"] > 0:
-            line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
-        traffic_file = os.path.join(REPO, "profiles", "r01", "d_pmc_traffic.json")
-        if os.path.exists(traffic_file) and dom_name == "mle_multifold":
-            try:
-                tj = json.load(open(traffic_file))
-                if tj.get("batch") == batch and tj.get("n") == n:
-                    line["roofline"]["traffic"] = tj["k_mle_multifold_mfma"]["per_launch_mean_bytes"]
-                    line["roofline"]["traffic_source"] = "profiles/r01/d_pmc_traffic.json (rocprofv3 --pmc passes of this command)"
-            except Exception:
-                pass
-        if args.proofs > 0:
-            # second half of the metric, on its own context, once the sumcheck workload's 32 GiB are released
-            ctx.free(tables)
-            tables = None
-            line["aggregated_proofs"] = proofs_per_sec(local_rank, args.proofs)
-            line["aggregated_proofs"]["proofs_per_sec_all_ranks"] = line["aggregated_proofs"]["proofs_per_sec"] * world
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-
-    if tables is not None:
-        ctx.free(tables)
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def proofs_per_sec(device, n_proofs):
-    """"aggregated proofs/sec": full GKR proofs (gkr_prove = prover::prove, rust/src/gkr/prover.rs:6-96) of
-    one layered circuit of the size class SURVEY appendix B.4 estimates for t.circom (4 gate layers,
-    k = [5, 6, 7, 7 | input 7]) for `n_proofs` different witnesses (BASELINE configs[3]: 64 inputs).
-    Proofs are independent (aggregator.rs:350-355 proves them from a rayon par_iter): one context per
-    host thread.  Rank 0 measures its own share; other ranks would do the same work."""
-    from gkr_amd import Context, synth
-    ks = synth.PROOF_BATCH_KS
-    circuit = synth.proof_batch_circuit()
-    inputs = synth.proof_batch_witnesses(n_proofs)   # what tests/test_gpu_config_scale.py checks against the oracle
-    ctx = Context(device)
-    ctx.prove_batch_raw(circuit, inputs[: min(8, n_proofs)])   # warm-up: code objects, workspaces
-    ctx.prove_batch_raw(circuit, inputs)
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ctx.prove_batch_raw(circuit, inputs)
-    dt = (time.perf_counter() - t0) / reps
-    ctx.close()
-    return {"proofs_per_sec": n_proofs / dt, "proofs": n_proofs, "ms_per_batch": dt * 1e3,
-            "circuit": "synthetic layered circuit, 4 gate layers, k = %s, random add/mult gates, %d witnesses" % (ks, n_proofs),
-            "how": "gkr_prove_batch: all proofs advance together, every layer sumcheck batched (one round trip per round for all)"}
+PEAK_GBPS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md; measured copy ceiling 6.29 TB/s)
 
 
 def usable_cpus():
-    """Affinity mask capped by the cgroup CPU quota (the GPU box runs this in a
-    container with cpu.max = 16 CPUs although 256 are visible)."""
+    """Affinity mask capped by the cgroup CPU quota (the GPU box runs this in a container with cpu.max = 16 CPUs
+    although 256 are visible)."""
     n = len(os.sched_getaffinity(0))
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -228,23 +54,438 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(n, seconds):
-    """The oracle's dense C prover (a port of the reference algorithm's dense form;
-    the reference itself is Rust and cannot be built here) on the host cores."""
+class World:
+    """The ranks of this job: process group first, GPU second."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # test hooks (single-GPU boxes): several ranks on one device over gloo exercise the N > 1 code path
+        self.backend = os.environ.get("GKR_BENCH_BACKEND", "nccl")
+        if "GKR_BENCH_DEVICE" in os.environ:
+            self.local_rank = int(os.environ["GKR_BENCH_DEVICE"])
+        if self.size > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+        self.device = "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self, ctx=None):
+        if self.size > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        if ctx is not None:
+            ctx.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.size == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.size > 1:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(world, ctx, step, warmup, steps):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    if ctx is not None:
+        ctx.profile_reset()
+    world.barrier(ctx)
+    each = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = time.perf_counter()
+        step()
+        each.append(time.perf_counter() - t)
+    world.barrier(ctx)
+    return world.max_over_ranks(time.perf_counter() - t0), each
+
+
+# ------------------------------------------------------------------------------------------------ mode: mle
+
+def run_mle(args, world):
+    from gkr_amd import Context
+    n, batch = args.n, args.batch
+    count = 1 << n
+    ctx = Context(world.local_rank)
+    ctx.set_transcript(1 if args.transcript == "host" else 0)
+    tables = ctx.alloc(batch * count * 32)
+    for b in range(batch):
+        ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, 0xC0FFEE + 2 + 1000 * world.rank + b)
+    ctx.synchronize()
+    outputs = [None]   # the proof arrays of the previous step are reused (no fresh pages inside the timed call)
+
+    def step():
+        outputs[0] = ctx.sumcheck_mle_batch_device(tables, n, batch, out=outputs[0])
+
+    ctx.profile(0 if args.no_profile else 2)   # on during warm-up too: the event pool is created lazily
+    elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
+    ctx.profile(False)
+    ops_per_sumcheck = 5 * (count - 1)
+    value = ops_per_sumcheck * batch * args.steps * world.size / elapsed
+
+    names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",           # multi-round passes (default)
+             "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]  # per-round paths
+    prof = {k: ctx.profile_get(k) for k in names}
+    line = None
+    if world.rank == 0:
+        dom_name = "mle_multifold" if prof["mle_multifold"]["launches"] else "mle_fold_sum"
+        dom = prof[dom_name]
+        achieved = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
+        kernel_ms_total = sum(v["total_ms"] for v in prof.values())
+        scheduled_bytes = sum(v["bytes"] for v in prof.values())
+        sumchecks = batch * args.steps
+        line = {
+            "metric": "BN254-Fr sumcheck field-ops/sec @ 2^20 vars",
+            "value": value, "unit": "field-ops/s", "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (BN254 Fr, 254-bit modular integers; the fold pass's constant-by-table products as exact i8 MFMA with i32 sums)",
+            "data": "synthetic",
+            "config": {"workload": "plain MLE sumcheck (prove_sumcheck), 2^%d points per table, BASELINE configs[2]" % n,
+                       "log2_points": n, "batch_per_gpu": batch, "sumchecks_per_step": batch * world.size,
+                       "transcript": "MiMC7-91 on %s, included in the timed region" % args.transcript,
+                       "parallelism": "independent sumchecks per rank, no collective"},
+            "sumchecks_per_sec": batch * args.steps * world.size / elapsed,
+            "step_ms_each": [round(x * 1e3, 3) for x in each],
+            "host_threads": {"usable_cpus": usable_cpus(), "GKR_HOST_THREADS": os.environ.get("GKR_HOST_THREADS"),
+                             "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE")},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_mle_multifold_mfma" if dom_name == "mle_multifold" else "k_" + dom_name,
+                "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS,
+                "traffic": None, "launches": dom["launches"],
+                "avg_launch_us": (dom["total_ms"] * 1e3 / dom["launches"]) if dom["launches"] else None,
+                "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
+                "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
+                              "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair",
+            },
+            "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
+            # every byte the schedule moves (pass 0 reads the tables once, every fold pass reads its source and writes
+            # its output: ~66 * 2^n per sumcheck with five rounds per pass) over WALL time: the whole step as bandwidth
+            "end_to_end_GBps": scheduled_bytes / elapsed / 1e9 if not args.no_profile else None,
+            "scheduled_bytes_per_sumcheck": scheduled_bytes / sumchecks if sumchecks and not args.no_profile else None,
+            # SURVEY 8d's per-round accounting (128 * 2^n bytes per sumcheck) over ALL kernel time of the step: the
+            # multi-round schedule moves about half of that, so this figure is NOT a bandwidth and can exceed HBM's
+            "survey_accounting_GBps": (128.0 * count * sumchecks) / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total else None,
+        }
+        # which of the fold pass's placement-dependent bandwidth modes this process drew: the big launches one by one
+        avg_bytes = dom["bytes"] / max(1, dom["launches"])
+        big = [(ms, by) for ms, by in ctx.profile_samples("mle_multifold") if by > avg_bytes]   # the 2^n -> 2^(n-5) launches
+        if big:
+            rates = sorted(by / (ms * 1e-3) / 1e9 for ms, by in big if ms > 0)
+            line["roofline"]["first_fold_pass_GBps"] = {"min": rates[0], "median": statistics.median(rates), "max": rates[-1],
+                                                        "launches": len(rates)}
+        first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
+        if first["total_ms"] > 0:
+            line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
+        for rnd in ("r02", "r01"):   # PMC passes are separate runs (profiles/), never part of this run
+            traffic_file = os.path.join(REPO, "profiles", rnd, "d_pmc_traffic.json")
+            if os.path.exists(traffic_file) and dom_name == "mle_multifold":
+                try:
+                    tj = json.load(open(traffic_file))
+                    if tj.get("batch") == batch and tj.get("n") == n:
+                        line["roofline"]["traffic"] = tj["k_mle_multifold_mfma"]["per_launch_mean_bytes"]
+                        line["roofline"]["traffic_source"] = ("profiles/%s/d_pmc_traffic.json: separate rocprofv3 --pmc passes of "
+                                                              "this command on an earlier box, NOT measured in this run" % rnd)
+                        break
+                except Exception:
+                    pass
+    # single-sumcheck latency and the 2^16 size (configs[1]) on the same resident tables
+    extras = {}
+    if not args.no_extras:
+        lat = []
+        ctx.sumcheck_mle_batch_device(tables, n, 1)
+        for _ in range(20):
+            t = time.perf_counter()
+            ctx.sumcheck_mle_batch_device(tables, n, 1)
+            lat.append(time.perf_counter() - t)
+        extras["latency_ms_batch1"] = statistics.median(lat) * 1e3
+        extras["field_ops_per_sec_batch1"] = ops_per_sumcheck / statistics.median(lat)
+        n16, b16 = 16, min(4096, batch * (count >> 16)) if n >= 16 else 0
+        if b16:
+            out16 = [None]
+
+            def step16():
+                out16[0] = ctx.sumcheck_mle_batch_device(tables, n16, b16, out=out16[0])
+            for _ in range(2):
+                step16()
+            ctx.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                step16()
+            ctx.synchronize()
+            dt = (time.perf_counter() - t) / 5
+            extras["n16"] = {"workload": "BASELINE configs[1]: 2^16 points per table, batch %d" % b16,
+                             "value": 5 * ((1 << 16) - 1) * b16 / dt, "unit": "field-ops/s", "ms_per_step": dt * 1e3}
+    ctx.free(tables)
+    ctx.close()
+    # second half of the metric: every rank proves its own share of the inputs; MAX over ranks
+    proofs = None
+    if args.proofs > 0:
+        proofs = aggregated_proofs(world, args.proofs)
+    if world.rank == 0:
+        line.update(extras)
+        if proofs:
+            line["aggregated_proofs"] = proofs
+        if world.size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_dense(n, args.cpu_seconds)
+            line["cpu_ref_algo"] = cpu_ref_algo(args.ref_algo_seconds)
+            line["cpu_pipeline"] = cpu_pipeline()
+        print(json.dumps(line), flush=True)
+
+
+def aggregated_proofs(world, n_inputs):
+    """"aggregated proofs/sec" on the circuit the reference's own test uses (aggregator.rs:441-457: t.circom with
+    example/input{1,2,3}.json): its R1CS (hand-written equivalent, gkr_amd.synth) compiled to the 12 layered
+    circuits, every (circuit, input) pair proven (gkr_prove_batch = prover::prove, prover.rs:6-96) -- for the three
+    example inputs (configs[0]) and for `n_inputs` inputs split over the ranks (configs[3]).  One "proof" = one
+    prover::prove call = one sub-circuit of one input.  Checked against the oracle in tests/test_gpu_circom_pipeline.py."""
+    import numpy as np
+    from gkr_amd import Context, parallel, synth
+    from gkr_amd.aggregate import ProvingStep
+    from gkr_amd.field import as_limbs
+    t0 = time.perf_counter()
+    r1cs = synth.mimc7_demo_r1cs()
+    step = ProvingStep(r1cs)
+    compile_ms = (time.perf_counter() - t0) * 1e3
+    subs = len(step.circuits)
+    ctx = Context(world.local_rank)
+    out = {"circuit": "R1CS equivalent to rust/t.circom (MiMC7-91, 364 constraints) -> %d layered circuits, k lists %s"
+                      % (subs, [c.get_k_list() for c in step.circuits]),
+           "compile_ms": compile_ms, "proof": "one prover::prove call (one sub-circuit of one input)",
+           "how": "gkr_prove_batch per sub-circuit: the proofs of all inputs advance together (one round trip per round)"}
+
+    def measure(witnesses, reps):
+        inputs = step.inputs_for(np.stack([as_limbs(w) for w in witnesses])) if witnesses else None
+        if inputs is not None:
+            step.prove_raw(ctx, inputs)     # warm-up: code objects, workspaces
+        world.barrier(ctx)
+        t = time.perf_counter()
+        for _ in range(reps):
+            if inputs is not None:
+                step.prove_raw(ctx, inputs)
+        world.barrier(ctx)
+        return world.max_over_ranks((time.perf_counter() - t) / reps)
+    ex = [synth.mimc7_demo_witness(a, b) for a, b in synth.EXAMPLE_INPUTS]
+    dt3 = measure(ex if world.rank == 0 else [], 3)     # configs[0] is one rank's work
+    mine = parallel.shard_units(n_inputs, world.rank, world.size)
+    dt = measure([synth.mimc7_demo_witness(2 + i, 3 + (i % 5)) for i in mine], 3)
+    out["config0_three_inputs"] = {"inputs": 3, "proofs": 3 * subs, "ms": dt3 * 1e3, "proofs_per_sec": 3 * subs / dt3}
+    out["config3"] = {"inputs": n_inputs, "inputs_per_rank": [len(parallel.shard_units(n_inputs, r, world.size)) for r in range(world.size)],
+                      "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt}
+    out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
+    ctx.close()
+    step.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ mode: proofs
+
+def run_proofs(args, world):
+    import numpy as np
+    from gkr_amd import Context, parallel, synth
+    from gkr_amd.aggregate import ProvingStep
+    from gkr_amd.field import as_limbs
+    step_obj = ProvingStep(synth.mimc7_demo_r1cs())
+    subs = len(step_obj.circuits)
+    mine = parallel.shard_units(args.proofs, world.rank, world.size)
+    ctx = Context(world.local_rank)
+    inputs = step_obj.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in mine])) if len(mine) else None
+
+    def step():
+        if inputs is not None:
+            step_obj.prove_raw(ctx, inputs)
+    elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
+    if world.rank == 0:
+        print(json.dumps({
+            "metric": "aggregated proofs/sec", "value": args.proofs * subs * args.steps / elapsed, "unit": "proofs/s",
+            "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d inputs of the t.circom-equivalent R1CS, %d layered circuits each, "
+                                   "inputs split over the ranks, no collective" % (args.proofs, subs),
+                       "inputs_per_rank": [len(parallel.shard_units(args.proofs, r, world.size)) for r in range(world.size)],
+                       "proof": "one prover::prove call (one sub-circuit of one input)"},
+            "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
+    ctx.close()
+    step_obj.close()
+
+
+# ------------------------------------------------------------------------------------------------ mode: layer-split
+
+def run_layer_split(args, world):
+    from gkr_amd import Context, parallel, synth
+    from gkr_amd.field import from_limbs
+    k_i, k = args.k_i, args.k
+    lay, z, W = synth.config5_layer(k_i, k)
+    gt, l, r = lay.arrays()
+    first, cnt = parallel.gate_range(k_i, world.rank, world.size)
+    gt, l, r = gt[first:first + cnt].copy(), l[first:first + cnt].copy(), r[first:first + cnt].copy()
+    zi, Wi = from_limbs(z), from_limbs(W)
+    ctx = Context(world.local_rank)
+    coll = parallel.TorchCollective() if world.size > 1 else None
+    sum_limbs = coll.sum_limbs if coll else (lambda limbs: limbs)
+    result = [None]
+
+    def step():
+        result[0] = parallel.prove_sumcheck_opt_gate_sharded(ctx, k_i, k, first, gt, l, r, zi, Wi, sum_limbs)
+    ctx.profile(1)
+    elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
+    ctx.profile(False)
+    names = ["gate_lists", "gate_uv", "gate_rows", "layer_uv_round", "layer_c_round"]
+    prof = {n_: ctx.profile_get(n_) for n_ in names}
+    if world.rank == 0:
+        import numpy as np
+        from gkr_amd.field import to_limbs
+        proof, rs = result[0]
+        C = np.zeros((2 * k, 3, 4), dtype=np.uint64)
+        L = np.zeros(2 * k, dtype=np.uint32)
+        for j, vec in enumerate(proof):
+            C[j, 3 - len(vec):] = to_limbs(vec)
+            L[j] = len(vec)
+        digest = synth.transcript_digest(C, L, to_limbs(rs))
+        want = synth.golden_digest("layer", "k_i=%d,k=%d" % (k_i, k))
+        N = 1 << (2 * k)
+        gate_ms = (prof["gate_lists"]["total_ms"] + prof["gate_uv"]["total_ms"] + prof["gate_rows"]["total_ms"]) / args.steps
+        gate_bytes = (prof["gate_lists"]["bytes"] + prof["gate_uv"]["bytes"] + prof["gate_rows"]["bytes"]) / args.steps
+        print(json.dumps({
+            "metric": "BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" % k_i, "value": 25 * (N - 1) * args.steps / elapsed,
+            "unit": "field-ops/s", "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: one GKR layer, k_i = %d, k = %d, gates split over the ranks, two "
+                                   "sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" % (k_i, k),
+                       "gates_per_rank": cnt, "host_upload_included": "this rank's gate arrays (9 B per gate) cross PCIe in every step"},
+            "matches_golden_digest": None if want is None else digest == want, "transcript_sha256": digest,
+            "roofline": {"bound": "hbm", "kernel": "k_gate_count/_fill + k_gate_uv + k_gate_rows (this rank's gate passes)",
+                         "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9 if gate_ms else None, "peak": PEAK_GBPS, "unit": "GB/s",
+                         "frac": gate_bytes / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None, "traffic": None,
+                         "note": "gather / atomic bound, not a streaming kernel"},
+            "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / args.steps for n_ in names},
+            "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
+        if want is not None and digest != want:
+            raise SystemExit("WRONG TRANSCRIPT")
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
+
+def cpu_dense(n, seconds):
+    """The oracle's dense C prover (a port of the reference algorithm's dense form; the reference itself is Rust and
+    cannot be built here), throughput-fair: one whole sumcheck per host core, all cores busy."""
+    import threading
     from oracle import cdense
     cores = min(cdense.max_threads(), usable_cpus())
     table = cdense.fill_table(1 << n, 0xC0FFEE + 2)
-    cdense.sumcheck_mle_raw(table, n, cores)   # warm-up (constants, page faults)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        cdense.sumcheck_mle_raw(table, n, cores)
-        done += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or done >= 2000:
+    cdense.sumcheck_mle_raw(table, n, 1)   # warm-up (constants, page faults)
+    done = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        while time.perf_counter() < stop:
+            cdense.sumcheck_mle_raw(table, n, 1)
+            done[i] += 1
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) * 5 * ((1 << n) - 1) / dt, "unit": "field-ops/s", "cores": cores, "kind": "port",
+            "sample": "%d 2^%d-point sumchecks (MiMC7 included) in %.1f s, one single-threaded sumcheck per core on %d cores"
+                      % (sum(done), n, dt, cores)}
+
+
+def cpu_ref_algo(cap_seconds):
+    """The reference's ACTUAL algorithm (term lists, sumcheck.rs:36-156) as the oracle restates it in Python
+    (oracle/termlist.py), at the largest size whose run stays under the cap -- size stated, nothing extrapolated.
+    It documents the algorithmic gap (time grows ~16x per extra variable pair), not a speed to compare with."""
+    import random
+    from oracle import termlist
+    from oracle.field import P
+    best = None
+    for k in range(1, 8):
+        rng = random.Random(99 + k)
+        k_i = k
+        g = 1 << k_i
+        gt = [rng.randint(0, 1) for _ in range(g)]
+        l = [rng.randrange(1 << k) for _ in range(g)]
+        r = [rng.randrange(1 << k) for _ in range(g)]
+        layer = termlist.build_layer(k_i, k, gt, l, r)
+        z = [rng.randrange(P) for _ in range(k_i)]
+        w = termlist.get_multi_ext([rng.randrange(P) for _ in range(1 << k)], k)
+        t = time.perf_counter()
+        add_i = termlist.partial_eval_binary_form(layer.add, z)
+        mult_i = termlist.partial_eval_binary_form(layer.mult, z)
+        f1 = [termlist.extend_length(t_, 2 * k + 1) for t_ in w]
+        f2 = termlist.modify_poly_from_k(w, k)
+        termlist.prove_sumcheck_opt(layer.wire[0], layer.wire[1], add_i, mult_i, f1, f2, 2 * k)
+        dt = time.perf_counter() - t
+        if dt > cap_seconds:
             break
-    return {"value": done * 5 * ((1 << n) - 1) / dt, "unit": "field-ops/s", "cores": cores, "kind": "port",
-            "sample": "%d sequential 2^%d-point sumchecks (MiMC7 included) in %.1f s, OpenMP over %d threads"
-                      % (done, n, dt, cores)}
+        best = {"v": 2 * k, "gates": g, "seconds": dt, "value": 25 * ((1 << (2 * k)) - 1) / dt}
+        if dt * 16 > cap_seconds:
+            break
+    if best is None:
+        return None
+    return {"value": best["value"], "unit": "field-ops/s", "cores": 1, "kind": "port",
+            "sample": "prove_sumcheck_opt term-list algorithm (pure-Python restatement of sumcheck.rs:36-156), largest layer under "
+                      "%.0f s: v = %d variables, %d gates, %.2f s" % (cap_seconds, best["v"], best["gates"], best["seconds"])}
+
+
+def cpu_pipeline():
+    """The oracle proving the demo circuit's 12 sub-circuits for the three example inputs (dense C prover)."""
+    from gkr_amd import synth
+    from oracle import cdense
+    from oracle import convert as oconv
+    r = oconv.read_r1cs(synth.mimc7_demo_r1cs().serialize())
+    t0 = time.perf_counter()
+    proofs = 0
+    for a, b in synth.EXAMPLE_INPUTS:
+        for sub in oconv.convert_r1cs_wtns_gkr(r, synth.mimc7_demo_witness(a, b)):
+            cdense.prove(sub["layers"], sub["input_values"])
+            proofs += 1
+    dt = time.perf_counter() - t0
+    return {"value": proofs / dt, "unit": "proofs/s", "cores": min(cdense.max_threads(), usable_cpus()), "kind": "port",
+            "sample": "%d proofs (3 example inputs x 12 sub-circuits of the t.circom-equivalent R1CS), compile included, %.2f s" % (proofs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["mle", "proofs", "layer-split"], default="mle")
+    ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
+    ap.add_argument("--batch", type=int, default=1024, help="independent sumchecks per rank per step (32 GiB of tables)")
+    ap.add_argument("--transcript", choices=["host", "device"], default="host",
+                    help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-1 latency and the 2^16 leg")
+    ap.add_argument("--proofs", type=int, default=64, help="inputs of the demo circuit (configs[3]); 0 = skip in mle mode")
+    ap.add_argument("--k-i", type=int, default=24, help="layer-split: log2 gates")
+    ap.add_argument("--k", type=int, default=12, help="layer-split: log2 entries of the next layer")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--ref-algo-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+    world = World()
+    try:
+        {"mle": run_mle, "proofs": run_proofs, "layer-split": run_layer_split}[args.mode](args, world)
+    finally:
+        world.close()
 
 
 if __name__ == "__main__":

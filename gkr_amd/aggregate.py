@@ -13,7 +13,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 
 from . import _native as N
-from .field import MODULUS, to_limbs
+from .field import MODULUS, from_limbs, to_limbs
 from .prover import GkrError, Proof
 
 
@@ -99,6 +99,72 @@ def circom_input(proof: Proof, index: int) -> Dict[str, list]:
     if rc:
         raise GkrError(rc, "gkr_circom_input_json")
     return json.loads(text.value.decode())
+
+
+def _text_call(fn, *args):
+    need = ctypes.c_size_t()
+    rc = fn(*args, None, ctypes.c_size_t(0), ctypes.byref(need))
+    if rc:
+        raise GkrError(rc, fn.__name__)
+    buf = ctypes.create_string_buffer(need.value)
+    rc = fn(*args, buf, ctypes.c_size_t(need.value), ctypes.byref(need))
+    if rc:
+        raise GkrError(rc, fn.__name__)
+    return buf.value.decode()
+
+
+def verifier_source(metas: Sequence[Sequence[int]]) -> str:
+    """The circom text modify_circom_file renders for a list of proofs (aggregator.rs:216-290)."""
+    flat = np.asarray([x for m in metas for x in m], dtype=np.uint32)
+    lens = (ctypes.c_size_t * max(len(metas), 1))(*[len(m) for m in metas])
+    return _text_call(N.lib().gkr_circom_verifier_source, flat.ctypes.data_as(ctypes.c_void_p), lens, ctypes.c_size_t(len(metas)))
+
+
+def modify_circom_file(circuit_text: str, metas: Sequence[Sequence[int]]) -> str:
+    """modify_circom_file (aggregator.rs:215-314) as a text function: the circuit with the verifier components of the
+    previous round's proofs injected.  (The reference writes it to aggregated.circom and runs circom on it.)"""
+    return _text_call(N.lib().gkr_circom_inject, circuit_text.encode(), verifier_source(metas).encode())
+
+
+def prove_step(ctx, r1cs, witnesses, require_zero_output=True):
+    """The proving step of one aggregation round (aggregator.rs:341-355, 399-416): compile the R1CS into its
+    <= 20 layered circuits (convert_r1cs_wtns_gkr) and prove every (circuit, input) pair.  The reference maps
+    prover::prove over the pairs of ONE witness with a rayon par_iter; with several witnesses of the same R1CS
+    (BASELINE configs[3]: 64 inputs of one circom circuit) the sub-circuits coincide, so each sub-circuit's proofs
+    for all witnesses advance together (gkr_prove_batch).  -> proofs[w][j] for witness w and sub-circuit j."""
+    from .field import as_limbs
+    layered = r1cs.compile()
+    try:
+        wl = [as_limbs(w) for w in witnesses]
+        out = [[None] * len(layered) for _ in witnesses]
+        for j in range(len(layered)):
+            circuit = layered.circuit(j)
+            inputs = [from_limbs(layered.input_values_raw(j, w)) for w in wl]
+            for w, proof in enumerate(ctx.prove_batch(circuit, inputs, require_zero_output)):
+                out[w][j] = proof
+    finally:
+        layered.close()
+    return out
+
+
+class ProvingStep:
+    """prove_step with the compile done once and no decoding of the proofs into Python integers: what bench.py
+    times.  inputs_for gathers the witnesses into every sub-circuit's input layer (calculate_input, convert.rs:796-
+    810); prove_raw runs gkr_prove_batch per sub-circuit and returns the challenge arrays."""
+
+    def __init__(self, r1cs):
+        self._layered = r1cs.compile()
+        self.circuits = [self._layered.circuit(j) for j in range(len(self._layered))]
+
+    def inputs_for(self, witness_limbs):
+        """witness_limbs: (W, n_wires, 4) uint64 -> one (W, 2^input_k, 4) array per sub-circuit."""
+        return [np.stack([self._layered.input_values_raw(j, w) for w in witness_limbs]) for j in range(len(self.circuits))]
+
+    def prove_raw(self, ctx, inputs):
+        return [ctx.prove_batch_raw(c, x) for c, x in zip(self.circuits, inputs)]
+
+    def close(self):
+        self._layered.close()
 
 
 def aggregated_input(circuit_input: Dict[str, object], proofs: Sequence[Proof]) -> Dict[str, object]:

@@ -213,9 +213,120 @@ std::string json_of(const View& v, int index) {
     return s;
 }
 
+// ---- the circom source the reference injects into the user's circuit (modify_circom_file, aggregator.rs:215-314) ----
+// One `component verifier[total];` declaration, then per proof: the VerifyGKR instance, its seven input signals with
+// the dimensions get_meta computed, and the loops that wire the circuit's new inputs to the component.  The text is
+// built from two small tables (signals and their wiring loops); the reference renders the same text from a tera
+// template (:219-269) -- `tests/test_circom_input.py` renders that template independently and compares.
+struct SignalDim {
+    const char* name;
+    std::vector<std::string> dims;    // declaration: [dim]...
+    std::vector<std::string> bounds;  // wiring loops, outermost first: for (var i = 0; i < bound; i++)
+};
+
+std::string verifier_block(const std::vector<uint32_t>& m, size_t num) {
+    const std::string n = std::to_string(num);
+    auto M = [&](int i) { return std::to_string(m[i]); };
+    const std::string d = "d" + n, lk = "largest_k" + n, a = "a" + n;
+    const std::vector<SignalDim> sig = {
+        {"sumcheckProof", {d + " - 1", "2 * " + lk, M(4)}, {a, "2 * " + M(1), M(4)}},
+        {"sumcheckr", {d + " - 1", "2 * " + lk}, {a, "2 * " + M(1)}},
+        {"q", {d + " - 1", M(5)}, {a, M(5)}},
+        {"D", {M(3), M(2) + " + 1"}, {M(3), M(2) + " + 1"}},
+        {"z", {d, lk}, {a + " + 1", M(1)}},
+        {"r", {d + " - 1"}, {a}},
+        {"inputFunc", {M(6), M(7) + " + 1"}, {M(6), M(7) + " + 1"}},
+    };
+    std::string meta_dbg = "[";   // format!("{:?}", Vec<usize>)
+    for (size_t i = 0; i < m.size(); ++i) meta_dbg += (i ? ", " : "") + std::to_string(m[i]);
+    meta_dbg += "]";
+    std::string s = "\n";
+    const std::string ind = "    ";
+    s += ind + "var " + d + " = " + M(0) + ";\n";
+    s += ind + "var " + lk + " = " + M(1) + ";\n";
+    for (const SignalDim& g : sig) {
+        s += ind + "signal input " + g.name + n;
+        for (const std::string& dim : g.dims) s += "[" + dim + "]";
+        s += ";\n";
+    }
+    s += ind + "verifier[" + n + "] = VerifyGKR(" + meta_dbg + ");\n";
+    s += ind + "var " + a + " = " + M(0) + " - 1;\n";
+    const char* iv[3] = {"i", "j", "k"};
+    for (const SignalDim& g : sig) {
+        std::string idx;
+        for (size_t l = 0; l < g.bounds.size(); ++l) {
+            s += ind;
+            for (size_t t = 0; t < l; ++t) s += ind;
+            s += std::string("for (var ") + iv[l] + " = 0; " + iv[l] + " < " + g.bounds[l] + "; " + iv[l] + "++) {\n";
+            idx += std::string("[") + iv[l] + "]";
+        }
+        s += ind;
+        for (size_t t = 0; t < g.bounds.size(); ++t) s += ind;
+        s += "verifier[" + n + "]." + g.name + idx + " <== " + g.name + n + idx + ";\n";
+        for (size_t l = g.bounds.size(); l-- > 0;) {
+            s += ind;
+            for (size_t t = 0; t < l; ++t) s += ind;
+            s += "}\n";
+        }
+    }
+    s += ind;
+    return s;
+}
+
+int copy_text(const std::string& s, char* out, size_t capacity, size_t* needed) {
+    if (!needed) return GKR_ERR_INVALID;
+    *needed = s.size() + 1;
+    if (!out) return GKR_OK;
+    if (capacity < s.size() + 1) return GKR_ERR_NOMEM;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return GKR_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// metas: the proofs' meta vectors one after the other, meta_len[i] entries each (gkr_circom_meta's output)
+int gkr_circom_verifier_source(const uint32_t* metas, const size_t* meta_len, size_t proofs, char* out, size_t capacity, size_t* needed) {
+    if ((!metas || !meta_len) && proofs) return GKR_ERR_INVALID;
+    std::string v = "\n    component verifier[" + std::to_string(proofs) + "];\n    ";
+    size_t off = 0;
+    for (size_t i = 0; i < proofs; ++i) {
+        if (meta_len[i] < 9) return GKR_ERR_INVALID;   // depth, ..., k_i(d - 1), and at least one k
+        const std::vector<uint32_t> m(metas + off, metas + off + meta_len[i]);
+        off += meta_len[i];
+        v += "\n" + verifier_block(m, i);             // v = format!("{}\n{}", v, s), aggregator.rs:289
+    }
+    return copy_text(v, out, capacity, needed);
+}
+
+// The user's circuit with the verifier source injected (aggregator.rs:292-309): the exact line
+// `pragma circom 2.0.0;` is followed by the include of verifier.circom (and whatever came before that line is
+// dropped, as in the reference, which reassigns the text there), the FIRST line that is exactly `}` is preceded by
+// the verifier source, every other line is kept.
+int gkr_circom_inject(const char* circuit_text, const char* verifier_source, char* out, size_t capacity, size_t* needed) {
+    if (!circuit_text || !verifier_source) return GKR_ERR_INVALID;
+    std::string text(circuit_text), result;
+    bool added = false;
+    size_t pos = 0;
+    while (pos < text.size()) {   // str::lines(): split at \n, a trailing \r is dropped, no empty last line
+        size_t end = text.find('\n', pos);
+        const bool last = end == std::string::npos;
+        if (last) end = text.size();
+        std::string line = text.substr(pos, end - pos);
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        pos = last ? text.size() : end + 1;
+        if (line == "pragma circom 2.0.0;") {
+            result = line + "\ninclude \"../gkr-verifier-circuits/circom/circom/verifier.circom\";\n";
+        } else if (line == "}" && !added) {
+            result = result + "\n" + verifier_source + "\n}";
+            added = true;
+        } else {
+            result += line + "\n";
+        }
+    }
+    return copy_text(result, out, capacity, needed);
+}
 
 int gkr_circom_meta(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, uint32_t* meta, size_t capacity, size_t* count) {
     const View v = view(circuit, proof);

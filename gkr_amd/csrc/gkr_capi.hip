@@ -36,7 +36,9 @@ struct ProfileRow {
     uint64_t launches = 0;
     double total_ms = 0.0;
     double bytes = 0.0;
+    std::vector<std::pair<float, double>> samples;   // (ms, algorithmic bytes) of single launches, the first kMaxSamples
 };
+constexpr size_t kMaxSamples = 4096;
 
 struct PendingEvent {
     hipEvent_t start, stop;
@@ -282,6 +284,7 @@ struct gkr_ctx {
             r.launches += 1;
             r.total_ms += ms;
             r.bytes += p.bytes;
+            if (r.samples.size() < kMaxSamples) r.samples.emplace_back(ms, p.bytes);
             event_pool.push_back(p.start);
             event_pool.push_back(p.stop);
         }
@@ -1523,6 +1526,19 @@ int gkr_ctx_profile_get(gkr_ctx* ctx, const char* kernel, uint64_t* launches, do
     if (launches) *launches = r.launches;
     if (total_ms) *total_ms = r.total_ms;
     if (bytes) *bytes = r.bytes;
+    return GKR_OK;
+}
+
+int gkr_ctx_profile_samples(gkr_ctx* ctx, const char* kernel, double* ms, double* bytes, size_t capacity, size_t* count) {
+    if (!ctx || !kernel || !count) return GKR_ERR_INVALID;
+    ctx->drain_events();
+    auto it = ctx->prof.find(kernel);
+    const size_t n = it == ctx->prof.end() ? 0 : it->second.samples.size();
+    *count = n;
+    for (size_t i = 0; i < n && i < capacity; ++i) {
+        if (ms) ms[i] = it->second.samples[i].first;
+        if (bytes) bytes[i] = it->second.samples[i].second;
+    }
     return GKR_OK;
 }
 

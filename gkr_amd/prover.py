@@ -161,6 +161,16 @@ class Context:
         self._check(N.lib().gkr_ctx_profile_get(self._h, kernel.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)))
         return dict(launches=n.value, total_ms=ms.value, bytes=b.value)
 
+    def profile_samples(self, kernel, capacity=4096):
+        """[(ms, algorithmic bytes)] of the single launches of `kernel` since the last reset."""
+        ms = np.zeros(capacity, dtype=np.float64)
+        by = np.zeros(capacity, dtype=np.float64)
+        n = ctypes.c_size_t()
+        self._check(N.lib().gkr_ctx_profile_samples(self._h, kernel.encode(), _ptr(ms), _ptr(by), ctypes.c_size_t(capacity),
+                                                    ctypes.byref(n)))
+        k = min(n.value, capacity)
+        return list(zip(ms[:k].tolist(), by[:k].tolist()))
+
     # -- device memory
     def alloc(self, nbytes):
         p = ctypes.c_void_p()

@@ -67,3 +67,77 @@ def golden_digest(kind, key):
             return json.load(f).get(kind, {}).get(key)
     except OSError:
         return None
+
+
+# ---------------------------------------------------------------------------------------- configs[0] / configs[3]
+# rust/t.circom: circomlib MiMC7(91) of the public input in1 with key 0 (in2 is a private input that is not used),
+# public output out.  circom is not available in this image, so its R1CS is written by hand: four quadratic
+# constraints per round after circom's linear simplification.  Wires: 0 one, 1 out, 2 in1, 3 in2, then t2, t4, t6, t7
+# of every round.  circom's own coefficient signs and wire order are NOT reproduced (byte-equality with its
+# output is impossible without it); style "negated" writes (-A) * B = -C, the shape circom tends to emit.
+
+def _mimc7_constants():
+    import ctypes
+    from . import _native as N
+    from .field import from_limbs
+    out = np.zeros((91, 4), dtype=np.uint64)
+    for i in range(91):
+        rc = N.lib().gkr_mimc7_constant(ctypes.c_int(i), out[i].ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise RuntimeError("gkr_mimc7_constant(%d) -> %d" % (i, rc))
+    return from_limbs(out)
+
+
+def mimc7_demo_constraints(nrounds=91, style="plain"):
+    """-> (n_wires, constraints) with constraints as [(A, B, C)], each a list of (coefficient, wire)."""
+    from .field import MODULUS as P
+    cts = _mimc7_constants()
+    wire, cons, prev_t7 = 4, [], None
+
+    def emit(a, b, c):
+        if style == "negated":
+            a = [((P - co) % P, w) for co, w in a]
+            c = [((P - co) % P, w) for co, w in c]
+        cons.append((a, b, c))
+    for i in range(nrounds):
+        t = [(1, 2)] if i == 0 else ([(cts[i], 0), (1, prev_t7)] if cts[i] else [(1, prev_t7)])
+        t2, t4, t6 = wire, wire + 1, wire + 2
+        wire += 3
+        emit(list(t), list(t), [(1, t2)])
+        emit([(1, t2)], [(1, t2)], [(1, t4)])
+        emit([(1, t4)], [(1, t2)], [(1, t6)])
+        if i < nrounds - 1:
+            emit([(1, t6)], list(t), [(1, wire)])
+            prev_t7 = wire
+            wire += 1
+        else:
+            emit([(1, t6)], list(t), [(1, 1)])
+    return wire, cons
+
+
+def mimc7_demo_r1cs(nrounds=91, style="plain"):
+    from .convert import R1cs
+    n_wires, cons = mimc7_demo_constraints(nrounds, style)
+    return R1cs.build(n_wires, 1, 1, 1, cons)
+
+
+def mimc7_demo_witness(in1, in2, nrounds=91):
+    """What circom's generated witness calculator would produce for mimc7_demo_r1cs (wire order as above)."""
+    from .field import MODULUS as P
+    cts = _mimc7_constants()
+    w = [1, 0, in1 % P, in2 % P]
+    t7 = None
+    for i in range(nrounds):
+        t = in1 % P if i == 0 else (t7 + cts[i]) % P
+        t2 = t * t % P
+        t4 = t2 * t2 % P
+        t6 = t4 * t2 % P
+        w += [t2, t4, t6]
+        t7 = t6 * t % P
+        if i < nrounds - 1:
+            w.append(t7)
+    w[1] = t7
+    return w
+
+
+EXAMPLE_INPUTS = [(2, 3), (3, 3), (3, 4)]   # rust/example/input{1,2,3}.json: in1, in2

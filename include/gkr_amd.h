@@ -98,6 +98,9 @@ int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
 int  gkr_ctx_profile(gkr_ctx *ctx, int enable);
 int  gkr_ctx_profile_get(gkr_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms,
                          double *algorithmic_bytes);
+/* the single launches behind a row (duration and algorithmic bytes of each, in launch order; the first 4096 since
+ * the last reset): *count = how many there are, at most `capacity` are written */
+int  gkr_ctx_profile_samples(gkr_ctx *ctx, const char *kernel, double *ms, double *bytes, size_t capacity, size_t *count);
 int  gkr_ctx_profile_reset(gkr_ctx *ctx);
 
 /* ---- MiMC7 (host; no device needed) ------------------------------------ */
@@ -252,6 +255,16 @@ int  gkr_circom_meta(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof
                      size_t *count);
 int  gkr_circom_input_json(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof, int proof_index, char *out,
                            size_t capacity, size_t *needed);
+
+/* The circom source the reference adds to the user's circuit for the next aggregation round (modify_circom_file,
+ * aggregator.rs:215-314), as pure text functions (no circom is run): gkr_circom_verifier_source = the
+ * `component verifier[n]` declaration and, per proof, the VerifyGKR(meta) instance, its input signals and the
+ * wiring loops; metas = the proofs' meta vectors back to back, meta_len[i] entries each.  gkr_circom_inject = the
+ * circuit text with the verifier include after the line `pragma circom 2.0.0;` and the source in front of the
+ * first line that is exactly `}`.  Size protocol as gkr_circom_input_json. */
+int  gkr_circom_verifier_source(const uint32_t *metas, const size_t *meta_len, size_t proofs, char *out, size_t capacity,
+                                size_t *needed);
+int  gkr_circom_inject(const char *circuit_text, const char *verifier_source, char *out, size_t capacity, size_t *needed);
 
 /* ---- in front of the path: R1CS + witness -> layered circuits (host only) ------------------------------
  * What the reference does between circom's output files and prover::prove: read the iden3 `.r1cs` and `.wtns`

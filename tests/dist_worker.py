@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import torch.distributed as dist  # noqa: E402
 
 from gkr_amd import parallel  # noqa: E402
-from oracle import dense  # noqa: E402
+from oracle import dense, gatesum  # noqa: E402
 from oracle.field import P  # noqa: E402
 from oracle.mimc7 import multi_hash as oracle_hash  # noqa: E402
 
@@ -136,6 +136,36 @@ def main():
                                                   lambda kc, A, M, wb, Wc: OracleLayerTail(kc, A, M, wb, Wc),
                                                   hasher=oracle_hash)
     out["layer_short_ok"] = got == dense.sumcheck_layer(k_i, k, gt, l, r, z, w2)
+
+    # the gate-sharded form (gkr_sumcheck_layer_sharded): each rank sums its own gate range, the library's
+    # sum-over-ranks hook (make_allreduce_hook over this gloo group: widen -> SUM all-reduce -> narrow) completes
+    # U, V and then the row -- the hook and the collective are the product's, the per-rank sums the oracle's
+    import ctypes
+    import numpy as np
+    from gkr_amd.field import from_limbs, to_limbs
+    hook, hook_errors = parallel.make_allreduce_hook(coll.sum_limbs)
+
+    def reduce_through_hook(parts):   # parts: this rank's vector only
+        buf = to_limbs(parts[0])
+        assert hook(None, buf.ctypes.data_as(ctypes.c_void_p), len(parts[0])) == 0 and not hook_errors
+        return from_limbs(buf)
+    k_i2, k2 = 5, 3
+    g2 = 1 << k_i2
+    gt2 = [rng.randint(0, 1) for _ in range(g2)]
+    l2 = [rng.randrange(1 << k2) for _ in range(g2)]
+    r2 = [rng.randrange(1 << k2) for _ in range(g2)]
+    z2 = [rng.randrange(P) for _ in range(k_i2)]
+    ok = True
+    for wv in ([rng.randrange(P) for _ in range(1 << k2)], [(i >> (k2 - 1)) + 1 for i in range(1 << k2)]):
+        first, count = parallel.gate_range(k_i2, rank, world)
+        dep = dense.depends_on(wv, k2)
+        uv = reduce_through_hook([sum(gatesum.partial_uv(k_i2, k2, gt2, l2, r2, z2, wv, first, count), [])])
+        nn = 1 << k2
+        pb, rb, wu = gatesum.rounds_b(uv[:nn], uv[nn:], wv, dep)
+        rows = reduce_through_hook([sum(gatesum.partial_rows(k_i2, k2, gt2, l2, r2, z2, rb, first, count), [])])
+        pc, rc = gatesum.rounds_c(rows[:nn], rows[nn:], wv, wu, dep)
+        ok = ok and (pb + pc, rb + rc) == dense.sumcheck_layer(k_i2, k2, gt2, l2, r2, z2, wv)
+    out["gate_sharded_ok"] = ok
 
     # distributed plain sumcheck
     n = 6

@@ -264,3 +264,21 @@ def test_input_values_gather_constants_and_witness_entries():
     assert vals == [val if kind == "val" else w[val] for kind, val in spec]
     with pytest.raises(GkrError):
         lay.input_values(0, w[:2])
+
+
+def test_demo_circuit_builder_matches_the_committed_fixture_and_the_oracle():
+    """gkr_amd.synth builds the t.circom-equivalent R1CS and its witnesses for bench.py without the oracle: they
+    must be the committed fixture (written by the oracle's writers, tests/golden/make_mimc7_fixture.py) byte for
+    byte."""
+    import os
+    from gkr_amd import synth
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for style, name in (("plain", "t_mimc7.r1cs"), ("negated", "t_mimc7_negated.r1cs")):
+        assert synth.mimc7_demo_r1cs(style=style).serialize() == open(os.path.join(golden, name), "rb").read()
+    for i, (in1, in2) in enumerate(synth.EXAMPLE_INPUTS, 1):
+        w = synth.mimc7_demo_witness(in1, in2)
+        assert w == oracle.mimc7_witness(in1, in2)
+        assert product.write_wtns(w) == open(os.path.join(golden, "t_mimc7_input%d.wtns" % i), "rb").read()
+        r = oracle.mimc7_r1cs()
+        ev = lambda v: sum(c * w[j] for c, j in v) % P
+        assert all(ev(a) * ev(b) % P == ev(c) for a, b, c in r["constraints"])

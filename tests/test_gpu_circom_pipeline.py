@@ -1,0 +1,90 @@
+"""BASELINE configs[0] and configs[3] end to end on the GPU: the R1CS of rust/t.circom (hand-written equivalent,
+tests/golden/t_mimc7*.r1cs) and the witnesses of rust/example/input{1,2,3}.json -> R1CS compiler -> <= 20 layered
+circuits -> prover::prove on every (circuit, input) pair -> verifier.circom input signals; then the same circuit
+with 64 inputs, all proofs of a sub-circuit advancing together.
+
+Checked: the product's compiler output equals the oracle's restatement of convert.rs; every proof is bit-equal to
+the oracle prover's on the same circuit and input; output 0 of every sub-circuit is zero (convert.rs:838); every
+proof passes the verifier; the circom input signals follow aggregator.rs:92-213.
+What cannot be checked here: byte-equality with circom's own R1CS for t.circom (no circom offline), and the
+recursion steps for inputs 2 and 3 (they need circom to compile the aggregated circuit, aggregator.rs:316-363):
+each of the three inputs is proven as a first step."""
+
+import os
+
+import pytest
+
+from gkr_amd import Context, synth, verify
+from gkr_amd import convert as product
+from gkr_amd.aggregate import aggregated_input, circom_input, circom_meta, prove_step
+from helpers import canon_circom, expected_circom_input, expected_circom_meta
+from oracle import cdense
+from oracle import convert as oracle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _same_proof(pr, ref):
+    return (pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"] and pr.q == ref["q"]
+            and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"])
+
+
+@pytest.mark.parametrize("name", ["t_mimc7.r1cs", "t_mimc7_negated.r1cs"])
+def test_config0_three_example_inputs_end_to_end(ctx, name):
+    image = open(os.path.join(GOLDEN, name), "rb").read()
+    r1cs = product.R1cs.parse(image)
+    witnesses = [product.read_wtns(open(os.path.join(GOLDEN, "t_mimc7_input%d.wtns" % i), "rb").read()) for i in (1, 2, 3)]
+    assert [w[2:4] for w in witnesses] == [list(p) for p in synth.EXAMPLE_INPUTS]
+    proofs = prove_step(ctx, r1cs, witnesses)                     # require_zero_output: convert.rs:838
+    circuits, _ = product.convert_r1cs_wtns_gkr(r1cs, witnesses[0])
+    assert 1 <= len(circuits) <= 20 and all(len(p) == len(circuits) for p in proofs)
+    for w, witness in enumerate(witnesses):
+        want = oracle.convert_r1cs_wtns_gkr(oracle.read_r1cs(image), witness)
+        assert len(want) == len(circuits)
+        for j, (pr, sub) in enumerate(zip(proofs[w], want)):
+            ref = cdense.prove(sub["layers"], sub["input_values"])
+            assert ref["values"][0][0] == 0
+            assert _same_proof(pr, ref), (w, j)
+            assert pr.d == []                                      # every output of a satisfied sub-circuit is zero
+            assert verify(pr, circuits[j]), (w, j)
+            assert circom_meta(pr) == expected_circom_meta(pr)
+            assert canon_circom(circom_input(pr, j)) == canon_circom(expected_circom_input(pr, j))
+        merged = aggregated_input({"in1": str(witness[2]), "in2": str(witness[3])}, proofs[w])
+        assert len(merged) == 2 + 7 * len(circuits)
+
+
+def test_config0_unsatisfying_witness_is_refused(ctx):
+    from gkr_amd import GkrError
+    r1cs = synth.mimc7_demo_r1cs()
+    w = synth.mimc7_demo_witness(2, 3)
+    w[2] += 1      # in1 no longer matches t2[0] = in1 * in1: the first tree of the first sub-circuit is not zero
+    with pytest.raises(GkrError):
+        prove_step(ctx, r1cs, [w])
+
+
+def test_config3_sixty_four_inputs_of_the_demo_circuit(ctx):
+    """configs[3] on one GPU: 64 inputs of the t.circom-equivalent R1CS, 12 sub-circuits x 64 proofs, each
+    sub-circuit's 64 proofs advancing together.  Every proof against the oracle for four of the inputs, the
+    verifier on eight, and the built R1CS must be the committed fixture byte for byte."""
+    r1cs = synth.mimc7_demo_r1cs()
+    image = r1cs.serialize()
+    assert image == open(os.path.join(GOLDEN, "t_mimc7.r1cs"), "rb").read()
+    witnesses = [synth.mimc7_demo_witness(2 + i, 3 + (i % 5)) for i in range(64)]
+    assert witnesses[0] == oracle.mimc7_witness(2, 3) and witnesses[63] == oracle.mimc7_witness(65, 6)
+    proofs = prove_step(ctx, r1cs, witnesses)
+    circuits, _ = product.convert_r1cs_wtns_gkr(r1cs, witnesses[0])
+    assert len(proofs) == 64 and all(len(p) == len(circuits) == 12 for p in proofs)
+    parsed = oracle.read_r1cs(image)
+    for w in (0, 1, 31, 63):
+        for j, sub in enumerate(oracle.convert_r1cs_wtns_gkr(parsed, witnesses[w])):
+            assert _same_proof(proofs[w][j], cdense.prove(sub["layers"], sub["input_values"])), (w, j)
+    for w in range(0, 64, 8):
+        assert all(verify(proofs[w][j], circuits[j]) for j in range(12)), w

@@ -132,3 +132,24 @@ def test_sumcheck_verifier_relations(seed):
     assert claim == (av * (wb + wc) + mv * wb * wc) % P
     q = dense.line_restriction(rs[:k], rs[k:], w, k)
     assert _horner(q, 0) == wb and _horner(q, 1) == wc
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_linear_time_gate_sum_form_equals_dense_for_any_gate_partition(seed):
+    """oracle/gatesum.py: the (W, U, V) / single-row form of the layer sumcheck the product's gate-list kernels and
+    its gate-sharded multi-GPU form compute -- same transcript as the dense and term-list forms, however the gates
+    are partitioned."""
+    from oracle import gatesum
+    rng = random.Random(300 + seed)
+    k_i, k = rng.randint(0, 6), rng.randint(1, 4)
+    g = 1 << k_i
+    gt = [rng.randint(0, 1) for _ in range(g)]
+    l = [rng.randrange(1 << k) for _ in range(g)]
+    r = [rng.randrange(1 << k) for _ in range(g)]
+    z = [rng.randrange(P) for _ in range(k_i)]
+    w = _w_of_mode(rng, seed % 5, k)
+    ref = dense.sumcheck_layer(k_i, k, gt, l, r, z, w)
+    for shards in (1, 2, 3, 8):
+        assert gatesum.sumcheck_layer(k_i, k, gt, l, r, z, w, shards) == ref
+    if k_i <= 3 and k <= 3:
+        assert _termlist_layer(k_i, k, gt, l, r, z, w) == ref
