@@ -14,6 +14,7 @@
 #include <chrono>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -144,11 +145,130 @@ inline int hash_chunk_size(int tables, int threads) {
     return tables >= 32 * threads ? 16 : 8;
 }
 
-// device allocations of the library: optionally physically contiguous (experiment knob GKR_ALLOC_CONTIGUOUS)
+// Device allocations of the library.  Large buffers (the table batches) are built with the virtual-memory API: a
+// virtual range ALIGNED to kVmmAlign backed by physical handles of kVmmChunk bytes each.  Why: the streaming kernels'
+// bandwidth depends on how an allocation is mapped -- a plain hipMalloc of 8 GiB comes back 2 MiB-aligned and lands
+// in one of several "modes" (fold pass 5.3 / 5.8 / 6.1+ TB/s, decided at allocation time and fixed for its lifetime;
+// DESIGN.md section 4), because the page-table fragment a translation covers can be no larger than the alignment the
+// virtual and the physical side share, and a sweep over many GiB with small fragments lives on page walks.
+//   GKR_ALLOC_MODE=malloc      plain hipMalloc for everything (the round-1 behaviour)
+//   GKR_ALLOC_MODE=contiguous  hipExtMallocWithFlags(hipDeviceMallocContiguous)
+//   GKR_ALLOC_MODE=vmm         (default for >= kVmmMin bytes) aligned virtual range + large physical chunks
+//   GKR_VMM_ALIGN_LOG2 / GKR_VMM_CHUNK_LOG2   experiment knobs (defaults 30 / 30: 1 GiB)
+struct VmmAllocation {
+    size_t size = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> chunk_sizes;
+};
+std::mutex g_vmm_mu;
+std::map<void*, VmmAllocation> g_vmm;
+
+inline int alloc_mode() {   // 0 malloc, 1 contiguous, 2 vmm
+    static const int mode = [] {
+        if (getenv("GKR_ALLOC_CONTIGUOUS")) return 1;
+        const char* e = getenv("GKR_ALLOC_MODE");
+        if (!e) return 2;
+        if (!strcmp(e, "malloc")) return 0;
+        if (!strcmp(e, "contiguous")) return 1;
+        return 2;
+    }();
+    return mode;
+}
+constexpr size_t kVmmMin = (size_t)256 << 20;
+
+hipError_t vmm_malloc(void** out, size_t bytes) {
+    static const size_t align = (size_t)1 << [] { const char* e = getenv("GKR_VMM_ALIGN_LOG2"); const int v = e ? atoi(e) : 30; return v < 21 ? 21 : (v > 36 ? 36 : v); }();
+    static const size_t chunk = (size_t)1 << [] { const char* e = getenv("GKR_VMM_CHUNK_LOG2"); const int v = e ? atoi(e) : 30; return v < 21 ? 21 : (v > 36 ? 36 : v); }();
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    rc = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (rc != hipSuccess || gran == 0) return rc != hipSuccess ? rc : hipErrorNotSupported;
+    const size_t total = (bytes + gran - 1) / gran * gran;
+    void* va = nullptr;
+    rc = hipMemAddressReserve(&va, total, align, nullptr, 0);
+    if (rc != hipSuccess) return rc;
+    VmmAllocation a;
+    a.size = total;
+    size_t off = 0;
+    while (off < total && rc == hipSuccess) {
+        size_t sz = total - off < chunk ? total - off : chunk;
+        hipMemGenericAllocationHandle_t h;
+        rc = hipMemCreate(&h, sz, &prop, 0);
+        if (rc != hipSuccess) break;
+        rc = hipMemMap(static_cast<char*>(va) + off, sz, 0, h, 0);
+        if (rc != hipSuccess) {
+            (void)hipMemRelease(h);
+            break;
+        }
+        a.handles.push_back(h);
+        a.chunk_sizes.push_back(sz);
+        off += sz;
+    }
+    if (rc == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        rc = hipMemSetAccess(va, total, &acc, 1);
+    }
+    if (rc != hipSuccess) {
+        size_t o = 0;
+        for (size_t i = 0; i < a.handles.size(); ++i) {
+            (void)hipMemUnmap(static_cast<char*>(va) + o, a.chunk_sizes[i]);
+            (void)hipMemRelease(a.handles[i]);
+            o += a.chunk_sizes[i];
+        }
+        (void)hipMemAddressFree(va, total);
+        return rc;
+    }
+    {
+        std::lock_guard<std::mutex> g(g_vmm_mu);
+        g_vmm[va] = std::move(a);
+    }
+    *out = va;
+    return hipSuccess;
+}
+
 inline hipError_t device_malloc(void** p, size_t bytes) {
-    static const bool contiguous = getenv("GKR_ALLOC_CONTIGUOUS") != nullptr;
-    if (contiguous) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    const int mode = alloc_mode();
+    if (mode == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    if (mode == 2 && bytes >= kVmmMin) {
+        const hipError_t rc = vmm_malloc(p, bytes);
+        if (rc == hipSuccess || rc == hipErrorOutOfMemory) return rc;
+        (void)hipGetLastError();   // the virtual-memory API is not usable here: fall back to the plain allocator
+    }
     return hipMalloc(p, bytes);
+}
+
+inline hipError_t device_free(void* p) {
+    VmmAllocation a;
+    bool vmm = false;
+    {
+        std::lock_guard<std::mutex> g(g_vmm_mu);
+        auto it = g_vmm.find(p);
+        if (it != g_vmm.end()) {
+            a = std::move(it->second);
+            g_vmm.erase(it);
+            vmm = true;
+        }
+    }
+    if (!vmm) return hipFree(p);
+    hipError_t rc = hipDeviceSynchronize();
+    size_t o = 0;
+    for (size_t i = 0; i < a.handles.size(); ++i) {
+        const hipError_t u = hipMemUnmap(static_cast<char*>(p) + o, a.chunk_sizes[i]);
+        const hipError_t r = hipMemRelease(a.handles[i]);
+        if (rc == hipSuccess) rc = u != hipSuccess ? u : r;
+        o += a.chunk_sizes[i];
+    }
+    const hipError_t f = hipMemAddressFree(p, a.size);
+    return rc != hipSuccess ? rc : f;
 }
 
 int default_host_threads() {
@@ -207,7 +327,7 @@ struct gkr_ctx {
     hipError_t workspace(const char* slot, size_t bytes, void** out) {
         auto& e = ws[slot];
         if (e.second < bytes) {
-            if (e.first) (void)hipFree(e.first);
+            if (e.first) (void)device_free(e.first);
             e.first = nullptr;
             e.second = 0;
             hipError_t rc = device_malloc(&e.first, bytes);
@@ -233,7 +353,7 @@ struct gkr_ctx {
     }
     void release_buffers() {
         for (auto& kv : ws)
-            if (kv.second.first) (void)hipFree(kv.second.first);
+            if (kv.second.first) (void)device_free(kv.second.first);
         ws.clear();
         for (auto& kv : pinned)
             if (kv.second.first) (void)hipHostFree(kv.second.first);
@@ -2441,7 +2561,7 @@ int gkr_device_alloc(gkr_ctx* ctx, size_t bytes, void** d_ptr) {
 int gkr_device_free(gkr_ctx* ctx, void* d_ptr) {
     if (!ctx) return GKR_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipFree(d_ptr));
+    HIP_TRY(ctx, device_free(d_ptr));
     return GKR_OK;
 }
 

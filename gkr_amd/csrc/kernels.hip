@@ -1575,16 +1575,26 @@ void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, si
         hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
 }
 
-// blocks per table for a multifold pass of S output entries split into 2^jout sub-blocks.  The matrix-core
-// kernel pays a per-block set-up (digit matrix of the sumcheck), so it wants few, long chunks: a power of two
-// >= 2^jout, ~1024 blocks over the batch (two resident per CU), chunks of at least 256 entries (MI355X,
-// 64 x 2^17: 16 blocks per table 5.7 TB/s, 128 blocks 5.3).
+// blocks per table for a multifold pass of S output entries split into 2^jout sub-blocks: a power of two >= 2^jout.
+// The matrix-core kernel pays a per-block set-up (the sumcheck's digit matrix into LDS), which argues for few, long
+// chunks -- but what decides its bandwidth is how many TABLES the resident blocks work on at once: every table is
+// read as 2^J streams 32 * S bytes apart, and with 8 long chunks per table the ~512 resident blocks spread over 64
+// tables = 2048 concurrent DRAM streams, whose bandwidth then depends on where the allocation's pages happen to sit
+// (5.3 / 5.8 / 6.1+ TB/s "modes", fixed per allocation; profiles/r02/c_fold_blocks_sweep.txt).  With 128 short
+// chunks per table (256 entries = one 64-entry tile per wave) the same blocks cover 4 tables, and every placement
+// runs at the fast rate (6.1 - 6.5 TB/s in 13 of 13 allocations).  Hence: as many blocks as chunks of
+// GKR_FOLD_MIN_CHUNK (default 256) entries allow, up to GKR_FOLD_BLOCKS (default 65536) over the batch.
 uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch) {
     static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
     if (off) return mle_pass_blocks(S, jout, batch);
-    static const uint32_t target = [] { const char* e = getenv("GKR_FOLD_BLOCKS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1024u; }();
+    static const uint32_t target = [] { const char* e = getenv("GKR_FOLD_BLOCKS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u; }();
+    static const uint32_t min_chunk = [] {
+        const char* e = getenv("GKR_FOLD_MIN_CHUNK");
+        const uint32_t v = e ? (uint32_t)atoi(e) : 256u;
+        return v >= 64u && (v & (v - 1u)) == 0 ? v : 256u;
+    }();
     uint32_t b = 1u << jout;
-    while ((uint64_t)b * batch < target && S / (2u * b) >= 256u && 2u * b <= kMaxBlocksPerTable) b <<= 1;
+    while ((uint64_t)b * batch < target && S / (2u * b) >= min_chunk && 2u * b <= kMaxBlocksPerTable) b <<= 1;
     if (b > S) b = S;
     return b;
 }
