@@ -145,16 +145,16 @@ inline int hash_chunk_size(int tables, int threads) {
     return tables >= 32 * threads ? 16 : 8;
 }
 
-// Device allocations of the library.  Large buffers (the table batches) are built with the virtual-memory API: a
-// virtual range ALIGNED to kVmmAlign backed by physical handles of kVmmChunk bytes each.  Why: the streaming kernels'
-// bandwidth depends on how an allocation is mapped -- a plain hipMalloc of 8 GiB comes back 2 MiB-aligned and lands
-// in one of several "modes" (fold pass 5.3 / 5.8 / 6.1+ TB/s, decided at allocation time and fixed for its lifetime;
-// DESIGN.md section 4), because the page-table fragment a translation covers can be no larger than the alignment the
-// virtual and the physical side share, and a sweep over many GiB with small fragments lives on page walks.
-//   GKR_ALLOC_MODE=malloc      plain hipMalloc for everything (the round-1 behaviour)
+// Device allocations of the library: plain hipMalloc.  Two experiment modes stay behind GKR_ALLOC_MODE because the
+// question they answered may come back on other driver versions: whether the streaming kernels' bandwidth depends
+// on how an allocation is mapped (it seemed to: round 1's "allocation modes").  Measured in round 2
+// (profiles/r02/c_placement_map_modes.txt): hipMemAddressReserve does not honour an alignment above 2 MiB here,
+// physical handles of 2 MiB / 64 MiB / 1 GiB / 8 GiB behave like hipMalloc, and the modes were a property of the
+// fold kernel's launch geometry, not of the mapping (kernels.hip, mle_multifold_blocks).
+//   GKR_ALLOC_MODE=malloc      (default) hipMalloc
 //   GKR_ALLOC_MODE=contiguous  hipExtMallocWithFlags(hipDeviceMallocContiguous)
-//   GKR_ALLOC_MODE=vmm         (default for >= kVmmMin bytes) aligned virtual range + large physical chunks
-//   GKR_VMM_ALIGN_LOG2 / GKR_VMM_CHUNK_LOG2   experiment knobs (defaults 30 / 30: 1 GiB)
+//   GKR_ALLOC_MODE=vmm         buffers >= 256 MiB: reserved virtual range + physical handles of
+//                              2^GKR_VMM_CHUNK_LOG2 bytes (default 1 GiB), alignment request 2^GKR_VMM_ALIGN_LOG2
 struct VmmAllocation {
     size_t size = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
@@ -167,10 +167,9 @@ inline int alloc_mode() {   // 0 malloc, 1 contiguous, 2 vmm
     static const int mode = [] {
         if (getenv("GKR_ALLOC_CONTIGUOUS")) return 1;
         const char* e = getenv("GKR_ALLOC_MODE");
-        if (!e) return 2;
-        if (!strcmp(e, "malloc")) return 0;
+        if (!e || !strcmp(e, "malloc")) return 0;
         if (!strcmp(e, "contiguous")) return 1;
-        return 2;
+        return !strcmp(e, "vmm") ? 2 : 0;
     }();
     return mode;
 }
