@@ -263,32 +263,39 @@ def aggregated_proofs(world, n_inputs):
     step = ProvingStep(r1cs)
     compile_ms = (time.perf_counter() - t0) * 1e3
     subs = len(step.circuits)
-    ctx = Context(world.local_rank)
+    cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    ctxs = ProvingStep.contexts_for(world.local_rank, cpus, limit=subs)
+    ctx = ctxs[0]
     out = {"circuit": "R1CS equivalent to rust/t.circom (MiMC7-91, 364 constraints) -> %d layered circuits, k lists %s"
                       % (subs, [c.get_k_list() for c in step.circuits]),
            "compile_ms": compile_ms, "proof": "one prover::prove call (one sub-circuit of one input)",
-           "how": "gkr_prove_batch per sub-circuit: the proofs of all inputs advance together (one round trip per round)"}
+           "how": "gkr_prove_batch per sub-circuit (the proofs of all inputs advance together, one round trip per round), "
+                  "%d sub-circuits in flight at a time from %d contexts / host threads (the reference's par_iter over the "
+                  "(circuit, input) pairs)" % (len(ctxs), len(ctxs)),
+           "contexts": len(ctxs), "cpus_per_rank": cpus}
 
     def measure(witnesses, reps):
         inputs = step.inputs_for(np.stack([as_limbs(w) for w in witnesses])) if witnesses else None
         if inputs is not None:
-            step.prove_raw(ctx, inputs)     # warm-up: code objects, workspaces
+            for _ in range(2):
+                step.prove_raw_concurrent(ctxs, inputs)     # warm-up: code objects, workspaces, circuit caches
         world.barrier(ctx)
         t = time.perf_counter()
         for _ in range(reps):
             if inputs is not None:
-                step.prove_raw(ctx, inputs)
+                step.prove_raw_concurrent(ctxs, inputs)
         world.barrier(ctx)
         return world.max_over_ranks((time.perf_counter() - t) / reps)
     ex = [synth.mimc7_demo_witness(a, b) for a, b in synth.EXAMPLE_INPUTS]
-    dt3 = measure(ex if world.rank == 0 else [], 3)     # configs[0] is one rank's work
+    dt3 = measure(ex if world.rank == 0 else [], 5)     # configs[0] is one rank's work
     mine = parallel.shard_units(n_inputs, world.rank, world.size)
-    dt = measure([synth.mimc7_demo_witness(2 + i, 3 + (i % 5)) for i in mine], 3)
+    dt = measure([synth.mimc7_demo_witness(2 + i, 3 + (i % 5)) for i in mine], 5)
     out["config0_three_inputs"] = {"inputs": 3, "proofs": 3 * subs, "ms": dt3 * 1e3, "proofs_per_sec": 3 * subs / dt3}
     out["config3"] = {"inputs": n_inputs, "inputs_per_rank": [len(parallel.shard_units(n_inputs, r, world.size)) for r in range(world.size)],
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt}
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
-    ctx.close()
+    for c in ctxs:
+        c.close()
     step.close()
     return out
 
@@ -303,12 +310,14 @@ def run_proofs(args, world):
     step_obj = ProvingStep(synth.mimc7_demo_r1cs())
     subs = len(step_obj.circuits)
     mine = parallel.shard_units(args.proofs, world.rank, world.size)
-    ctx = Context(world.local_rank)
+    cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    ctxs = ProvingStep.contexts_for(world.local_rank, cpus, limit=subs)
+    ctx = ctxs[0]
     inputs = step_obj.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in mine])) if len(mine) else None
 
     def step():
         if inputs is not None:
-            step_obj.prove_raw(ctx, inputs)
+            step_obj.prove_raw_concurrent(ctxs, inputs)
     elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
     if world.rank == 0:
         print(json.dumps({
@@ -318,9 +327,11 @@ def run_proofs(args, world):
             "config": {"workload": "BASELINE configs[3]: %d inputs of the t.circom-equivalent R1CS, %d layered circuits each, "
                                    "inputs split over the ranks, no collective" % (args.proofs, subs),
                        "inputs_per_rank": [len(parallel.shard_units(args.proofs, r, world.size)) for r in range(world.size)],
-                       "proof": "one prover::prove call (one sub-circuit of one input)"},
+                       "proof": "one prover::prove call (one sub-circuit of one input)",
+                       "contexts_per_rank": len(ctxs), "cpus_per_rank": cpus},
             "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     step_obj.close()
 
 

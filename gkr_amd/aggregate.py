@@ -163,6 +163,49 @@ class ProvingStep:
     def prove_raw(self, ctx, inputs):
         return [ctx.prove_batch_raw(c, x) for c, x in zip(self.circuits, inputs)]
 
+    def prove_raw_concurrent(self, ctxs, inputs):
+        """The sub-circuits proven from len(ctxs) threads, one context each (the reference's par_iter over the
+        (circuit, input) pairs, aggregator.rs:350-355): a layer round is latency-bound (launch, tiny kernel, hand-off,
+        hash), so independent sub-circuits in flight together fill each other's gaps.  Sub-circuits are dealt out
+        largest first."""
+        import threading
+        order = sorted(range(len(self.circuits)), key=lambda j: -sum(self.circuits[j].get_k_list()))
+        out, errs, lock = [None] * len(self.circuits), [], threading.Lock()
+
+        def work(ctx):
+            while True:
+                with lock:
+                    if not order or errs:
+                        return
+                    j = order.pop(0)
+                try:
+                    out[j] = ctx.prove_batch_raw(self.circuits[j], inputs[j])
+                except Exception as e:
+                    errs.append(e)
+                    return
+        threads = [threading.Thread(target=work, args=(c,)) for c in ctxs[1:]]
+        for t in threads:
+            t.start()
+        work(ctxs[0])
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    @staticmethod
+    def contexts_for(device, cpus, limit=12):
+        """One context per concurrently proven sub-circuit, sized to the CPUs this process may use: every context's
+        calling thread spins on its rounds' hand-off records, so contexts + workers must not exceed the cores
+        (two are left to the runtime's own threads).  -> list of Context."""
+        from .prover import Context
+        n = max(1, min(limit, cpus - 2))
+        each = max(1, (cpus - 2) // n)
+        ctxs = [Context(device) for _ in range(n)]
+        for c in ctxs:
+            c.set_host_threads(each)
+        return ctxs
+
     def close(self):
         self._layered.close()
 

@@ -278,7 +278,10 @@ int default_host_threads() {
     int cpus = usable_cpus();
     int local = 1;   // one process per GPU: share the host cores between the ranks of this node
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) local = atoi(e) > 0 ? atoi(e) : 1;
-    int t = cpus / local - 2;   // leave room for the HIP runtime's own threads and the interpreter
+    // leave room for the HIP runtime's own threads and the interpreter -- unless the rank's share is so small that
+    // the transcript needs all of it (a rank of the 2^20 workload needs ~2 hashing threads to keep its GPU fed)
+    const int share = cpus / local;
+    int t = share >= 6 ? share - 2 : (share >= 3 ? share - 1 : share);
     if (t < 1) t = 1;
     if (t > 64) t = 64;
     return t;
@@ -304,8 +307,39 @@ bool all_canonical(const gkr_fr* v, size_t n) {
 
 }  // namespace
 
+// Gate arrays of a circuit kept on the device across gkr_prove / gkr_prove_batch calls, with each layer's gate
+// lists (the counting sort by left / right operand the linear-time layer sumcheck sums over): they depend only on
+// the circuit, and an aggregation step proves the same <= 20 circuits for input after input.
+struct GateLists {
+    uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
+    bool ready = false;
+};
+struct PreparedCircuit {
+    uint64_t h1 = 0, h2 = 0;
+    std::vector<uint32_t> k;
+    std::vector<uint8_t*> gt;
+    std::vector<uint32_t*> l, r;
+    std::vector<GateLists> lists;
+    void release() {
+        for (auto p : gt) (void)hipFree(p);
+        for (auto p : l) (void)hipFree(p);
+        for (auto p : r) (void)hipFree(p);
+        for (auto& g : lists) {
+            if (g.offsets) (void)hipFree(g.offsets);
+            if (g.cursor) (void)hipFree(g.cursor);
+            if (g.list) (void)hipFree(g.list);
+        }
+        gt.clear();
+        l.clear();
+        r.clear();
+        lists.clear();
+    }
+};
+
 struct gkr_ctx {
     int device = 0;
+    int host_threads = 0;                      // 0: from GKR_HOST_THREADS / the usable CPUs; else this many (caller included)
+    std::vector<std::unique_ptr<PreparedCircuit>> circuits;   // most recently used last; bounded
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
     std::vector<hipEvent_t> aux_events;        // one per group of a batch: "the side kernel of this group is done"
@@ -351,6 +385,8 @@ struct gkr_ctx {
         return hipSuccess;
     }
     void release_buffers() {
+        for (auto& c : circuits) c->release();
+        circuits.clear();
         for (auto& kv : ws)
             if (kv.second.first) (void)device_free(kv.second.first);
         ws.clear();
@@ -358,8 +394,9 @@ struct gkr_ctx {
             if (kv.second.first) (void)hipHostFree(kv.second.first);
         pinned.clear();
     }
+    int threads() const { return host_threads > 0 ? host_threads : default_host_threads(); }
     gkr::SpinPool* host_pool() {
-        if (!pool) pool.reset(new gkr::SpinPool(default_host_threads() - 1));
+        if (!pool) pool.reset(new gkr::SpinPool(threads() - 1));
         return pool.get();
     }
     hipError_t aux_stream(int events) {
@@ -1170,7 +1207,7 @@ struct LayerShardArgs {
 
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                     const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
-                    const LayerShardArgs* shard = nullptr) {
+                    const LayerShardArgs* shard = nullptr, GateLists* cached = nullptr) {
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
@@ -1226,18 +1263,34 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     if (sparse) {
         uint32_t *g_counts = nullptr, *g_bsums = nullptr;
         const size_t nb2 = (size_t)2 << k;
-        WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
-        WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
-        WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
-        WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
-        WS(ctx, "gates.list", uint32_t, 2 * span.count + 1, g_list);
         WS(ctx, "pred.bad", uint32_t, 1, bad);
         rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
-        HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
-        Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
-        gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
+        if (cached && cached->ready) {
+            g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
+            g_cursor = cached->cursor;
+            g_list = cached->list;
+        } else {
+            WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
+            WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
+            if (cached) {
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), (2 * span.count + 1) * sizeof(uint32_t)));
+                g_offsets = cached->offsets;
+                g_cursor = cached->cursor;
+                g_list = cached->list;
+            } else {
+                WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
+                WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
+                WS(ctx, "gates.list", uint32_t, 2 * span.count + 1, g_list);
+            }
+            HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
+            Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
+            gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
+            if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
+        }
     } else {
         rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
         if (rc) return rc;
@@ -1508,38 +1561,49 @@ void mobius_msb(std::vector<gkr::h64::F>& c, int k) {
 }
 
 // reduce_multiple_polynomial (poly.rs:469-500): q(t) = W(b + t (c - b)).
-// coeffs: monomial coefficients of W.  out: k+1 slots right-aligned, highest first.
-void line_restriction(const std::vector<gkr::h64::F>& coeffs, int k, const gkr_fr* b, const gkr_fr* c, gkr_fr* out,
-                      uint32_t* out_len) {
+// vals: the evaluation table of W (canonical); coeffs: its monomial coefficients (only their support is used).
+// out: k+1 slots right-aligned, highest first; *out_len = 1 + the largest total degree of a non-zero monomial of W
+// (:484-497).  The reference expands every monomial along the line (2^k products of up to k linear factors); the
+// same polynomial comes out of binding the variables one after the other on the evaluation table with the linear
+// polynomial l_j(t) = b_j + t (c_j - b_j) in place of a challenge:
+//     P'[i](t) = P[i](t) + l_j(t) (P[i + h](t) - P[i](t)),
+// entries being coefficient vectors in t whose degree grows by one per variable -- about 4 * 2^k products instead
+// of ~k^2 * 2^(k-1), and the coefficients above the largest monomial degree come out as the zeros they are.
+void line_restriction(const std::vector<gkr::h64::F>& vals, const std::vector<gkr::h64::F>& coeffs, int k, const gkr_fr* b,
+                      const gkr_fr* c, gkr_fr* out, uint32_t* out_len) {
     using gkr::h64::F;
     const F zero = {{0, 0, 0, 0}};
-    std::vector<F> grad(k), cst(k), res(k + 1, zero), poly(k + 2);
-    for (int j = 0; j < k; ++j) {
+    int maxdeg = 0;
+    const size_t n = (size_t)1 << k;
+    for (size_t mono = 0; mono < n; ++mono)
+        if (!gkr::h64::is_zero(coeffs[mono])) {
+            const int deg = __builtin_popcountll((unsigned long long)mono);
+            if (deg > maxdeg) maxdeg = deg;
+        }
+    // table of polynomials, stride k + 1 coefficients (lowest degree first); canonical values, Montgomery multipliers
+    const size_t stride = (size_t)k + 1;
+    std::vector<F> tab(n * stride, zero);
+    for (size_t i = 0; i < n; ++i) tab[i * stride] = vals[i];
+    size_t h = n >> 1;
+    for (int j = 0; j < k; ++j, h >>= 1) {
         F bj, cj;
         memcpy(&bj, &b[j], 32);
         memcpy(&cj, &c[j], 32);
-        grad[j] = gkr::h64::to_mont(gkr::h64::sub(cj, bj));
-        cst[j] = gkr::h64::to_mont(bj);
-    }
-    int maxdeg = 0;
-    const size_t n = (size_t)1 << k;
-    for (size_t mono = 0; mono < n; ++mono) {
-        if (gkr::h64::is_zero(coeffs[mono])) continue;
-        int deg = 0;
-        poly[0] = coeffs[mono];
-        for (int j = 0; j < k; ++j) {
-            if (!((mono >> (k - 1 - j)) & 1)) continue;
-            poly[deg + 1] = zero;
-            for (int d = deg + 1; d >= 1; --d)
-                poly[d] = gkr::h64::add(gkr::h64::mont_mul(poly[d - 1], grad[j]), gkr::h64::mont_mul(poly[d], cst[j]));
-            poly[0] = gkr::h64::mont_mul(poly[0], cst[j]);
-            ++deg;
+        const F grad = gkr::h64::to_mont(gkr::h64::sub(cj, bj)), cst = gkr::h64::to_mont(bj);
+        for (size_t i = 0; i < h; ++i) {
+            F* lo = &tab[i * stride];
+            const F* hi = &tab[(i + h) * stride];
+            F carry = zero;   // grad * d[m - 1]
+            for (int m = 0; m <= j + 1; ++m) {
+                const F d = m <= j ? gkr::h64::sub(hi[m], lo[m]) : zero;
+                const F v = gkr::h64::add(gkr::h64::add(m <= j ? lo[m] : zero, gkr::h64::mont_mul(d, cst)), carry);
+                carry = gkr::h64::mont_mul(d, grad);
+                lo[m] = v;
+            }
         }
-        if (deg > maxdeg) maxdeg = deg;
-        for (int d = 0; d <= deg; ++d) res[d] = gkr::h64::add(res[d], poly[d]);
     }
     *out_len = (uint32_t)(maxdeg + 1);
-    for (int d = 0; d <= k; ++d) memcpy(&out[k - d], &res[d], 32);
+    for (int d = 0; d <= k; ++d) memcpy(&out[k - d], &tab[d], 32);
 }
 
 int check_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c) {
@@ -1622,6 +1686,15 @@ const char* gkr_last_error(const gkr_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int gkr_ctx_set_transcript(gkr_ctx* ctx, int mode) {
     if (!ctx || (mode != GKR_TRANSCRIPT_DEVICE && mode != GKR_TRANSCRIPT_HOST)) return GKR_ERR_INVALID;
     ctx->transcript = mode;
+    return GKR_OK;
+}
+
+int gkr_ctx_set_host_threads(gkr_ctx* ctx, int threads) {
+    if (!ctx || threads < 0 || threads > 256) return GKR_ERR_INVALID;
+    if (threads != ctx->host_threads) {
+        ctx->pool.reset();   // joins the workers; the next call that needs them starts the new number
+        ctx->host_threads = threads;
+    }
     return GKR_OK;
 }
 
@@ -1815,6 +1888,20 @@ int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
         }
     }
     *out = to_abi(r);
+    return GKR_OK;
+}
+
+// q(t) = W(b + t (c - b)) the way gkr_prove computes it on the host (Moebius transform for the length, variable-by-
+// variable binding for the coefficients); out: k + 1 slots right-aligned
+int gkr_selftest_line_restriction(int k, const gkr_fr* W, const gkr_fr* b, const gkr_fr* c, gkr_fr* out, uint32_t* out_len) {
+    if (k < 1 || k > 20 || !W || !b || !c || !out || !out_len) return GKR_ERR_INVALID;
+    const size_t n = (size_t)1 << k;
+    if (!all_canonical(W, n) || !all_canonical(b, k) || !all_canonical(c, k)) return GKR_ERR_NON_CANONICAL;
+    std::vector<gkr::h64::F> vals(n);
+    memcpy(vals.data(), W, n * 32);
+    std::vector<gkr::h64::F> co(vals);
+    mobius_msb(co, k);
+    line_restriction(vals, co, k, b, c, out, out_len);
     return GKR_OK;
 }
 
@@ -2060,36 +2147,105 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
     }
     const uint32_t L = c->depth;
-    for (uint32_t i = 0; i < L; ++i) {
+    for (uint32_t i = 0; i < L; ++i)
         if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
-        const size_t gates = (size_t)1 << c->k[i];
-        for (size_t g = 0; g < gates; ++g)
-            if (c->gate_type[i][g] > 1 || (c->left[i][g] >> c->k[i + 1]) || (c->right[i][g] >> c->k[i + 1]))
-                return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
-    }
     const size_t n_in = (size_t)1 << c->k[L];
     if (!all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
-    // upload the circuit; forward-evaluate every layer of every proof on the device (calculate_input, convert.rs:787-831)
-    std::vector<DevBuf<uint8_t>> dgt(L);
-    std::vector<DevBuf<uint32_t>> dl(L), dr(L);
-    std::vector<DevBuf<Fr>> dW(L + 1);
+    // the circuit on the device: from the context's cache when this circuit was proven before (two independent
+    // 64-bit hashes over the k list and the gate arrays decide), else validated, uploaded and remembered
+    uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x9E3779B97F4A7C15ULL;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* q = static_cast<const unsigned char*>(p);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, q + i, 8);
+            h1 = (h1 ^ w) * 0x100000001b3ULL;
+            h2 = (h2 + w) * 0xBF58476D1CE4E5B9ULL;
+            h2 ^= h2 >> 29;
+        }
+        for (; i < n; ++i) {
+            h1 = (h1 ^ q[i]) * 0x100000001b3ULL;
+            h2 = (h2 + q[i]) * 0x94D049BB133111EBULL;
+        }
+    };
+    mix(&L, sizeof L);
+    mix(c->k, (L + 1) * sizeof(uint32_t));
     for (uint32_t i = 0; i < L; ++i) {
-        rc = upload_gates(ctx, (size_t)1 << c->k[i], c->gate_type[i], c->left[i], c->right[i], dgt[i], dl[i], dr[i]);
-        if (rc) return rc;
-        HIP_TRY(ctx, dW[i].alloc((size_t)batch << c->k[i]));
+        const size_t gates = (size_t)1 << c->k[i];
+        mix(c->gate_type[i], gates);
+        mix(c->left[i], gates * 4);
+        mix(c->right[i], gates * 4);
     }
-    HIP_TRY(ctx, dW[L].alloc(n_in * batch));
-    HIP_TRY(ctx, hipMemcpyAsync(dW[L].p, input_values, n_in * batch * sizeof(Fr), hipMemcpyHostToDevice, s));
+    PreparedCircuit* pc = nullptr;
+    for (size_t i = 0; i < ctx->circuits.size(); ++i)
+        if (ctx->circuits[i]->h1 == h1 && ctx->circuits[i]->h2 == h2 && ctx->circuits[i]->k.size() == L + 1 &&
+            memcmp(ctx->circuits[i]->k.data(), c->k, (L + 1) * sizeof(uint32_t)) == 0) {
+            std::unique_ptr<PreparedCircuit> hit = std::move(ctx->circuits[i]);
+            ctx->circuits.erase(ctx->circuits.begin() + i);
+            ctx->circuits.push_back(std::move(hit));   // most recently used last
+            pc = ctx->circuits.back().get();
+            break;
+        }
+    static const bool no_cache = getenv("GKR_NO_CIRCUIT_CACHE") != nullptr;
+    std::unique_ptr<PreparedCircuit> fresh;
+    struct DropFresh {   // an uncached or failed circuit's device arrays do not outlive the call
+        gkr_ctx* ctx;
+        std::unique_ptr<PreparedCircuit>& p;
+        ~DropFresh() {
+            if (p) {
+                (void)hipStreamSynchronize(ctx->stream);
+                p->release();
+            }
+        }
+    } drop_fresh{ctx, fresh};
+    if (!pc) {
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t gates = (size_t)1 << c->k[i];
+            for (size_t g = 0; g < gates; ++g)
+                if (c->gate_type[i][g] > 1 || (c->left[i][g] >> c->k[i + 1]) || (c->right[i][g] >> c->k[i + 1]))
+                    return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+        }
+        fresh.reset(new PreparedCircuit());
+        fresh->h1 = h1;
+        fresh->h2 = h2;
+        fresh->k.assign(c->k, c->k + L + 1);
+        fresh->lists.resize(L);
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t gates = (size_t)1 << c->k[i];
+            uint8_t* dg = nullptr;
+            uint32_t *dl_ = nullptr, *dr_ = nullptr;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dg), gates));
+            fresh->gt.push_back(dg);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dl_), gates * 4));
+            fresh->l.push_back(dl_);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dr_), gates * 4));
+            fresh->r.push_back(dr_);
+            HIP_TRY(ctx, hipMemcpyAsync(dg, c->gate_type[i], gates, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(dl_, c->left[i], gates * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(dr_, c->right[i], gates * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(s));   // the caller's gate arrays may go away after the call
+        pc = fresh.get();
+    }
+
+    // forward-evaluate every layer of every proof on the device (calculate_input, convert.rs:787-831)
+    std::vector<Fr*> dW(L + 1, nullptr);
+    for (uint32_t i = 0; i <= L; ++i) {
+        const std::string slot = "prove.W" + std::to_string(i);
+        HIP_TRY(ctx, ctx->workspace(slot.c_str(), ((size_t)batch << c->k[i]) * sizeof(Fr), reinterpret_cast<void**>(&dW[i])));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, n_in * batch * sizeof(Fr), hipMemcpyHostToDevice, s));
     for (int i = (int)L - 1; i >= 0; --i)
-        gkr::launch_layer_eval(1u << c->k[i], dgt[i].p, dl[i].p, dr[i].p, dW[i + 1].p, dW[i].p, (uint32_t)batch, 1u << c->k[i + 1], s);
+        gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<std::vector<F>> hW(L + 1);
     for (uint32_t i = 0; i <= L; ++i) {
         hW[i].resize((size_t)batch << c->k[i]);
-        HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i].p, sizeof(Fr) * hW[i].size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i], sizeof(Fr) * hW[i].size(), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     for (int b = 0; b < batch; ++b) {
@@ -2118,8 +2274,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             slp[b] = outs[b].sumcheck_len + row_off;
             srp[b] = outs[b].sumcheck_r + row_off;
         }
-        rc = run_layer_batch(ctx, batch, k_i, k, dgt[i].p, dl[i].p, dr[i].p, z_cur.data(), dW[i + 1].p, scp.data(), slp.data(),
-                             srp.data());
+        rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
+                             srp.data(), nullptr, &pc->lists[i]);
         if (rc) return rc;
         std::vector<gkr_fr> z_next((size_t)batch * k);
         auto finish = [&](int b) {
@@ -2127,9 +2283,10 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             const gkr_fr* b_star = sr;
             const gkr_fr* c_star = sr + k;
             // q_i = W_{i+1} restricted to the line b* -> c* (prover.rs:70)
-            std::vector<F> co(hW[i + 1].begin() + ((size_t)b << k), hW[i + 1].begin() + ((size_t)(b + 1) << k));
+            const std::vector<F> vals(hW[i + 1].begin() + ((size_t)b << k), hW[i + 1].begin() + ((size_t)(b + 1) << k));
+            std::vector<F> co(vals);
             mobius_msb(co, k);
-            line_restriction(co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
+            line_restriction(vals, co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
             // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector and key as the
             // sumcheck's last challenge, so it is that challenge
             const gkr_fr r_star = sr[2 * k - 1];
@@ -2165,6 +2322,14 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         row_off += (size_t)2 * k;
         q_off += (size_t)k + 1;
         z_off += (size_t)k_i;
+    }
+    if (fresh && !no_cache) {
+        constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
+        if (ctx->circuits.size() >= kMaxCachedCircuits) {
+            ctx->circuits.front()->release();
+            ctx->circuits.erase(ctx->circuits.begin());
+        }
+        ctx->circuits.push_back(std::move(fresh));
     }
     return GKR_OK;
 }

@@ -147,6 +147,10 @@ class Context:
     def set_transcript(self, mode):
         self._check(N.lib().gkr_ctx_set_transcript(self._h, ctypes.c_int(mode)))
 
+    def set_host_threads(self, threads):
+        """Host threads the context may use for the transcript, the caller included (0 = default)."""
+        self._check(N.lib().gkr_ctx_set_host_threads(self._h, ctypes.c_int(threads)))
+
     def profile(self, enable=True):
         """0/False off, 1/True every kernel, 2 the bandwidth-bound kernels only (see gkr_amd.h)."""
         self._check(N.lib().gkr_ctx_profile(self._h, ctypes.c_int(int(enable))))

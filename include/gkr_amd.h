@@ -87,6 +87,11 @@ int  gkr_ctx_create(int device_id, gkr_ctx **out);
 void gkr_ctx_destroy(gkr_ctx *ctx);
 const char *gkr_last_error(const gkr_ctx *ctx);
 int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
+/* Host threads this context may keep busy with the transcript (the calling thread included); 0 = the default:
+ * GKR_HOST_THREADS, else (CPUs of the affinity mask and cgroup quota) / LOCAL_WORLD_SIZE - 2.  A process that drives
+ * several contexts from several threads (the reference proves its <= 20 sub-circuits from a rayon par_iter,
+ * aggregator.rs:350-355) gives each context its share; 1 = hash on the calling thread, no workers. */
+int  gkr_ctx_set_host_threads(gkr_ctx *ctx, int threads);
 int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
 
 /* Per-kernel timing with HIP events on the stream each kernel is launched on (bench.py's
@@ -118,6 +123,9 @@ int  gkr_selftest_dot(const gkr_fr *a, const gkr_fr *b, size_t n, gkr_fr *out);
 /* the pass schedule of a 2^n-point plain sumcheck (host logic): rounds covered by each pass; mfma = 1 default
  * (up to 5 rounds per pass), 0 the v_mad_u64_u32 fold's (up to 3).  *passes = number of passes. */
 int  gkr_selftest_pass_schedule(int n, int mfma, uint32_t *rounds, size_t capacity, size_t *passes);
+/* q(t) = W(b + t (c - b)) (reduce_multiple_polynomial, poly.rs:469-500) as gkr_prove computes it on the host: W = 2^k
+ * evaluations; out = k + 1 slots right-aligned, highest degree first; *out_len = 1 + largest monomial degree of W */
+int  gkr_selftest_line_restriction(int k, const gkr_fr *W, const gkr_fr *b, const gkr_fr *c, gkr_fr *out, uint32_t *out_len);
 /* lo + r (hi - lo) through the fixed-multiplier table the fold kernels use */
 int  gkr_selftest_fold(const gkr_fr *lo, const gkr_fr *hi, const gkr_fr *r, gkr_fr *out);
 

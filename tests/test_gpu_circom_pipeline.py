@@ -88,3 +88,23 @@ def test_config3_sixty_four_inputs_of_the_demo_circuit(ctx):
             assert _same_proof(proofs[w][j], cdense.prove(sub["layers"], sub["input_values"])), (w, j)
     for w in range(0, 64, 8):
         assert all(verify(proofs[w][j], circuits[j]) for j in range(12)), w
+
+
+def test_concurrent_contexts_prove_the_same_transcripts(ctx):
+    """The sub-circuits proven from several contexts at once (the reference's par_iter over the pairs,
+    aggregator.rs:350-355), twice (second time from the cached circuits): same challenges as one context in turn."""
+    import numpy as np
+    from gkr_amd.aggregate import ProvingStep
+    from gkr_amd.field import as_limbs
+    step = ProvingStep(synth.mimc7_demo_r1cs())
+    inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(5 + i, i)) for i in range(20)]))
+    want = step.prove_raw(ctx, inputs)
+    ctxs = ProvingStep.contexts_for(0, 8)
+    try:
+        for _ in range(2):
+            got = step.prove_raw_concurrent(ctxs, inputs)
+            assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    finally:
+        for c in ctxs:
+            c.close()
+        step.close()

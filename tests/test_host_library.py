@@ -249,3 +249,26 @@ def test_gate_ranges_partition_the_layer():
         spans = [parallel.gate_range(k_i, r, world) for r in range(world)]
         assert spans[0][0] == 0 and sum(c for _, c in spans) == 1 << k_i
         assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7])
+def test_line_restriction_by_binding_equals_the_monomial_expansion(k):
+    """q(t) = W(b + t (c - b)) (reduce_multiple_polynomial, poly.rs:469-500): the library binds the variables one by
+    one on the evaluation table; the oracle expands every monomial as the reference does.  Same coefficients, same
+    length (1 + largest degree of a stored monomial), also when W lacks variables or is constant."""
+    from oracle import dense
+    rng = random.Random(50 + k)
+    n = 1 << k
+    tables = [[rng.randrange(P) for _ in range(n)], [7] * n, [0] * n, [(i >> (k - 1)) + 3 for i in range(n)],
+              [bin(i).count("1") % 2 for i in range(n)], [rng.randrange(3) for _ in range(n)]]
+    for w in tables:
+        b = [rng.randrange(P) for _ in range(k)]
+        c = [rng.randrange(P) for _ in range(k)]
+        out = np.zeros((k + 1, 4), dtype=np.uint64)
+        ln = ctypes.c_uint32()
+        rc = N.lib().gkr_selftest_line_restriction(ctypes.c_int(k), _p(to_limbs(w)), _p(to_limbs(b)), _p(to_limbs(c)), _p(out),
+                                                  ctypes.byref(ln))
+        assert rc == 0
+        want = dense.line_restriction(b, c, w, k)
+        got = from_limbs(out)
+        assert got[k + 1 - ln.value:] == want and all(v == 0 for v in got[:k + 1 - ln.value])
