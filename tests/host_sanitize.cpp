@@ -1,0 +1,210 @@
+// Host-only units of the product under AddressSanitizer + UBSan (gkr_amd/csrc/Makefile, targets `asan`): the R1CS /
+// witness containers and the R1CS -> layered-circuit compiler (r1cs.cpp), the proof -> verifier.circom text
+// (circom_input.cpp), keccak-256 and the MiMC7 constants (keccak.cpp), the 8/16-lane IFMA MiMC7 (mimc_ifma.cpp),
+// driven through the C ABI with valid, ragged and hostile inputs.  Sanitizers cannot run on the GPU box's device
+// code; this is the CPU side.  Exit status 0 and no sanitizer report = pass.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../include/gkr_amd.h"
+#include "../gkr_amd/csrc/fr64.h"
+#include "../gkr_amd/csrc/keccak.h"
+#include "../gkr_amd/csrc/mimc7.h"
+#include "../gkr_amd/csrc/mimc_ifma.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            printf("CHECK failed line %d: %s\n", __LINE__, #cond);      \
+            ++failures;                                                  \
+        }                                                                \
+    } while (0)
+
+static const uint64_t kMod[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+
+static gkr_fr small(uint64_t v) { return gkr_fr{{v, 0, 0, 0}}; }
+static gkr_fr minus_one() { return gkr_fr{{kMod[0] - 1, kMod[1], kMod[2], kMod[3]}}; }
+
+static void r1cs_round_trips(std::mt19937_64& rng) {
+    for (int trial = 0; trial < 40; ++trial) {
+        const uint32_t n_wires = 2 + rng() % 40;
+        const size_t n_cons = 1 + rng() % 60;
+        std::vector<uint32_t> counts, wires;
+        std::vector<gkr_fr> coeffs;
+        for (size_t i = 0; i < n_cons; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t n = 1 + rng() % 5;
+                counts.push_back(n);
+                for (uint32_t t = 0; t < n; ++t) {
+                    wires.push_back((uint32_t)(rng() % n_wires));
+                    const int kind = rng() % 4;
+                    coeffs.push_back(kind == 0 ? small(1) : kind == 1 ? minus_one() : kind == 2 ? small(0) : gkr_fr{{rng(), rng(), rng(), rng() >> 4}});
+                }
+            }
+        gkr_r1cs* r = nullptr;
+        CHECK(gkr_r1cs_build(n_wires, 1, 1, n_wires > 3 ? n_wires - 3 : 0, n_cons, counts.data(), wires.data(), coeffs.data(), &r) == GKR_OK);
+        if (!r) continue;
+        size_t need = 0;
+        CHECK(gkr_r1cs_serialize(r, nullptr, 0, &need) == GKR_OK && need > 12);
+        std::vector<uint8_t> image(need);
+        CHECK(gkr_r1cs_serialize(r, image.data(), need - 1, &need) == GKR_ERR_NOMEM);
+        CHECK(gkr_r1cs_serialize(r, image.data(), need, &need) == GKR_OK);
+        gkr_r1cs* again = nullptr;
+        CHECK(gkr_r1cs_parse(image.data(), image.size(), &again) == GKR_OK);
+        gkr_r1cs_info_t a, b;
+        CHECK(gkr_r1cs_info(r, &a) == GKR_OK && gkr_r1cs_info(again, &b) == GKR_OK && a.n_terms == b.n_terms && a.n_constraints == n_cons);
+        // every truncation and a few corruptions of the image: a status, never an out-of-bounds read
+        for (size_t cut = 0; cut < image.size(); cut += 1 + image.size() / 97) {
+            gkr_r1cs* bad = nullptr;
+            const int rc = gkr_r1cs_parse(image.data(), cut, &bad);
+            CHECK(rc != GKR_OK || bad != nullptr);
+            gkr_r1cs_free(bad);
+        }
+        for (int c = 0; c < 60; ++c) {
+            std::vector<uint8_t> mut = image;
+            mut[rng() % mut.size()] ^= (uint8_t)(1u << (rng() % 8));
+            gkr_r1cs* bad = nullptr;
+            (void)gkr_r1cs_parse(mut.data(), mut.size(), &bad);
+            if (bad) {
+                gkr_layered* L = nullptr;
+                (void)gkr_r1cs_compile(bad, &L, nullptr);
+                gkr_layered_free(L);
+            }
+            gkr_r1cs_free(bad);
+        }
+        gkr_layered* L = nullptr;
+        size_t bad_idx = 0;
+        CHECK(gkr_r1cs_compile(again, &L, &bad_idx) == GKR_OK);
+        uint32_t n_circ = 0;
+        CHECK(gkr_layered_count(L, &n_circ) == GKR_OK && n_circ >= 1 && n_circ <= 20);
+        std::vector<gkr_fr> witness(n_wires);
+        for (auto& w : witness) w = gkr_fr{{rng(), rng(), rng(), rng() >> 4}};
+        for (uint32_t j = 0; j < n_circ; ++j) {
+            gkr_circuit_desc d;
+            CHECK(gkr_layered_circuit(L, j, &d) == GKR_OK);
+            for (uint32_t i = 0; i < d.depth; ++i)
+                for (size_t g = 0; g < ((size_t)1 << d.k[i]); ++g)
+                    CHECK(d.gate_type[i][g] <= 1 && (d.left[i][g] >> d.k[i + 1]) == 0 && (d.right[i][g] >> d.k[i + 1]) == 0);
+            size_t slots = 0;
+            CHECK(gkr_layered_input_layer(L, j, nullptr, nullptr, &slots) == GKR_OK && slots == ((size_t)1 << d.k[d.depth]));
+            std::vector<gkr_fr> vals(slots);
+            CHECK(gkr_layered_input_values(L, j, witness.data(), witness.size(), vals.data()) == GKR_OK);
+            CHECK(gkr_layered_input_values(L, j, witness.data(), 1, vals.data()) != GKR_OK || n_wires == 1);
+        }
+        CHECK(gkr_layered_circuit(L, n_circ, nullptr) == GKR_ERR_INVALID);
+        gkr_layered_free(L);
+        gkr_r1cs_free(again);
+        gkr_r1cs_free(r);
+    }
+    // witness container
+    std::vector<gkr_fr> vals(33);
+    for (auto& v : vals) v = gkr_fr{{rng(), rng(), rng(), rng() >> 4}};
+    size_t need = 0;
+    CHECK(gkr_wtns_serialize(vals.data(), vals.size(), nullptr, 0, &need) == GKR_OK);
+    std::vector<uint8_t> image(need);
+    CHECK(gkr_wtns_serialize(vals.data(), vals.size(), image.data(), need, &need) == GKR_OK);
+    std::vector<gkr_fr> back(33);
+    size_t count = 0;
+    CHECK(gkr_wtns_parse(image.data(), image.size(), back.data(), back.size(), &count) == GKR_OK && count == 33);
+    CHECK(memcmp(back.data(), vals.data(), 33 * 32) == 0);
+    CHECK(gkr_wtns_parse(image.data(), image.size(), back.data(), 32, &count) == GKR_ERR_NOMEM);
+    for (size_t cut = 0; cut < image.size(); cut += 7) (void)gkr_wtns_parse(image.data(), cut, back.data(), back.size(), &count);
+}
+
+static void circom_text(std::mt19937_64& rng) {
+    for (int trial = 0; trial < 30; ++trial) {
+        const uint32_t L = 1 + rng() % 4;
+        std::vector<uint32_t> k(L + 1);
+        for (auto& x : k) x = rng() % 5;
+        for (uint32_t i = 1; i <= L; ++i) k[i] = 1 + k[i] % 4;
+        size_t rounds = 0, qs = 0, zs = 0;
+        for (uint32_t i = 0; i < L; ++i) {
+            rounds += 2 * k[i + 1];
+            qs += k[i + 1] + 1;
+        }
+        for (uint32_t i = 0; i <= L; ++i) zs += k[i];
+        auto rnd = [&](size_t n) {
+            std::vector<gkr_fr> v(n ? n : 1);
+            for (auto& x : v) x = (rng() % 3 == 0) ? small(0) : gkr_fr{{rng(), rng(), rng(), rng() >> 4}};
+            return v;
+        };
+        std::vector<gkr_fr> sc = rnd(rounds * 3), sr = rnd(rounds), q = rnd(qs), z = rnd(zs), r = rnd(L), d = rnd((size_t)1 << k[0]),
+                            in = rnd((size_t)1 << k[L]);
+        std::vector<uint32_t> sl(rounds ? rounds : 1), ql(L);
+        for (auto& x : sl) x = 1 + rng() % 3;
+        for (uint32_t i = 0; i < L; ++i) ql[i] = 1 + rng() % (k[i + 1] + 1);
+        gkr_circuit_desc desc{L, k.data(), nullptr, nullptr, nullptr};
+        gkr_proof_buf p{sc.data(), sl.data(), sr.data(), q.data(), ql.data(), z.data(), r.data(), d.data(), in.data()};
+        std::vector<uint32_t> meta(8 + L + 1);
+        size_t count = 0;
+        CHECK(gkr_circom_meta(&desc, &p, meta.data(), meta.size(), &count) == GKR_OK && count == 8 + L + 1);
+        size_t need = 0;
+        CHECK(gkr_circom_input_json(&desc, &p, trial, nullptr, 0, &need) == GKR_OK);
+        std::string text(need, '\0');
+        CHECK(gkr_circom_input_json(&desc, &p, trial, &text[0], need, &need) == GKR_OK && text[0] == '{');
+        CHECK(gkr_circom_input_json(&desc, &p, trial, &text[0], need - 1, &need) == GKR_ERR_NOMEM);
+        const size_t len = count;
+        CHECK(gkr_circom_verifier_source(meta.data(), &len, 1, nullptr, 0, &need) == GKR_OK);
+        std::string src(need, '\0');
+        CHECK(gkr_circom_verifier_source(meta.data(), &len, 1, &src[0], need, &need) == GKR_OK);
+        const char* circuit = "pragma circom 2.0.0;\ntemplate A(){\n    signal input a;\n}\ncomponent main = A();\n";
+        CHECK(gkr_circom_inject(circuit, src.c_str(), nullptr, 0, &need) == GKR_OK);
+        std::string outc(need, '\0');
+        CHECK(gkr_circom_inject(circuit, src.c_str(), &outc[0], need, &need) == GKR_OK && outc.find("VerifyGKR(") != std::string::npos);
+        sl[0] = 9;   // malformed length: refused
+        if (rounds) CHECK(gkr_circom_meta(&desc, &p, meta.data(), meta.size(), &count) == GKR_ERR_INVALID);
+    }
+}
+
+static void hashes(std::mt19937_64& rng) {
+    uint8_t out[32];
+    gkr::keccak256(reinterpret_cast<const uint8_t*>(""), 0, out);
+    static const uint8_t empty[4] = {0xc5, 0xd2, 0x46, 0x01};
+    CHECK(memcmp(out, empty, 4) == 0);
+    std::vector<uint8_t> msg(500);
+    for (size_t n = 0; n < msg.size(); n += 17) gkr::keccak256(msg.data(), n, out);
+    gkr::Fr cts[gkr::kMimcRounds];
+    gkr::mimc7_make_constants(cts);
+    if (gkr::gkr_ifma_available()) {
+        static uint64_t canon[gkr::kMimcRounds][4];
+        for (int i = 0; i < gkr::kMimcRounds; ++i) {
+            gkr::h64::F m;
+            memcpy(&m, &cts[i], 32);
+            const gkr::h64::F c = gkr::h64::from_mont(m);
+            memcpy(canon[i], &c, 32);
+        }
+        gkr::gkr_ifma_init(canon);
+        uint64_t v[16][3][4], o8[8][4], o16[16][4];
+        uint32_t len[16];
+        for (int k = 0; k < 16; ++k) {
+            len[k] = rng() % 4;
+            for (int s = 0; s < 3; ++s) {
+                v[k][s][0] = rng();
+                v[k][s][1] = rng();
+                v[k][s][2] = rng();
+                v[k][s][3] = rng() >> 4;
+            }
+        }
+        gkr::gkr_ifma_multi_hash8(v, len, 3, o8);
+        gkr::gkr_ifma_multi_hash16(v, len, 3, o16);
+        CHECK(memcmp(o8, o16, sizeof o8) == 0);   // the first eight lanes agree between the two forms
+    } else {
+        printf("(no AVX-512 IFMA on this CPU: lane hash skipped)\n");
+    }
+}
+
+int main() {
+    std::mt19937_64 rng(20261002);
+    r1cs_round_trips(rng);
+    circom_text(rng);
+    hashes(rng);
+    printf("host_sanitize: %s (%d failures)\n", failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}

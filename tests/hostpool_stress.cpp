@@ -37,6 +37,26 @@ int main(int argc, char** argv) {
     pool.begin_session(nullptr);
     for (long r = 0; r < rounds; ++r) one_round(pool, 2 + (int)(r % 3), 0x1000u + (unsigned)(r & 0xFFF));
     pool.end_session();
+    // sessions opened and closed in quick succession, each with its own try_work function in the caller's frame
+    // (the shape of the plain-sumcheck scheduler: workers spin on the function until the session closes)
+    for (long sidx = 0; sidx < rounds / 100 + 10; ++sidx) {
+        std::atomic<int> left{50};
+        std::atomic<int> taken{0};
+        const std::function<bool()> try_work = [&]() -> bool {
+            int v = left.load(std::memory_order_relaxed);
+            while (v > 0)
+                if (left.compare_exchange_weak(v, v - 1)) {
+                    taken.fetch_add(1, std::memory_order_relaxed);
+                    return true;
+                }
+            return false;
+        };
+        {
+            gkr::SpinPool::Session session(&pool, &try_work);
+            while (left.load() > 0) try_work();
+        }   // the guard closes the session: no worker may touch try_work / left / taken after this line
+        if (taken.load() != 50) bad.fetch_add(1);
+    }
     printf("workers=%d rounds=%ld bad=%ld\n", workers, rounds, bad.load());
     return bad.load() ? 1 : 0;
 }

@@ -108,3 +108,25 @@ def test_concurrent_contexts_prove_the_same_transcripts(ctx):
         for c in ctxs:
             c.close()
         step.close()
+
+
+def test_cli_prove_demo_on_the_gpu(tmp_path):
+    """`gkr-aggregator prove -c t.circom -i input1.json input2.json input3.json` (bin.rs:17-22) with the real prover:
+    the artefacts of the first step and the inputs of the second (tests/test_cli.py checks their content on the CPU
+    with an injected prover; here the proofs come from the GPU and must satisfy the verifier)."""
+    import json
+    from gkr_amd import cli
+    paths = []
+    for i, (a, b) in enumerate(synth.EXAMPLE_INPUTS, 1):
+        p = tmp_path / ("input%d.json" % i)
+        p.write_text(json.dumps({"in1": str(a), "in2": str(b)}))
+        paths.append(str(p))
+    circuit = tmp_path / "t.circom"
+    circuit.write_text("pragma circom 2.0.0;\ntemplate A(){\n    signal input in1;\n}\ncomponent main = A();\n")
+    args = cli.argparse.Namespace(circuit=str(circuit), inputs=paths, r1cs=None, sym=None, wtns=None, demo=True, out_dir=str(tmp_path), device=0)
+    proofs, written = cli.prove_all(args, log=lambda *_: None)
+    circuits, _ = product.convert_r1cs_wtns_gkr(synth.mimc7_demo_r1cs(), synth.mimc7_demo_witness(2, 3))
+    assert len(proofs) == 12 and all(verify(p, c) for p, c in zip(proofs, circuits))
+    assert [os.path.basename(w) for w in written] == ["input1_output.json", "aggregated.json", "aggregated.circom"]
+    agg = json.load(open(tmp_path / "aggregated.json"))
+    assert agg["in1"] == "3" and len(agg) == 2 + 7 * 12

@@ -24,3 +24,29 @@ def stress_binary(tmp_path_factory):
 def test_run_now_never_calls_a_retired_job(stress_binary, workers):
     out = subprocess.run([stress_binary, str(workers), "2000000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout + out.stderr
+
+
+def test_worker_pool_under_thread_sanitizer():
+    """`make tsan` (gkr_amd/csrc/Makefile): the same stress under -fsanitize=thread -- run_now's retire handshake and
+    the session guard must be free of data races, not just of wrong results."""
+    build = subprocess.run(["make", "-C", os.path.join(REPO, "gkr_amd", "csrc"), "tsan"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + build.stderr[-200:])
+    exe = os.path.join(REPO, "gkr_amd", "build_san", "hostpool_stress_tsan")
+    for workers in ("1", "3"):
+        out = subprocess.run([exe, workers, "60000"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
+        assert out.returncode == 0 and "bad=0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
+
+
+def test_host_only_units_under_address_and_ub_sanitizers():
+    """`make asan`: the R1CS / witness containers and compiler, the circom text generators, keccak and the IFMA hash
+    driven through the C ABI with valid, truncated and bit-flipped inputs (tests/host_sanitize.cpp)."""
+    build = subprocess.run(["make", "-C", os.path.join(REPO, "gkr_amd", "csrc"), "asan"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("no AddressSanitizer runtime for this compiler: " + build.stderr[-200:])
+    exe = os.path.join(REPO, "gkr_amd", "build_san", "host_sanitize")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0 and "host_sanitize: ok" in out.stdout, out.stdout + out.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
