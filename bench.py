@@ -139,7 +139,7 @@ def run_mle(args, world):
     ops_per_sumcheck = 5 * (count - 1)
     value = ops_per_sumcheck * batch * args.steps * world.size / elapsed
 
-    names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",           # multi-round passes (default)
+    names = ["mle_multifold", "mle_multifold_late", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",   # multi-round passes (default)
              "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]  # per-round paths
     prof = {k: ctx.profile_get(k) for k in names}
     line = None
@@ -165,13 +165,15 @@ def run_mle(args, world):
             "host_threads": {"usable_cpus": usable_cpus(), "GKR_HOST_THREADS": os.environ.get("GKR_HOST_THREADS"),
                              "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE")},
             "roofline": {
-                "bound": "hbm", "kernel": "k_mle_multifold_mfma" if dom_name == "mle_multifold" else "k_" + dom_name,
+                "bound": "hbm", "kernel": "k_mle_multifold_mfma<5> (the 2^n -> 2^(n-5) fold pass)" if dom_name == "mle_multifold" else "k_" + dom_name,
                 "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS,
                 "traffic": None, "launches": dom["launches"],
                 "avg_launch_us": (dom["total_ms"] * 1e3 / dom["launches"]) if dom["launches"] else None,
                 "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
                 "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
-                              "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair",
+                              "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair.  The later, small "
+                              "fold passes run on a high-priority stream beside other groups' streaming passes and are booked "
+                              "separately (kernel_ms.mle_multifold_late): their elapsed time is not their own cost",
             },
             "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
             # every byte the schedule moves (pass 0 reads the tables once, every fold pass reads its source and writes
@@ -184,7 +186,7 @@ def run_mle(args, world):
         }
         # which of the fold pass's placement-dependent bandwidth modes this process drew: the big launches one by one
         avg_bytes = dom["bytes"] / max(1, dom["launches"])
-        big = [(ms, by) for ms, by in ctx.profile_samples("mle_multifold") if by > avg_bytes]   # the 2^n -> 2^(n-5) launches
+        big = [(ms, by) for ms, by in ctx.profile_samples("mle_multifold") if by >= 0.99 * avg_bytes]   # the 2^n -> 2^(n-5) launches
         if big:
             rates = sorted(by / (ms * 1e-3) / 1e9 for ms, by in big if ms > 0)
             line["roofline"]["first_fold_pass_GBps"] = {"min": rates[0], "median": statistics.median(rates), "max": rates[-1],
@@ -198,7 +200,8 @@ def run_mle(args, world):
                 try:
                     tj = json.load(open(traffic_file))
                     if tj.get("batch") == batch and tj.get("n") == n:
-                        line["roofline"]["traffic"] = tj["k_mle_multifold_mfma"]["per_launch_mean_bytes"]
+                        var = tj["k_mle_multifold_mfma"].get("variants", {}).get("gkr::k_mle_multifold_mfma<5>")
+                        line["roofline"]["traffic"] = (var or tj["k_mle_multifold_mfma"])["per_launch_mean_bytes"]
                         line["roofline"]["traffic_source"] = ("profiles/%s/d_pmc_traffic.json: separate rocprofv3 --pmc passes of "
                                                               "this command on an earlier box, NOT measured in this run" % rnd)
                         break

@@ -342,6 +342,7 @@ struct gkr_ctx {
     std::vector<std::unique_ptr<PreparedCircuit>> circuits;   // most recently used last; bounded
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
+    hipStream_t late = nullptr;                // high-priority stream for a group's small late passes (lazy), see late_stream()
     std::vector<hipEvent_t> aux_events;        // one per group of a batch: "the side kernel of this group is done"
     Fr* d_cts = nullptr;
     int transcript = GKR_TRANSCRIPT_HOST;
@@ -398,6 +399,21 @@ struct gkr_ctx {
     gkr::SpinPool* host_pool() {
         if (!pool) pool.reset(new gkr::SpinPool(threads() - 1));
         return pool.get();
+    }
+    // The passes of one group are ordered by the host (a pass is launched after the previous one's record has
+    // landed), not by the stream.  Its LATE passes -- tables of a few thousand entries, latency-bound round trips --
+    // go to their own high-priority stream: on the main stream they would queue behind the other groups' multi-GiB
+    // streaming passes launched earlier, and all groups' tails would pile up at the end of the call (measured: 1.9 of
+    // 13.1 ms per 1024 sumchecks).
+    hipError_t late_stream(hipStream_t* out) {
+        if (!late) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lower = higher priority
+            hipError_t rc = hipStreamCreateWithPriority(&late, hipStreamNonBlocking, hi);
+            if (rc != hipSuccess) return rc;
+        }
+        *out = late;
+        return hipSuccess;
     }
     hipError_t aux_stream(int events) {
         if (!aux) {
@@ -598,14 +614,46 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         int pass = 0;
         int index = 0;
     };
+    // Shares of the batch per group, in per cent (GKR_GROUP_SPLIT="40,30,20,10"): the groups finish in order, and the
+    // LAST one's latency-bound late passes (four host round trips with nothing left to overlap them) are the exposed
+    // tail of the call -- a smaller last group has a shorter tail (fewer hash chunks per round trip).
+    static const std::vector<int> split = [] {
+        std::vector<int> v;
+        if (const char* e = getenv("GKR_GROUP_SPLIT")) {
+            int sum = 0;
+            for (const char* p = e; *p;) {
+                const int x = atoi(p);
+                if (x > 0) {
+                    v.push_back(x);
+                    sum += x;
+                }
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+            if (sum != 100 || v.size() > (size_t)kMaxGroups) v.clear();
+        }
+        return v;
+    }();
+    if (!split.empty() && batch >= 16 * (int)split.size()) groups = (int)split.size();
     std::vector<Group> grp(groups);
     HIP_TRY(ctx, ctx->aux_stream(groups));
-    for (int g = 0; g < groups; ++g) {
-        grp[g].index = g;
-        grp[g].b0 = (int)((long long)batch * g / groups);
-        grp[g].nb = (int)((long long)batch * (g + 1) / groups) - grp[g].b0;
-        grp[g].m = n;
-        grp[g].j = j_first;
+    {
+        int start = 0, acc = 0;
+        for (int g = 0; g < groups; ++g) {
+            grp[g].index = g;
+            int end;
+            if (!split.empty() && groups == (int)split.size()) {
+                acc += split[g];
+                end = g + 1 == groups ? batch : (int)((long long)batch * acc / 100);
+            } else {
+                end = (int)((long long)batch * (g + 1) / groups);
+            }
+            grp[g].b0 = start;
+            grp[g].nb = end - start;
+            start = end;
+            grp[g].m = n;
+            grp[g].j = j_first;
+        }
     }
     // pass 0: sub-block sums of the input tables
     auto launch_first = [&](Group& G) {
@@ -627,6 +675,9 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
     };
     // a fold pass: bind the jin variables just hashed, produce the sums of the next jout rounds
+    static const bool no_late = getenv("GKR_NO_LATE_STREAM") != nullptr;
+    hipStream_t late = s;
+    if (!no_late && groups > 1) HIP_TRY(ctx, ctx->late_stream(&late));
     auto launch_fold = [&](Group& G, int jin) {
         const int b0 = G.b0, nb = G.nb;
         const size_t src_len = (size_t)1 << G.m, S = src_len >> jin;
@@ -634,15 +685,17 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         const Fr* src = from_input ? d_tables + (size_t)b0 * len : work + (size_t)b0 * work_len;
         const size_t src_stride = from_input ? len : work_len;
         Fr* dst = work + (size_t)b0 * work_len;
+        // small source tables: a latency-bound late pass, not to be queued behind other groups' streaming passes
+        hipStream_t st = (!from_input && src_len <= ((size_t)1 << 16)) ? late : s;
         G.m -= jin;
         G.round0 += jin;
         G.j = rounds_for(G.m);
         G.ticket = ++ctx->ticket;
         const double bytes = (double)nb * ((double)src_len + (double)S) * 32.0;
         if (S <= gkr::kSmallPassEntries) {
-            Timed t(ctx, "mle_pass_small", bytes, nullptr, true);
+            Timed t(ctx, "mle_pass_small", bytes, st, true);
             gkr::launch_mle_multifold_small(jin, src, src_stride, dst, work_len, (uint32_t)S, (uint32_t)G.j, nb,
-                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
+                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, st);
             return;
         }
         const uint32_t nblk = gkr::mle_multifold_blocks((uint32_t)S, (uint32_t)G.j, nb);
@@ -652,8 +705,8 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             // the digit matrices only depend on the weights the host just wrote: built on the side stream, so the
             // main stream (busy with another group's pass) pays one event wait, not a launch round trip
             static const bool plan_inline = getenv("GKR_PLAN_MAIN") != nullptr;
-            if (plan_inline) {
-                gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, s);
+            if (plan_inline || st != s) {
+                gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, st);
             } else {
                 {
                     Timed t(ctx, "mle_fold_plan", 0.0, ctx->aux, true);
@@ -664,12 +717,14 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             }
         }
         {
-            Timed t(ctx, "mle_multifold", bytes);
+            // late passes run beside other groups' streaming passes: their elapsed time is not their own cost, so they
+            // are booked under their own name and stay out of the streaming fold pass's bandwidth figure
+            Timed t(ctx, st == s ? "mle_multifold" : "mle_multifold_late", bytes, st);
             gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub,
-                                      plan, part, s);
+                                      plan, part, st);
         }
-        Timed t(ctx, "mle_sub_reduce", 0.0, nullptr, true);
-        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
+        Timed t(ctx, "mle_sub_reduce", 0.0, st, true);
+        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st);
     };
     // the J rounds of up to eight sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
@@ -816,11 +871,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     session.close();
     if (rc) {
         (void)hipStreamSynchronize(s);
+        if (late != s) (void)hipStreamSynchronize(late);
         return rc;
     }
     dbg_d = dbg_us();
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (late != s) HIP_TRY(ctx, hipStreamSynchronize(late));
     dbg_e = dbg_us();
     if (ctx->pending.size() > 8192) ctx->drain_events();   // otherwise when the profile is read
     if (dbg)
@@ -1670,6 +1727,7 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    if (ctx->late) (void)hipStreamSynchronize(ctx->late);
     ctx->drain_events();
     ctx->drain_events();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1677,6 +1735,7 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (ctx->d_cts) (void)hipFree(ctx->d_cts);
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->late) (void)hipStreamDestroy(ctx->late);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -98,7 +98,8 @@ int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
  * roofline leg).  enable: 0 off, 1 every kernel, 2 only the bandwidth-bound kernels ("mle_multifold",
  * "mle_sub_sums", "mle_fold_sum", "layer_round", ...): the small kernels on the round-trip path are
  * left alone so that the event records do not show in the wall time being measured.
- * kernel: "mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",
+ * kernel: "mle_multifold" (streaming fold passes on the main stream), "mle_multifold_late" (the small late fold
+ * passes on the high-priority stream, overlapping other groups' passes), "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",
  * "mle_fold_sum", "mle_sum_first", "mle_round_hash", "layer_round", "layer_fold", "layer_round_hash". */
 int  gkr_ctx_profile(gkr_ctx *ctx, int enable);
 int  gkr_ctx_profile_get(gkr_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms,
