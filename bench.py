@@ -71,9 +71,9 @@ class World:
         if self.size > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            if self.backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+            if self.backend == "nccl":   # the process group comes first, the first GPU call after it
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                torch.cuda.set_device(self.local_rank)
             else:
                 dist.init_process_group(self.backend)
         if not torch.cuda.is_available():

@@ -1319,6 +1319,112 @@ __global__ void __launch_bounds__(256) k_c_round(Fr* __restrict__ A, Fr* __restr
     publish_round(acc, smem, host_rec + blockIdx.x, ticket);
 }
 
+// ---------------------------------------------------------------------------
+// The same two rounds for SMALL tables (h <= 64 pairs: every layer of a circom-sized circuit).  A round of such a
+// layer is pure latency -- a chain of load, fold, product, reduction, reduction mod r, store to the host -- and the
+// general kernels above spend it serially: the folded tables go to global memory and come back, and every lane
+// reduces all three round sums one after the other.  Here the folded tables stay in LDS (and are written to global
+// memory on the side, for the next round's launch), and the three sums belong to three different waves: wave 0
+// sums c0, wave 1 g(1), wave 2 c2, each one wave-level reduction; their lane 0 reduces mod r and stores its field
+// of the host record; one barrier later thread 0 releases the sequence number.  grid = (batch), block = 256.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kSmallRoundPairs = 64;
+
+__device__ __forceinline__ void publish_round_waves(const Acc<9>& a, uint32_t wave, uint32_t lane, LayerHostRec* r, uint32_t ticket) {
+    if (wave < 3 && lane == 0) {
+        const Fr v = acc_reduce(a);
+        Fr* dst = wave == 0 ? &r->c0 : (wave == 1 ? &r->g1 : &r->c2);
+        *dst = v;
+        __threadfence_system();   // this lane's record stores are ordered ahead of the barrier and the release below
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_uv_round_small(Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t h,
+                                                        const FixedMul* __restrict__ rtab, LayerHostRec* __restrict__ host_rec,
+                                                        uint32_t ticket, uint32_t wstride) {
+    __shared__ Fr sT[3][2 * kSmallRoundPairs];   // U, V, W of this round: 2h entries each
+    Fr* T[3] = {U + (size_t)blockIdx.x * wstride, V + (size_t)blockIdx.x * wstride, W + (size_t)blockIdx.x * wstride};
+    const uint32_t hw = 2u * h;
+    if (FOLD) {
+        const FixedMul F = rtab[blockIdx.x];
+        // entry i of the folded table is read (slots i, i + hw) and written (slot i) by one thread only
+        for (uint32_t idx = threadIdx.x; idx < 3u * hw; idx += blockDim.x) {
+            const uint32_t t = idx / hw, i = idx - t * hw;
+            const Fr x = fr_fold_fixed(load_fr(T[t] + i), load_fr(T[t] + i + hw), F);
+            sT[t][i] = x;
+            store_fr(T[t] + i, x);
+        }
+    } else {
+        for (uint32_t idx = threadIdx.x; idx < 3u * hw; idx += blockDim.x) {
+            const uint32_t t = idx / hw, i = idx - t * hw;
+            sT[t][i] = load_fr(T[t] + i);
+        }
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    Acc<9> a = acc_zero<9>();
+    if (wave < 3 && lane < h) {
+        if (wave == 0) {
+            acc_add_fr(a, mont_mul(sT[0][lane], sT[2][lane]));
+            acc_add_fr(a, sT[1][lane]);
+        } else if (wave == 1) {
+            acc_add_fr(a, mont_mul(sT[0][lane + h], sT[2][lane + h]));
+            acc_add_fr(a, sT[1][lane + h]);
+        } else {
+            acc_add_fr(a, mont_mul(fr_sub(sT[0][lane + h], sT[0][lane]), fr_sub(sT[2][lane + h], sT[2][lane])));
+        }
+    }
+    if (wave < 3) a = wave_sum(a);
+    publish_round_waves(a, wave, lane, host_rec + blockIdx.x, ticket);
+}
+
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_c_round_small(Fr* __restrict__ A, Fr* __restrict__ M, Fr* __restrict__ Wc,
+                                                       const Fr* __restrict__ Wb, uint32_t h, const FixedMul* __restrict__ rtab,
+                                                       LayerHostRec* __restrict__ host_rec, uint32_t ticket, LayerBatch lb) {
+    __shared__ Fr sT[3][2 * kSmallRoundPairs];   // A, M, then Wc; after the set-up below slot 2 holds S = p + Wc
+    __shared__ Fr sPQ[2 * kSmallRoundPairs];     // p * Wc
+    Fr* T[3] = {A + blockIdx.x * lb.tstride, M + blockIdx.x * lb.tstride, Wc + blockIdx.x * lb.wstride};
+    const Fr p = load_fr(Wb + blockIdx.x * lb.wstride);
+    const uint32_t hw = 2u * h;
+    FixedMul F;
+    if (FOLD) F = rtab[blockIdx.x];
+    for (uint32_t idx = threadIdx.x; idx < 3u * hw; idx += blockDim.x) {
+        const uint32_t t = idx / hw, i = idx - t * hw;
+        Fr x;
+        if (FOLD) {
+            x = fr_fold_fixed(load_fr(T[t] + i), load_fr(T[t] + i + hw), F);
+            store_fr(T[t] + i, x);
+        } else {
+            x = load_fr(T[t] + i);
+        }
+        if (t == 2) {   // the thread that holds W(c) also prepares the two factors every pair needs of it
+            sPQ[i] = mont_mul(p, x);
+            x = fr_add(p, x);
+        }
+        sT[t][i] = x;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    Acc<9> a = acc_zero<9>();
+    if (wave < 3 && lane < h) {
+        const uint32_t i = lane, j = lane + h;
+        if (wave == 0) {
+            acc_add_fr(a, fr_add(mont_mul(sT[0][i], sT[2][i]), mont_mul(sT[1][i], sPQ[i])));
+        } else if (wave == 1) {
+            acc_add_fr(a, fr_add(mont_mul(sT[0][j], sT[2][j]), mont_mul(sT[1][j], sPQ[j])));
+        } else {
+            acc_add_fr(a, fr_add(mont_mul(fr_sub(sT[0][j], sT[0][i]), fr_sub(sT[2][j], sT[2][i])),
+                                 mont_mul(fr_sub(sT[1][j], sT[1][i]), fr_sub(sPQ[j], sPQ[i]))));
+        }
+    }
+    if (wave < 3) a = wave_sum(a);
+    publish_round_waves(a, wave, lane, host_rec + blockIdx.x, ticket);
+}
+
 // Row collapse, stage 1: partial[chunk][c] = sum over the chunk's rows of eq[row] * T[row][c] for T = A (z = 0)
 // and M (z = 1).  eq: Montgomery, the same value for the whole wave.  grid = (column blocks, chunks, 2 * batch).
 __global__ void __launch_bounds__(256) k_layer_collapse_rows(const Fr* __restrict__ A, const Fr* __restrict__ M,
@@ -1636,6 +1742,14 @@ void launch_layer_uv(const Fr* A, const Fr* M, const Fr* W, Fr* U, Fr* V, uint32
 
 void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec,
                     uint32_t ticket, LayerBatch lb, hipStream_t s) {
+    static const bool general = getenv("GKR_NO_SMALL_ROUNDS") != nullptr;
+    if (h <= kSmallRoundPairs && !general) {
+        if (fold)
+            hipLaunchKernelGGL(k_c_round_small<true>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
+        else
+            hipLaunchKernelGGL(k_c_round_small<false>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
+        return;
+    }
     if (fold)
         hipLaunchKernelGGL(k_c_round<true>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
     else
@@ -1644,6 +1758,14 @@ void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, c
 
 void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,
                      LayerBatch lb, hipStream_t s) {
+    static const bool general = getenv("GKR_NO_SMALL_ROUNDS") != nullptr;
+    if (h <= kSmallRoundPairs && !general) {
+        if (fold)
+            hipLaunchKernelGGL(k_uv_round_small<true>, dim3(lb.batch), dim3(256), 0, s, W, U, V, h, rtab, host_rec, ticket, (uint32_t)lb.wstride);
+        else
+            hipLaunchKernelGGL(k_uv_round_small<false>, dim3(lb.batch), dim3(256), 0, s, W, U, V, h, rtab, host_rec, ticket, (uint32_t)lb.wstride);
+        return;
+    }
     if (fold)
         hipLaunchKernelGGL(k_uv_round<true>, dim3(lb.batch), dim3(256), 0, s, W, U, V, h, rtab, host_rec, ticket, (uint32_t)lb.wstride);
     else
