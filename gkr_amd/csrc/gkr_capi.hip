@@ -407,9 +407,15 @@ struct gkr_ctx {
     // 13.1 ms per 1024 sumchecks).
     hipError_t late_stream(hipStream_t* out) {
         if (!late) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lower = higher priority
-            hipError_t rc = hipStreamCreateWithPriority(&late, hipStreamNonBlocking, hi);
+            static const bool high = getenv("GKR_LATE_HIGH_PRIORITY") != nullptr;
+            hipError_t rc;
+            if (high) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lower = higher priority
+                rc = hipStreamCreateWithPriority(&late, hipStreamNonBlocking, hi);
+            } else {
+                rc = hipStreamCreateWithFlags(&late, hipStreamNonBlocking);
+            }
             if (rc != hipSuccess) return rc;
         }
         *out = late;
@@ -1268,6 +1274,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
+    const double t_entry_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
     if (shard && (!host_tx || batch != 1 || k > 13))
@@ -1290,7 +1297,16 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     // gate lists pay when the layer is sparse in its 2^{2k} cells (every circom layer is); for a layer with a gate in
     // (nearly) every cell the dense tables' counting sort is the cheaper grouping (k_i = 24, k = 12: 8.9 ms against 9.1)
     static const bool gate_lists_always = getenv("GKR_LAYER_GATE_LISTS") != nullptr;
-    const bool sparse = shard || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k));
+    // Small layers (every layer of a circom-sized circuit) can run their whole sumcheck as ONE resident kernel, tables
+    // in LDS, rounds handed over through pinned memory (kernels.hip, k_layer_persistent): GKR_LAYER_PERSISTENT=1.
+    // Opt-in: measured on MI355X it saves the launch per round but a round stays at 70 - 80 us, because what
+    // dominates is the host's 24 - 30 us hash call and ~20 us of PCIe latency per hand-off in either form (64 inputs
+    // x 12 sub-circuits: 63 instead of 75 ms from one context, 19.6 instead of 22 ms from six) -- not enough to make a
+    // kernel that waits on the host the default.
+    static const bool want_persistent = getenv("GKR_LAYER_PERSISTENT") != nullptr;
+    const bool persistent = lin_b && !shard && !dense_tables && want_persistent && !gate_lists_always && k <= (int)gkr::kPersistentMaxK &&
+                            k_i <= k + 4;
+    const bool sparse = shard || persistent || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k));
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -1354,10 +1370,14 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     }
     gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, tlen, wlen};
     HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
-    gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
-    HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
+    if (!persistent) {
+        gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
+        HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
+    }
     gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
-    if (sparse) {
+    if (persistent) {
+        // U, V, the rounds and the row are all inside the one kernel launched below
+    } else if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
         gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_r, e_hi, e_lo, kl, Wc, U, V, lb, s);
     } else if (lin_b) {
@@ -1406,6 +1426,171 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         HIP_TRY(ctx, hipStreamSynchronize(s));
         if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
         if (batch >= 16) pool = ctx->host_pool();
+    }
+    if (persistent) {
+        static const bool dbg_s = getenv("GKR_DEBUG_TIMING") != nullptr;
+        if (dbg_s)
+            fprintf(stderr, "[gkr timing] resident layer set-up (eq upload, gate lists, dep readback): %.0f us\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_entry_us);
+        gkr::LayerChallenge* chal = nullptr;
+        uint32_t* abort_flag = nullptr;
+        HIP_TRY(ctx, ctx->pinned_host("layer.chal", sizeof(gkr::LayerChallenge) * batch, reinterpret_cast<void**>(&chal)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.abort", 64, reinterpret_cast<void**>(&abort_flag)));
+        __atomic_store_n(abort_flag, 0u, __ATOMIC_RELEASE);
+        const uint32_t base = ctx->ticket + 1;
+        ctx->ticket += v;
+        static const bool dbg_p = getenv("GKR_DEBUG_TIMING") != nullptr;
+        const auto tp0 = std::chrono::steady_clock::now();
+        {
+            Timed t(ctx, "layer_persistent", 0.0);
+            gkr::launch_layer_persistent(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, d_r, e_hi, e_lo, kl, d_W,
+                                         rec, chal, abort_flag, base, lb, s);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        struct AbortGuard {   // whatever path leaves this scope early, the resident kernel is told to stop waiting
+            uint32_t* flag;
+            bool armed = true;
+            ~AbortGuard() {
+                if (armed) __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);
+            }
+        } guard{abort_flag};
+        std::atomic<int> slice_rc{GKR_OK};
+        // a slice of proofs, each advanced independently: whichever records have landed are answered (hashed up to
+        // sixteen at a time), so a proof never waits for another one's block to become resident
+        static const bool dbg_r = getenv("GKR_DEBUG_TIMING") != nullptr;
+        auto run_slice = [&](int first, int count) {
+            std::vector<uint32_t> round(count, 0);
+            int done = 0;
+            double us_gather = 0, us_hash = 0, us_write = 0, us_wait = 0;
+            long calls = 0, lanes = 0;
+            auto t_mark = std::chrono::steady_clock::now();
+            auto lap_us = [&](double& bucket) {
+                const auto t = std::chrono::steady_clock::now();
+                bucket += std::chrono::duration<double, std::micro>(t - t_mark).count();
+                t_mark = t;
+            };
+            auto last_progress = std::chrono::steady_clock::now();
+            uint32_t idle = 0;
+            while (done < count && slice_rc.load(std::memory_order_relaxed) == GKR_OK) {
+                int idx[kHashChunkMax], nr = 0;
+                auto scan = [&] {
+                    nr = 0;
+                    for (int i = 0; i < count && nr < kHashChunkMax; ++i)
+                        if (round[i] < v && __atomic_load_n(&rec[first + i].seq, __ATOMIC_ACQUIRE) == base + round[i]) idx[nr++] = i;
+                };
+                scan();
+                if (nr > 0 && dbg_r) lap_us(us_wait);
+                // A hash call costs the same for one lane as for sixteen (one serial chain of ~1100 products either
+                // way: 24 - 30 us), so answering a few records now and the rest in a second call doubles every proof's
+                // round time -- and the two cohorts then stay out of phase for the rest of the layer.  So a record waits
+                // for the slice's other unfinished proofs, up to about two hash calls' time (blocks that are not resident
+                // yet must not hold the others up for ever).
+                if (nr > 0 && nr < (count - done < kHashChunkMax ? count - done : kHashChunkMax)) {
+                    const int want = count - done < kHashChunkMax ? count - done : kHashChunkMax;
+                    const auto t_gather = std::chrono::steady_clock::now();
+                    while (nr < want && std::chrono::steady_clock::now() - t_gather < std::chrono::microseconds(50)) {
+                        GKR_CPU_RELAX();
+                        scan();
+                    }
+                }
+                if (nr == 0) {
+                    GKR_CPU_RELAX();
+                    // No HIP call in here: another context's thread may sit inside the runtime waiting for work that is
+                    // queued BEHIND this context's resident kernel (streams share hardware queues), and a runtime lock
+                    // taken by this loop would then wait for a kernel that waits for this loop.  Only the clock.
+                    if ((++idle & 0x3FFF) == 0 && std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(30))
+                        slice_rc.store(-2);   // no record for 30 s
+                    continue;
+                }
+                idle = 0;
+                last_progress = std::chrono::steady_clock::now();
+                if (dbg_r) {
+                    lap_us(us_gather);
+                    ++calls;
+                    lanes += nr;
+                }
+                gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
+                uint32_t ln[kHashChunkMax] = {};
+                for (int j = 0; j < nr; ++j) {
+                    const int b = first + idx[j];
+                    gkr::h64::F g1;
+                    memcpy(&c0[j], &rec[b].c0, 32);
+                    memcpy(&g1, &rec[b].g1, 32);
+                    memcpy(&c2[j], &rec[b].c2, 32);
+                    lin[j] = gkr::h64::sub(gkr::h64::sub(g1, c0[j]), c2[j]);
+                    ln[j] = 2u + (h_dep[(size_t)b * 32 + round[idx[j]] % k] ? 1u : 0u);
+                }
+                if (ifma && nr >= 3) {
+                    uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
+                    memset(vec, 0, sizeof vec);
+                    for (int j = 0; j < nr; ++j) {
+                        memcpy(vec[j][0], &c2[j], 32);
+                        memcpy(vec[j][1], &lin[j], 32);
+                        memcpy(vec[j][2], &c0[j], 32);
+                    }
+                    ifma_hash_chunk(vec, ln, nr, out);
+                    for (int j = 0; j < nr; ++j) memcpy(&r[j], out[j], 32);
+                } else {
+                    for (int j = 0; j < nr; ++j) {
+                        gkr::h64::F vec[3] = {c2[j], lin[j], c0[j]};
+                        r[j] = gkr::h64::mimc7_multi_hash(vec + (3 - ln[j]), (int)ln[j], cts64, nullptr);
+                    }
+                }
+                if (dbg_r) lap_us(us_hash);
+                for (int j = 0; j < nr; ++j) {
+                    const int i = idx[j], b = first + i;
+                    const uint32_t rd = round[i];
+                    const gkr::h64::F rm = gkr::h64::to_mont(r[j]);
+                    memcpy(&chal[b].r_mont, &rm, 32);
+                    __atomic_store_n(&chal[b].seq, base + rd, __ATOMIC_RELEASE);   // the device folds while the host writes out
+                    gkr_fr* oc = out_coeffs[b] + (size_t)rd * 3;
+                    memset(&oc[0], 0, 32);
+                    if (ln[j] == 3) memcpy(&oc[0], &c2[j], 32);
+                    memcpy(&oc[1], &lin[j], 32);
+                    memcpy(&oc[2], &c0[j], 32);
+                    out_len[b][rd] = ln[j];
+                    memcpy(&out_r[b][rd], &r[j], 32);
+                    if (++round[i] == v) ++done;
+                }
+                if (dbg_r) lap_us(us_write);
+            }
+            if (dbg_r)
+                fprintf(stderr, "[gkr timing] slice of %d proofs: %ld hash calls, %.1f lanes each; per call: waiting %.1f us, gathering %.1f, hashing %.1f, writing %.1f\n",
+                        count, calls, calls ? (double)lanes / calls : 0.0, calls ? us_wait / calls : 0.0, calls ? us_gather / calls : 0.0,
+                        calls ? us_hash / calls : 0.0, calls ? us_write / calls : 0.0);
+        };
+        if (pool) {
+            const int want = (batch + 15) / 16, most = pool->workers() + 1;
+            const int slices = want < most ? want : most;
+            std::atomic<int> next{0};
+            const std::function<bool()> work = [&]() -> bool {
+                const int sidx = next.fetch_add(1, std::memory_order_relaxed);
+                if (sidx >= slices) return false;
+                const int f = (int)((long long)batch * sidx / slices), e = (int)((long long)batch * (sidx + 1) / slices);
+                run_slice(f, e - f);
+                return true;
+            };
+            gkr::SpinPool::Session session(pool, nullptr);
+            pool->run_now(&work);
+        } else {
+            run_slice(0, batch);
+        }
+        if (const int src = slice_rc.load()) {
+            __atomic_store_n(abort_flag, 1u, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(s);
+            (void)src;
+            return ctx->fail(GKR_ERR_HIP, "timed out waiting for the resident layer kernel to publish a round");
+        }
+        guard.armed = false;
+        const auto tp1 = std::chrono::steady_clock::now();
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->drain_events();
+        if (dbg_p) {
+            const auto tp2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[gkr timing] resident layer k_i=%d k=%d batch=%d: launch + %u rounds %.0f us, final sync %.0f us\n", k_i, k, batch, v,
+                    std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(tp2 - tp1).count());
+        }
+        return GKR_OK;
     }
     // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
     // (get_univariate_coeff, poly.rs:388-420), hashed together (eight-lane IFMA where available)
@@ -2307,6 +2492,9 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i], sizeof(Fr) * hW[i].size(), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const auto tpb0 = std::chrono::steady_clock::now();
+    if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
     for (int b = 0; b < batch; ++b) {
         if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
             return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
@@ -2333,9 +2521,11 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             slp[b] = outs[b].sumcheck_len + row_off;
             srp[b] = outs[b].sumcheck_r + row_off;
         }
+        const auto tl0 = std::chrono::steady_clock::now();
         rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
                              srp.data(), nullptr, &pc->lists[i]);
         if (rc) return rc;
+        const auto tl1 = std::chrono::steady_clock::now();
         std::vector<gkr_fr> z_next((size_t)batch * k);
         auto finish = [&](int b) {
             const gkr_fr* sr = srp[b];
@@ -2377,6 +2567,11 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         } else {
             for (int b = 0; b < batch; ++b) finish(b);
         }
+        if (dbg_pb)
+            fprintf(stderr, "[gkr timing] prove layer %u: sumcheck %.0f us, q / z on the host %.0f us (since entry of the hand-off: %.0f us)\n", i,
+                    std::chrono::duration<double, std::micro>(tl1 - tl0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl1).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tpb0).count());
         z_cur.swap(z_next);
         row_off += (size_t)2 * k;
         q_off += (size_t)k + 1;

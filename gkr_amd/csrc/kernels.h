@@ -95,6 +95,21 @@ void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* off
 void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
                       const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s);
+// One launch per layer (small layers): the whole layer sumcheck of `batch` proofs as one resident kernel, one block
+// per proof, tables in LDS; rounds are handed to the host and challenges taken back through pinned memory, no
+// launch per round (kernels.hip, k_layer_persistent).
+constexpr uint32_t kPersistentMaxK = 8;      // tables of 2^k <= 256 entries per proof in LDS
+struct LayerChallenge {   // pinned, written by the host: challenge r_j in Montgomery form, then seq = the round's ticket
+    Fr r_mont;
+    uint32_t seq;
+    uint32_t pad[7];
+};
+static_assert(sizeof(LayerChallenge) == 64, "challenge slot layout");
+void launch_layer_persistent(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor,
+                             const uint32_t* list, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                             const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, LayerHostRec* host_rec,
+                             const LayerChallenge* challenges, const uint32_t* abort_flag, uint32_t ticket_base, LayerBatch lb,
+                             hipStream_t s);
 // b-phase in linear time (kernels.hip): U, V tables of 2^k entries per proof, their rounds, the row collapse
 void launch_layer_uv(const Fr* A, const Fr* M, const Fr* W, Fr* U, Fr* V, uint32_t k, LayerBatch lb, hipStream_t s);
 void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,

@@ -1425,6 +1425,224 @@ __global__ void __launch_bounds__(256) k_c_round_small(Fr* __restrict__ A, Fr* _
     publish_round_waves(a, wave, lane, host_rec + blockIdx.x, ticket);
 }
 
+// ---------------------------------------------------------------------------
+// A whole layer sumcheck as ONE resident kernel (small layers, host transcript): one block per proof; W, U, V and
+// later the row a_u, m_u live in LDS for all 2k rounds.  A round is: the three sums (one wave each) -> the pinned
+// host record -> thread 0 polls the proof's challenge slot in pinned host memory until the host has hashed the
+// round -> every table is bound to the challenge in LDS.  No launch, no global-memory traffic and no stream
+// operation per round: what is left of a round's latency is the PCIe hop each way and the host's hash.
+// Proofs advance independently (the host answers each record as it lands), so blocks that are not resident yet
+// hold nobody up; `abort_flag` (pinned) ends the waiting if the host gives up.
+// ---------------------------------------------------------------------------
+#ifdef GKR_PERSIST_DEBUG
+__device__ unsigned long long g_persist_dbg[4096];
+#define PDBG(slot_)                                                                  \
+    do {                                                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && dbg_n < 2040) {                   \
+            g_persist_dbg[2 * dbg_n] = wall_clock64();                               \
+            g_persist_dbg[2 * dbg_n + 1] = ((unsigned long long)(slot_) << 56) | (clock64() & 0xFFFFFFFFFFFFFFull); \
+            ++dbg_n;                                                                 \
+        }                                                                            \
+    } while (0)
+#else
+#define PDBG(slot_) do { } while (0)
+#endif
+
+__device__ __forceinline__ bool wait_challenge(const LayerChallenge* slot, const uint32_t* abort_flag, uint32_t ticket, Fr* s_r,
+                                               uint32_t* s_abort) {
+    if (threadIdx.x == 0) {
+        uint32_t aborted = 0;
+        for (uint32_t spins = 0;; ++spins) {
+            // relaxed polls (an acquire load would invalidate the caches on every try); one acquire fence at the end
+            if (__hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ticket) break;
+            if ((spins & 15u) == 15u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                aborted = 1;
+                break;
+            }
+            // every poll is a PCIe read that paces itself; a short sleep in between, longer once the host is clearly
+            // busy (a hash call takes 24 - 30 us), so that hundreds of waiting blocks do not flood the link
+            if (spins < 64u)
+                __builtin_amdgcn_s_sleep(2);
+            else
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        Fr r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.l[i] = __hip_atomic_load(&slot->r_mont.l[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *s_r = r;
+        *s_abort = aborted;
+    }
+    __syncthreads();
+    return *s_abort == 0;
+}
+
+__global__ void __launch_bounds__(256) k_layer_persistent(GateSpan span, uint32_t k, const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ list,
+                                                          const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+                                                          const uint32_t* __restrict__ right, const Fr* __restrict__ e_hi,
+                                                          const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
+                                                          const Fr* __restrict__ W, LayerHostRec* __restrict__ host_rec,
+                                                          const LayerChallenge* __restrict__ challenges,
+                                                          const uint32_t* __restrict__ abort_flag, uint32_t ticket_base,
+                                                          uint32_t wstride) {
+    constexpr uint32_t kMax = 1u << kPersistentMaxK;
+    __shared__ Fr sA[kMax], sB[kMax], sW[kMax], sWc[kMax], sPQ[kMax];   // b-phase: U, V, W(b); c-phase: a_u, m_u, p + W(c), W(c), p W(c)
+    __shared__ Fr s_r;
+    __shared__ uint32_t s_abort;
+    const uint32_t n = 1u << k, lmask = (1u << kl) - 1u, gate_base = (uint32_t)span.base;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    e_hi += (size_t)blockIdx.x << kh;
+    e_lo_mont += (size_t)blockIdx.x << kl;
+    W += (size_t)blockIdx.x * wstride;
+    LayerHostRec* rec = host_rec + blockIdx.x;
+    const LayerChallenge* slot = challenges + blockIdx.x;
+    // W in Montgomery form, once for b and once for c
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const Fr w = to_mont(load_fr(W + i));
+        sW[i] = w;
+        sWc[i] = w;
+    }
+    __syncthreads();
+    // U[b], V[b]: thread b sums the gates whose left operand is b (k_gate_uv's sums, one thread per bucket)
+    for (uint32_t b = threadIdx.x; b < n; b += blockDim.x) {
+        Fr u = fr_zero(), v = fr_zero();
+        for (uint32_t i = offsets[b]; i < cursor[b]; ++i) {
+            const uint32_t g = list[i], gg = g + gate_base;
+            const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
+            const Fr ew = mont_mul(e, sWc[right[g]]);
+            if (gate_type[g]) {
+                u = fr_add(u, ew);
+            } else {
+                u = fr_add(u, e);
+                v = fr_add(v, ew);
+            }
+        }
+        sA[b] = u;
+        sB[b] = v;
+    }
+    __syncthreads();
+    uint32_t ticket = ticket_base;
+#ifdef GKR_PERSIST_DEBUG
+    uint32_t dbg_n = 0;
+#endif
+    PDBG(0);
+    // ---- the k rounds that bind b: g(x) = sum_i W_i(x) U_i(x) + V_i(x)
+    for (uint32_t h = n >> 1; h >= 1; h >>= 1, ++ticket) {
+        PDBG(1);
+        Acc<9> a = acc_zero<9>();
+        if (wave < 3) {
+            for (uint32_t i = lane; i < h; i += 64u) {
+                if (wave == 0) {
+                    acc_add_fr(a, mont_mul(sA[i], sW[i]));
+                    acc_add_fr(a, sB[i]);
+                } else if (wave == 1) {
+                    acc_add_fr(a, mont_mul(sA[i + h], sW[i + h]));
+                    acc_add_fr(a, sB[i + h]);
+                } else {
+                    acc_add_fr(a, mont_mul(fr_sub(sA[i + h], sA[i]), fr_sub(sW[i + h], sW[i])));
+                }
+            }
+            a = wave_sum(a);
+        }
+        PDBG(2);
+        publish_round_waves(a, wave, lane, rec, ticket);
+        PDBG(3);
+        if (!wait_challenge(slot, abort_flag, ticket, &s_r, &s_abort)) return;
+        PDBG(4);
+        const Fr r = s_r;
+        // bind the variable in U, V, W and grow eq(u, .) by it -- one product per thread: thread t < 3h folds entry
+        // t % h of table t / h (h <= 64: all at once; h = 128: two turns), the next `cur` threads make the two
+        // children of an eq entry (kept in sPQ, Montgomery, first variable most significant as host_eq_table has it)
+        const uint32_t cur = n / (2u * h);   // eq entries before this round's variable
+        auto tabs = [&](uint32_t tb) -> Fr* { return tb == 0u ? sA : (tb == 1u ? sB : sW); };
+        Fr folded[2], lo_v, hi_v;
+        uint32_t nf = 0;
+        for (uint32_t idx = threadIdx.x; idx < 3u * h; idx += blockDim.x, ++nf) {
+            const uint32_t tb = idx / h, i = idx - tb * h;
+            folded[nf] = fr_fold(tabs(tb)[i], tabs(tb)[i + h], r);
+        }
+        const uint32_t et = threadIdx.x >= blockDim.x - cur ? threadIdx.x - (blockDim.x - cur) : 0xFFFFFFFFu;   // the last `cur` threads
+        if (et != 0xFFFFFFFFu) {
+            Fr one = fr_zero();
+            one.l[0] = 1u;
+            const Fr e = cur == 1u ? to_mont(one) : sPQ[et];
+            hi_v = mont_mul(e, r);
+            lo_v = fr_sub(e, hi_v);
+        }
+        __syncthreads();
+        nf = 0;
+        for (uint32_t idx = threadIdx.x; idx < 3u * h; idx += blockDim.x, ++nf) {
+            const uint32_t tb = idx / h, i = idx - tb * h;
+            tabs(tb)[i] = folded[nf];
+        }
+        if (et != 0xFFFFFFFFu) {
+            sPQ[2u * et] = lo_v;
+            sPQ[2u * et + 1u] = hi_v;
+        }
+        __syncthreads();
+    }
+    PDBG(5);
+    const Fr p = sW[0];   // W(u), Montgomery
+    // ---- the row at b = u: thread c sums the gates whose right operand is c (k_gate_rows)
+    for (uint32_t c = threadIdx.x; c < n; c += blockDim.x) {
+        Fr am[2] = {fr_zero(), fr_zero()};
+        const uint32_t bucket = n + c;
+        for (uint32_t i = offsets[bucket]; i < cursor[bucket]; ++i) {
+            const uint32_t g = list[i], gg = g + gate_base;
+            const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
+            const Fr tt = mont_mul(e, sPQ[left[g]]);
+            const uint32_t w = gate_type[g] ? 1u : 0u;
+            am[w] = fr_add(am[w], tt);
+        }
+        sA[c] = am[0];
+        sB[c] = am[1];
+    }
+    __syncthreads();
+    // ---- the k rounds that bind c, on the row: a (p + W) + m p W
+    for (uint32_t h = n >> 1; h >= 1; h >>= 1, ++ticket) {
+        for (uint32_t i = threadIdx.x; i < 2u * h; i += blockDim.x) {
+            const Fr w = sWc[i];
+            sPQ[i] = mont_mul(p, w);
+            sW[i] = fr_add(p, w);
+        }
+        __syncthreads();
+        Acc<9> a = acc_zero<9>();
+        if (wave < 3) {
+            for (uint32_t i = lane; i < h; i += 64u) {
+                const uint32_t j = i + h;
+                if (wave == 0) {
+                    acc_add_fr(a, fr_add(mont_mul(sA[i], sW[i]), mont_mul(sB[i], sPQ[i])));
+                } else if (wave == 1) {
+                    acc_add_fr(a, fr_add(mont_mul(sA[j], sW[j]), mont_mul(sB[j], sPQ[j])));
+                } else {
+                    acc_add_fr(a, fr_add(mont_mul(fr_sub(sA[j], sA[i]), fr_sub(sW[j], sW[i])),
+                                         mont_mul(fr_sub(sB[j], sB[i]), fr_sub(sPQ[j], sPQ[i]))));
+                }
+            }
+            a = wave_sum(a);
+        }
+        publish_round_waves(a, wave, lane, rec, ticket);
+        if (h == 1) break;   // the last challenge binds nothing the device still needs
+        if (!wait_challenge(slot, abort_flag, ticket, &s_r, &s_abort)) return;
+        const Fr r = s_r;
+        auto tabs = [&](uint32_t tb) -> Fr* { return tb == 0u ? sA : (tb == 1u ? sB : sWc); };
+        Fr folded[2];
+        uint32_t nf = 0;
+        for (uint32_t idx = threadIdx.x; idx < 3u * h; idx += blockDim.x, ++nf) {
+            const uint32_t tb = idx / h, i = idx - tb * h;
+            folded[nf] = fr_fold(tabs(tb)[i], tabs(tb)[i + h], r);
+        }
+        __syncthreads();
+        nf = 0;
+        for (uint32_t idx = threadIdx.x; idx < 3u * h; idx += blockDim.x, ++nf) {
+            const uint32_t tb = idx / h, i = idx - tb * h;
+            tabs(tb)[i] = folded[nf];
+        }
+        __syncthreads();
+    }
+}
+
 // Row collapse, stage 1: partial[chunk][c] = sum over the chunk's rows of eq[row] * T[row][c] for T = A (z = 0)
 // and M (z = 1).  eq: Montgomery, the same value for the whole wave.  grid = (column blocks, chunks, 2 * batch).
 __global__ void __launch_bounds__(256) k_layer_collapse_rows(const Fr* __restrict__ A, const Fr* __restrict__ M,
@@ -1754,6 +1972,22 @@ void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, c
         hipLaunchKernelGGL(k_c_round<true>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
     else
         hipLaunchKernelGGL(k_c_round<false>, dim3(lb.batch), dim3(256), 0, s, A, M, Wc, Wb, h, rtab, host_rec, ticket, lb);
+}
+
+#ifdef GKR_PERSIST_DEBUG
+extern "C" void gkr_debug_read_persist(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_persist_dbg), sizeof(unsigned long long) * 4096);
+}
+#endif
+
+void launch_layer_persistent(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor,
+                             const uint32_t* list, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                             const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, LayerHostRec* host_rec,
+                             const LayerChallenge* challenges, const uint32_t* abort_flag, uint32_t ticket_base, LayerBatch lb,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_persistent, dim3(lb.batch), dim3(256), 0, s, span, k, offsets, cursor, list, gate_type, left, right, e_hi,
+                       e_lo_mont, kl, k_i - kl, W, host_rec, challenges, abort_flag, ticket_base, (uint32_t)lb.wstride);
 }
 
 void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,

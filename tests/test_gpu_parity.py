@@ -238,7 +238,7 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"}, {"GKR_LAYER_DENSE_B": "1"},
-                                 {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"},
+                                 {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_LAYER_PERSISTENT": "1"},
                                  {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
                                  {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")

@@ -12,6 +12,7 @@ from gkr_amd import Context, synth  # noqa: E402
 from gkr_amd.aggregate import ProvingStep  # noqa: E402
 from gkr_amd.field import as_limbs  # noqa: E402
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("GKR_HW_QUEUES", "4"))
 n_inputs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 step = ProvingStep(synth.mimc7_demo_r1cs())
 inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in range(n_inputs)]))
