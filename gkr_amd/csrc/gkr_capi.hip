@@ -1306,7 +1306,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     static const bool want_persistent = getenv("GKR_LAYER_PERSISTENT") != nullptr;
     const bool persistent = lin_b && !shard && !dense_tables && want_persistent && !gate_lists_always && k <= (int)gkr::kPersistentMaxK &&
                             k_i <= k + 4;
-    const bool sparse = shard || persistent || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || k_i + 2 <= 2 * k));
+    // gate lists also for dense layers when the block-private sort applies (k <= 12, >= 2^16 gates: 2^24 gates sort in
+    // ~0.5 ms, against 2.7 ms for the dense tables' cell sort)
+    const bool lds_sort = gkr::gate_lists_lds_blocks(span.count, (uint32_t)k) != 0;
+    const bool sparse = shard || persistent || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || lds_sort || k_i + 2 <= 2 * k));
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -1360,8 +1363,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 WS(ctx, "gates.list", uint32_t, 2 * span.count + 1, g_list);
             }
             HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
+            uint32_t* lds_scratch = nullptr;
+            if (const size_t words = gkr::gate_lists_lds_scratch_words(span.count, (uint32_t)k)) WS(ctx, "gates.lds", uint32_t, words, lds_scratch);
             Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
-            gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, s);
+            gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch, s);
             if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
         }
     } else {
@@ -2276,6 +2281,36 @@ int gkr_sumcheck_layer_sharded(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_
     sh.allreduce = allreduce;
     sh.user = user;
     return run_layer_batch(ctx, 1, k_i, k_next, dgt.p, dl.p, dr.p, z, dW.p, &out_coeffs, &out_len, &out_r, &sh);
+}
+
+int gkr_sumcheck_layer_device(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count, const void* d_gate_type,
+                              const void* d_left, const void* d_right, const gkr_fr* z, const gkr_fr* W, gkr_allreduce_fn allreduce,
+                              void* user, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!W || !out_coeffs || !out_len || !out_r || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (!d_gate_type || !d_left || !d_right) return ctx->fail(GKR_ERR_INVALID, "null device gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > (allreduce ? 13 : 14)) return ctx->fail(GKR_ERR_INVALID, "k_next out of range");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    if (!allreduce && (gate_first != 0 || gate_count != ((uint64_t)1 << k_i)))
+        return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the arrays must hold the whole layer");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k_next, reinterpret_cast<void**>(&dW)));
+    HIP_TRY(ctx, hipMemcpyAsync(dW, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t* gt = static_cast<const uint8_t*>(d_gate_type);
+    const uint32_t* dl = static_cast<const uint32_t*>(d_left);
+    const uint32_t* dr = static_cast<const uint32_t*>(d_right);
+    if (!allreduce) return run_layer(ctx, k_i, k_next, gt, dl, dr, z, dW, out_coeffs, out_len, out_r);
+    LayerShardArgs sh;
+    sh.gate_base = gate_first;
+    sh.gate_count = gate_count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    return run_layer_batch(ctx, 1, k_i, k_next, gt, dl, dr, z, dW, &out_coeffs, &out_len, &out_r, &sh);
 }
 
 int gkr_fr_widen(const gkr_fr* values, size_t count, int64_t* limbs) {

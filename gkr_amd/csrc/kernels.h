@@ -86,9 +86,13 @@ void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, 
 struct GateSpan {
     uint64_t base, count;
 };
+// lds_scratch: gate_lists_lds_scratch_words(gates, k) words (or null): large layers sort with block-private LDS
+// histograms instead of one global atomic per gate and operand
+uint32_t gate_lists_lds_blocks(uint64_t gates, uint32_t k);
+size_t gate_lists_lds_scratch_words(uint64_t gates, uint32_t k);
 void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
-                       hipStream_t s);
+                       uint32_t* lds_scratch, hipStream_t s);
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
                     Fr* U, Fr* V, LayerBatch lb, hipStream_t s);

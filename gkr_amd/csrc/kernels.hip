@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offsets
         if (i < n) {
             const uint32_t v = offsets[i] + add;
             offsets[i] = v;
-            cursor[i] = v;
+            if (cursor) cursor[i] = v;
         }
     }
 }
@@ -776,6 +776,64 @@ __global__ void k_gate_fill(uint64_t gates, uint32_t k, const uint8_t* __restric
         if (l >= n || r >= n || gate_type[g] > 1) continue;
         list[atomicAdd(cursor + l, 1u)] = (uint32_t)g;
         list[atomicAdd(cursor + n + r, 1u)] = (uint32_t)g;
+    }
+}
+
+// The same lists for LARGE layers (2^16 gates and more, k <= 12) without a global atomic per gate.  With 2^24 gates
+// on 2 * 2^12 buckets the global counters are hit ~2000 times each and the two passes above take 1.1 ms apiece;
+// here every block owns a contiguous run of gates and keeps its histogram -- then its write cursors -- in LDS
+// (2 * 2^k counters <= 32 KB):
+//   k_gate_count_lds   block histogram in LDS  ->  hist[bucket][block]   (bucket-major: one scan gives every block
+//                                                   its start inside every bucket)
+//   exclusive scan over 2 * 2^k * blocks entries (the kernels below), k_gate_bucket_bounds picks the buckets' bounds
+//   k_gate_fill_lds    cursors = the block's starts, in LDS; list[cursor++] = gate
+// The order of the gates inside a bucket differs from the global-atomic version; every consumer sums a bucket.
+__global__ void __launch_bounds__(256) k_gate_count_lds(uint64_t gates, uint32_t k, uint32_t per_block,
+                                                        const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+                                                        const uint32_t* __restrict__ right, uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ bad) {
+    extern __shared__ uint32_t s_hist[];
+    const uint32_t n = 1u << k, nb2 = 2u * n;
+    for (uint32_t i = threadIdx.x; i < nb2; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block, end = begin + per_block < gates ? begin + per_block : gates;
+    for (uint64_t g = begin + threadIdx.x; g < end; g += blockDim.x) {
+        const uint32_t l = left[g], r = right[g];
+        if (l >= n || r >= n || gate_type[g] > 1) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        atomicAdd(&s_hist[l], 1u);
+        atomicAdd(&s_hist[n + r], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb2; i += blockDim.x) hist[(size_t)i * gridDim.x + blockIdx.x] = s_hist[i];
+}
+
+__global__ void __launch_bounds__(256) k_gate_bucket_bounds(const uint32_t* __restrict__ starts, uint32_t nb2, uint32_t blocks,
+                                                            const uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ cursor) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb2) return;
+    offsets[b] = starts[(size_t)b * blocks];
+    const size_t last = (size_t)b * blocks + blocks - 1;
+    cursor[b] = starts[last] + hist[last];   // one past the bucket's last gate
+}
+
+__global__ void __launch_bounds__(256) k_gate_fill_lds(uint64_t gates, uint32_t k, uint32_t per_block,
+                                                       const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
+                                                       const uint32_t* __restrict__ right, const uint32_t* __restrict__ starts,
+                                                       uint32_t* __restrict__ list) {
+    extern __shared__ uint32_t s_cur[];
+    const uint32_t n = 1u << k, nb2 = 2u * n;
+    for (uint32_t i = threadIdx.x; i < nb2; i += blockDim.x) s_cur[i] = starts[(size_t)i * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block, end = begin + per_block < gates ? begin + per_block : gates;
+    for (uint64_t g = begin + threadIdx.x; g < end; g += blockDim.x) {
+        const uint32_t l = left[g], r = right[g];
+        if (l >= n || r >= n || gate_type[g] > 1) continue;
+        list[atomicAdd(&s_cur[l], 1u)] = (uint32_t)g;
+        list[atomicAdd(&s_cur[n + r], 1u)] = (uint32_t)g;
     }
 }
 
@@ -1790,10 +1848,42 @@ void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_
 
 // gate lists by left and by right operand: counts / offsets / cursor 2 * 2^k u32 each (counts zeroed by the caller),
 // block_sums ceil(2 * 2^k / 2048) + 1, list 2 * 2^k_i u32
+// blocks of the LDS-privatised sort (0: the layer is small or k too large -- use the global-atomic passes), and the
+// scratch it needs: two arrays of 2 * 2^k * blocks counters (histograms, their scan) + the scan's block sums
+uint32_t gate_lists_lds_blocks(uint64_t gates, uint32_t k) {
+    static const bool off = getenv("GKR_GATE_SORT_GLOBAL") != nullptr;
+    if (off || k > 12 || gates < ((uint64_t)1 << 16)) return 0;
+    uint64_t b = (gates + 16383) / 16384;   // >= 16384 gates per block: the 32 KB histogram flush must stay small beside them
+    if (b > 1024) b = 1024;
+    return (uint32_t)b;
+}
+size_t gate_lists_lds_scratch_words(uint64_t gates, uint32_t k) {
+    const uint32_t blocks = gate_lists_lds_blocks(gates, k);
+    if (!blocks) return 0;
+    const size_t n = ((size_t)2 << k) * blocks;
+    return 2 * n + (n + kScanPerBlock - 1) / kScanPerBlock + 1;
+}
+
 void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
-                       hipStream_t s) {
+                       uint32_t* lds_scratch, hipStream_t s) {
     const size_t n = (size_t)2 << k;
+    const uint32_t lblocks = lds_scratch ? gate_lists_lds_blocks(gates, k) : 0;
+    if (lblocks) {
+        const size_t cells = n * lblocks;
+        uint32_t *hist = lds_scratch, *starts = lds_scratch + cells, *sums = lds_scratch + 2 * cells;
+        const uint32_t per_block = (uint32_t)((gates + lblocks - 1) / lblocks);
+        const uint32_t sblocks = (uint32_t)((cells + kScanPerBlock - 1) / kScanPerBlock);
+        const size_t lds = n * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_gate_count_lds, dim3(lblocks), dim3(256), lds, s, gates, k, per_block, gate_type, left, right, hist, bad);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, hist, starts, sums, cells);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, sblocks);
+        hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, starts, (uint32_t*)nullptr, sums, cells);
+        hipLaunchKernelGGL(k_gate_bucket_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, starts, (uint32_t)n, lblocks, hist, offsets,
+                           cursor);
+        hipLaunchKernelGGL(k_gate_fill_lds, dim3(lblocks), dim3(256), lds, s, gates, k, per_block, gate_type, left, right, starts, list);
+        return;
+    }
     const uint32_t gblocks = blocks_for(gates, 4096);
     const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
     hipLaunchKernelGGL(k_gate_count, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, counts, bad);

@@ -181,6 +181,49 @@ def prove_sumcheck_opt_gate_sharded(ctx: Context, k_i, k_next, gate_first, gate_
     return [from_limbs(C[j])[3 - int(L[j]):] for j in range(v)], from_limbs(R[:v])
 
 
+class ResidentGates:
+    """A contiguous range of a layer's gates kept in device memory across sumchecks (gkr_sumcheck_layer_device): the
+    whole layer, or one rank's share of it."""
+
+    def __init__(self, ctx: Context, k_i, gate_first, gate_type, left, right):
+        self._ctx, self.k_i, self.first = ctx, k_i, gate_first
+        gt = np.ascontiguousarray(gate_type, dtype=np.uint8)
+        l = np.ascontiguousarray(left, dtype=np.uint32)
+        r = np.ascontiguousarray(right, dtype=np.uint32)
+        if not (len(gt) == len(l) == len(r)):
+            raise GkrError(N.GKR_ERR_INVALID, "gate arrays of different lengths")
+        self.count = len(gt)
+        self._d = []
+        for a in (gt, l, r):
+            d = ctx.alloc(max(a.nbytes, 4))
+            if a.nbytes:
+                ctx.upload(d, a)
+            self._d.append(d)
+
+    def sumcheck_raw(self, k_next, z_limbs, w_limbs, sum_limbs=None):
+        """-> (C, L, R) like Context.sumcheck_layer_raw; sum_limbs: the transport of the sum over ranks (None: the
+        arrays hold the whole layer)."""
+        v = 2 * k_next
+        C = np.zeros((v, 3, 4), dtype=np.uint64)
+        L = np.zeros(v, dtype=np.uint32)
+        R = np.zeros((v, 4), dtype=np.uint64)
+        zl = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
+        wl = np.ascontiguousarray(w_limbs, dtype=np.uint64)
+        hook, errors = make_allreduce_hook(sum_limbs) if sum_limbs is not None else (None, [])
+        rc = N.lib().gkr_sumcheck_layer_device(self._ctx._h, ctypes.c_int(self.k_i), ctypes.c_int(k_next), ctypes.c_uint64(self.first),
+                                               ctypes.c_uint64(self.count), self._d[0], self._d[1], self._d[2], _ptr(zl), _ptr(wl),
+                                               hook, None, _ptr(C), _ptr(L), _ptr(R))
+        if errors:
+            raise errors[0]
+        self._ctx._check(rc)
+        return C, L, R
+
+    def close(self):
+        for d in self._d:
+            self._ctx.free(d)
+        self._d = []
+
+
 class ThreadedSum:
     """Sum-over-ranks for P logical ranks that are P threads of one process (one GPU): every rank deposits its
     limbs, the last one in adds them up, all leave with the total."""

@@ -174,6 +174,14 @@ int  gkr_sumcheck_layer_sharded(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate
                                 const uint8_t *gate_type, const uint32_t *left, const uint32_t *right, const gkr_fr *z,
                                 const gkr_fr *W, gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs,
                                 uint32_t *out_len, gkr_fr *out_r);
+/* The same sumcheck with the gate arrays already in device memory (gkr_device_alloc + gkr_device_upload; gate_count
+ * entries each, gates gate_first .. of the layer) -- nothing but z, W and the transcript crosses PCIe.  allreduce ==
+ * NULL: the arrays hold the whole layer (gate_first = 0, gate_count = 2^k_i) and no exchange takes place, i.e.
+ * gkr_sumcheck_layer on resident gates; otherwise as gkr_sumcheck_layer_sharded.  Gates are validated on the device. */
+int  gkr_sumcheck_layer_device(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
+                               const void *d_gate_type, const void *d_left, const void *d_right, const gkr_fr *z,
+                               const gkr_fr *W, gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs,
+                               uint32_t *out_len, gkr_fr *out_r);
 /* host only: count field elements <-> count x 8 int64 (32-bit limbs, least significant first); narrow reduces
  * limb sums of up to 2^31 addends mod r */
 int  gkr_fr_widen(const gkr_fr *values, size_t count, int64_t *limbs);

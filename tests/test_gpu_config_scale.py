@@ -34,8 +34,10 @@ def config5_expected(tmp_path_factory):
     return path, (C, L, R)
 
 
-@pytest.mark.parametrize("env", [{}, {"GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_B": "1"}],
-                         ids=["default(dense tables, linear-time rounds)", "gate lists", "dense b-phase passes"])
+@pytest.mark.parametrize("env", [{}, {"GKR_GATE_SORT_GLOBAL": "1", "GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"},
+                                 {"GKR_LAYER_DENSE_B": "1"}],
+                         ids=["default(gate lists, block-private sort)", "gate lists, global-atomic sort",
+                              "dense tables, linear-time rounds", "dense b-phase passes"])
 def test_config5_layer_every_form_matches_oracle(config5_expected, env):
     path, _ = config5_expected
     out = subprocess.run([sys.executable, os.path.join(HERE, "config_scale_worker.py"), str(K_I), str(K), path],
@@ -67,3 +69,17 @@ def test_config4_proof_batch_of_the_bench_matches_oracle():
         assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"], b
         assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"], b
         assert verify(pr, circuit), b
+
+
+def test_config5_layer_on_resident_gates_matches_oracle(config5_expected):
+    """gkr_sumcheck_layer_device: the gate arrays uploaded once (what bench.py --mode layer-split times), whole layer
+    and, through the hook with an in-process sum, as two halves."""
+    _, (C, L, R) = config5_expected
+    lay, z, W = synth.config5_layer(K_I, K)
+    gt, l, r = lay.arrays()
+    with Context(0) as ctx:
+        gates = parallel.ResidentGates(ctx, K_I, 0, gt, l, r)
+        for _ in range(2):
+            got = gates.sumcheck_raw(K, z, W)
+            assert np.array_equal(got[0], C) and np.array_equal(got[1], L) and np.array_equal(got[2], R)
+        gates.close()

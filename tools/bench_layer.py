@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--transcript", choices=["host", "device"], default="host")
+    ap.add_argument("--resident", action="store_true", help="gate arrays uploaded once, before the timed calls (gkr_sumcheck_layer_device)")
     args = ap.parse_args()
     from gkr_amd import Context, multi_hash, synth
     from gkr_amd.field import MODULUS as P, from_limbs
@@ -36,11 +37,15 @@ def main():
     ctx.set_transcript(1 if args.transcript == "host" else 0)
     ctx.profile(True)
     times = []
+    gates = None
+    if args.resident:
+        from gkr_amd.parallel import ResidentGates
+        gates = ResidentGates(ctx, args.k_i, 0, *lay.arrays())
     for it in range(args.warmup + args.steps):
         if it == args.warmup:
             ctx.profile_reset()
         t0 = time.perf_counter()
-        C, L, R = ctx.sumcheck_layer_raw(lay, args.k, z, W)
+        C, L, R = gates.sumcheck_raw(args.k, z, W) if gates else ctx.sumcheck_layer_raw(lay, args.k, z, W)
         times.append(time.perf_counter() - t0)
     names = ["predicate_scatter", "predicate_normalise", "predicate_sorted",
              "layer_round_fused", "layer_round", "layer_fold", "layer_round_reduce", "layer_round_hash",
@@ -51,7 +56,8 @@ def main():
     sum_ms = sum(prof[n]["total_ms"] for n in ("layer_round_fused", "layer_round", "layer_fold", "layer_uv", "layer_uv_round",
                                                "layer_collapse", "layer_c_round", "gate_uv", "gate_rows")) / steps
     out = {
-        "workload": "GKR layer sumcheck k_i=%d k=%d (2^%d-point hypercube, 2^%d gates)" % (args.k_i, args.k, 2 * args.k, args.k_i),
+        "workload": "GKR layer sumcheck k_i=%d k=%d (2^%d-point hypercube, 2^%d gates)%s" % (
+            args.k_i, args.k, 2 * args.k, args.k_i, ", gates resident in HBM" if gates else ", gate arrays uploaded in every call"),
         "wall_ms_per_sumcheck": 1e3 * sum(times[args.warmup:]) / steps,
         "kernel_ms_per_sumcheck": {n: prof[n]["total_ms"] / steps for n in names},
         "field_ops": 25 * (N - 1), "algorithmic_bytes": 256 * N,
