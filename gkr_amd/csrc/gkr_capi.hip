@@ -561,6 +561,54 @@ static int mle_pass_rounds(int m, int n, int jmax) {
 }
 
 // ------------------------------------------------------------- plain MLE sumcheck, multi-round passes
+// The host's share of one multi-round pass, scalar form (the IFMA-lane form is gkr_ifma_pass, mimc_ifma.cpp; same
+// arguments, same results): per lane k and round t the round polynomial's coefficients from the sub-block sums, the
+// vector's length, the challenge, then the sums with that variable bound; at the end the 2^J weights of the fold pass
+// that binds the J variables, w_b = prod_t (bit_t(b) ? r_t : 1 - r_t), bit_0 = most significant, Montgomery form.
+static void host_pass_scalar(const uint64_t* sums, size_t sums_row_words, int count, int J, const uint32_t* final_len,
+                             uint64_t (*c0)[16][4], uint64_t (*c1)[16][4], uint64_t (*r)[16][4], uint32_t (*len)[16],
+                             uint64_t* weights, size_t w_row_words) {
+    using gkr::h64::F;
+    const F* cts = host_mimc_constants64();
+    const F one_m = gkr::h64::to_mont(F{{1, 0, 0, 0}});
+    for (int k = 0; k < count; ++k) {
+        F S[gkr::kMleMaxSub], rm[gkr::kMlePassMaxRounds];
+        memcpy(S, sums + (size_t)k * sums_row_words, sizeof(F) << J);
+        for (int t = 0; t < J; ++t) {
+            const int half = 1 << (J - t - 1);
+            F lo = S[0], hi = S[half];
+            for (int b = 1; b < half; ++b) {
+                lo = gkr::h64::add(lo, S[b]);
+                hi = gkr::h64::add(hi, S[half + b]);
+            }
+            const F d = gkr::h64::sub(hi, lo);
+            const uint32_t ln = (final_len && t == J - 1) ? final_len[k] : (gkr::h64::is_zero(d) ? 1u : 2u);
+            const F vec[2] = {d, lo};
+            const F rc = gkr::h64::mimc7_multi_hash(vec + (2 - ln), (int)ln, cts, nullptr);
+            memcpy(c0[t][k], &lo, 32);
+            memcpy(c1[t][k], &d, 32);
+            memcpy(r[t][k], &rc, 32);
+            len[t][k] = ln;
+            rm[t] = gkr::h64::to_mont(rc);
+            for (int b = 0; b < half; ++b) S[b] = gkr::h64::add(S[b], gkr::h64::mont_mul(gkr::h64::sub(S[half + b], S[b]), rm[t]));
+        }
+        if (!weights) continue;
+        F* w = reinterpret_cast<F*>(weights + (size_t)k * w_row_words);
+        F tmp[gkr::kMleMaxSub];
+        tmp[0] = one_m;
+        int cur = 1;
+        for (int t = 0; t < J; ++t) {
+            const F nr = gkr::h64::sub(one_m, rm[t]);
+            for (int b = cur; b-- > 0;) {
+                tmp[2 * b + 1] = gkr::h64::mont_mul(tmp[b], rm[t]);
+                tmp[2 * b] = gkr::h64::mont_mul(tmp[b], nr);
+            }
+            cur <<= 1;
+        }
+        memcpy(w, tmp, sizeof(F) << J);
+    }
+}
+
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
 // eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
@@ -595,8 +643,8 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     WS(ctx, "mlep.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
     HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
     HIP_TRY(ctx, ctx->pinned_host("mlep.w", sizeof(Fr) * gkr::kMleMaxSub * batch, reinterpret_cast<void**>(&h_w)));
-    const F* cts = host_mimc_constants64();
     const bool ifma = host_ifma_ready();
+    const bool scalar_book = getenv("GKR_HOST_PASS_SCALAR") != nullptr;   // A/B switch: host_pass_scalar even where the CPU has IFMA
     std::vector<uint32_t> dep_last(batch, 0);
     gkr::SpinPool* pool = ctx->host_pool();
     const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
@@ -732,78 +780,31 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         Timed t(ctx, "mle_sub_reduce", 0.0, st, true);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st);
     };
-    // the J rounds of up to eight sumchecks whose sub-block sums have landed
+    // the J rounds of up to sixteen sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
         const int J = G.j;
-        F sums[kHashChunkMax][gkr::kMleMaxSub], rr[kHashChunkMax][gkr::kMlePassMaxRounds];
+        uint64_t c0[gkr::kMlePassMaxRounds][16][4], c1[gkr::kMlePassMaxRounds][16][4], r[gkr::kMlePassMaxRounds][16][4];
+        uint32_t ln[gkr::kMlePassMaxRounds][16], final_len[16];
+        const bool final_pass = G.round0 + J == n;
         for (int i = 0; i < count; ++i) {
-            memcpy(sums[i], rec[b_first + i].sums, sizeof(F) << J);
             if (G.round0 == 0) dep_last[b_first + i] = rec[b_first + i].dep;
+            final_len[i] = dep_last[b_first + i] ? 2u : 1u;
         }
-        for (int t = 0; t < J; ++t) {
-            const int half = 1 << (J - t - 1), round = G.round0 + t;
-            F c0[kHashChunkMax], c1[kHashChunkMax];
-            uint32_t ln[kHashChunkMax] = {};
-            for (int i = 0; i < count; ++i) {
-                F lo = sums[i][0], hi = sums[i][half];
-                for (int b = 1; b < half; ++b) {
-                    lo = gkr::h64::add(lo, sums[i][b]);
-                    hi = gkr::h64::add(hi, sums[i][half + b]);
-                }
-                c0[i] = lo;
-                c1[i] = gkr::h64::sub(hi, lo);
-                if (round + 1 < n)
-                    ln[i] = gkr::h64::is_zero(c1[i]) ? 1u : 2u;
-                else
-                    ln[i] = dep_last[b_first + i] ? 2u : 1u;
-            }
-            F r[kHashChunkMax];
-            if (ifma && count >= 3) {
-                uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
-                memset(vec, 0, sizeof vec);
-                for (int i = 0; i < count; ++i) {
-                    memcpy(vec[i][1], &c1[i], 32);
-                    memcpy(vec[i][2], &c0[i], 32);
-                }
-                ifma_hash_chunk(vec, ln, count, out);
-                for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
-            } else {
-                for (int i = 0; i < count; ++i) {
-                    F vec[2] = {c1[i], c0[i]};
-                    r[i] = gkr::h64::mimc7_multi_hash(vec + (2 - ln[i]), (int)ln[i], cts, nullptr);
-                }
-            }
-            for (int i = 0; i < count; ++i) {
-                const int b = b_first + i;
+        static_assert(sizeof(gkr::MleHostRecSub) % 8 == 0, "hand-off records are addressed in 64-bit words");
+        const uint64_t* sums = reinterpret_cast<const uint64_t*>(rec[b_first].sums);
+        uint64_t* weights = G.m - J > 0 ? reinterpret_cast<uint64_t*>(h_w + (size_t)b_first * gkr::kMleMaxSub) : nullptr;
+        (ifma && count >= 3 && !scalar_book ? gkr::gkr_ifma_pass : host_pass_scalar)(
+            sums, sizeof(gkr::MleHostRecSub) / 8, count, J, final_pass ? final_len : nullptr, c0, c1, r, ln, weights, 4 * gkr::kMleMaxSub);
+        for (int i = 0; i < count; ++i) {
+            const int b = b_first + i;
+            for (int t = 0; t < J; ++t) {
+                const int round = G.round0 + t;
                 gkr_fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
                 memset(&oc[0], 0, 32);
-                if (ln[i] == 2) memcpy(&oc[0], &c1[i], 32);
-                memcpy(&oc[1], &c0[i], 32);
-                out_len[(size_t)b * n + round] = ln[i];
-                memcpy(&out_r[(size_t)b * n + round], &r[i], 32);
-                rr[i][t] = gkr::h64::to_mont(r[i]);
-                // the sub-block sums of the table with this variable bound
-                for (int bb = 0; bb < half; ++bb)
-                    sums[i][bb] = gkr::h64::add(sums[i][bb], gkr::h64::mont_mul(gkr::h64::sub(sums[i][half + bb], sums[i][bb]), rr[i][t]));
-            }
-        }
-        if (G.m - J > 0) {
-            // weights of the pass that binds these J variables: w_b = prod_t (bit_t(b) ? r_t : 1 - r_t),
-            // bit_0 = most significant; Montgomery form
-            const F one_m = gkr::h64::to_mont(F{{1, 0, 0, 0}});
-            for (int i = 0; i < count; ++i) {
-                F w[gkr::kMleMaxSub];
-                w[0] = one_m;
-                int cur = 1;
-                for (int t = 0; t < J; ++t) {
-                    const F nr = gkr::h64::sub(one_m, rr[i][t]);
-                    for (int b = cur; b-- > 0;) {
-                        w[2 * b + 1] = gkr::h64::mont_mul(w[b], rr[i][t]);
-                        w[2 * b] = gkr::h64::mont_mul(w[b], nr);
-                    }
-                    cur <<= 1;
-                }
-                memcpy(h_w + (size_t)(b_first + i) * gkr::kMleMaxSub, w, sizeof(F) << J);
+                if (ln[t][i] == 2) memcpy(&oc[0], c1[t][i], 32);
+                memcpy(&oc[1], c0[t][i], 32);
+                out_len[(size_t)b * n + round] = ln[t][i];
+                memcpy(&out_r[(size_t)b * n + round], r[t][i], 32);
             }
         }
     };
@@ -2045,9 +2046,6 @@ int gkr_selftest_fold(const gkr_fr* lo, const gkr_fr* hi, const gkr_fr* r, gkr_f
     return GKR_OK;
 }
 
-// eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
-// host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1; its sixteen-lane
-// form is cross-checked on the way), else scalar
 // the pass schedule of a 2^n-point sumcheck (host logic only): rounds[i] = rounds covered by pass i, *passes = how many.
 // mfma != 0: the default schedule (up to 5 rounds per pass), 0: the v_mad_u64_u32 fold's (up to 3).
 int gkr_selftest_pass_schedule(int n, int mfma, uint32_t* rounds, size_t capacity, size_t* passes) {
@@ -2064,6 +2062,58 @@ int gkr_selftest_pass_schedule(int n, int mfma, uint32_t* rounds, size_t capacit
     return (rounds && count > capacity) ? GKR_ERR_NOMEM : GKR_OK;
 }
 
+// The host's share of one multi-round pass (host logic only): `count` <= 16 sumchecks, each with 2^J sub-block sums
+// (rows of 32: sums[k * 32 + b]) -> per round t < J the coefficients c0[t * count + k], c1[..], the vector length
+// len[..] (final_len non-null: the last round's lengths are given, as in a sumcheck's final round), the challenge
+// r[..]; and w[k * 32 + b], b < 2^J: the weights eq((r_0..r_{J-1}), b) of the fold pass that follows, canonical.
+// Scalar code always; the IFMA-lane form runs beside it when the CPU has it (*used_ifma = 1) and any difference is
+// GKR_ERR_INVALID.
+int gkr_selftest_host_pass(const gkr_fr* sums, int count, int J, const uint32_t* final_len, gkr_fr* c0, gkr_fr* c1, uint32_t* len,
+                           gkr_fr* r, gkr_fr* w, int* used_ifma) {
+    using gkr::h64::F;
+    if (!sums || !c0 || !c1 || !len || !r || !w || count < 1 || count > kHashChunkMax || J < 1 || J > gkr::kMlePassMaxRounds)
+        return GKR_ERR_INVALID;
+    static_assert(gkr::kMleMaxSub == 32 && kHashChunkMax == 16, "shapes of the self-test's arrays");
+    if (!all_canonical(sums, (size_t)count * 32)) return GKR_ERR_NON_CANONICAL;
+    if (final_len)
+        for (int k = 0; k < count; ++k)
+            if (final_len[k] != 1 && final_len[k] != 2) return GKR_ERR_INVALID;
+    struct Out {
+        uint64_t c0[gkr::kMlePassMaxRounds][16][4], c1[gkr::kMlePassMaxRounds][16][4], r[gkr::kMlePassMaxRounds][16][4];
+        uint32_t len[gkr::kMlePassMaxRounds][16];
+        std::vector<F> w;
+    } a, b;
+    a.w.assign((size_t)count * 32, F{{0, 0, 0, 0}});
+    host_pass_scalar(reinterpret_cast<const uint64_t*>(sums), 4 * 32, count, J, final_len, a.c0, a.c1, a.r, a.len, &a.w[0].l[0], 4 * 32);
+    const bool ifma = host_ifma_ready();
+    if (used_ifma) *used_ifma = ifma ? 1 : 0;
+    if (ifma) {
+        b.w.assign((size_t)count * 32, F{{0, 0, 0, 0}});
+        gkr::gkr_ifma_pass(reinterpret_cast<const uint64_t*>(sums), 4 * 32, count, J, final_len, b.c0, b.c1, b.r, b.len, &b.w[0].l[0], 4 * 32);
+        for (int t = 0; t < J; ++t)
+            for (int k = 0; k < count; ++k)
+                if (memcmp(a.c0[t][k], b.c0[t][k], 32) || memcmp(a.c1[t][k], b.c1[t][k], 32) || memcmp(a.r[t][k], b.r[t][k], 32) ||
+                    a.len[t][k] != b.len[t][k])
+                    return GKR_ERR_INVALID;
+        if (memcmp(a.w.data(), b.w.data(), sizeof(F) * a.w.size()) != 0) return GKR_ERR_INVALID;
+    }
+    for (int t = 0; t < J; ++t)
+        for (int k = 0; k < count; ++k) {
+            memcpy(&c0[(size_t)t * count + k], a.c0[t][k], 32);
+            memcpy(&c1[(size_t)t * count + k], a.c1[t][k], 32);
+            memcpy(&r[(size_t)t * count + k], a.r[t][k], 32);
+            len[(size_t)t * count + k] = a.len[t][k];
+        }
+    for (size_t i = 0; i < a.w.size(); ++i) {
+        const F wc = gkr::h64::from_mont(a.w[i]);
+        memcpy(&w[i], &wc, 32);
+    }
+    return GKR_OK;
+}
+
+// eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
+// host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1; its sixteen-lane
+// form is cross-checked on the way), else scalar
 int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int* used_ifma) {
     if (!vecs || !len || !out) return GKR_ERR_INVALID;
     if (!all_canonical(vecs, 24)) return GKR_ERR_NON_CANONICAL;

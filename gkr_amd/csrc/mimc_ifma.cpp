@@ -73,7 +73,7 @@ static void dbl_mod(uint64_t x[4]) {
     memcpy(x, t, 32);
 }
 
-static uint64_t g_p52[5], g_pinv52, g_r2_52[5], g_one52[5];
+static uint64_t g_p52[5], g_pinv52, g_r2_52[5], g_one52[5], g_r256_52[5];   // g_r256: 2^256 mod p (the 4x64-bit code's Montgomery one)
 static uint64_t g_cts52[91][5];   // MiMC constants, Montgomery (radix 2^260)
 static bool g_ready = false;
 
@@ -281,6 +281,9 @@ static void init_constants(const uint64_t (*cts_canonical)[4]) {
     to52(x, g_r2_52);
     uint64_t one[4] = {1, 0, 0, 0};
     to52(one, g_one52);
+    uint64_t r256[4] = {1, 0, 0, 0};
+    for (int i = 0; i < 256; ++i) dbl_mod(r256);
+    to52(r256, g_r256_52);
     g_ready = true;   // mont_mul usable from here
     const V r2 = splat(g_r2_52);
     for (int base = 0; base < 91; base += 8) {
@@ -417,7 +420,161 @@ static void multi_hash_w(const uint64_t (*vec)[3][4], const uint32_t* len, int s
     for (int w = 0; w < W; ++w) store8(mont_mul(r[w], one), out + 8 * w);
 }
 
+// (a - b) mod p, inputs < p with 52-bit limbs: a + (p - b), the difference formed with a borrow chain
+static inline V sub_mod(const V& a, const V& b) {
+    const __m512i mask = bc(M52);
+    const __m512i p0 = bc(g_p52[0]), p1 = bc(g_p52[1]), p2 = bc(g_p52[2]), p3 = bc(g_p52[3]), p4 = bc(g_p52[4]);
+    V n;
+    __m512i d0 = _mm512_sub_epi64(p0, b.l[0]);
+    __m512i d1 = _mm512_sub_epi64(_mm512_sub_epi64(p1, b.l[1]), _mm512_srli_epi64(d0, 63));
+    __m512i d2 = _mm512_sub_epi64(_mm512_sub_epi64(p2, b.l[2]), _mm512_srli_epi64(d1, 63));
+    __m512i d3 = _mm512_sub_epi64(_mm512_sub_epi64(p3, b.l[3]), _mm512_srli_epi64(d2, 63));
+    __m512i d4 = _mm512_sub_epi64(_mm512_sub_epi64(p4, b.l[4]), _mm512_srli_epi64(d3, 63));
+    n.l[0] = _mm512_and_si512(d0, mask);
+    n.l[1] = _mm512_and_si512(d1, mask);
+    n.l[2] = _mm512_and_si512(d2, mask);
+    n.l[3] = _mm512_and_si512(d3, mask);
+    n.l[4] = _mm512_and_si512(d4, mask);   // p - b in [1, p]; add_mod folds a + p back below p
+    return add_mod(a, n);
+}
+
+// eight canonical 4x64 values at base + k * stride_words (lanes >= count read lane 0's) <-> limb-major 5x52, all in
+// vector registers: four gathers / scatters of the 64-bit words and shifts between the two radices
+static inline __m512i lane_offsets(size_t stride_words, int count) {
+    alignas(64) uint64_t o[8];
+    for (int k = 0; k < 8; ++k) o[k] = (k < count ? (uint64_t)k : 0) * stride_words;
+    return _mm512_load_si512(o);
+}
+static inline V gather8(const uint64_t* base, __m512i off) {
+    const __m512i mask = bc(M52);
+    const __m512i w0 = _mm512_i64gather_epi64(off, base + 0, 8), w1 = _mm512_i64gather_epi64(off, base + 1, 8);
+    const __m512i w2 = _mm512_i64gather_epi64(off, base + 2, 8), w3 = _mm512_i64gather_epi64(off, base + 3, 8);
+    V v;
+    v.l[0] = _mm512_and_si512(w0, mask);
+    v.l[1] = _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w0, 52), _mm512_slli_epi64(w1, 12)), mask);
+    v.l[2] = _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w1, 40), _mm512_slli_epi64(w2, 24)), mask);
+    v.l[3] = _mm512_and_si512(_mm512_or_si512(_mm512_srli_epi64(w2, 28), _mm512_slli_epi64(w3, 36)), mask);
+    v.l[4] = _mm512_srli_epi64(w3, 16);
+    return v;
+}
+static inline void scatter8(const V& v, uint64_t* base, __m512i off, __mmask8 lanes) {
+    const __m512i w0 = _mm512_or_si512(v.l[0], _mm512_slli_epi64(v.l[1], 52));
+    const __m512i w1 = _mm512_or_si512(_mm512_srli_epi64(v.l[1], 12), _mm512_slli_epi64(v.l[2], 40));
+    const __m512i w2 = _mm512_or_si512(_mm512_srli_epi64(v.l[2], 24), _mm512_slli_epi64(v.l[3], 28));
+    const __m512i w3 = _mm512_or_si512(_mm512_srli_epi64(v.l[3], 36), _mm512_slli_epi64(v.l[4], 16));
+    _mm512_mask_i64scatter_epi64(base + 0, lanes, off, w0, 8);
+    _mm512_mask_i64scatter_epi64(base + 1, lanes, off, w1, 8);
+    _mm512_mask_i64scatter_epi64(base + 2, lanes, off, w2, 8);
+    _mm512_mask_i64scatter_epi64(base + 3, lanes, off, w3, 8);
+}
+static inline __mmask8 nonzero_lanes(const V& v) {
+    const __m512i any = _mm512_or_si512(_mm512_or_si512(v.l[0], v.l[1]), _mm512_or_si512(_mm512_or_si512(v.l[2], v.l[3]), v.l[4]));
+    return _mm512_test_epi64_mask(any, any);
+}
+
+// The host's whole share of one multi-round pass for 8 W sumchecks side by side (gkr_ifma_pass below): the 2^J
+// sub-block sums stay in vector registers / L1 from the load to the last binding, the round vectors go into the
+// hash without passing through memory.
+template <int W>
+static void pass_w(const uint64_t* sums, size_t sums_row_words, int count, int J, const uint32_t* final_len, uint64_t (*c0)[16][4],
+                   uint64_t (*c1)[16][4], uint64_t (*r)[16][4], uint32_t (*len)[16], uint64_t* weights, size_t w_row_words) {
+    const V r2 = splat(g_r2_52), one = splat(g_one52);
+    V zero;
+    for (int i = 0; i < 5; ++i) zero.l[i] = _mm512_setzero_si512();
+    V S[W][32], rm[5][W];
+    __m512i off_in[W], off_out[W], off_w[W];
+    __mmask8 valid[W];
+    int cnt[W];
+    for (int w = 0; w < W; ++w) {
+        cnt[w] = count - 8 * w < 0 ? 0 : (count - 8 * w > 8 ? 8 : count - 8 * w);
+        valid[w] = (__mmask8)((1u << cnt[w]) - 1);
+        off_in[w] = lane_offsets(sums_row_words, cnt[w]);
+        off_out[w] = lane_offsets(4, cnt[w]);
+        off_w[w] = lane_offsets(w_row_words, cnt[w]);
+        const uint64_t* base = sums + (size_t)(cnt[w] ? 8 * w : 0) * sums_row_words;
+        for (int b = 0; b < (1 << J); ++b) S[w][b] = gather8(base + 4 * (size_t)b, off_in[w]);
+    }
+    for (int t = 0; t < J; ++t) {
+        const int half = 1 << (J - t - 1);
+        V lo[W], d[W], a[W], acc[W], h[W];
+        __mmask8 two[W];
+        unsigned any_two = 0;
+        for (int w = 0; w < W; ++w) {
+            V l = S[w][0], u = S[w][half];
+            for (int b = 1; b < half; ++b) {
+                l = add_mod(l, S[w][b]);
+                u = add_mod(u, S[w][half + b]);
+            }
+            lo[w] = l;
+            d[w] = sub_mod(u, l);
+            if (final_len && t == J - 1) {
+                two[w] = 0;
+                for (int k = 0; k < cnt[w]; ++k)
+                    if (final_len[8 * w + k] == 2) two[w] |= (__mmask8)(1u << k);
+            } else {
+                two[w] = nonzero_lanes(d[w]) & valid[w];
+            }
+            any_two |= two[w];
+            alignas(32) uint32_t ln[8];
+            for (int k = 0; k < 8; ++k) ln[k] = (two[w] >> k) & 1 ? 2u : 1u;
+            memcpy(&len[t][8 * w], ln, sizeof ln);
+            scatter8(l, &c0[t][8 * w][0], off_out[w], valid[w]);
+            scatter8(d[w], &c1[t][8 * w][0], off_out[w], valid[w]);
+            acc[w] = zero;
+        }
+        // multi_hash([c1, c0]) where the vector has two entries, multi_hash([c0]) where it has one
+        if (any_two) {
+            for (int w = 0; w < W; ++w) a[w] = mont_mul(d[w], r2);
+            mimc7_hash_w<W>(a, acc, h);
+            for (int w = 0; w < W; ++w) {
+                const V nr = add_mod(add_mod(acc[w], a[w]), h[w]);
+                for (int i = 0; i < 5; ++i) acc[w].l[i] = _mm512_mask_blend_epi64(two[w], acc[w].l[i], nr.l[i]);
+            }
+        }
+        for (int w = 0; w < W; ++w) a[w] = mont_mul(lo[w], r2);
+        mimc7_hash_w<W>(a, acc, h);
+        for (int w = 0; w < W; ++w) {
+            rm[t][w] = add_mod(add_mod(acc[w], a[w]), h[w]);   // the challenge, Montgomery form (radix 2^260)
+            scatter8(mont_mul(rm[t][w], one), &r[t][8 * w][0], off_out[w], valid[w]);
+            for (int b = 0; b < half; ++b) S[w][b] = add_mod(S[w][b], mont_mul(sub_mod(S[w][half + b], S[w][b]), rm[t][w]));
+        }
+    }
+    if (!weights) return;
+    for (int w = 0; w < W; ++w) {
+        if (!cnt[w]) continue;
+        V* wv = S[w];   // the sums are spent
+        wv[0] = splat(g_r256_52);
+        int cur = 1;
+        for (int t = 0; t < J; ++t) {
+            for (int b = cur; b-- > 0;) {
+                const V hi = mont_mul(wv[b], rm[t][w]);
+                wv[2 * b + 1] = hi;
+                wv[2 * b] = sub_mod(wv[b], hi);
+            }
+            cur <<= 1;
+        }
+        uint64_t* base = weights + (size_t)8 * w * w_row_words;
+        for (int b = 0; b < cur; ++b) scatter8(wv[b], base + 4 * (size_t)b, off_w[w], valid[w]);
+    }
+}
+
 }  // namespace ifma
+
+// The host's share of one multi-round pass of `count` <= 16 plain sumchecks (lanes), J <= 5 rounds:
+//   in   sums[k * sums_row_words + 4 b .. +4), b < 2^J: lane k's sub-block sums (canonical)
+//        final_len: null, or the vector length (1 | 2) of each lane's LAST round where that round is the sumcheck's
+//        final one (its length follows the table's dependence on the last variable, not the coefficient)
+//   out  per round t < J and lane k: c0[t][k] = sum of the lower half, c1[t][k] = upper - lower (the round polynomial
+//        c1 x + c0), len[t][k] = 1 if c1 == 0 else 2, r[t][k] = multi_hash(the vector, key 0); all canonical
+//        weights (may be null): lane k's 2^J weights eq((r_0..r_{J-1}), b) times 2^256 at weights[k * w_row_words + 4 b]
+// Round t+1's sums come from binding round t's variable in the sub-block sums (linear in the table).
+void gkr_ifma_pass(const uint64_t* sums, size_t sums_row_words, int count, int J, const uint32_t* final_len, uint64_t (*c0)[16][4],
+                   uint64_t (*c1)[16][4], uint64_t (*r)[16][4], uint32_t (*len)[16], uint64_t* weights, size_t w_row_words) {
+    if (count > 8)
+        ifma::pass_w<2>(sums, sums_row_words, count, J, final_len, c0, c1, r, len, weights, w_row_words);
+    else
+        ifma::pass_w<1>(sums, sums_row_words, count, J, final_len, c0, c1, r, len, weights, w_row_words);
+}
 
 bool gkr_ifma_available() {
 #if defined(__x86_64__)

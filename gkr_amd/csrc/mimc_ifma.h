@@ -9,4 +9,7 @@ void gkr_ifma_init(const uint64_t (*cts_canonical)[4]);
 // vec[k][s]: slot s of lane k (right-aligned round vector, `slots` <= 3 slots); len[k] trailing slots are hashed
 void gkr_ifma_multi_hash8(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]);
 void gkr_ifma_multi_hash16(const uint64_t (*vec)[3][4], const uint32_t* len, int slots, uint64_t (*out)[4]);
+// the host's whole share of one multi-round pass, `count` <= 16 sumchecks side by side (see mimc_ifma.cpp)
+void gkr_ifma_pass(const uint64_t* sums, size_t sums_row_words, int count, int J, const uint32_t* final_len, uint64_t (*c0)[16][4],
+                   uint64_t (*c1)[16][4], uint64_t (*r)[16][4], uint32_t (*len)[16], uint64_t* weights, size_t w_row_words);
 }  // namespace gkr

@@ -119,6 +119,14 @@ int  gkr_selftest_mul(const gkr_fr *a, const gkr_fr *b, gkr_fr *out);
 int  gkr_selftest_wide_sum(const gkr_fr *vals, size_t n, gkr_fr *out);
 /* the host transcript's batched hash: eight right-aligned 3-slot round vectors at once */
 int  gkr_selftest_hash8(const gkr_fr *vecs, const uint32_t *len, gkr_fr *out, int *used_ifma);
+/* the host's share of one multi-round pass of the plain sumcheck: `count` <= 16 sumchecks with 2^J <= 32 sub-block
+ * sums each (rows of 32: sums[k*32 + b]) -> per round t < J and sumcheck k (index t*count + k) the round polynomial
+ * c1 x + c0, the vector's length (final_len non-null: the lengths of the last round are given), the challenge
+ * multi_hash(vector); w[k*32 + b], b < 2^J: the weights eq(r, b) of the fold pass that follows (canonical, first
+ * challenge = most significant index bit).  Scalar code; its IFMA-lane form runs beside it when the CPU has it and
+ * must agree. */
+int  gkr_selftest_host_pass(const gkr_fr *sums, int count, int J, const uint32_t *final_len, gkr_fr *c0, gkr_fr *c1,
+                            uint32_t *len, gkr_fr *r, gkr_fr *w, int *used_ifma);
 /* sum_i a_i b_i through the unreduced 544-bit dot-product accumulator of the fused layer kernel */
 int  gkr_selftest_dot(const gkr_fr *a, const gkr_fr *b, size_t n, gkr_fr *out);
 /* the pass schedule of a 2^n-point plain sumcheck (host logic): rounds covered by each pass; mfma = 1 default

@@ -195,6 +195,29 @@ static void hashes(std::mt19937_64& rng) {
         gkr::gkr_ifma_multi_hash8(v, len, 3, o8);
         gkr::gkr_ifma_multi_hash16(v, len, 3, o16);
         CHECK(memcmp(o8, o16, sizeof o8) == 0);   // the first eight lanes agree between the two forms
+        // the whole-pass form: heap buffers of exactly the advertised size, every lane count, so that an out-of-range
+        // gather or scatter of a partially filled lane group is an ASan report; round 0's challenge against the hash above
+        for (int count = 1; count <= 16; ++count) {
+            const int J = 1 + count % 5;
+            std::vector<uint64_t> sums((size_t)count * 128), w((size_t)count * 128);
+            for (size_t i = 0; i < sums.size(); ++i) sums[i] = (i % 4 == 3) ? rng() >> 4 : rng();
+            std::vector<uint64_t> c0(5 * 16 * 4), c1(5 * 16 * 4), r(5 * 16 * 4);
+            std::vector<uint32_t> ln(5 * 16);
+            gkr::gkr_ifma_pass(sums.data(), 128, count, J, nullptr, reinterpret_cast<uint64_t(*)[16][4]>(c0.data()),
+                               reinterpret_cast<uint64_t(*)[16][4]>(c1.data()), reinterpret_cast<uint64_t(*)[16][4]>(r.data()),
+                               reinterpret_cast<uint32_t(*)[16]>(ln.data()), w.data(), 128);
+            uint64_t hv[8][3][4], ho[8][4];
+            uint32_t hl[8] = {};
+            memset(hv, 0, sizeof hv);
+            const int lanes = count < 8 ? count : 8;
+            for (int k = 0; k < lanes; ++k) {
+                memcpy(hv[k][1], &c1[(size_t)k * 4], 32);
+                memcpy(hv[k][2], &c0[(size_t)k * 4], 32);
+                hl[k] = ln[k];
+            }
+            gkr::gkr_ifma_multi_hash8(hv, hl, 3, ho);
+            for (int k = 0; k < lanes; ++k) CHECK(memcmp(ho[k], &r[(size_t)k * 4], 32) == 0);
+        }
     } else {
         printf("(no AVX-512 IFMA on this CPU: lane hash skipped)\n");
     }

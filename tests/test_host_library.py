@@ -118,6 +118,52 @@ def test_batched_transcript_hash_matches_oracle():
             assert got[k] == mimc7.multi_hash(vals[k][3 - lens[k]:]), (trial, k, lens[k])
 
 
+def test_host_pass_matches_big_integers():
+    """the host's share of a multi-round pass (round coefficients from the sub-block sums, vector lengths, MiMC7
+    challenges, binding, the next fold's weights): scalar and IFMA-lane forms against Python integers and the
+    oracle's hash, every lane count and pass depth, zero linear coefficients and edge values included"""
+    lib = N.lib()
+    rng = random.Random(21)
+    for count in (1, 2, 3, 7, 8, 9, 16):
+        for J in (1, 2, 3, 5):
+            for final in (False, True):
+                sums = [[rng.randrange(P) for _ in range(32)] for _ in range(count)]
+                sums[0][:1 << J] = [rng.randrange(P)] * (1 << J)          # every c1 of lane 0 is zero
+                if count > 1:
+                    sums[1][:1 << J] = [P - 1, 0] * (1 << (J - 1))
+                flen = [rng.choice((1, 2)) for _ in range(count)]
+                S = to_limbs([x for row in sums for x in row])
+                FL = np.asarray(flen, dtype=np.uint32)
+                C0, C1, R = (np.zeros((J * count, 4), dtype=np.uint64) for _ in range(3))
+                L = np.zeros(J * count, dtype=np.uint32)
+                W = np.zeros((count * 32, 4), dtype=np.uint64)
+                used = ctypes.c_int(-1)
+                rc = lib.gkr_selftest_host_pass(_p(S), ctypes.c_int(count), ctypes.c_int(J), _p(FL) if final else None, _p(C0), _p(C1),
+                                                _p(L), _p(R), _p(W), ctypes.byref(used))
+                assert rc == 0, (count, J, final, rc)
+                c0, c1, r, w_got = from_limbs(C0), from_limbs(C1), from_limbs(R), from_limbs(W)
+                for k in range(count):
+                    row = list(sums[k][:1 << J])
+                    w = [1]
+                    for t in range(J):
+                        half = 1 << (J - t - 1)
+                        lo, hi = sum(row[:half]) % P, sum(row[half:2 * half]) % P
+                        d = (hi - lo) % P
+                        ln = flen[k] if final and t == J - 1 else (1 if d == 0 else 2)
+                        want_r = mimc7.multi_hash([d, lo][2 - ln:])
+                        i = t * count + k
+                        assert (c0[i], c1[i], int(L[i]), r[i]) == (lo, d, ln, want_r), (count, J, final, k, t)
+                        row = [(row[b] + (row[half + b] - row[b]) * want_r) % P for b in range(half)]
+                        w = [x for v in w for x in ((v * (1 - want_r)) % P, (v * want_r) % P)]
+                    assert w_got[k * 32:k * 32 + (1 << J)] == w, (count, J, final, k)
+    bad = to_limbs([0] * 32)
+    bad[3] = 0xFFFFFFFFFFFFFFFF
+    out = [np.zeros((1, 4), dtype=np.uint64) for _ in range(3)]
+    assert lib.gkr_selftest_host_pass(_p(bad), ctypes.c_int(1), ctypes.c_int(1), None, _p(out[0]), _p(out[1]),
+                                      _p(np.zeros(1, dtype=np.uint32)), _p(out[2]), _p(np.zeros((32, 4), dtype=np.uint64)), None) \
+        == N.GKR_ERR_NON_CANONICAL
+
+
 def test_non_canonical_inputs_are_rejected():
     lib = N.lib()
     bad = np.full((1, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
