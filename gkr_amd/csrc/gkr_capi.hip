@@ -620,6 +620,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     const auto dbg_t0 = std::chrono::steady_clock::now();
     auto dbg_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
     double dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_d = 0, dbg_e = 0;
+    std::atomic<uint64_t> dbg_busy_ns{0};   // time inside process_chunk, all threads
     const size_t len = (size_t)1 << n;
     hipStream_t s = ctx->stream;
     // rounds per pass: up to 5 with the matrix-core fold (fewer passes, ~2.07 N elements moved instead of 2.29 N),
@@ -649,10 +650,15 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     gkr::SpinPool* pool = ctx->host_pool();
     const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
-    // four groups (measured on MI355X at batch 1024, same box: groups of 256 4.13e11 field-ops/s, of 128 4.00e11, of
-    // 64 3.75e11 -- larger launches stream better, and four groups are enough for one group's latency-bound late
-    // passes to hide behind the others' bandwidth-bound early ones)
-    int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
+    // Groups of ~4 GiB of tables, at least four and at most eight (1024 x 2^20: eight groups of 128).  Larger launches
+    // stream slightly better, smaller groups feed the host's hashing more evenly and leave a shorter exposed tail (the
+    // last group's late passes); measured on MI355X, 1024 x 2^20, interleaved repeats on one box, ms per step with
+    // 14 / 3 / 2 host threads: 4 groups, all pass 0s queued first 12.3-12.9 / 15.0-16.3 / 18.5-19.0; 8 groups, pass 0
+    // queue depth 2 (below) 12.0-12.5 / 13.5-14.0 / 16.5-17.8; 6, 10 and 12 groups in between.
+    const double batch_bytes = (double)batch * (double)len * 32.0;
+    int want_groups = (int)(batch_bytes / (4.0 * 1024 * 1024 * 1024));
+    want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? 8 : want_groups);
+    int group_size = batch >= 128 ? (batch + want_groups - 1) / want_groups : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
     if (groups > kMaxGroups) groups = kMaxGroups;
@@ -808,22 +814,33 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             }
         }
     };
+    // A hashing thread takes its next chunk from the group that is EARLIEST in its schedule (generation = pass number):
+    // the hashes of an early pass release the next streaming pass, whose results are most of the host work still to
+    // come, while the late passes' hashes release microseconds of GPU work -- they fill the time in between.
     const std::function<bool()> try_work = [&]() -> bool {
-        for (int g = 0; g < groups; ++g) {
-            Group& G = grp[g];
-            uint64_t c = G.claim.load(std::memory_order_acquire);
-            while ((uint32_t)c < (uint32_t)G.nb && (c >> 32) != 0) {
-                const uint32_t first = (uint32_t)c;
-                const uint32_t left = (uint32_t)G.nb - first;
-                const uint32_t take = left < chunk_tables ? left : chunk_tables;
-                if (G.claim.compare_exchange_weak(c, c + take, std::memory_order_acq_rel)) {
-                    process_chunk(G, G.b0 + (int)first, (int)take);
-                    G.done.fetch_add((int)take, std::memory_order_release);
-                    return true;
+        for (;;) {
+            int best = -1;
+            uint64_t best_c = 0;
+            for (int g = 0; g < groups; ++g) {
+                const uint64_t c = grp[g].claim.load(std::memory_order_acquire);
+                if ((c >> 32) == 0 || (uint32_t)c >= (uint32_t)grp[g].nb) continue;
+                if (best < 0 || (c >> 32) < (best_c >> 32)) {
+                    best = g;
+                    best_c = c;
                 }
             }
+            if (best < 0) return false;
+            Group& G = grp[best];
+            const uint32_t first = (uint32_t)best_c;
+            const uint32_t left = (uint32_t)G.nb - first;
+            const uint32_t take = left < chunk_tables ? left : chunk_tables;
+            if (!G.claim.compare_exchange_strong(best_c, best_c + take, std::memory_order_acq_rel)) continue;   // lost a race: look again
+            const double t_in = dbg ? dbg_us() : 0.0;
+            process_chunk(G, G.b0 + (int)first, (int)take);
+            G.done.fetch_add((int)take, std::memory_order_release);
+            if (dbg) dbg_busy_ns.fetch_add((uint64_t)((dbg_us() - t_in) * 1e3), std::memory_order_relaxed);
+            return true;
         }
-        return false;
     };
     auto records_landed = [&](const Group& G) {
         for (int i = G.nb - 1; i >= 0; --i)
@@ -833,14 +850,24 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     dbg_a = dbg_us();
     gkr::SpinPool::Session session(pool, &try_work);
     int rc = GKR_OK;
-    for (int g = 0; g < groups; ++g) launch_first(grp[g]);
+    // Pass 0 of the first `depth` groups is queued up front, pass 0 of a later group right behind the first fold of an
+    // earlier one: the stream then alternates between pass 0 of later groups and the first fold of earlier ones
+    // (P0 P0 F0 P0 F1 P0 F2 F3 with four groups), and the host's hashing -- which with few threads takes as long as the
+    // GPU's work -- is fed from the first millisecond to the last instead of in one burst after all the pass 0s.
+    // (All pass 0s first: 2 host threads 19.0 ms per 1024 x 2^20 at 77 % hashing occupancy, 3 threads 15.6 ms at 63 %.)
+    static const int depth = [] {
+        const char* e = getenv("GKR_PASS_QUEUE_DEPTH");
+        return e && atoi(e) > 0 ? atoi(e) : 2;
+    }();
+    int next_first = 0;   // groups [next_first, groups): pass 0 still to launch
+    while (next_first < groups && next_first < depth) launch_first(grp[next_first++]);
     dbg_b = dbg_us();
     int active = groups;
     auto t0 = std::chrono::steady_clock::now();
     uint32_t idle = 0;
     while (active > 0 && rc == GKR_OK) {
         bool progress = false;
-        for (int g = 0; g < groups; ++g) {
+        for (int g = 0; g < next_first; ++g) {
             Group& G = grp[g];
             if (G.state == 0 && records_landed(G)) {
                 G.done.store(0, std::memory_order_relaxed);
@@ -850,11 +877,14 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             } else if (G.state == 1 && G.done.load(std::memory_order_acquire) == G.nb) {
                 G.claim.store(0, std::memory_order_release);
                 if (G.m - G.j > 0) {
+                    const bool first_fold = G.m == n;
                     launch_fold(G, G.j);
                     G.state = 0;
+                    if (first_fold && next_first < groups) launch_first(grp[next_first++]);
                 } else {
                     G.state = 2;
                     --active;
+                    if (next_first < groups) launch_first(grp[next_first++]);   // single-pass sumchecks: no fold to ride on
                 }
                 progress = true;
             }
@@ -888,8 +918,11 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     dbg_e = dbg_us();
     if (ctx->pending.size() > 8192) ctx->drain_events();   // otherwise when the profile is read
     if (dbg)
-        fprintf(stderr, "[gkr timing] setup %.0f us, first launches %.0f, loop %.0f, end_session %.0f, sync %.0f, drain %.0f\n", dbg_a,
-                dbg_b - dbg_a, dbg_c - dbg_b, dbg_d - dbg_c, dbg_e - dbg_d, dbg_us() - dbg_e);
+        fprintf(stderr,
+                "[gkr timing] setup %.0f us, first launches %.0f, loop %.0f, end_session %.0f, sync %.0f, drain %.0f; hashing %.0f us "
+                "over %d threads = %.0f%% of the loop\n",
+                dbg_a, dbg_b - dbg_a, dbg_c - dbg_b, dbg_d - dbg_c, dbg_e - dbg_d, dbg_us() - dbg_e, dbg_busy_ns.load() * 1e-3,
+                pool->workers() + 1, dbg_busy_ns.load() * 1e-3 / ((dbg_c - dbg_b) * (pool->workers() + 1)) * 100.0);
     return GKR_OK;
 }
 
