@@ -172,7 +172,7 @@ def run_mle(args, world):
                 "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
                 "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
                               "writes one), J = 5 on the large tables; k_mle_fold_sum: 192 B per output pair.  The later, small "
-                              "fold passes run on a high-priority stream beside other groups' streaming passes and are booked "
+                              "fold passes run on their own stream beside other groups' streaming passes and are booked "
                               "separately (kernel_ms.mle_multifold_late): their elapsed time is not their own cost",
             },
             "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
@@ -201,9 +201,12 @@ def run_mle(args, world):
                     tj = json.load(open(traffic_file))
                     if tj.get("batch") == batch and tj.get("n") == n:
                         var = tj["k_mle_multifold_mfma"].get("variants", {}).get("gkr::k_mle_multifold_mfma<5>")
-                        line["roofline"]["traffic"] = (var or tj["k_mle_multifold_mfma"])["per_launch_mean_bytes"]
-                        line["roofline"]["traffic_source"] = ("profiles/%s/d_pmc_traffic.json: separate rocprofv3 --pmc passes of "
-                                                              "this command on an earlier box, NOT measured in this run" % rnd)
+                        per_launch = (var or tj["k_mle_multifold_mfma"])["per_launch_mean_bytes"]
+                        # the counters' launches must be launches of this size (the group size is the library's choice)
+                        if 0.9 < per_launch / avg_bytes < 1.2:
+                            line["roofline"]["traffic"] = per_launch
+                            line["roofline"]["traffic_source"] = ("profiles/%s/d_pmc_traffic.json: separate rocprofv3 --pmc passes "
+                                                                  "of this command on an earlier box, NOT measured in this run" % rnd)
                         break
                 except Exception:
                     pass
