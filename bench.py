@@ -270,28 +270,29 @@ def aggregated_proofs(world, n_inputs):
     compile_ms = (time.perf_counter() - t0) * 1e3
     subs = len(step.circuits)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    ctxs = ProvingStep.contexts_for(world.local_rank, cpus, limit=subs)
-    ctx = ctxs[0]
+    threads = max(1, min(subs, cpus - 2))
+    ctx = Context(world.local_rank)
     out = {"circuit": "R1CS equivalent to rust/t.circom (MiMC7-91, 364 constraints) -> %d layered circuits, k lists %s"
                       % (subs, [c.get_k_list() for c in step.circuits]),
            "compile_ms": compile_ms, "proof": "one prover::prove call (one sub-circuit of one input)",
-           "how": "gkr_prove_batch per sub-circuit (the proofs of all inputs advance together, one round trip per round), "
-                  "%d sub-circuits in flight at a time from %d contexts / host threads (the reference's par_iter over the "
-                  "(circuit, input) pairs)" % (len(ctxs), len(ctxs)),
-           "contexts": len(ctxs), "cpus_per_rank": cpus}
+           "how": "gkr_prove_many: one call per proving step, one gkr_prove_batch per sub-circuit (the proofs of all inputs "
+                  "advance together, one round trip per round), %d sub-circuits in flight at a time on the library's own "
+                  "threads and child contexts (the reference's par_iter over the (circuit, input) pairs); threads that wait "
+                  "or are done take pieces of the others' host work" % threads,
+           "contexts": threads, "cpus_per_rank": cpus}
 
     def measure(witnesses, reps):
         inputs = step.inputs_for(np.stack([as_limbs(w) for w in witnesses])) if witnesses else None
         if inputs is not None:
             for _ in range(2):
-                step.prove_raw_concurrent(ctxs, inputs)     # warm-up: code objects, workspaces, circuit caches
+                step.prove_raw_many(ctx, inputs, threads)     # warm-up: code objects, workspaces, circuit caches
         world.barrier(ctx)
         each = []
         t = time.perf_counter()
         for _ in range(reps):
             t1 = time.perf_counter()
             if inputs is not None:
-                step.prove_raw_concurrent(ctxs, inputs)
+                step.prove_raw_many(ctx, inputs, threads)
             each.append(round((time.perf_counter() - t1) * 1e3, 3))
         world.barrier(ctx)
         return world.max_over_ranks((time.perf_counter() - t) / reps), each
@@ -304,8 +305,7 @@ def aggregated_proofs(world, n_inputs):
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt,
                       "ms_each_rank0": each}
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
-    for c in ctxs:
-        c.close()
+    ctx.close()
     step.close()
     return out
 
@@ -321,13 +321,13 @@ def run_proofs(args, world):
     subs = len(step_obj.circuits)
     mine = parallel.shard_units(args.proofs, world.rank, world.size)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    ctxs = ProvingStep.contexts_for(world.local_rank, cpus, limit=subs)
-    ctx = ctxs[0]
+    threads = max(1, min(subs, cpus - 2))
+    ctx = Context(world.local_rank)
     inputs = step_obj.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in mine])) if len(mine) else None
 
     def step():
         if inputs is not None:
-            step_obj.prove_raw_concurrent(ctxs, inputs)
+            step_obj.prove_raw_many(ctx, inputs, threads)
     elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
     if world.rank == 0:
         print(json.dumps({
@@ -338,10 +338,9 @@ def run_proofs(args, world):
                                    "inputs split over the ranks, no collective" % (args.proofs, subs),
                        "inputs_per_rank": [len(parallel.shard_units(args.proofs, r, world.size)) for r in range(world.size)],
                        "proof": "one prover::prove call (one sub-circuit of one input)",
-                       "contexts_per_rank": len(ctxs), "cpus_per_rank": cpus},
+                       "how": "gkr_prove_many, %d threads / child contexts per rank" % threads, "cpus_per_rank": cpus},
             "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
-    for c in ctxs:
-        c.close()
+    ctx.close()
     step_obj.close()
 
 

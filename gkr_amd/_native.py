@@ -26,7 +26,7 @@ GKR_TRANSCRIPT_HOST = 1
 # every symbol include/gkr_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "gkr_strerror", "gkr_version", "gkr_ctx_create", "gkr_ctx_destroy", "gkr_last_error",
-    "gkr_ctx_set_transcript", "gkr_ctx_set_host_threads", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get", "gkr_ctx_profile_samples",
+    "gkr_ctx_set_transcript", "gkr_ctx_set_host_threads", "gkr_host_help_while", "gkr_prove_many", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get", "gkr_ctx_profile_samples",
     "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
     "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
     "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
@@ -58,6 +58,11 @@ class ProofBuf(ctypes.Structure):
                 ("sumcheck_coeffs", "sumcheck_len", "sumcheck_r", "q", "q_len", "z", "r", "d_coeffs", "input_coeffs")]
 
 
+class ProveItem(ctypes.Structure):
+    _fields_ = [("circuit", ctypes.c_void_p), ("input_values", ctypes.c_void_p), ("batch", ctypes.c_int),
+                ("require_zero_output", ctypes.c_int), ("outs", ctypes.c_void_p), ("status", ctypes.c_int)]
+
+
 class R1csInfo(ctypes.Structure):
     _fields_ = [("n_wires", ctypes.c_uint32), ("n_pub_out", ctypes.c_uint32), ("n_pub_in", ctypes.c_uint32),
                 ("n_prv_in", ctypes.c_uint32), ("n_labels", ctypes.c_uint64), ("n_constraints", ctypes.c_size_t),
@@ -83,6 +88,8 @@ def lib():
         L.gkr_version.restype = ctypes.c_char_p
         L.gkr_last_error.restype = ctypes.c_char_p
         L.gkr_last_error.argtypes = [ctypes.c_void_p]
+        L.gkr_host_help_while.restype = ctypes.c_long
+        L.gkr_host_help_while.argtypes = [ctypes.c_void_p]
         L.gkr_ctx_destroy.restype = None
         L.gkr_ctx_destroy.argtypes = [ctypes.c_void_p]
         for fn in (L.gkr_layer_session_close, L.gkr_mle_session_close):

@@ -171,18 +171,26 @@ class ProvingStep:
         import threading
         order = sorted(range(len(self.circuits)), key=lambda j: -sum(self.circuits[j].get_k_list()))
         out, errs, lock = [None] * len(self.circuits), [], threading.Lock()
+        busy = ctypes.c_int32(len(ctxs))   # threads still proving; the others lend themselves to them
 
         def work(ctx):
-            while True:
-                with lock:
-                    if not order or errs:
+            try:
+                while True:
+                    with lock:
+                        if not order or errs:
+                            return
+                        j = order.pop(0)
+                    try:
+                        out[j] = ctx.prove_batch_raw(self.circuits[j], inputs[j])
+                    except Exception as e:
+                        errs.append(e)
                         return
-                    j = order.pop(0)
-                try:
-                    out[j] = ctx.prove_batch_raw(self.circuits[j], inputs[j])
-                except Exception as e:
-                    errs.append(e)
-                    return
+            finally:
+                with lock:
+                    busy.value -= 1
+                # the sub-circuits differ in depth: a thread that is out of work takes pieces of the host work (hash
+                # calls, line restrictions) of the contexts still proving (gkr_host_help_while), until all are done
+                N.lib().gkr_host_help_while(ctypes.byref(busy))
         threads = [threading.Thread(target=work, args=(c,)) for c in ctxs[1:]]
         for t in threads:
             t.start()
@@ -192,6 +200,15 @@ class ProvingStep:
         if errs:
             raise errs[0]
         return out
+
+    def prove_raw_many(self, ctx, inputs, max_concurrent=0):
+        """The same step through gkr_prove_many: one call, the library's own threads and child contexts instead of
+        interpreter threads (no GIL hand-offs, no thread start per call).  -> the challenge arrays, as prove_raw."""
+        key = tuple(x.ctypes.data for x in inputs) + tuple(x.shape[0] for x in inputs)
+        if getattr(self, "_prepared_key", None) != (id(ctx), key):
+            self._prepared = ctx.prepare_many(list(zip(self.circuits, inputs)))
+            self._prepared_key = (id(ctx), key)
+        return [arrs[2] for arrs in ctx.prove_many_raw(self._prepared, max_concurrent)]
 
     @staticmethod
     def contexts_for(device, cpus, limit=12):

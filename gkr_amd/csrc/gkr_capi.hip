@@ -11,7 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -336,6 +338,8 @@ struct PreparedCircuit {
     }
 };
 
+struct ProveCrew;
+
 struct gkr_ctx {
     int device = 0;
     int host_threads = 0;                      // 0: from GKR_HOST_THREADS / the usable CPUs; else this many (caller included)
@@ -354,6 +358,9 @@ struct gkr_ctx {
     char name[256] = {0};
     uint32_t ticket = 0;                       // unique per hand-off, never reused within a context
     std::unique_ptr<gkr::SpinPool> pool;       // host transcript workers (lazy)
+    std::unique_ptr<gkr::SpinPool> solo_pool;  // the empty pool a context uses while it is one of a crew (gkr_prove_many)
+    bool crew_member = false;                  // one thread of several proving side by side: no workers of its own
+    std::unique_ptr<ProveCrew, void (*)(ProveCrew*)> crew{nullptr, nullptr};   // gkr_prove_many's threads and child contexts (lazy)
     std::map<std::string, std::pair<void*, size_t>> ws;        // grow-only device workspaces
     std::map<std::string, std::pair<void*, size_t>> pinned;    // grow-only pinned host buffers
 
@@ -397,6 +404,10 @@ struct gkr_ctx {
     }
     int threads() const { return host_threads > 0 ? host_threads : default_host_threads(); }
     gkr::SpinPool* host_pool() {
+        if (crew_member) {
+            if (!solo_pool) solo_pool.reset(new gkr::SpinPool(0));
+            return solo_pool.get();
+        }
         if (!pool) pool.reset(new gkr::SpinPool(threads() - 1));
         return pool.get();
     }
@@ -470,6 +481,25 @@ struct gkr_ctx {
     }
 };
 
+// gkr_prove_many's crew: member 0 is the calling thread with the parent context, every other member a thread with a
+// child context of its own.  The threads sleep between calls.
+struct ProveCrew {
+    struct Member {
+        gkr_ctx* ctx = nullptr;
+        std::thread th;
+        std::vector<int> items;   // indices into the current call's item list, in proving order
+    };
+    std::vector<std::unique_ptr<Member>> members;
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    uint64_t generation = 0;
+    bool stop = false;
+    int active = 0;               // members taking part in the current call (the first `active`)
+    int finished = 0;             // of the threads (members 1 ..), in the current call
+    gkr_prove_item* items = nullptr;
+    int32_t busy = 0;             // members still proving (atomic access); the others lend themselves
+};
+
 // RAII timing bracket around one launch (only when profiling is on)
 struct Timed {
     gkr_ctx* c;
@@ -518,9 +548,33 @@ struct DevBuf {
 // Spin on the seq words the reduce kernel stores last (system-scope release) into
 // pinned host memory.  Bounded: a device fault or a lost launch turns into an
 // error status instead of a hang.
+// Host work in pieces (`work` claims and runs one per call): this thread, this context's pool workers if a session is
+// open, and -- while the job is on the process-wide board -- threads of OTHER contexts that are waiting for their GPU
+// (wait_records).  Returns when every piece has been run to its end.  GKR_NO_HELP=1: no sharing between contexts.
+static bool help_enabled() {
+    static const bool on = getenv("GKR_NO_HELP") == nullptr;
+    return on;
+}
+static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, bool several) {
+    auto run = [&] {
+        if (pool)
+            pool->run_now(work);
+        else
+            while ((*work)()) {
+            }
+    };
+    if (several && help_enabled()) {
+        gkr::HelpBoard::Posted posted(work);
+        run();
+    } else {
+        run();
+    }
+}
+
 template <typename Rec>
 int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t ticket) {
     const auto t0 = std::chrono::steady_clock::now();
+    const bool help = help_enabled();
     static const int wait_mode = [] { const char* e = getenv("GKR_WAIT_MODE"); return e ? atoi(e) : 0; }();
     if (wait_mode == 1) {   // diagnostic: classic stream synchronisation instead of polling the records
         hipError_t q = hipStreamSynchronize(ctx->stream);
@@ -529,6 +583,9 @@ int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t tic
     for (int b = 0; b < count; ++b) {
         uint32_t spins = 0;
         while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
+            // this thread has nothing to do until its round lands: a piece of another context's posted host work
+            // (a 16-lane hash call, ~30 us) instead of spinning
+            if (help && gkr::HelpBoard::instance().help()) continue;
             GKR_CPU_RELAX();
             if ((++spins & 0xFFFF) == 0) {
                 hipError_t q = wait_mode == 2 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
@@ -1189,51 +1246,23 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
 
 // ------------------------------------------------------------- predicate tables
 // builds canonical A, M (2^{2k} each) in device memory from device gate arrays
-// eq(z[lo..hi), .) over hi - lo variables, first variable most significant (host, 4x64-bit)
-static void host_eq_table(const gkr_fr* z, int lo, int hi, std::vector<gkr::h64::F>& out) {
-    using namespace gkr::h64;
-    out.assign((size_t)1 << (hi - lo), F{{0, 0, 0, 0}});
-    out[0] = F{{1, 0, 0, 0}};
-    size_t cur = 1;
-    for (int i = lo; i < hi; ++i) {
-        F zi;
-        memcpy(&zi, &z[i], 32);
-        const F zm = to_mont(zi);
-        for (size_t g = cur; g-- > 0;) {
-            const F hi_v = mont_mul(out[g], zm);   // e * z
-            const F lo_v = sub(out[g], hi_v);      // e * (1 - z)
-            out[2 * g] = lo_v;
-            out[2 * g + 1] = hi_v;
-        }
-        cur <<= 1;
-    }
-}
 
 // shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries.
 // batch > 1: `batch` proofs of one circuit -- same gates (the cell lists are built once), z is batch x k_i,
 // d_A / d_M hold batch tables of N entries each.
-// E[g] = eq(z, g) = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the host (2^kh + 2^kl
-// products), E_lo in Montgomery form so that the product of the two is canonical.  The uploads are asynchronous on
-// the context's stream from pinned buffers.
+// E[g] = eq(z, g) = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the device from the points
+// the host left in pinned memory (k_eq_table), E_lo in Montgomery form so that the product of the two is canonical.
 static int upload_eq_tables(gkr_ctx* ctx, int k_i, const gkr_fr* z, int batch, Fr** e_hi_out, Fr** e_lo_out) {
     const int kl = k_i / 2, kh = k_i - kl;
     Fr *e_hi = nullptr, *e_lo = nullptr;
     WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
     WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
-    gkr::h64::F *hhi = nullptr, *hlo = nullptr;
-    HIP_TRY(ctx, ctx->pinned_host("pred.hhi", sizeof(gkr::h64::F) * ((size_t)batch << kh), reinterpret_cast<void**>(&hhi)));
-    HIP_TRY(ctx, ctx->pinned_host("pred.hlo", sizeof(gkr::h64::F) * ((size_t)batch << kl), reinterpret_cast<void**>(&hlo)));
-    std::vector<gkr::h64::F> tmp;
-    for (int b = 0; b < batch; ++b) {
-        const gkr_fr* zb = z + (size_t)b * k_i;
-        host_eq_table(zb, 0, kh, tmp);
-        memcpy(hhi + ((size_t)b << kh), tmp.data(), sizeof(gkr::h64::F) << kh);
-        host_eq_table(zb, kh, k_i, tmp);
-        for (auto& v : tmp) v = gkr::h64::to_mont(v);
-        memcpy(hlo + ((size_t)b << kl), tmp.data(), sizeof(gkr::h64::F) << kl);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(e_hi, hhi, sizeof(Fr) * ((size_t)batch << kh), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(e_lo, hlo, sizeof(Fr) * ((size_t)batch << kl), hipMemcpyHostToDevice, ctx->stream));
+    // the points go to pinned memory, the tables are built on the device from there (k_eq_table): no transfer call
+    gkr_fr* hz = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz)));
+    memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
+    gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, 0u, (uint32_t)kh, e_hi, false, (uint32_t)batch, ctx->stream);
+    gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, (uint32_t)kl, e_lo, true, (uint32_t)batch, ctx->stream);
     *e_hi_out = e_hi;
     *e_lo_out = e_lo;
     return GKR_OK;
@@ -1356,7 +1385,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
     WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
     Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
-    Fr* h_eq = nullptr;   // pinned: eq(u, .) of every proof, Montgomery
+    gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr;
     const uint32_t kl = (uint32_t)(k_i / 2);
@@ -1366,10 +1395,11 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         WS(ctx, "layer.eq", Fr, wlen * batch, d_eq);
         if (!sparse)
             WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
-        HIP_TRY(ctx, ctx->pinned_host("layer.heq", sizeof(Fr) * wlen * batch, reinterpret_cast<void**>(&h_eq)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.u", sizeof(gkr_fr) * (size_t)k * batch, reinterpret_cast<void**>(&h_u)));
     }
     int rc = GKR_OK;
     uint32_t* bad = nullptr;
+    bool lists_fresh = true;   // the gate lists are built (and the gates validated) in this call
     if (sparse) {
         uint32_t *g_counts = nullptr, *g_bsums = nullptr;
         const size_t nb2 = (size_t)2 << k;
@@ -1378,6 +1408,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
         if (cached && cached->ready) {
+            lists_fresh = false;
             g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
             g_cursor = cached->cursor;
             g_list = cached->list;
@@ -1411,7 +1442,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
     if (!persistent) {
         gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
-        HIP_TRY(ctx, hipMemcpyAsync(Wc, Wb, sizeof(Fr) * wlen * batch, hipMemcpyDeviceToDevice, s));
+        gkr::launch_to_mont(d_W, Wc, (uint32_t)(wlen * batch), s);
     }
     gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
     if (persistent) {
@@ -1452,18 +1483,22 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
 
     gkr::LayerHostRec* rec = nullptr;
     gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
-    std::vector<uint32_t> h_dep(32 * (size_t)batch, 0);
+    uint32_t* h_dep = nullptr;   // pinned: which variables W depends on, per proof; the device leaves it there before round 0
     const gkr::h64::F* cts64 = host_mimc_constants64();
     const bool ifma = host_ifma_ready();
     gkr::SpinPool* pool = nullptr;
     if (host_tx) {
         HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
-        HIP_TRY(ctx, hipMemcpyAsync(h_dep.data(), dep, sizeof(uint32_t) * 32 * batch, hipMemcpyDeviceToHost, s));
-        uint32_t hbad = 0;
-        if (sparse) HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+        // h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record
+        HIP_TRY(ctx, ctx->pinned_host("layer.hdep", sizeof(uint32_t) * 32 * batch, reinterpret_cast<void**>(&h_dep)));
+        gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
+        if (sparse && lists_fresh) {   // lists found in the circuit cache were validated when they were built
+            uint32_t hbad = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+        }
         if (batch >= 16) pool = ctx->host_pool();
     }
     if (persistent) {
@@ -1678,16 +1713,23 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
     static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
     static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
-    double t_launch = 0, t_wait = 0, t_hash = 0;
+    double t_launch = 0, t_wait = 0, t_hash = 0, worst_lap = 0;
+    int worst_round = -1, worst_kind = 0, cur_round = 0;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now_us();
     auto lap = [&](double& bucket) {
         const double t = now_us();
         bucket += t - t_mark;
+        if (t - t_mark > worst_lap) {
+            worst_lap = t - t_mark;
+            worst_round = cur_round;
+            worst_kind = &bucket == &t_launch ? 0 : (&bucket == &t_wait ? 1 : 2);
+        }
         t_mark = t;
     };
     gkr::SpinPool::Session session(pool, nullptr);   // closed on every path out of the round loop
     for (uint32_t round = 0; round < v; ++round) {
+        cur_round = (int)round;
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
         const uint32_t hb = phase == 0 ? (h >> k) : 0u;
@@ -1695,18 +1737,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         bool published = false;   // the round's kernel wrote the host record itself
         if (lin_b && round == (uint32_t)k) {
             // all of b is bound: collapse the rows of A, M at u = (r_1 .. r_k) into the single row the c-phase works on
-            std::vector<gkr::h64::F> tmp;
-            for (int b = 0; b < batch; ++b) {
-                host_eq_table(out_r[b], 0, k, tmp);
-                for (size_t i = 0; i < wlen; ++i) {
-                    const gkr::h64::F m = gkr::h64::to_mont(tmp[i]);
-                    memcpy(&h_eq[(size_t)b * wlen + i], &m, 32);
-                }
-            }
-            if (hipError_t ce = hipMemcpyAsync(d_eq, h_eq, sizeof(Fr) * wlen * batch, hipMemcpyHostToDevice, s); ce != hipSuccess) {
-                rc = ctx->hip_fail(ce, "upload of eq(u, .)");
-                break;
-            }
+            for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
+            gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
             if (sparse) {
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
@@ -1779,7 +1811,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             // while the host already writes round j+1's
             gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
             const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
-            if (pool) {
+            {
                 std::atomic<int> next{0};
                 const std::function<bool()> work = [&]() -> bool {
                     const int first = next.fetch_add(chunk, std::memory_order_relaxed);
@@ -1787,10 +1819,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
                     return true;
                 };
-                pool->run_now(&work);
-            } else {
-                for (int first = 0; first < batch; first += chunk)
-                    hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
+                run_pieces(pool, &work, batch > chunk);
             }
             lap(t_hash);
             // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc); the linear-time
@@ -1808,8 +1837,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     }
     session.close();
     if (dbg)
-        fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us\n", k, batch, v, t_launch,
-                t_wait, t_hash);
+        fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us; longest single step %.0f us (%s, round %d)\n",
+                k, batch, v, t_launch, t_wait, t_hash, worst_lap, worst_kind == 0 ? "launch" : (worst_kind == 1 ? "wait" : "hash"), worst_round);
     if (rc) {
         (void)hipStreamSynchronize(s);
         return rc;
@@ -1948,6 +1977,7 @@ int gkr_ctx_create(int device_id, gkr_ctx** out) {
 
 void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (!ctx) return;
+    ctx->crew.reset();   // joins gkr_prove_many's threads and destroys their contexts
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
@@ -1979,6 +2009,25 @@ int gkr_ctx_set_host_threads(gkr_ctx* ctx, int threads) {
         ctx->host_threads = threads;
     }
     return GKR_OK;
+}
+
+long gkr_host_help_while(const volatile int32_t* busy) {
+    if (!busy) return 0;
+    long pieces = 0;
+    unsigned idle = 0;
+    while (__atomic_load_n(busy, __ATOMIC_ACQUIRE) != 0) {
+        if (help_enabled() && gkr::HelpBoard::instance().help()) {
+            ++pieces;
+            idle = 0;
+            continue;
+        }
+        GKR_CPU_RELAX();
+        if (++idle > 4096) {   // nothing posted for a while: give the core away for a moment rather than spin at full rate
+            std::this_thread::yield();
+            idle = 0;
+        }
+    }
+    return pieces;
 }
 
 int gkr_ctx_device_name(const gkr_ctx* ctx, char* buf, size_t len) {
@@ -2499,6 +2548,7 @@ int gkr_proof_sizes(const gkr_circuit_desc* c, gkr_proof_sizes_t* out) {
 static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch,
                             int require_zero_output, gkr_proof_buf* outs) {
     using gkr::h64::F;
+    const auto t_entry = std::chrono::steady_clock::now();
     int rc = check_circuit(ctx, c);
     if (rc) return rc;
     if (!input_values || !outs || batch < 1 || batch > 4096) return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of [1, 4096]");
@@ -2600,15 +2650,44 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         const std::string slot = "prove.W" + std::to_string(i);
         HIP_TRY(ctx, ctx->workspace(slot.c_str(), ((size_t)batch << c->k[i]) * sizeof(Fr), reinterpret_cast<void**>(&dW[i])));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, n_in * batch * sizeof(Fr), hipMemcpyHostToDevice, s));
+    // Small transfers go through pinned buffers and a copy kernel, not through the runtime's transfer calls (see
+    // k_copy_words); large ones (a 2^20-value input layer) keep the copy engine's bandwidth.
+    constexpr size_t kKernelCopyLimit = (size_t)4 << 20;
+    const size_t in_bytes = n_in * batch * sizeof(Fr);
+    if (in_bytes <= kKernelCopyLimit) {
+        gkr_fr* h_in = nullptr;
+        HIP_TRY(ctx, ctx->pinned_host("prove.in", in_bytes, reinterpret_cast<void**>(&h_in)));
+        memcpy(h_in, input_values, in_bytes);
+        gkr::launch_copy_words(h_in, dW[L], in_bytes / 4, s);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, in_bytes, hipMemcpyHostToDevice, s));
+    }
     for (int i = (int)L - 1; i >= 0; --i)
         gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s);
     HIP_TRY(ctx, hipGetLastError());
-    std::vector<std::vector<F>> hW(L + 1);
-    for (uint32_t i = 0; i <= L; ++i) {
-        hW[i].resize((size_t)batch << c->k[i]);
-        HIP_TRY(ctx, hipMemcpyAsync(hW[i].data(), dW[i], sizeof(Fr) * hW[i].size(), hipMemcpyDeviceToHost, s));
+    // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
+    const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
+    std::vector<F> hW_big[2];
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t i = e ? L : 0;
+        const size_t bytes = ((size_t)batch << c->k[i]) * sizeof(Fr);
+        if (bytes <= kKernelCopyLimit) {
+            F* dst = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host(e ? "prove.hWL" : "prove.hW0", bytes, reinterpret_cast<void**>(&dst)));
+            gkr::launch_copy_words(dW[i], dst, bytes / 4, s);
+            hW[e] = dst;
+        } else {
+            hW_big[e].resize((size_t)batch << c->k[i]);
+            HIP_TRY(ctx, hipMemcpyAsync(hW_big[e].data(), dW[i], bytes, hipMemcpyDeviceToHost, s));
+            hW[e] = hW_big[e].data();
+        }
     }
+    std::vector<std::vector<F>> hWm(L + 1);   // (A/B switch GKR_LINE_ON_HOST: the middle layers too)
+    if (getenv("GKR_LINE_ON_HOST"))
+        for (uint32_t i = 1; i <= L; ++i) {
+            hWm[i].resize((size_t)batch << c->k[i]);
+            HIP_TRY(ctx, hipMemcpyAsync(hWm[i].data(), dW[i], sizeof(Fr) * hWm[i].size(), hipMemcpyDeviceToHost, s));
+        }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
     const auto tpb0 = std::chrono::steady_clock::now();
@@ -2617,10 +2696,10 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
             return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
         // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
-        std::vector<F> co(hW[0].begin() + ((size_t)b << c->k[0]), hW[0].begin() + ((size_t)(b + 1) << c->k[0]));
+        std::vector<F> co(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
         mobius_msb(co, c->k[0]);
         memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
-        co.assign(hW[L].begin() + ((size_t)b << c->k[L]), hW[L].begin() + ((size_t)(b + 1) << c->k[L]));
+        co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
         mobius_msb(co, c->k[L]);
         memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
         // z[0] = 0 (prover.rs:16-21)
@@ -2632,6 +2711,23 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     std::vector<uint32_t*> slp(batch);
     size_t row_off = 0, q_off = 0, z_off = 0;
     gkr::SpinPool* pool = batch >= 16 ? ctx->host_pool() : nullptr;
+    // q_i (W_{i+1} on the line b* -> c*, prover.rs:70) is output only -- nothing later in the proof depends on it -- so
+    // it is computed on the side stream while the next layers' sumchecks run, and read back once at the end
+    uint32_t kmax = 0;
+    size_t q_total = 0;
+    for (uint32_t i = 1; i <= L; ++i) {
+        kmax = c->k[i] > kmax ? c->k[i] : kmax;
+        q_total += (size_t)c->k[i] + 1;
+    }
+    gkr_fr* h_lines = nullptr;   // pinned: per layer and proof b*_1..b*_k, c*_1..c*_k; the kernel reads it in place
+    Fr *d_q = nullptr, *d_lr = nullptr;
+    uint32_t* d_qlen = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("prove.lines", (size_t)L * batch * 2 * kmax * sizeof(gkr_fr), reinterpret_cast<void**>(&h_lines)));
+    // (the kernel stores q and its length straight into pinned host memory: read after the side stream's last kernel)
+    HIP_TRY(ctx, ctx->pinned_host("prove.q", q_total * batch * sizeof(Fr), reinterpret_cast<void**>(&d_q)));
+    HIP_TRY(ctx, ctx->pinned_host("prove.qlen", (size_t)L * batch * sizeof(uint32_t), reinterpret_cast<void**>(&d_qlen)));
+    WS(ctx, "prove.lr", Fr, (size_t)batch * 3 * ((size_t)1 << kmax), d_lr);
+    HIP_TRY(ctx, ctx->aux_stream(0));
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = c->k[i], k = c->k[i + 1];
         for (int b = 0; b < batch; ++b) {
@@ -2645,15 +2741,25 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         if (rc) return rc;
         const auto tl1 = std::chrono::steady_clock::now();
         std::vector<gkr_fr> z_next((size_t)batch * k);
+        static const bool line_on_host = getenv("GKR_LINE_ON_HOST") != nullptr;   // A/B: q on the host's threads, as before
+        if (!line_on_host) {
+            gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
+            for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
+            Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
+            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_q + q_off * batch,
+                                         d_qlen + (size_t)i * batch, (uint32_t)batch, ctx->aux);
+        }
         auto finish = [&](int b) {
             const gkr_fr* sr = srp[b];
             const gkr_fr* b_star = sr;
             const gkr_fr* c_star = sr + k;
-            // q_i = W_{i+1} restricted to the line b* -> c* (prover.rs:70)
-            const std::vector<F> vals(hW[i + 1].begin() + ((size_t)b << k), hW[i + 1].begin() + ((size_t)(b + 1) << k));
-            std::vector<F> co(vals);
-            mobius_msb(co, k);
-            line_restriction(vals, co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
+            if (line_on_host) {
+                std::vector<F> vals((size_t)1 << k);
+                memcpy(vals.data(), &hWm[i + 1][(size_t)b << k], vals.size() * sizeof(F));
+                std::vector<F> co(vals);
+                mobius_msb(co, k);
+                line_restriction(vals, co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
+            }
             // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector and key as the
             // sumcheck's last challenge, so it is that challenge
             const gkr_fr r_star = sr[2 * k - 1];
@@ -2672,7 +2778,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
                 memcpy(&z_next[(size_t)b * k + j], &v, 32);
             }
         };
-        if (pool) {
+        {
             std::atomic<int> next{0};
             const std::function<bool()> work = [&]() -> bool {
                 const int b = next.fetch_add(1, std::memory_order_relaxed);
@@ -2681,9 +2787,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
                 return true;
             };
             gkr::SpinPool::Session session(pool, nullptr);
-            pool->run_now(&work);
-        } else {
-            for (int b = 0; b < batch; ++b) finish(b);
+            run_pieces(pool, &work, batch > 1);
         }
         if (dbg_pb)
             fprintf(stderr, "[gkr timing] prove layer %u: sumcheck %.0f us, q / z on the host %.0f us (since entry of the hand-off: %.0f us)\n", i,
@@ -2694,6 +2798,27 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         row_off += (size_t)2 * k;
         q_off += (size_t)k + 1;
         z_off += (size_t)k_i;
+    }
+    if (!getenv("GKR_LINE_ON_HOST")) {
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+        const F* hq = reinterpret_cast<const F*>(d_q);
+        const uint32_t* hqlen = d_qlen;
+        size_t off = 0;
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t kq = (size_t)c->k[i + 1] + 1;
+            for (int b = 0; b < batch; ++b) {
+                memcpy(outs[b].q + off, &hq[off * batch + (size_t)b * kq], kq * sizeof(F));
+                outs[b].q_len[i] = hqlen[(size_t)i * batch + b];
+            }
+            off += kq;
+        }
+    }
+    if (dbg_pb) {
+        const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gkr timing] prove batch=%d depth=%u: %.0f us before the layers (circuit lookup, forward evaluation, readback), "
+                        "%.0f us layers + q readback, since entry %.0f us\n", batch, L, us(t_entry, tpb0), us(tpb0, t_end), us(t_entry, t_end));
     }
     if (fresh && !no_cache) {
         constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
@@ -2716,6 +2841,133 @@ int gkr_prove_batch(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input
                     gkr_proof_buf* outs) {
     if (!ctx) return GKR_ERR_INVALID;
     return prove_batch_impl(ctx, c, input_values, batch, require_zero_output, outs);
+}
+
+// ---- gkr_prove_many: the items of one aggregation step proven side by side ----------------------------------------
+static void crew_prove_items(ProveCrew* crew, ProveCrew::Member* m) {
+    for (int idx : m->items) {
+        gkr_prove_item& it = crew->items[idx];
+        if (!it.circuit || !it.input_values || !it.outs) {
+            it.status = m->ctx->fail(GKR_ERR_INVALID, "null pointer in a prove item");
+            continue;
+        }
+        it.status = prove_batch_impl(m->ctx, it.circuit, it.input_values, it.batch, it.require_zero_output, it.outs);
+    }
+    __atomic_fetch_sub(&crew->busy, 1, __ATOMIC_ACQ_REL);
+    (void)gkr_host_help_while(&crew->busy);   // out of items: pieces of the others' host work until all are done
+}
+
+static void crew_thread(ProveCrew* crew, int index) {
+    ProveCrew::Member* m = crew->members[index].get();
+    (void)hipSetDevice(m->ctx->device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> g(crew->mu);
+            crew->cv_start.wait(g, [&] { return crew->stop || crew->generation != seen; });
+            if (crew->stop) return;
+            seen = crew->generation;
+            if (index >= crew->active) continue;   // not needed in this call
+        }
+        crew_prove_items(crew, m);
+        {
+            std::lock_guard<std::mutex> g(crew->mu);
+            ++crew->finished;
+        }
+        crew->cv_done.notify_one();
+    }
+}
+
+static void destroy_crew(ProveCrew* crew) {
+    if (!crew) return;
+    {
+        std::lock_guard<std::mutex> g(crew->mu);
+        crew->stop = true;
+    }
+    crew->cv_start.notify_all();
+    for (size_t i = 1; i < crew->members.size(); ++i) {
+        if (crew->members[i]->th.joinable()) crew->members[i]->th.join();
+        gkr_ctx_destroy(crew->members[i]->ctx);
+    }
+    delete crew;
+}
+
+int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_concurrent) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if ((!items && n_items) || max_concurrent < 0 || n_items > (size_t)1 << 20) return ctx->fail(GKR_ERR_INVALID, "null item list or negative thread count");
+    if (n_items == 0) return GKR_OK;
+    if (ctx->crew_member) return ctx->fail(GKR_ERR_INVALID, "gkr_prove_many from inside a crew");
+    int want = max_concurrent ? max_concurrent : (usable_cpus() > 3 ? usable_cpus() - 2 : 1);
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) {   // ranks of one node share its CPUs
+        const int ranks = atoi(e);
+        if (!max_concurrent && ranks > 1) want = want / ranks > 1 ? want / ranks : 1;
+    }
+    if ((size_t)want > n_items) want = (int)n_items;
+    if (want > 64) want = 64;
+    if (!ctx->crew) {
+        ctx->crew = std::unique_ptr<ProveCrew, void (*)(ProveCrew*)>(new ProveCrew(), destroy_crew);
+        ctx->crew->members.emplace_back(new ProveCrew::Member());
+        ctx->crew->members[0]->ctx = ctx;
+    }
+    ProveCrew* crew = ctx->crew.get();
+    while ((int)crew->members.size() < want) {
+        gkr_ctx* child = nullptr;
+        const int rc = gkr_ctx_create(ctx->device, &child);
+        if (rc) return ctx->fail(rc, "child context of gkr_prove_many");
+        child->crew_member = true;
+        child->transcript = GKR_TRANSCRIPT_HOST;
+        crew->members.emplace_back(new ProveCrew::Member());
+        crew->members.back()->ctx = child;
+        const int index = (int)crew->members.size() - 1;
+        crew->members.back()->th = std::thread(crew_thread, crew, index);
+    }
+    // deal the items out by estimated cost, longest first, each to the member with the least so far (deterministic)
+    std::vector<std::pair<double, int>> cost(n_items);
+    for (size_t i = 0; i < n_items; ++i) {
+        double rounds = 0;
+        const gkr_circuit_desc* c = items[i].circuit;
+        if (c && c->k && c->depth <= 4096)
+            for (uint32_t l = 1; l <= c->depth; ++l) rounds += 2.0 * c->k[l];
+        cost[i] = {rounds * (50.0 + 2.0 * (items[i].batch > 0 ? items[i].batch : 1)), (int)i};
+        items[i].status = GKR_OK;
+    }
+    std::stable_sort(cost.begin(), cost.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    std::vector<double> load(want, 0.0);
+    for (int m = 0; m < want; ++m) crew->members[m]->items.clear();
+    for (const auto& ci : cost) {
+        int best = 0;
+        for (int m = 1; m < want; ++m)
+            if (load[m] < load[best]) best = m;
+        load[best] += ci.first;
+        crew->members[best]->items.push_back(ci.second);
+    }
+    const int saved_transcript = ctx->transcript;
+    ctx->transcript = GKR_TRANSCRIPT_HOST;
+    ctx->crew_member = true;   // the parent proves its share like the others: one thread, no workers of its own
+    {
+        std::lock_guard<std::mutex> g(crew->mu);
+        crew->items = items;
+        crew->active = want;
+        crew->finished = 0;
+        __atomic_store_n(&crew->busy, want, __ATOMIC_RELEASE);
+        ++crew->generation;
+    }
+    crew->cv_start.notify_all();
+    crew_prove_items(crew, crew->members[0].get());
+    {
+        std::unique_lock<std::mutex> g(crew->mu);
+        crew->cv_done.wait(g, [&] { return crew->finished == want - 1; });
+        crew->items = nullptr;
+    }
+    ctx->crew_member = false;
+    ctx->transcript = saved_transcript;
+    for (int m = 0; m < want; ++m)
+        for (int idx : crew->members[m]->items)
+            if (items[idx].status != GKR_OK) {
+                if (m) ctx->err = crew->members[m]->ctx->err;
+                return items[idx].status;
+            }
+    return GKR_OK;
 }
 
 // ---- step-wise sessions: one sumcheck split across GPUs ------------------------

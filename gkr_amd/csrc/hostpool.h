@@ -24,6 +24,77 @@
 
 namespace gkr {
 
+// Process-wide board of host work that ANY thread of the library may take a piece of while it waits for its own
+// GPU: contexts proving side by side (one calling thread each, gkr_amd.aggregate.ProvingStep) otherwise leave every
+// thread that waits for a round's record spinning while another one works through its 64 hashes alone.
+//   owner:   slot = post(&work); run `work` itself until it returns false; retire(slot)
+//   helper:  help() -- runs one piece of one posted job, or returns false
+// `work` claims and runs one piece per call (true) or reports that nothing is left to claim (false); it must be safe
+// to call from many threads.  retire() returns once no helper is inside the job any more, so the job and everything
+// it references may live on the owner's stack.
+class HelpBoard {
+   public:
+    static HelpBoard& instance() {
+        static HelpBoard board;
+        return board;
+    }
+    // -1: no free slot (the owner then simply works alone)
+    int post(const std::function<bool()>* work) {
+        for (int i = 0; i < kSlots; ++i) {
+            const std::function<bool()>* expected = nullptr;
+            if (slots_[i].job.compare_exchange_strong(expected, work, std::memory_order_seq_cst)) {
+                posted_.fetch_add(1, std::memory_order_seq_cst);
+                return i;
+            }
+        }
+        return -1;
+    }
+    void retire(int slot) {
+        if (slot < 0) return;
+        // store, then load another variable; the helper does the mirror image (count up, then read the job): both
+        // sides sequentially consistent, as in SpinPool::run_now
+        slots_[slot].job.store(nullptr, std::memory_order_seq_cst);
+        posted_.fetch_sub(1, std::memory_order_seq_cst);
+        while (slots_[slot].inside.load(std::memory_order_seq_cst) != 0) GKR_CPU_RELAX();
+    }
+    bool help() {
+        if (posted_.load(std::memory_order_acquire) == 0) return false;
+        const int start = next_.fetch_add(1, std::memory_order_relaxed);   // helpers spread over the posted jobs
+        for (int n = 0; n < kSlots; ++n) {
+            Slot& sl = slots_[(start + n) % kSlots];
+            if (sl.job.load(std::memory_order_acquire) == nullptr) continue;
+            sl.inside.fetch_add(1, std::memory_order_seq_cst);
+            const std::function<bool()>* job = sl.job.load(std::memory_order_seq_cst);
+            const bool did = job && (*job)();
+            sl.inside.fetch_sub(1, std::memory_order_seq_cst);
+            if (did) return true;
+        }
+        return false;
+    }
+
+    // Scope guard: the job is on the board for the lifetime of the guard
+    class Posted {
+       public:
+        explicit Posted(const std::function<bool()>* work) : slot_(HelpBoard::instance().post(work)) {}
+        ~Posted() { HelpBoard::instance().retire(slot_); }
+        Posted(const Posted&) = delete;
+        Posted& operator=(const Posted&) = delete;
+
+       private:
+        int slot_;
+    };
+
+   private:
+    static constexpr int kSlots = 64;
+    struct alignas(64) Slot {
+        std::atomic<const std::function<bool()>*> job{nullptr};
+        std::atomic<int> inside{0};
+    };
+    Slot slots_[kSlots];
+    std::atomic<int> posted_{0};
+    std::atomic<unsigned> next_{0};
+};
+
 class SpinPool {
    public:
     explicit SpinPool(int workers) {
@@ -115,6 +186,7 @@ class SpinPool {
                         if (job) did = (*job)();
                         job_busy_.fetch_sub(1, std::memory_order_seq_cst);
                     }
+                    if (!did) did = HelpBoard::instance().help();   // nothing of this context's: another context's posted work
                     if (did) {
                         idle = 0;
                     } else {

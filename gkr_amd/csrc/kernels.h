@@ -136,6 +136,15 @@ void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t r
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s);
+// words 32-bit words src -> dst (16-byte aligned when words >= 4); either side may be pinned host memory
+void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s);
+// out[proof][g] = eq(points[proof * stride + first ..+nvars), g), nvars <= 28; points may be pinned host memory
+void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
+                     hipStream_t s);
+// q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, out batch x (k + 1)
+// highest degree first, out_len batch
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
+                             hipStream_t s);
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, uint32_t batch, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,

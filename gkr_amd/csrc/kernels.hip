@@ -534,6 +534,111 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
     }
 }
 
+// Small transfers as kernels: `words` 32-bit words from src to dst, either of which may be pinned host memory.  The
+// round path of a proof makes no transfer call of the runtime (measured: with twelve contexts proving side by side, an
+// asynchronous 256 KB host-to-device copy per layer now and then held every context's launches up for 6 - 8 ms).
+__global__ void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t words) {
+    const size_t quads = words / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = quads * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// out[proof][g] = eq(point, g) = prod_i (bit_i(g) ? x_i : 1 - x_i) over the `nvars` coordinates x_i = point[first + i] of
+// the proof's point (variable `first` = most significant index bit), canonical or in Montgomery form.  The points are
+// read where the host wrote them (pinned memory): no copy engine, no transfer call on the round path.  Every entry is
+// its own product of nvars factors (the host's doubling construction gives the same field elements).
+// grid = (blocks over 2^nvars, batch), block = 256
+__global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
+                                                  Fr* __restrict__ out, uint32_t montgomery) {
+    __shared__ Fr s_f[2][32];   // Montgomery forms of 1 - x_i and x_i
+    const Fr* pt = points + (size_t)blockIdx.y * stride + first;
+    if (threadIdx.x < nvars) {
+        const Fr x = load_fr(pt + threadIdx.x);
+        Fr one = fr_zero();
+        one.l[0] = 1u;
+        s_f[1][threadIdx.x] = to_mont(x);
+        s_f[0][threadIdx.x] = to_mont(fr_sub(one, x));
+    }
+    __syncthreads();
+    const uint32_t n = 1u << nvars;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+        Fr p = fr_zero();
+        p.l[0] = 1u;
+        if (nvars) {
+            p = s_f[(g >> (nvars - 1u)) & 1u][0];
+            for (uint32_t i = 1; i < nvars; ++i) p = mont_mul(p, s_f[(g >> (nvars - 1u - i)) & 1u][i]);
+            if (!montgomery) p = from_mont(p);
+        } else if (montgomery) {
+            p = to_mont(p);
+        }
+        store_fr(out + ((size_t)blockIdx.y << nvars) + g, p);
+    }
+}
+
+// q(t) = W(b + t (c - b)): the layer's values restricted to the line through the two points the sumcheck ended at
+// (reduce_multiple_polynomial, poly.rs:469-500) -- the variables bound one after the other on the evaluation table
+// with l_j(t) = b_j + t (c_j - b_j) in place of a challenge,
+//     P'[i](t) = P[i](t) + l_j(t) (P[i + h](t) - P[i](t)),
+// entries being coefficient vectors in t (lowest degree first) that grow by one coefficient per variable.  One block
+// per proof; the table ping-pongs between two halves of `scratch` (entry i of the table with j variables bound at
+// i * (j + 1); never more than 2^k elements); a third 2^k elements hold W's monomial coefficients (Moebius
+// transform), of which only the support counts: *q_len = 1 + the largest total degree of a non-zero monomial
+// (:484-497).  out: k + 1 slots, highest degree first.  bc: b_1..b_k, c_1..c_k per proof (canonical; may be pinned
+// host memory).  grid = (batch), block = 256.
+__global__ void __launch_bounds__(256) k_line_restriction(const Fr* __restrict__ W, uint32_t k, const Fr* __restrict__ bc,
+                                                          Fr* __restrict__ scratch, Fr* __restrict__ out,
+                                                          uint32_t* __restrict__ out_len) {
+    __shared__ uint32_t s_maxdeg;
+    const uint32_t n = 1u << k, tid = threadIdx.x;
+    const Fr* w = W + ((size_t)blockIdx.x << k);
+    const Fr* line = bc + (size_t)blockIdx.x * 2u * k;
+    Fr* buf[2] = {scratch + (size_t)blockIdx.x * 3u * n, scratch + (size_t)blockIdx.x * 3u * n + n};
+    Fr* mono = scratch + (size_t)blockIdx.x * 3u * n + 2u * n;
+    if (tid == 0) s_maxdeg = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const Fr v = load_fr(w + i);
+        store_fr(buf[0] + i, v);
+        store_fr(mono + i, v);
+    }
+    __syncthreads();
+    // monomial coefficients, variable 1 = most significant index bit (get_multi_ext, poly.rs:502-536)
+    for (uint32_t bit = n >> 1; bit; bit >>= 1) {
+        for (uint32_t i = tid; i < n; i += blockDim.x)
+            if (i & bit) store_fr(mono + i, fr_sub(load_fr(mono + i), load_fr(mono + (i ^ bit))));
+        __syncthreads();
+    }
+    uint32_t deg = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x)
+        if (!fr_is_zero(load_fr(mono + i))) deg = max(deg, (uint32_t)__popc(i));
+    if (deg) atomicMax(&s_maxdeg, deg);
+    // the k bindings
+    uint32_t h = n >> 1;
+    for (uint32_t j = 0; j < k; ++j, h >>= 1) {
+        const Fr* src = buf[j & 1];
+        Fr* dst = buf[(j & 1) ^ 1];
+        const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
+        const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+        const uint32_t in_len = j + 1, out_len_j = j + 2;
+        for (uint32_t item = tid; item < h * out_len_j; item += blockDim.x) {
+            const uint32_t i = item / out_len_j, m = item - i * out_len_j;
+            const Fr* lo = src + (size_t)i * in_len;
+            const Fr* hi = src + (size_t)(i + h) * in_len;
+            Fr v = fr_zero();
+            if (m < in_len) {
+                const Fr l = load_fr(lo + m);
+                v = fr_add(l, mont_mul(fr_sub(load_fr(hi + m), l), cst));
+            }
+            if (m > 0) v = fr_add(v, mont_mul(fr_sub(load_fr(hi + m - 1), load_fr(lo + m - 1)), grad));
+            store_fr(dst + (size_t)i * out_len_j + m, v);
+        }
+        __syncthreads();
+    }
+    const Fr* fin = buf[k & 1];
+    for (uint32_t d = tid; d <= k; d += blockDim.x) store_fr(out + (size_t)blockIdx.x * (k + 1u) + (k - d), load_fr(fin + d));
+    if (tid == 0) out_len[blockIdx.x] = s_maxdeg + 1u;
+}
+
 // canonical -> Montgomery copy of a small table (W for the layer kernel)
 __global__ void k_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, uint32_t count) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
@@ -1795,6 +1900,23 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
                        const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s) {
     hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096), batch), dim3(256), 0, s, gates, gate_type, left, right,
                        prev, out, prev_stride);
+}
+
+void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) {
+    if (!words) return;
+    hipLaunchKernelGGL(k_copy_words, dim3(blocks_for(words / 4 + 1, 1024)), dim3(256), 0, s, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), words);
+}
+
+void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_eq_table, dim3(blocks_for(1u << nvars, 1024), batch), dim3(256), 0, s, points, stride, first, nvars, out,
+                       montgomery ? 1u : 0u);
+}
+
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), 0, s, W, k, bc, scratch, out, out_len);
 }
 
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s) {

@@ -101,6 +101,16 @@ def multi_hash(values, key=0):
     return from_limbs(out)[0]
 
 
+def _proof_bufs(arrays, B):
+    """The B gkr_proof_buf structures (nine pointers each) over arrays whose first axis is the proof: one address
+    matrix, base + b * stride per array, built in numpy -- not B x 9 ctypes objects (0.5 - 1 ms of interpreter time per
+    call, which the proving threads of ProvingStep.prove_raw_concurrent pay one after the other under the GIL)."""
+    addr = np.empty((B, len(arrays)), dtype=np.uint64)
+    for j, a in enumerate(arrays):
+        addr[:, j] = a.ctypes.data + np.arange(B, dtype=np.uint64) * np.uint64(a.strides[0])
+    return (N.ProofBuf * B).from_buffer(addr)
+
+
 def _terms_from_coeffs(coeffs, k):
     """monomial-coefficient table -> reference term list (non-zero terms only)."""
     vals = from_limbs(coeffs)
@@ -302,8 +312,7 @@ class Context:
         rr = np.zeros((B, L, 4), dtype=np.uint64)
         dco = np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64)
         ico = np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)
-        bufs = (N.ProofBuf * B)(*[N.ProofBuf(*[a[b].ctypes.data for a in (sc, sl, sr, q, ql, z, rr, dco, ico)])
-                                  for b in range(B)])
+        bufs = _proof_bufs((sc, sl, sr, q, ql, z, rr, dco, ico), B)
         self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B),
                                             ctypes.c_int(1 if require_zero_output else 0), bufs))
         out = []
@@ -325,6 +334,50 @@ class Context:
                              r=from_limbs(rr[b]), depth=L + 1, input_func=_terms_from_coeffs(ico[b], ks[-1]), k=ks))
         return out
 
+    def _circuit_desc(self, circuit: GKRCircuit):
+        """-> (gkr_circuit_desc, objects that must outlive its use)"""
+        L = circuit.depth()
+        karr = np.asarray(circuit.get_k_list(), dtype=np.uint32)
+        gates = [lay.arrays() for lay in circuit.layer]
+        gt_p = (ctypes.c_void_p * L)(*[g[0].ctypes.data for g in gates])
+        l_p = (ctypes.c_void_p * L)(*[g[1].ctypes.data for g in gates])
+        r_p = (ctypes.c_void_p * L)(*[g[2].ctypes.data for g in gates])
+        desc = N.CircuitDesc(L, karr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), gt_p, l_p, r_p)
+        return desc, (karr, gates, gt_p, l_p, r_p)
+
+    def prepare_many(self, work):
+        """work: [(GKRCircuit, inputs_limbs (B, 2^input_k, 4) uint64)] -> a prepared item list for prove_many_raw:
+        circuit descriptions, output arrays and the gkr_prove_item array built once (an aggregation step proves the same
+        circuits for every batch of inputs; only the input values change)."""
+        keep, outs = [], []
+        items = (N.ProveItem * len(work))()
+        for i, (circuit, inputs_limbs) in enumerate(work):
+            desc, alive = self._circuit_desc(circuit)
+            sizes = N.ProofSizes()
+            self._check(N.lib().gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(sizes)))
+            inp = np.ascontiguousarray(inputs_limbs, dtype=np.uint64)
+            B, L = inp.shape[0], circuit.depth()
+            arrs = [np.zeros((B, sizes.rounds, 3, 4), dtype=np.uint64), np.zeros((B, sizes.rounds), dtype=np.uint32),
+                    np.zeros((B, sizes.rounds, 4), dtype=np.uint64), np.zeros((B, sizes.q_slots, 4), dtype=np.uint64),
+                    np.zeros((B, L), dtype=np.uint32), np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64),
+                    np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
+                    np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
+            bufs = _proof_bufs(arrs, B)
+            items[i] = N.ProveItem(ctypes.cast(ctypes.pointer(desc), ctypes.c_void_p), inp.ctypes.data, B, 0,
+                                   ctypes.cast(bufs, ctypes.c_void_p), 0)
+            keep.append((desc, alive, inp, arrs, bufs))
+            outs.append(arrs)
+        return {"items": items, "keep": keep, "outs": outs}
+
+    def prove_many_raw(self, prepared, max_concurrent=0):
+        """gkr_prove_many on a prepare_many() list: every item proven by its own thread / child context of this context
+        (the reference's par_iter over the (circuit, input) pairs).  -> per item the list of output arrays
+        [coeffs, lens, challenges, q, q_len, z, r, d, input] (first axis = proof)."""
+        items = prepared["items"]
+        rc = N.lib().gkr_prove_many(self._h, items, ctypes.c_size_t(len(items)), ctypes.c_int(max_concurrent))
+        self._check(rc)
+        return prepared["outs"]
+
     def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs):
         """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg).
         inputs_limbs: (B, 2^input_k, 4) uint64.  Returns the challenge arrays (B, rounds, 4)."""
@@ -345,7 +398,7 @@ class Context:
                 np.zeros((B, L), dtype=np.uint32), np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64),
                 np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
                 np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
-        bufs = (N.ProofBuf * B)(*[N.ProofBuf(*[a[b].ctypes.data for a in arrs]) for b in range(B)])
+        bufs = _proof_bufs(arrs, B)
         self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B), ctypes.c_int(0), bufs))
         return arrs[2]
 

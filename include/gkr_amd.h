@@ -93,6 +93,13 @@ int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
  * aggregator.rs:350-355) gives each context its share; 1 = hash on the calling thread, no workers. */
 int  gkr_ctx_set_host_threads(gkr_ctx *ctx, int threads);
 int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
+/* Contexts proving side by side (one calling thread each -- the reference's par_iter over the (circuit, input) pairs,
+ * aggregator.rs:350-355) share their host work: a thread that waits for its own GPU round takes pieces of another
+ * context's posted work (a 16-lane hash call, a proof's line restriction).  A thread that has run out of proving
+ * calls can lend itself to the others: gkr_host_help_while runs such pieces on the calling thread while *busy != 0
+ * (the caller's count of threads still proving) and returns the number of pieces it ran.  GKR_NO_HELP=1 disables
+ * the sharing. */
+long gkr_host_help_while(const volatile int32_t *busy);
 
 /* Per-kernel timing with HIP events on the stream each kernel is launched on (bench.py's
  * roofline leg).  enable: 0 off, 1 every kernel, 2 only the bandwidth-bound kernels ("mle_multifold",
@@ -263,6 +270,25 @@ int  gkr_prove(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *inpu
  * batch x 2^k[L] values; outs: `batch` caller-allocated proof buffers.  Needs the host transcript. */
 int  gkr_prove_batch(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr *input_values, int batch,
                      int require_zero_output, gkr_proof_buf *outs);
+
+/* The proving step of one aggregation round in ONE call (aggregator.rs:341-355: prover::prove mapped over the
+ * (circuit, input) pairs with a rayon par_iter): every item is a gkr_prove_batch (one circuit, `batch` witnesses); the
+ * items are proven side by side, each by its own thread and child context (stream, workspaces, circuit cache) of `ctx`,
+ * kept between calls.  A layer round of a small circuit is latency-bound -- launch, a tiny kernel, the hand-off, the
+ * hash -- so independent items in flight fill each other's gaps; threads whose items are done, and threads waiting
+ * for a round, take pieces of the others' host work (see gkr_host_help_while).  Items are dealt out by estimated cost,
+ * the same way for the same list (so a child context finds its circuits in its cache on the next call).
+ * max_concurrent: threads / child contexts to use at most; 0 = the CPUs this process may use, less two.
+ * Every item's `status` is set; the return value is the first status that is not GKR_OK (gkr_last_error has its text). */
+typedef struct {
+    const gkr_circuit_desc *circuit;
+    const gkr_fr *input_values;      /* batch x 2^k[L] */
+    int batch;
+    int require_zero_output;
+    gkr_proof_buf *outs;             /* `batch` proof buffers */
+    int status;                      /* out */
+} gkr_prove_item;
+int  gkr_prove_many(gkr_ctx *ctx, gkr_prove_item *items, size_t n_items, int max_concurrent);
 
 /* ---- the proof as input signals of verifier.circom (host only) -----------
  * What the reference does with a Proof right after the path: pad its ragged vectors to the dimensions of

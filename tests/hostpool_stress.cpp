@@ -1,10 +1,12 @@
-// Stress of SpinPool::run_now (gkr_amd/csrc/hostpool.h): many very short jobs whose state lives in the caller's
+// Stress of SpinPool::run_now and HelpBoard (gkr_amd/csrc/hostpool.h): many very short jobs whose state lives in the caller's
 // stack frame.  A worker that still calls a job after run_now has returned (the retire-then-check race) finds the
 // frame re-used: the job then sees a poisoned tag and the run fails.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <thread>
+#include <vector>
 
 #include "hostpool.h"
 
@@ -56,6 +58,44 @@ int main(int argc, char** argv) {
             while (left.load() > 0) try_work();
         }   // the guard closes the session: no worker may touch try_work / left / taken after this line
         if (taken.load() != 50) bad.fetch_add(1);
+    }
+    // HelpBoard: several owner threads post very short jobs from their own stack frames and help each other between
+    // their own jobs (the shape of contexts proving side by side); a helper that still runs a job after its owner's
+    // retire() has returned finds the frame poisoned
+    {
+        const int owners = workers + 2;
+        const long jobs = rounds / 20 + 100;
+        std::vector<std::thread> ts;
+        for (int o = 0; o < owners; ++o)
+            ts.emplace_back([o, jobs] {
+                gkr::HelpBoard& board = gkr::HelpBoard::instance();
+                for (long j = 0; j < jobs; ++j) {
+                    struct Frame {
+                        std::atomic<int> next{0};
+                        std::atomic<unsigned> tag{0};
+                        std::atomic<int> done{0};
+                    } f;
+                    const unsigned tag_value = 0x2000u + (unsigned)((o * 977 + j) & 0xFFF);
+                    f.tag.store(tag_value);
+                    const int n = 1 + (int)(j % 5);
+                    const std::function<bool()> work = [&]() -> bool {
+                        if (f.tag.load(std::memory_order_relaxed) != tag_value) bad.fetch_add(1);
+                        const int i = f.next.fetch_add(1, std::memory_order_relaxed);
+                        if (i >= n) return false;
+                        f.done.fetch_add(1, std::memory_order_relaxed);
+                        return true;
+                    };
+                    {
+                        gkr::HelpBoard::Posted posted(&work);
+                        while (work()) {
+                        }
+                    }   // retired: every claimed piece has been run to its end
+                    if (f.done.load() != n) bad.fetch_add(1);
+                    f.tag.store(0xDEADBEEFu);
+                    for (int h = 0; h < 3; ++h) board.help();   // "waiting for the GPU": take pieces of the others' jobs
+                }
+            });
+        for (auto& t : ts) t.join();
     }
     printf("workers=%d rounds=%ld bad=%ld\n", workers, rounds, bad.load());
     return bad.load() ? 1 : 0;

@@ -110,6 +110,49 @@ def test_concurrent_contexts_prove_the_same_transcripts(ctx):
         step.close()
 
 
+def test_prove_many_matches_proofs_proven_one_by_one(ctx):
+    """gkr_prove_many (the whole proving step in one call, the library's own threads and child contexts): every output
+    array of every item equals the same item proven alone with gkr_prove_batch -- for 1, 5 and all-CPUs threads, twice
+    (the second call finds the circuits in the children's caches), with ragged batch sizes; a bad item fails alone."""
+    import ctypes
+    import numpy as np
+    from gkr_amd import _native as N
+    from gkr_amd.aggregate import ProvingStep
+    from gkr_amd.field import as_limbs
+    from gkr_amd.prover import GkrError
+    step = ProvingStep(synth.mimc7_demo_r1cs())
+    inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(7 + i, 2 * i)) for i in range(18)]))
+    inputs = [x[:3 + (5 * j) % 16].copy() for j, x in enumerate(inputs)]       # 3 .. 18 witnesses per sub-circuit
+    work = list(zip(step.circuits, inputs))
+    with Context(0) as one:
+        alone = one.prepare_many(work)
+        for item, (circuit, x) in zip(alone["keep"], work):
+            bufs = item[4]
+            desc, _ = one._circuit_desc(circuit)
+            rc = N.lib().gkr_prove_batch(one._h, ctypes.byref(desc), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]),
+                                                       ctypes.c_int(1), bufs)
+            assert rc == 0
+    want = alone["outs"]
+    with Context(0) as many:
+        for threads in (1, 5, 0, 5):
+            prepared = many.prepare_many(work)
+            got = many.prove_many_raw(prepared, threads)
+            for j in range(len(work)):
+                for a, b in zip(got[j], want[j]):
+                    assert np.array_equal(a, b), (threads, j)
+        # an item whose witness does not satisfy the circuit: that item's status, the others still proven
+        bad = many.prepare_many(work)
+        bad["items"][0].require_zero_output = 1
+        bad["keep"][0][2][0, :, 0] ^= 1                                    # every input value of one witness changed
+        with pytest.raises(GkrError):
+            many.prove_many_raw(bad, 4)
+        assert [it.status for it in bad["items"]].count(0) == len(work) - 1 and bad["items"][0].status != 0
+        for j in range(len(work)):
+            if j != 0:
+                assert np.array_equal(bad["outs"][j][2], want[j][2]), j
+    step.close()
+
+
 def test_cli_prove_demo_on_the_gpu(tmp_path):
     """`gkr-aggregator prove -c t.circom -i input1.json input2.json input3.json` (bin.rs:17-22) with the real prover:
     the artefacts of the first step and the inputs of the second (tests/test_cli.py checks their content on the CPU
