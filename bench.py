@@ -194,8 +194,8 @@ def run_mle(args, world):
         first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
         if first["total_ms"] > 0:
             line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
-        for rnd in ("r02", "r01"):   # PMC passes are separate runs (profiles/), never part of this run
-            traffic_file = os.path.join(REPO, "profiles", rnd, "d_pmc_traffic.json")
+        for rel in ("r02/l_pmc_traffic.json", "r02/d_pmc_traffic.json", "r01/d_pmc_traffic.json"):   # PMC passes are separate runs, never part of this run
+            traffic_file = os.path.join(REPO, "profiles", rel)
             if os.path.exists(traffic_file) and dom_name == "mle_multifold":
                 try:
                     tj = json.load(open(traffic_file))
@@ -205,9 +205,9 @@ def run_mle(args, world):
                         # the counters' launches must be launches of this size (the group size is the library's choice)
                         if 0.9 < per_launch / avg_bytes < 1.2:
                             line["roofline"]["traffic"] = per_launch
-                            line["roofline"]["traffic_source"] = ("profiles/%s/d_pmc_traffic.json: separate rocprofv3 --pmc passes "
-                                                                  "of this command on an earlier box, NOT measured in this run" % rnd)
-                        break
+                            line["roofline"]["traffic_source"] = ("profiles/%s: separate rocprofv3 --pmc passes of this command on "
+                                                                  "an earlier box, NOT measured in this run" % rel)
+                            break
                 except Exception:
                     pass
     # single-sumcheck latency and the 2^16 size (configs[1]) on the same resident tables
@@ -270,15 +270,15 @@ def aggregated_proofs(world, n_inputs):
     compile_ms = (time.perf_counter() - t0) * 1e3
     subs = len(step.circuits)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    threads = max(1, min(subs, cpus - 2))
+    threads = max(1, cpus - 2)   # one per sub-circuit in flight; the rest lend themselves to them from the start
     ctx = Context(world.local_rank)
     out = {"circuit": "R1CS equivalent to rust/t.circom (MiMC7-91, 364 constraints) -> %d layered circuits, k lists %s"
                       % (subs, [c.get_k_list() for c in step.circuits]),
            "compile_ms": compile_ms, "proof": "one prover::prove call (one sub-circuit of one input)",
            "how": "gkr_prove_many: one call per proving step, one gkr_prove_batch per sub-circuit (the proofs of all inputs "
-                  "advance together, one round trip per round), %d sub-circuits in flight at a time on the library's own "
-                  "threads and child contexts (the reference's par_iter over the (circuit, input) pairs); threads that wait "
-                  "or are done take pieces of the others' host work" % threads,
+                  "advance together, one round trip per round), the %d sub-circuits in flight together on %d of the library's "
+                  "own threads with child contexts (the reference's par_iter over the (circuit, input) pairs); threads that "
+                  "wait, are done or have no item take pieces of the others' host work" % (subs, threads),
            "contexts": threads, "cpus_per_rank": cpus}
 
     def measure(witnesses, reps):
@@ -321,7 +321,7 @@ def run_proofs(args, world):
     subs = len(step_obj.circuits)
     mine = parallel.shard_units(args.proofs, world.rank, world.size)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    threads = max(1, min(subs, cpus - 2))
+    threads = max(1, cpus - 2)   # one per sub-circuit in flight; the rest lend themselves to them from the start
     ctx = Context(world.local_rank)
     inputs = step_obj.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in mine])) if len(mine) else None
 

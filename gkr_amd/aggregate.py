@@ -131,20 +131,17 @@ def prove_step(ctx, r1cs, witnesses, require_zero_output=True):
     <= 20 layered circuits (convert_r1cs_wtns_gkr) and prove every (circuit, input) pair.  The reference maps
     prover::prove over the pairs of ONE witness with a rayon par_iter; with several witnesses of the same R1CS
     (BASELINE configs[3]: 64 inputs of one circom circuit) the sub-circuits coincide, so each sub-circuit's proofs
-    for all witnesses advance together (gkr_prove_batch).  -> proofs[w][j] for witness w and sub-circuit j."""
+    for all witnesses advance together (one gkr_prove_batch each), and the sub-circuits are proven side by side
+    (gkr_prove_many -- the par_iter).  -> proofs[w][j] for witness w and sub-circuit j."""
     from .field import as_limbs
     layered = r1cs.compile()
     try:
         wl = [as_limbs(w) for w in witnesses]
-        out = [[None] * len(layered) for _ in witnesses]
-        for j in range(len(layered)):
-            circuit = layered.circuit(j)
-            inputs = [from_limbs(layered.input_values_raw(j, w)) for w in wl]
-            for w, proof in enumerate(ctx.prove_batch(circuit, inputs, require_zero_output)):
-                out[w][j] = proof
+        work = [(layered.circuit(j), np.stack([layered.input_values_raw(j, w) for w in wl])) for j in range(len(layered))]
+        per_circuit = ctx.prove_many(work, require_zero_output)     # the sub-circuits side by side (gkr_prove_many)
+        return [[per_circuit[j][w] for j in range(len(layered))] for w in range(len(witnesses))]
     finally:
         layered.close()
-    return out
 
 
 class ProvingStep:

@@ -2902,7 +2902,8 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         const int ranks = atoi(e);
         if (!max_concurrent && ranks > 1) want = want / ranks > 1 ? want / ranks : 1;
     }
-    if ((size_t)want > n_items) want = (int)n_items;
+    // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
+    if (!max_concurrent && (size_t)want > n_items) want = (int)n_items;
     if (want > 64) want = 64;
     if (!ctx->crew) {
         ctx->crew = std::unique_ptr<ProveCrew, void (*)(ProveCrew*)>(new ProveCrew(), destroy_crew);

@@ -111,6 +111,30 @@ def _proof_bufs(arrays, B):
     return (N.ProofBuf * B).from_buffer(addr)
 
 
+def _decode_proofs(arrays, ks):
+    """The nine output arrays of gkr_prove_batch / one gkr_prove_many item (first axis = proof) -> Proof objects."""
+    sc, sl, sr, q, ql, z, rr, dco, ico = arrays
+    L = len(ks) - 1
+    out = []
+    for b in range(sc.shape[0]):
+        proofs, rs, qs, zs = [], [], [], []
+        ro = qo = 0
+        for i in range(L):
+            k = ks[i + 1]
+            proofs.append([from_limbs(sc[b, ro + j])[3 - int(sl[b, ro + j]):] for j in range(2 * k)])
+            rs.append(from_limbs(sr[b, ro:ro + 2 * k]))
+            qs.append(from_limbs(q[b, qo:qo + k + 1])[k + 1 - int(ql[b, i]):])
+            ro += 2 * k
+            qo += k + 1
+        zo = 0
+        for i in range(L + 1):
+            zs.append(from_limbs(z[b, zo:zo + ks[i]]) if ks[i] else [])
+            zo += ks[i]
+        out.append(Proof(sumcheck_proofs=proofs, sumcheck_r=rs, d=_terms_from_coeffs(dco[b], ks[0]), q=qs, z=zs,
+                         r=from_limbs(rr[b]), depth=L + 1, input_func=_terms_from_coeffs(ico[b], ks[-1]), k=ks))
+    return out
+
+
 def _terms_from_coeffs(coeffs, k):
     """monomial-coefficient table -> reference term list (non-zero terms only)."""
     vals = from_limbs(coeffs)
@@ -315,23 +339,7 @@ class Context:
         bufs = _proof_bufs((sc, sl, sr, q, ql, z, rr, dco, ico), B)
         self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B),
                                             ctypes.c_int(1 if require_zero_output else 0), bufs))
-        out = []
-        for b in range(B):
-            proofs, rs, qs, zs = [], [], [], []
-            ro = qo = 0
-            for i in range(L):
-                k = ks[i + 1]
-                proofs.append([from_limbs(sc[b, ro + j])[3 - int(sl[b, ro + j]):] for j in range(2 * k)])
-                rs.append(from_limbs(sr[b, ro:ro + 2 * k]))
-                qs.append(from_limbs(q[b, qo:qo + k + 1])[k + 1 - int(ql[b, i]):])
-                ro += 2 * k
-                qo += k + 1
-            zo = 0
-            for i in range(L + 1):
-                zs.append(from_limbs(z[b, zo:zo + ks[i]]) if ks[i] else [])
-                zo += ks[i]
-            out.append(Proof(sumcheck_proofs=proofs, sumcheck_r=rs, d=_terms_from_coeffs(dco[b], ks[0]), q=qs, z=zs,
-                             r=from_limbs(rr[b]), depth=L + 1, input_func=_terms_from_coeffs(ico[b], ks[-1]), k=ks))
+        out = _decode_proofs((sc, sl, sr, q, ql, z, rr, dco, ico), ks)
         return out
 
     def _circuit_desc(self, circuit: GKRCircuit):
@@ -345,7 +353,7 @@ class Context:
         desc = N.CircuitDesc(L, karr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), gt_p, l_p, r_p)
         return desc, (karr, gates, gt_p, l_p, r_p)
 
-    def prepare_many(self, work):
+    def prepare_many(self, work, require_zero_output=False):
         """work: [(GKRCircuit, inputs_limbs (B, 2^input_k, 4) uint64)] -> a prepared item list for prove_many_raw:
         circuit descriptions, output arrays and the gkr_prove_item array built once (an aggregation step proves the same
         circuits for every batch of inputs; only the input values change)."""
@@ -363,8 +371,8 @@ class Context:
                     np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
                     np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
             bufs = _proof_bufs(arrs, B)
-            items[i] = N.ProveItem(ctypes.cast(ctypes.pointer(desc), ctypes.c_void_p), inp.ctypes.data, B, 0,
-                                   ctypes.cast(bufs, ctypes.c_void_p), 0)
+            items[i] = N.ProveItem(ctypes.cast(ctypes.pointer(desc), ctypes.c_void_p), inp.ctypes.data, B,
+                                   1 if require_zero_output else 0, ctypes.cast(bufs, ctypes.c_void_p), 0)
             keep.append((desc, alive, inp, arrs, bufs))
             outs.append(arrs)
         return {"items": items, "keep": keep, "outs": outs}
@@ -377,6 +385,12 @@ class Context:
         rc = N.lib().gkr_prove_many(self._h, items, ctypes.c_size_t(len(items)), ctypes.c_int(max_concurrent))
         self._check(rc)
         return prepared["outs"]
+
+    def prove_many(self, work, require_zero_output=False, max_concurrent=0) -> List[List[Proof]]:
+        """gkr_prove_many, decoded: work = [(GKRCircuit, inputs_limbs)] -> per item its proofs (one per witness)."""
+        prepared = self.prepare_many(work, require_zero_output)
+        outs = self.prove_many_raw(prepared, max_concurrent)
+        return [_decode_proofs(arrs, circuit.get_k_list()) for arrs, (circuit, _) in zip(outs, work)]
 
     def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs):
         """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg).
