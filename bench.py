@@ -284,8 +284,8 @@ def aggregated_proofs(world, n_inputs):
     def measure(witnesses, reps):
         inputs = step.inputs_for(np.stack([as_limbs(w) for w in witnesses])) if witnesses else None
         if inputs is not None:
-            for _ in range(2):
-                step.prove_raw_many(ctx, inputs, threads)     # warm-up: code objects, workspaces, circuit caches
+            for _ in range(4):
+                step.prove_raw_many(ctx, inputs, threads)     # warm-up: code objects, workspaces, circuit caches, the crew's threads
         world.barrier(ctx)
         each = []
         t = time.perf_counter()
