@@ -666,6 +666,71 @@ static void host_pass_scalar(const uint64_t* sums, size_t sums_row_words, int co
     }
 }
 
+// The host's share of one product pass of the layer sumcheck, scalar form (the IFMA-lane form is gkr_ifma_prod_pass,
+// mimc_ifma.cpp; same arguments, same results).  Lane k: the 8 x 8 cross-sum matrix m[a][b] (W sub-block a times X
+// sub-block b) and the Y sums sy[a] of its 2^J sub-blocks.  Round t (half = 2^(J-t-1)): with
+//     P_xy = sum_{a < half} m[x half + a][y half + a],   S_x = sum_{a < half} sy[x half + a]
+// the round polynomial is c2 X^2 + lin X + c0,  c0 = P_00 + S_0,  g(1) = P_11 + S_1,  c2 = P_11 - P_10 - P_01 + P_00,
+// lin = g(1) - c0 - c2; the challenge is the hash of [c2, lin, c0] (2 + dep entries); binding the variable folds the
+// matrix along both indices and sy along its one.  At the end the 2^J weights of the fold that binds the J variables.
+static void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16],
+                                  uint64_t (*c2)[16][4], uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4],
+                                  uint64_t* weights, size_t w_row_words) {
+    using namespace gkr::h64;
+    const F* cts = host_mimc_constants64();
+    const F one_m = to_mont(F{{1, 0, 0, 0}});
+    for (int k = 0; k < count; ++k) {
+        F M[64], SY[8], rm[gkr::kProdMaxJ];
+        const F* rec = reinterpret_cast<const F*>(recs + (size_t)k * rec_row_words);
+        const int n = 1 << J;
+        for (int a = 0; a < n; ++a) {
+            for (int b = 0; b < n; ++b) M[a * 8 + b] = rec[a * 8 + b];
+            SY[a] = rec[64 + a];
+        }
+        for (int t = 0; t < J; ++t) {
+            const int half = 1 << (J - t - 1);
+            F p00 = M[0], p01 = M[half], p10 = M[half * 8], p11 = M[half * 8 + half], s0 = SY[0], s1 = SY[half];
+            for (int x = 1; x < half; ++x) {
+                p00 = add(p00, M[x * 8 + x]);
+                p01 = add(p01, M[x * 8 + half + x]);
+                p10 = add(p10, M[(half + x) * 8 + x]);
+                p11 = add(p11, M[(half + x) * 8 + half + x]);
+                s0 = add(s0, SY[x]);
+                s1 = add(s1, SY[half + x]);
+            }
+            const F vc0 = add(p00, s0), g1 = add(p11, s1);
+            const F vc2 = sub(add(p11, p00), add(p10, p01));
+            const F vlin = sub(sub(g1, vc0), vc2);
+            const uint32_t ln = vec_len[t][k];
+            const F vec[3] = {vc2, vlin, vc0};
+            const F rc = mimc7_multi_hash(vec + (3 - ln), (int)ln, cts, nullptr);
+            memcpy(c2[t][k], &vc2, 32);
+            memcpy(lin[t][k], &vlin, 32);
+            memcpy(c0[t][k], &vc0, 32);
+            memcpy(r[t][k], &rc, 32);
+            rm[t] = to_mont(rc);
+            for (int ra = 0; ra < half; ++ra)
+                for (int cb = 0; cb < 2 * half; ++cb) M[ra * 8 + cb] = add(M[ra * 8 + cb], mont_mul(sub(M[(half + ra) * 8 + cb], M[ra * 8 + cb]), rm[t]));
+            for (int ra = 0; ra < half; ++ra)
+                for (int cb = 0; cb < half; ++cb) M[ra * 8 + cb] = add(M[ra * 8 + cb], mont_mul(sub(M[ra * 8 + half + cb], M[ra * 8 + cb]), rm[t]));
+            for (int ra = 0; ra < half; ++ra) SY[ra] = add(SY[ra], mont_mul(sub(SY[half + ra], SY[ra]), rm[t]));
+        }
+        if (!weights) continue;
+        F tmp[8];
+        tmp[0] = one_m;
+        int cur = 1;
+        for (int t = 0; t < J; ++t) {
+            const F nr = sub(one_m, rm[t]);
+            for (int b = cur; b-- > 0;) {
+                tmp[2 * b + 1] = mont_mul(tmp[b], rm[t]);
+                tmp[2 * b] = mont_mul(tmp[b], nr);
+            }
+            cur <<= 1;
+        }
+        memcpy(weights + (size_t)k * w_row_words, tmp, sizeof(F) << J);
+    }
+}
+
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
 // eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
@@ -1708,6 +1773,98 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             gkr::h64::make_fixed_mul(r[i], slot[b].w);
         }
     };
+    // Product passes (kernels.hip): both phases as sumchecks of W X + Y over three small tables, up to three rounds per
+    // device round trip.  The default for the linear-time form over gate lists; GKR_LAYER_PER_ROUND=1: one round per trip.
+    static const bool per_round = getenv("GKR_LAYER_PER_ROUND") != nullptr;
+    if (lin_b && sparse && !shard && k <= 13 && !per_round) {
+        gkr::ProdPassRec* prec = nullptr;
+        Fr *h_pw = nullptr, *d_ppart = nullptr, *Xc = nullptr, *Yc = nullptr;
+        const uint32_t max_blocks = gkr::prod_pass_blocks(1u << (k - 1));
+        HIP_TRY(ctx, ctx->pinned_host("layer.prec", sizeof(gkr::ProdPassRec) * batch, reinterpret_cast<void**>(&prec)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.pw", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_pw)));
+        WS(ctx, "layer.ppart", Fr, (size_t)batch * max_blocks * gkr::kProdRecValues, d_ppart);
+        WS(ctx, "layer.X", Fr, wlen * batch, Xc);
+        WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
+        gkr::SpinPool::Session session(pool, nullptr);
+        uint32_t round0 = 0, jp = 0;
+        for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
+            Fr *Tw = Wb, *Tx = U, *Ty = V;
+            if (phase == 1) {
+                // all of b is bound: the rows of a, m at u = (r_1 .. r_k), then the c-phase's tables X = a_u + W(u) m_u,
+                // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
+                for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
+                gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
+                {
+                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq, A, M, lb, s);
+                }
+                gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
+                Tw = Wc;
+                Tx = Xc;
+                Ty = Yc;
+                jp = 0;
+            }
+            uint32_t m = (uint32_t)k;   // log2 of the tables' length before the pending fold
+            for (uint32_t rem = (uint32_t)k; rem > 0 && rc == GKR_OK;) {
+                const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
+                const uint32_t blocks = gkr::prod_pass_blocks(1u << (m - jp - J));
+                const uint32_t ticket = ++ctx->ticket;
+                {
+                    Timed t(ctx, "layer_prod_pass", 0.0);
+                    gkr::launch_prod_cross(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, (uint32_t)batch, s);
+                    gkr::launch_prod_publish(d_ppart, blocks, prec, ticket, (uint32_t)batch, s);
+                }
+                if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+                    rc = ctx->hip_fail(le, "launch of a layer pass");
+                    break;
+                }
+                m -= jp;
+                rc = wait_records(ctx, prec, batch, ticket);
+                if (rc) break;
+                const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
+                std::atomic<int> next{0};
+                const std::function<bool()> work = [&]() -> bool {
+                    const int first = next.fetch_add(chunk, std::memory_order_relaxed);
+                    if (first >= batch) return false;
+                    const int cnt = batch - first < chunk ? batch - first : chunk;
+                    uint64_t c2[gkr::kProdMaxJ][16][4], lin[gkr::kProdMaxJ][16][4], c0[gkr::kProdMaxJ][16][4], rr[gkr::kProdMaxJ][16][4];
+                    uint32_t vl[gkr::kProdMaxJ][16];
+                    for (uint32_t t = 0; t < J; ++t)
+                        for (int i = 0; i < cnt; ++i) vl[t][i] = 2u + (h_dep[(size_t)(first + i) * 32 + (round0 + t) % k] ? 1u : 0u);
+                    (ifma && cnt >= 3 ? gkr::gkr_ifma_prod_pass : host_prod_pass_scalar)(
+                        reinterpret_cast<const uint64_t*>(prec + first), sizeof(gkr::ProdPassRec) / 8, cnt, (int)J, vl, c2, lin, c0, rr,
+                        reinterpret_cast<uint64_t*>(h_pw + (size_t)first * 8), 32);
+                    for (int i = 0; i < cnt; ++i) {
+                        const int b = first + i;
+                        for (uint32_t t = 0; t < J; ++t) {
+                            const uint32_t round = round0 + t;
+                            gkr_fr* oc = out_coeffs[b] + (size_t)round * 3;
+                            memset(&oc[0], 0, 32);
+                            if (vl[t][i] == 3) memcpy(&oc[0], c2[t][i], 32);
+                            memcpy(&oc[1], lin[t][i], 32);
+                            memcpy(&oc[2], c0[t][i], 32);
+                            out_len[b][round] = vl[t][i];
+                            memcpy(&out_r[b][round], rr[t][i], 32);
+                        }
+                    }
+                    return true;
+                };
+                run_pieces(pool, &work, batch > chunk);
+                jp = J;
+                round0 += J;
+                rem -= J;
+            }
+        }
+        session.close();
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->drain_events();
+        return GKR_OK;
+    }
     // The fold with r_j is deferred into the pass that computes round j+1's sums (b-phase: the
     // fused kernel; c-phase: a separate fold of the single remaining row).
     const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
@@ -2190,6 +2347,57 @@ int gkr_selftest_host_pass(const gkr_fr* sums, int count, int J, const uint32_t*
         const F wc = gkr::h64::from_mont(a.w[i]);
         memcpy(&w[i], &wc, 32);
     }
+    return GKR_OK;
+}
+
+// The host's share of one product pass of the layer sumcheck (host logic only): `count` <= 16 sumchecks; recs: per
+// sumcheck 72 values (cross sums m[a * 8 + b], a, b < 2^J, then the Y sums at 64 + a); vec_len[t * count + k]: 2 or 3.
+// -> per round t < J (index t * count + k) the coefficients c2, lin, c0 and the challenge; w[k * 8 + b], b < 2^J: the
+// weights eq(r, b) of the fold that follows, canonical.  Scalar code always; the IFMA-lane form runs beside it when
+// the CPU has it (*used_ifma = 1) and any difference is GKR_ERR_INVALID.
+int gkr_selftest_host_prod_pass(const gkr_fr* recs, int count, int J, const uint32_t* vec_len, gkr_fr* c2, gkr_fr* lin, gkr_fr* c0,
+                                gkr_fr* r, gkr_fr* w, int* used_ifma) {
+    using gkr::h64::F;
+    if (!recs || !vec_len || !c2 || !lin || !c0 || !r || !w || count < 1 || count > kHashChunkMax || J < 1 || J > gkr::kProdMaxJ)
+        return GKR_ERR_INVALID;
+    if (!all_canonical(recs, (size_t)count * gkr::kProdRecValues)) return GKR_ERR_NON_CANONICAL;
+    uint32_t vl[gkr::kProdMaxJ][16] = {};
+    for (int t = 0; t < J; ++t)
+        for (int k = 0; k < count; ++k) {
+            vl[t][k] = vec_len[(size_t)t * count + k];
+            if (vl[t][k] != 2 && vl[t][k] != 3) return GKR_ERR_INVALID;
+        }
+    struct Out {
+        uint64_t c2[gkr::kProdMaxJ][16][4], lin[gkr::kProdMaxJ][16][4], c0[gkr::kProdMaxJ][16][4], r[gkr::kProdMaxJ][16][4];
+        F w[16][8];
+    } a, b;
+    memset(&a, 0, sizeof a);
+    memset(&b, 0, sizeof b);
+    host_prod_pass_scalar(reinterpret_cast<const uint64_t*>(recs), 4 * gkr::kProdRecValues, count, J, vl, a.c2, a.lin, a.c0, a.r, &a.w[0][0].l[0], 32);
+    const bool ifma = host_ifma_ready();
+    if (used_ifma) *used_ifma = ifma ? 1 : 0;
+    if (ifma) {
+        gkr::gkr_ifma_prod_pass(reinterpret_cast<const uint64_t*>(recs), 4 * gkr::kProdRecValues, count, J, vl, b.c2, b.lin, b.c0, b.r, &b.w[0][0].l[0], 32);
+        for (int t = 0; t < J; ++t)
+            for (int k = 0; k < count; ++k)
+                if (memcmp(a.c2[t][k], b.c2[t][k], 32) || memcmp(a.lin[t][k], b.lin[t][k], 32) || memcmp(a.c0[t][k], b.c0[t][k], 32) ||
+                    memcmp(a.r[t][k], b.r[t][k], 32))
+                    return GKR_ERR_INVALID;
+        for (int k = 0; k < count; ++k)
+            if (memcmp(a.w[k], b.w[k], sizeof(F) << J) != 0) return GKR_ERR_INVALID;
+    }
+    for (int t = 0; t < J; ++t)
+        for (int k = 0; k < count; ++k) {
+            memcpy(&c2[(size_t)t * count + k], a.c2[t][k], 32);
+            memcpy(&lin[(size_t)t * count + k], a.lin[t][k], 32);
+            memcpy(&c0[(size_t)t * count + k], a.c0[t][k], 32);
+            memcpy(&r[(size_t)t * count + k], a.r[t][k], 32);
+        }
+    for (int k = 0; k < count; ++k)
+        for (int bb = 0; bb < 8; ++bb) {
+            const F wc = bb < (1 << J) ? gkr::h64::from_mont(a.w[k][bb]) : F{{0, 0, 0, 0}};
+            memcpy(&w[(size_t)k * 8 + bb], &wc, 32);
+        }
     return GKR_OK;
 }
 

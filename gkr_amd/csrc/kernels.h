@@ -44,6 +44,30 @@ struct LayerHostRec {
 };
 static_assert(sizeof(MleHostRec) == 128 && sizeof(LayerHostRec) == 128, "hand-off records are one 128-byte line");
 
+// Multi-round passes of the layer sumcheck's product form (kernels.hip, "product passes"): a pass hands the host the
+// 4^J cross sums of the sub-blocks of W and X and the 2^J sub-block sums of Y, J <= kProdMaxJ rounds' worth.
+constexpr int kProdMaxJ = 3;
+constexpr int kProdRecValues = 72;   // m[a * 8 + b], a, b < 2^J; then sy[a] at 64 + a
+struct ProdPassRec {
+    Fr v[kProdRecValues];
+    uint32_t seq;
+    uint32_t pad[7];
+};
+static_assert(sizeof(ProdPassRec) == kProdRecValues * 32 + 32, "product-pass record layout");
+// entries per block of a pass (one tile) and blocks per proof for tables whose sub-blocks have S entries
+constexpr uint32_t kProdTile = 16;
+inline uint32_t prod_pass_blocks(uint32_t S) { return S <= kProdTile ? 1u : S / kProdTile; }
+// One pass on the tables W (Montgomery), X, Y (canonical) of 2^m_in entries per proof (stride wstride): bind the jp
+// variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
+// the cross sums for the next J rounds -> partials (batch x blocks x 72), summed and published by launch_prod_publish.
+void launch_prod_cross(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
+                       uint32_t batch, hipStream_t s);
+void launch_prod_publish(const Fr* partials, uint32_t blocks, ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s);
+// start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
+// the 2^k entries of the rows A, M (gate_rows), per proof
+void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
+                         uint32_t batch, hipStream_t s);
+
 constexpr uint32_t kSmallFoldQuarter = 2048;   // rounds whose output half has <= this many entries use one block per sumcheck
 void launch_mle_fold_sum_small(const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t q, uint32_t batch,
                                const FixedMul* rtab, MleHostRec* host_rec, uint32_t ticket, hipStream_t s);

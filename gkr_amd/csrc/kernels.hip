@@ -534,6 +534,96 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
     }
 }
 
+// ---------------------------------------------------------------------------
+// Product passes.  Both phases of the linear-time layer sumcheck are a sumcheck of  h(t) = W(t) X(t) + Y(t)  over
+// three tables of 2^k entries (b-phase: X = U, Y = V; c-phase: X = a_u + W(u) m_u, Y = W(u) a_u).  The sums a round
+// needs are bilinear in (W, X) and linear in Y, so -- as for the plain sumcheck's multi-round passes -- the sums of J
+// consecutive rounds follow from the sub-block CROSS sums
+//     m[a][b] = sum_i W[a S + i] X[b S + i],   sy[a] = sum_i Y[a S + i],   a, b < 2^J,  S = 2^(m - J):
+// round 1 reads the entries whose trailing bits agree, binding a variable folds the matrix along both indices.  One
+// device round trip per J <= 3 rounds instead of one per round; the host folds a 64-entry matrix between hashes.
+// Same round polynomials as the per-round kernels: bit-exact.
+// ---------------------------------------------------------------------------
+
+// grid = (blocks, batch), block = 256: this block's tile of i, all 2^J sub-blocks
+__global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
+                                                    const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride) {
+    __shared__ Fr s_w[8];
+    __shared__ Fr s_t[3][8][kProdTile];          // folded tile: table, sub-block, i
+    __shared__ Fr s_red[4][kProdRecValues];
+    const uint32_t tid = threadIdx.x, proof = blockIdx.y;
+    Fr* T[3] = {Wt + (size_t)proof * wstride, Xt + (size_t)proof * wstride, Yt + (size_t)proof * wstride};
+    const uint32_t m = m_in - jp, nsub = 1u << J, S = 1u << (m - J);
+    const uint32_t ti = S < kProdTile ? S : kProdTile, i0 = blockIdx.x * kProdTile;
+    if (tid < (1u << jp)) s_w[tid] = load_fr(weights + (size_t)proof * 8 + tid);
+    __syncthreads();
+    // the tile of the tables with the previous pass's variables bound (written back: later passes read it)
+    for (uint32_t e = tid; e < 3u * nsub * ti; e += blockDim.x) {
+        const uint32_t i = e % ti, a = (e / ti) % nsub, t = e / (ti * nsub);
+        const uint32_t idx = a * S + i0 + i;
+        Fr v;
+        if (jp) {
+            v = mont_mul(load_fr(T[t] + idx), s_w[0]);
+            for (uint32_t b = 1; b < (1u << jp); ++b) v = fr_add(v, mont_mul(load_fr(T[t] + ((size_t)b << m) + idx), s_w[b]));
+            store_fr(T[t] + idx, v);
+        } else {
+            v = load_fr(T[t] + idx);
+        }
+        s_t[t][a][i] = v;
+    }
+    __syncthreads();
+    const uint32_t p = tid & 63u, sub = tid >> 6, a = p >> 3, b = p & 7u;
+    Fr acc = fr_zero(), accy = fr_zero();
+    if (a < nsub && b < nsub)
+        for (uint32_t i = sub; i < ti; i += 4) acc = fr_add(acc, mont_mul(s_t[1][b][i], s_t[0][a][i]));
+    if (p < nsub)
+        for (uint32_t i = sub; i < ti; i += 4) accy = fr_add(accy, s_t[2][p][i]);
+    s_red[sub][p] = acc;
+    if (p < 8) s_red[sub][64 + p] = accy;
+    __syncthreads();
+    if (tid < (uint32_t)kProdRecValues) {
+        Fr v = fr_add(fr_add(s_red[0][tid], s_red[1][tid]), fr_add(s_red[2][tid], s_red[3][tid]));
+        store_fr(partials + ((size_t)proof * gridDim.x + blockIdx.x) * kProdRecValues + tid, v);
+    }
+}
+
+// grid = (batch), block = 128: totals of the blocks' partials -> the pinned record
+__global__ void __launch_bounds__(128) k_prod_publish(const Fr* __restrict__ partials, uint32_t blocks, ProdPassRec* __restrict__ rec,
+                                                      uint32_t ticket) {
+    const uint32_t tid = threadIdx.x;
+    ProdPassRec* r = rec + blockIdx.x;
+    if (tid < (uint32_t)kProdRecValues) {
+        const Fr* p = partials + (size_t)blockIdx.x * blocks * kProdRecValues + tid;
+        Fr v = load_fr(p);
+        for (uint32_t k = 1; k < blocks; ++k) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
+        store_fr(&r->v[tid], v);
+    }
+    __syncthreads();   // every record store is issued and waited for before the release below
+    if (tid == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// grid = (blocks over 2^k, batch), block = 256
+__global__ void __launch_bounds__(256) k_prod_c_setup(const Fr* __restrict__ Wb, uint32_t jp, const Fr* __restrict__ weights,
+                                                      const Fr* __restrict__ A, const Fr* __restrict__ M, Fr* __restrict__ X,
+                                                      Fr* __restrict__ Y, uint32_t k, uint32_t wstride) {
+    __shared__ Fr s_wu;
+    const size_t base = (size_t)blockIdx.y * wstride;
+    if (threadIdx.x == 0) {
+        // W(u): the last b pass's variables bound in what is left of Wb (Montgomery in, Montgomery out)
+        Fr wu = mont_mul(load_fr(Wb + base), load_fr(weights + (size_t)blockIdx.y * 8));
+        for (uint32_t b = 1; b < (1u << jp); ++b) wu = fr_add(wu, mont_mul(load_fr(Wb + base + b), load_fr(weights + (size_t)blockIdx.y * 8 + b)));
+        s_wu = wu;
+    }
+    __syncthreads();
+    const Fr wu = s_wu;
+    const uint32_t n = 1u << k;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const Fr a = load_fr(A + base + c), mm = load_fr(M + base + c);
+        store_fr(X + base + c, fr_add(a, mont_mul(mm, wu)));
+        store_fr(Y + base + c, mont_mul(a, wu));
+    }
+}
+
 // Small transfers as kernels: `words` 32-bit words from src to dst, either of which may be pinned host memory.  The
 // round path of a proof makes no transfer call of the runtime (measured: with twelve contexts proving side by side, an
 // asynchronous 256 KB host-to-device copy per layer now and then held every context's launches up for 6 - 8 ms).
@@ -1900,6 +1990,21 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
                        const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s) {
     hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096), batch), dim3(256), 0, s, gates, gate_type, left, right,
                        prev, out, prev_stride);
+}
+
+void launch_prod_cross(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
+                       uint32_t batch, hipStream_t s) {
+    const uint32_t S = 1u << (m_in - jp - J);
+    hipLaunchKernelGGL(k_prod_cross, dim3(prod_pass_blocks(S), batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride);
+}
+
+void launch_prod_publish(const Fr* partials, uint32_t blocks, ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(128), 0, s, partials, blocks, rec, ticket);
+}
+
+void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
+                         uint32_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_prod_c_setup, dim3(blocks_for(1u << k, 1024), batch), dim3(256), 0, s, Wb, jp, weights, A, M, X, Y, k, wstride);
 }
 
 void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) {

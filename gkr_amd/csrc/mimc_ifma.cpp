@@ -637,7 +637,122 @@ static void pass_w(const uint64_t* sums, size_t sums_row_words, int count, int J
     }
 }
 
+// The host's share of one product pass (kernels.hip, "product passes") for 8 W layer sumchecks side by side: the
+// 8 x 8 cross-sum matrix and the eight Y sums of every lane stay in vector registers / L1 from the gather to the
+// last fold; per round the three coefficients, the hash of [c2, lin, c0] (without c2 where the vector has two
+// entries), the matrix folded along both indices with the challenge.
+template <int W>
+static void prod_pass_w(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16], uint64_t (*c2)[16][4],
+                        uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4], uint64_t* weights, size_t w_row_words) {
+    const V r2 = splat(g_r2_52), one = splat(g_one52);
+    V zero;
+    for (int i = 0; i < 5; ++i) zero.l[i] = _mm512_setzero_si512();
+    V M[W][64], SY[W][8], rm[3][W];
+    __m512i off_in[W], off_out[W], off_w[W];
+    __mmask8 valid[W];
+    int cnt[W];
+    const int n = 1 << J;
+    for (int w = 0; w < W; ++w) {
+        cnt[w] = count - 8 * w < 0 ? 0 : (count - 8 * w > 8 ? 8 : count - 8 * w);
+        valid[w] = (__mmask8)((1u << cnt[w]) - 1);
+        off_in[w] = lane_offsets(rec_row_words, cnt[w]);
+        off_out[w] = lane_offsets(4, cnt[w]);
+        off_w[w] = lane_offsets(w_row_words, cnt[w]);
+        const uint64_t* base = recs + (size_t)(cnt[w] ? 8 * w : 0) * rec_row_words;
+        for (int a = 0; a < n; ++a) {
+            for (int b = 0; b < n; ++b) M[w][a * 8 + b] = gather8(base + 4 * (size_t)(a * 8 + b), off_in[w]);
+            SY[w][a] = gather8(base + 4 * (size_t)(64 + a), off_in[w]);
+        }
+    }
+    for (int t = 0; t < J; ++t) {
+        const int half = 1 << (J - t - 1);
+        V vc2[W], vlin[W], vc0[W], a[W], acc[W], h[W];
+        __mmask8 three[W];
+        unsigned any_three = 0;
+        for (int w = 0; w < W; ++w) {
+            V p00 = M[w][0], p01 = M[w][half], p10 = M[w][half * 8], p11 = M[w][half * 8 + half], s0 = SY[w][0], s1 = SY[w][half];
+            for (int x = 1; x < half; ++x) {
+                p00 = add_mod(p00, M[w][x * 8 + x]);
+                p01 = add_mod(p01, M[w][x * 8 + half + x]);
+                p10 = add_mod(p10, M[w][(half + x) * 8 + x]);
+                p11 = add_mod(p11, M[w][(half + x) * 8 + half + x]);
+                s0 = add_mod(s0, SY[w][x]);
+                s1 = add_mod(s1, SY[w][half + x]);
+            }
+            vc0[w] = add_mod(p00, s0);
+            const V g1 = add_mod(p11, s1);
+            vc2[w] = sub_mod(add_mod(p11, p00), add_mod(p10, p01));
+            vlin[w] = sub_mod(sub_mod(g1, vc0[w]), vc2[w]);
+            three[w] = 0;
+            for (int k = 0; k < cnt[w]; ++k)
+                if (vec_len[t][8 * w + k] == 3) three[w] |= (__mmask8)(1u << k);
+            any_three |= three[w];
+            scatter8(vc2[w], &c2[t][8 * w][0], off_out[w], valid[w]);
+            scatter8(vlin[w], &lin[t][8 * w][0], off_out[w], valid[w]);
+            scatter8(vc0[w], &c0[t][8 * w][0], off_out[w], valid[w]);
+            acc[w] = zero;
+        }
+        // multi_hash([c2, lin, c0]) or multi_hash([lin, c0])
+        if (any_three) {
+            for (int w = 0; w < W; ++w) a[w] = mont_mul(vc2[w], r2);
+            mimc7_hash_w<W>(a, acc, h);
+            for (int w = 0; w < W; ++w) {
+                const V nr = add_mod(add_mod(acc[w], a[w]), h[w]);
+                for (int i = 0; i < 5; ++i) acc[w].l[i] = _mm512_mask_blend_epi64(three[w], acc[w].l[i], nr.l[i]);
+            }
+        }
+        for (int w = 0; w < W; ++w) a[w] = mont_mul(vlin[w], r2);
+        mimc7_hash_w<W>(a, acc, h);
+        for (int w = 0; w < W; ++w) acc[w] = add_mod(add_mod(acc[w], a[w]), h[w]);
+        for (int w = 0; w < W; ++w) a[w] = mont_mul(vc0[w], r2);
+        mimc7_hash_w<W>(a, acc, h);
+        for (int w = 0; w < W; ++w) {
+            rm[t][w] = add_mod(add_mod(acc[w], a[w]), h[w]);   // the challenge, Montgomery form (radix 2^260)
+            scatter8(mont_mul(rm[t][w], one), &r[t][8 * w][0], off_out[w], valid[w]);
+            const V x = rm[t][w];
+            for (int ra = 0; ra < half; ++ra)        // rows: the W index
+                for (int cb = 0; cb < 2 * half; ++cb)
+                    M[w][ra * 8 + cb] = add_mod(M[w][ra * 8 + cb], mont_mul(sub_mod(M[w][(half + ra) * 8 + cb], M[w][ra * 8 + cb]), x));
+            for (int ra = 0; ra < half; ++ra)        // columns: the X index
+                for (int cb = 0; cb < half; ++cb)
+                    M[w][ra * 8 + cb] = add_mod(M[w][ra * 8 + cb], mont_mul(sub_mod(M[w][ra * 8 + half + cb], M[w][ra * 8 + cb]), x));
+            for (int ra = 0; ra < half; ++ra) SY[w][ra] = add_mod(SY[w][ra], mont_mul(sub_mod(SY[w][half + ra], SY[w][ra]), x));
+        }
+    }
+    if (!weights) return;
+    for (int w = 0; w < W; ++w) {
+        if (!cnt[w]) continue;
+        V* wv = M[w];   // the matrix is spent
+        wv[0] = splat(g_r256_52);
+        int cur = 1;
+        for (int t = 0; t < J; ++t) {
+            for (int b = cur; b-- > 0;) {
+                const V hi = mont_mul(wv[b], rm[t][w]);
+                wv[2 * b + 1] = hi;
+                wv[2 * b] = sub_mod(wv[b], hi);
+            }
+            cur <<= 1;
+        }
+        uint64_t* base = weights + (size_t)8 * w * w_row_words;
+        for (int b = 0; b < cur; ++b) scatter8(wv[b], base + 4 * (size_t)b, off_w[w], valid[w]);
+    }
+}
+
 }  // namespace ifma
+
+// The host's share of one product pass of `count` <= 16 layer sumchecks (lanes), J <= 3 rounds:
+//   in   recs[k * rec_row_words + 4 (a * 8 + b) ..]: lane k's cross sums m[a][b], a, b < 2^J, and at entry 64 + a its Y sums
+//        vec_len[t][k]: 2 or 3, the length of lane k's round-t vector (3: W depends on the variable, poly.rs:388-420)
+//   out  per round t < J and lane k the coefficients c2, lin, c0 of the round polynomial c2 x^2 + lin x + c0 and
+//        r = multi_hash([c2, lin, c0] or [lin, c0], key 0); all canonical
+//        weights (may be null): lane k's 2^J weights eq((r_0..r_{J-1}), b) times 2^256 at weights[k * w_row_words + 4 b]
+void gkr_ifma_prod_pass(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16], uint64_t (*c2)[16][4],
+                        uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4], uint64_t* weights, size_t w_row_words) {
+    if (count > 8)
+        ifma::prod_pass_w<2>(recs, rec_row_words, count, J, vec_len, c2, lin, c0, r, weights, w_row_words);
+    else
+        ifma::prod_pass_w<1>(recs, rec_row_words, count, J, vec_len, c2, lin, c0, r, weights, w_row_words);
+}
 
 // The host's share of one multi-round pass of `count` <= 16 plain sumchecks (lanes), J <= 5 rounds:
 //   in   sums[k * sums_row_words + 4 b .. +4), b < 2^J: lane k's sub-block sums (canonical)

@@ -12,4 +12,7 @@ void gkr_ifma_multi_hash16(const uint64_t (*vec)[3][4], const uint32_t* len, int
 // the host's whole share of one multi-round pass, `count` <= 16 sumchecks side by side (see mimc_ifma.cpp)
 void gkr_ifma_pass(const uint64_t* sums, size_t sums_row_words, int count, int J, const uint32_t* final_len, uint64_t (*c0)[16][4],
                    uint64_t (*c1)[16][4], uint64_t (*r)[16][4], uint32_t (*len)[16], uint64_t* weights, size_t w_row_words);
+// the host's share of one product pass of the layer sumcheck, `count` <= 16 sumchecks side by side (see mimc_ifma.cpp)
+void gkr_ifma_prod_pass(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16], uint64_t (*c2)[16][4],
+                        uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4], uint64_t* weights, size_t w_row_words);
 }  // namespace gkr

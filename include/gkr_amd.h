@@ -134,6 +134,13 @@ int  gkr_selftest_hash8(const gkr_fr *vecs, const uint32_t *len, gkr_fr *out, in
  * must agree. */
 int  gkr_selftest_host_pass(const gkr_fr *sums, int count, int J, const uint32_t *final_len, gkr_fr *c0, gkr_fr *c1,
                             uint32_t *len, gkr_fr *r, gkr_fr *w, int *used_ifma);
+/* the host's share of one product pass of the layer sumcheck (h = W X + Y over three tables): `count` <= 16 sumchecks,
+ * recs: 72 values each -- the cross sums m[a*8 + b] = sum_i W[aS+i] X[bS+i] of the 2^J <= 8 sub-blocks, then the Y sums
+ * at 64 + a; vec_len[t*count + k] = 2 or 3 -> per round t < J (index t*count + k) the coefficients of
+ * c2 X^2 + lin X + c0 and the challenge; w[k*8 + b]: the weights eq(r, b) of the fold that follows (canonical).
+ * Scalar code; its IFMA-lane form runs beside it when the CPU has it and must agree. */
+int  gkr_selftest_host_prod_pass(const gkr_fr *recs, int count, int J, const uint32_t *vec_len, gkr_fr *c2, gkr_fr *lin,
+                                 gkr_fr *c0, gkr_fr *r, gkr_fr *w, int *used_ifma);
 /* sum_i a_i b_i through the unreduced 544-bit dot-product accumulator of the fused layer kernel */
 int  gkr_selftest_dot(const gkr_fr *a, const gkr_fr *b, size_t n, gkr_fr *out);
 /* the pass schedule of a 2^n-point plain sumcheck (host logic): rounds covered by each pass; mfma = 1 default

@@ -12,9 +12,10 @@ from oracle.field import P  # noqa: E402
 
 def main():
     with Context(0) as ctx:
-        for seed in range(10):
+        for seed in range(12):
             rng = random.Random(7000 + seed)
-            k_i, k = (rng.randint(0, 9), rng.randint(1, 6)) if seed else (14, 7)
+            # (two wider layers: passes that span several blocks and leave 1, 2 or 3 rounds for the last pass)
+            k_i, k = {0: (14, 7), 10: (12, 9), 11: (13, 10)}.get(seed) or (rng.randint(0, 9), rng.randint(1, 6))
             g = 1 << k_i
             gt = [rng.randint(0, 1) for _ in range(g)]
             if seed % 4 == 1:

@@ -241,13 +241,15 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
 @pytest.mark.parametrize("env", [{}, {"GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"}, {"GKR_LAYER_DENSE_B": "1"},
                                  {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_LAYER_PERSISTENT": "1"},
                                  {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
-                                 {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}],
+                                 {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_LAYER_PER_ROUND": "1"},
+                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
     """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from
-    the gate lists (default), the same with U, V taken from dense predicate tables, and k passes over the dense
-    2^{2k}-entry tables (fused or round + fold kernels): the same transcript from each, single layers and a batch of
-    proofs.  The knobs are read once per process, hence the child."""
+    the gate lists (default: product passes, up to three rounds per device round trip; GKR_LAYER_PER_ROUND: one round
+    per trip), the same with U, V taken from dense predicate tables, and k passes over the dense 2^{2k}-entry tables
+    (fused or round + fold kernels): the same transcript from each, single layers and a batch of proofs, IFMA-lane and
+    scalar host passes.  The knobs are read once per process, hence the child."""
     import os
     import subprocess
     import sys

@@ -164,6 +164,54 @@ def test_host_pass_matches_big_integers():
         == N.GKR_ERR_NON_CANONICAL
 
 
+def test_host_prod_pass_matches_a_direct_product_sumcheck():
+    """the host's share of a product pass of the layer sumcheck: the cross-sum matrix of random tables W, X, Y is built
+    here, and the coefficients / challenges / weights the library derives from it alone (scalar and IFMA lanes) must
+    equal a sumcheck of sum_t W(t) X(t) + Y(t) run directly on the tables, round by round"""
+    lib = N.lib()
+    rng = random.Random(33)
+    for count in (1, 3, 8, 11, 16):
+        for J in (1, 2, 3):
+            m = J + rng.randint(0, 2)                       # tables of 2^m entries; the pass covers the first J variables
+            S = 1 << (m - J)
+            tabs = [[[rng.randrange(P) for _ in range(1 << m)] for _ in range(3)] for _ in range(count)]
+            if count > 1:
+                tabs[1][1] = [0] * (1 << m)                  # X = 0: every c2 is zero
+            recs = []
+            for Wt, Xt, Yt in tabs:
+                rec = [0] * 72
+                for a in range(1 << J):
+                    for b in range(1 << J):
+                        rec[a * 8 + b] = sum(Wt[a * S + i] * Xt[b * S + i] for i in range(S)) % P
+                    rec[64 + a] = sum(Yt[a * S + i] for i in range(S)) % P
+                recs += rec
+            vl = [[rng.choice((2, 3)) for _ in range(count)] for _ in range(J)]
+            R = to_limbs(recs)
+            VL = np.asarray([x for row in vl for x in row], dtype=np.uint32)
+            C2, LIN, C0, RR = (np.zeros((J * count, 4), dtype=np.uint64) for _ in range(4))
+            Wout = np.zeros((count * 8, 4), dtype=np.uint64)
+            used = ctypes.c_int(-1)
+            rc = lib.gkr_selftest_host_prod_pass(_p(R), ctypes.c_int(count), ctypes.c_int(J), _p(VL), _p(C2), _p(LIN), _p(C0), _p(RR),
+                                                 _p(Wout), ctypes.byref(used))
+            assert rc == 0, (count, J, rc)
+            c2, lin, c0, rr, w_got = from_limbs(C2), from_limbs(LIN), from_limbs(C0), from_limbs(RR), from_limbs(Wout)
+            for k, (Wt, Xt, Yt) in enumerate(tabs):
+                Wt, Xt, Yt = list(Wt), list(Xt), list(Yt)
+                w = [1]
+                for t in range(J):
+                    h = len(Wt) // 2
+                    want_c0 = sum(Wt[i] * Xt[i] + Yt[i] for i in range(h)) % P
+                    g1 = sum(Wt[h + i] * Xt[h + i] + Yt[h + i] for i in range(h)) % P
+                    want_c2 = sum((Wt[h + i] - Wt[i]) * (Xt[h + i] - Xt[i]) for i in range(h)) % P
+                    want_lin = (g1 - want_c0 - want_c2) % P
+                    want_r = mimc7.multi_hash([want_c2, want_lin, want_c0][3 - vl[t][k]:])
+                    i = t * count + k
+                    assert (c2[i], lin[i], c0[i], rr[i]) == (want_c2, want_lin, want_c0, want_r), (count, J, m, k, t)
+                    Wt, Xt, Yt = ([(T[j] + (T[h + j] - T[j]) * want_r) % P for j in range(h)] for T in (Wt, Xt, Yt))
+                    w = [x for v in w for x in ((v * (1 - want_r)) % P, (v * want_r) % P)]
+                assert w_got[k * 8:k * 8 + (1 << J)] == w, (count, J, k)
+
+
 def test_non_canonical_inputs_are_rejected():
     lib = N.lib()
     bad = np.full((1, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
