@@ -1481,9 +1481,9 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
             WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
             if (cached) {
-                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), (2 * span.count + 1) * sizeof(uint32_t)));
+                if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
+                if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
+                if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), (2 * span.count + 1) * sizeof(uint32_t)));
                 g_offsets = cached->offsets;
                 g_cursor = cached->cursor;
                 g_list = cached->list;
@@ -1807,12 +1807,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             uint32_t m = (uint32_t)k;   // log2 of the tables' length before the pending fold
             for (uint32_t rem = (uint32_t)k; rem > 0 && rc == GKR_OK;) {
                 const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
-                const uint32_t blocks = gkr::prod_pass_blocks(1u << (m - jp - J));
                 const uint32_t ticket = ++ctx->ticket;
                 {
                     Timed t(ctx, "layer_prod_pass", 0.0);
-                    gkr::launch_prod_cross(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, (uint32_t)batch, s);
-                    gkr::launch_prod_publish(d_ppart, blocks, prec, ticket, (uint32_t)batch, s);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s);
                 }
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) {
                     rc = ctx->hip_fail(le, "launch of a layer pass");
@@ -2651,6 +2649,90 @@ int gkr_sumcheck_layer_device(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_f
     sh.allreduce = allreduce;
     sh.user = user;
     return run_layer_batch(ctx, 1, k_i, k_next, gt, dl, dr, z, dW, &out_coeffs, &out_len, &out_r, &sh);
+}
+
+struct gkr_resident_layer {
+    int k_i = 0, k = 0;
+    uint64_t first = 0, count = 0;
+    uint8_t* gt = nullptr;
+    uint32_t *l = nullptr, *r = nullptr;
+    GateLists lists;
+};
+
+void gkr_resident_layer_free(gkr_ctx* ctx, gkr_resident_layer* layer) {
+    if (!layer) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (layer->gt) (void)hipFree(layer->gt);
+    if (layer->l) (void)hipFree(layer->l);
+    if (layer->r) (void)hipFree(layer->r);
+    if (layer->lists.offsets) (void)hipFree(layer->lists.offsets);
+    if (layer->lists.cursor) (void)hipFree(layer->lists.cursor);
+    if (layer->lists.list) (void)hipFree(layer->lists.list);
+    delete layer;
+}
+
+int gkr_resident_layer_create(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count, const uint8_t* gate_type,
+                              const uint32_t* left, const uint32_t* right, gkr_resident_layer** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!out) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    if ((!gate_type || !left || !right) && gate_count) return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > 14) return ctx->fail(GKR_ERR_INVALID, "k_next out of range");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<gkr_resident_layer, void (*)(gkr_resident_layer*)> L(new gkr_resident_layer(), [](gkr_resident_layer* p) {
+        gkr_resident_layer_free(nullptr, p);
+    });
+    L->k_i = k_i;
+    L->k = k_next;
+    L->first = gate_first;
+    L->count = gate_count;
+    const size_t n = gate_count ? (size_t)gate_count : 1;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->gt), n));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->l), n * 4));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->r), n * 4));
+    if (gate_count) {
+        HIP_TRY(ctx, hipMemcpy(L->gt, gate_type, gate_count, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(L->l, left, gate_count * 4, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(L->r, right, gate_count * 4, hipMemcpyHostToDevice));
+    }
+    *out = L.release();
+    return GKR_OK;
+}
+
+int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const gkr_fr* W, gkr_allreduce_fn allreduce,
+                                void* user, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    const int k_i = layer->k_i, k = layer->k;
+    if (!allreduce && (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)))
+        return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the layer must be whole");
+    if (allreduce && k > 13) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs k_next <= 13");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
+    gkr_fr* hW = nullptr;   // through pinned memory and a copy kernel (no transfer call on the path, see k_copy_words)
+    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
+    memcpy(hW, W, sizeof(gkr_fr) << k);
+    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    LayerShardArgs sh;
+    sh.gate_base = layer->first;
+    sh.gate_count = layer->count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    const int rc = run_layer_batch(ctx, 1, k_i, k, layer->gt, layer->l, layer->r, z, dW, &out_coeffs, &out_len, &out_r, allreduce ? &sh : nullptr,
+                                   &layer->lists);
+    if (rc) {   // a failed first use may have left half-built lists behind
+        layer->lists.ready = false;
+    }
+    return rc;
 }
 
 int gkr_fr_widen(const gkr_fr* values, size_t count, int64_t* limbs) {

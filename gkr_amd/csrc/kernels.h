@@ -59,10 +59,10 @@ constexpr uint32_t kProdTile = 16;
 inline uint32_t prod_pass_blocks(uint32_t S) { return S <= kProdTile ? 1u : S / kProdTile; }
 // One pass on the tables W (Montgomery), X, Y (canonical) of 2^m_in entries per proof (stride wstride): bind the jp
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
-// the cross sums for the next J rounds -> partials (batch x blocks x 72), summed and published by launch_prod_publish.
-void launch_prod_cross(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                       uint32_t batch, hipStream_t s);
-void launch_prod_publish(const Fr* partials, uint32_t blocks, ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s);
+// the cross sums for the next J rounds -> the pinned records (seq = ticket, system-scope release); partials: scratch of
+// batch x prod_pass_blocks(2^(m_in - jp - 1)) x 72 values for passes that span several blocks per proof.
+void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s);
 // start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
 // the 2^k entries of the rows A, M (gate_rows), per proof
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,

@@ -547,7 +547,8 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
 
 // grid = (blocks, batch), block = 256: this block's tile of i, all 2^J sub-blocks
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
-                                                    const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride) {
+                                                    const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
+                                                    ProdPassRec* __restrict__ rec, uint32_t ticket) {
     __shared__ Fr s_w[8];
     __shared__ Fr s_t[3][8][kProdTile];          // folded tile: table, sub-block, i
     __shared__ Fr s_red[4][kProdRecValues];
@@ -581,9 +582,15 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     s_red[sub][p] = acc;
     if (p < 8) s_red[sub][64 + p] = accy;
     __syncthreads();
+    // one block per proof (tables of <= 16 entries per sub-block): its sums are the pass's sums, published from here
+    const bool alone = gridDim.x == 1;
     if (tid < (uint32_t)kProdRecValues) {
         Fr v = fr_add(fr_add(s_red[0][tid], s_red[1][tid]), fr_add(s_red[2][tid], s_red[3][tid]));
-        store_fr(partials + ((size_t)proof * gridDim.x + blockIdx.x) * kProdRecValues + tid, v);
+        store_fr(alone ? &rec[proof].v[tid] : partials + ((size_t)proof * gridDim.x + blockIdx.x) * kProdRecValues + tid, v);
+    }
+    if (alone) {
+        __syncthreads();   // every record store is issued and waited for before the release below
+        if (tid == 0) __hip_atomic_store(&rec[proof].seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1992,14 +1999,11 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
                        prev, out, prev_stride);
 }
 
-void launch_prod_cross(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                       uint32_t batch, hipStream_t s) {
-    const uint32_t S = 1u << (m_in - jp - J);
-    hipLaunchKernelGGL(k_prod_cross, dim3(prod_pass_blocks(S), batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride);
-}
-
-void launch_prod_publish(const Fr* partials, uint32_t blocks, ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(128), 0, s, partials, blocks, rec, ticket);
+void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
+    const uint32_t blocks = prod_pass_blocks(1u << (m_in - jp - J));
+    hipLaunchKernelGGL(k_prod_cross, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
+    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(128), 0, s, partials, blocks, rec, ticket);
 }
 
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,

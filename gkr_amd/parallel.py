@@ -182,23 +182,27 @@ def prove_sumcheck_opt_gate_sharded(ctx: Context, k_i, k_next, gate_first, gate_
 
 
 class ResidentGates:
-    """A contiguous range of a layer's gates kept in device memory across sumchecks (gkr_sumcheck_layer_device): the
-    whole layer, or one rank's share of it."""
+    """A contiguous range of a layer's gates kept in device memory across sumchecks, with the gate lists sorted from
+    them on first use (gkr_resident_layer_*): the whole layer, or one rank's share of it."""
 
     def __init__(self, ctx: Context, k_i, gate_first, gate_type, left, right):
         self._ctx, self.k_i, self.first = ctx, k_i, gate_first
-        gt = np.ascontiguousarray(gate_type, dtype=np.uint8)
-        l = np.ascontiguousarray(left, dtype=np.uint32)
-        r = np.ascontiguousarray(right, dtype=np.uint32)
-        if not (len(gt) == len(l) == len(r)):
+        self._arrays = (np.ascontiguousarray(gate_type, dtype=np.uint8), np.ascontiguousarray(left, dtype=np.uint32),
+                        np.ascontiguousarray(right, dtype=np.uint32))
+        if not (len(self._arrays[0]) == len(self._arrays[1]) == len(self._arrays[2])):
             raise GkrError(N.GKR_ERR_INVALID, "gate arrays of different lengths")
-        self.count = len(gt)
-        self._d = []
-        for a in (gt, l, r):
-            d = ctx.alloc(max(a.nbytes, 4))
-            if a.nbytes:
-                ctx.upload(d, a)
-            self._d.append(d)
+        self.count = len(self._arrays[0])
+        self._handles = {}      # k_next -> gkr_resident_layer (the lists depend on the next layer's width)
+
+    def _layer(self, k_next):
+        if k_next not in self._handles:
+            h = ctypes.c_void_p()
+            gt, l, r = self._arrays
+            self._ctx._check(N.lib().gkr_resident_layer_create(self._ctx._h, ctypes.c_int(self.k_i), ctypes.c_int(k_next),
+                                                                ctypes.c_uint64(self.first), ctypes.c_uint64(self.count), _ptr(gt), _ptr(l),
+                                                                _ptr(r), ctypes.byref(h)))
+            self._handles[k_next] = h
+        return self._handles[k_next]
 
     def sumcheck_raw(self, k_next, z_limbs, w_limbs, sum_limbs=None):
         """-> (C, L, R) like Context.sumcheck_layer_raw; sum_limbs: the transport of the sum over ranks (None: the
@@ -210,18 +214,16 @@ class ResidentGates:
         zl = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
         wl = np.ascontiguousarray(w_limbs, dtype=np.uint64)
         hook, errors = make_allreduce_hook(sum_limbs) if sum_limbs is not None else (None, [])
-        rc = N.lib().gkr_sumcheck_layer_device(self._ctx._h, ctypes.c_int(self.k_i), ctypes.c_int(k_next), ctypes.c_uint64(self.first),
-                                               ctypes.c_uint64(self.count), self._d[0], self._d[1], self._d[2], _ptr(zl), _ptr(wl),
-                                               hook, None, _ptr(C), _ptr(L), _ptr(R))
+        rc = N.lib().gkr_resident_layer_sumcheck(self._ctx._h, self._layer(k_next), _ptr(zl), _ptr(wl), hook, None, _ptr(C), _ptr(L), _ptr(R))
         if errors:
             raise errors[0]
         self._ctx._check(rc)
         return C, L, R
 
     def close(self):
-        for d in self._d:
-            self._ctx.free(d)
-        self._d = []
+        for h in self._handles.values():
+            N.lib().gkr_resident_layer_free(self._ctx._h, h)
+        self._handles = {}
 
 
 class ThreadedSum:

@@ -204,6 +204,19 @@ int  gkr_sumcheck_layer_device(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate_
                                const void *d_gate_type, const void *d_left, const void *d_right, const gkr_fr *z,
                                const gkr_fr *W, gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs,
                                uint32_t *out_len, gkr_fr *out_r);
+/* A layer's gates -- the whole layer, or one rank's contiguous share gate_first .. gate_first + gate_count -- kept in
+ * device memory across sumchecks, together with the gate lists sorted from them on first use (what gkr_prove keeps per
+ * circuit in its cache, for callers that drive prove_sumcheck_opt themselves: one circuit, many z / W).
+ * gkr_resident_layer_sumcheck is gkr_sumcheck_layer_device on that layer: nothing but z, W and the transcript crosses
+ * PCIe and no sort runs after the first call.  allreduce == NULL needs the whole layer. */
+typedef struct gkr_resident_layer gkr_resident_layer;
+int  gkr_resident_layer_create(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
+                               const uint8_t *gate_type, const uint32_t *left, const uint32_t *right,
+                               gkr_resident_layer **out);
+int  gkr_resident_layer_sumcheck(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const gkr_fr *W,
+                                 gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs, uint32_t *out_len,
+                                 gkr_fr *out_r);
+void gkr_resident_layer_free(gkr_ctx *ctx, gkr_resident_layer *layer);
 /* host only: count field elements <-> count x 8 int64 (32-bit limbs, least significant first); narrow reduces
  * limb sums of up to 2^31 addends mod r */
 int  gkr_fr_widen(const gkr_fr *values, size_t count, int64_t *limbs);
