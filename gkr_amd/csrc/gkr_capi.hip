@@ -1483,14 +1483,14 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             if (cached) {
                 if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
                 if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
-                if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), (2 * span.count + 1) * sizeof(uint32_t)));
+                if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
                 g_offsets = cached->offsets;
                 g_cursor = cached->cursor;
                 g_list = cached->list;
             } else {
                 WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
                 WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
-                WS(ctx, "gates.list", uint32_t, 2 * span.count + 1, g_list);
+                WS(ctx, "gates.list", uint32_t, 2 * gkr::gate_list_words(span.count), g_list);
             }
             HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
             uint32_t* lds_scratch = nullptr;
@@ -1514,7 +1514,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         // U, V, the rounds and the row are all inside the one kernel launched below
     } else if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
-        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_r, e_hi, e_lo, kl, Wc, U, V, lb, s);
+        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, s);
     } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
@@ -1796,7 +1796,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
-                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq, A, M, lb, s);
+                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, s);
                 }
                 gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
                 Tw = Wc;
@@ -1897,7 +1897,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             if (sparse) {
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
-                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, e_hi, e_lo, kl, d_eq,
+                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
                                           A, M, lb, s);
                 }
                 if (shard) {

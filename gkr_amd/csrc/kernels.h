@@ -114,15 +114,18 @@ struct GateSpan {
 // histograms instead of one global atomic per gate and operand
 uint32_t gate_lists_lds_blocks(uint64_t gates, uint32_t k);
 size_t gate_lists_lds_scratch_words(uint64_t gates, uint32_t k);
+// `list`: 2 * gate_list_words(gates) words -- the gate indices of every bucket (left-operand buckets, then right-operand
+// buckets), and after them, entry for entry, what the sums over a bucket need of the gate besides its index: the OTHER
+// operand in the low bits, the gate type in bit 31 (read in list order instead of gathered by gate index)
+inline size_t gate_list_words(uint64_t gates) { return 2 * (size_t)gates + 1; }
 void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
                        uint32_t* lds_scratch, hipStream_t s);
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                    const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
-                    Fr* U, Fr* V, LayerBatch lb, hipStream_t s);
+                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, hipStream_t s);
 void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                      const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
-                      const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s);
+                      const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+                      hipStream_t s);
 // One launch per layer (small layers): the whole layer sumcheck of `batch` proofs as one resident kernel, one block
 // per proof, tables in LDS; rounds are handed to the host and challenges taken back through pinned memory, no
 // launch per round (kernels.hip, k_layer_persistent).

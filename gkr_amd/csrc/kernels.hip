@@ -971,13 +971,17 @@ __global__ void k_gate_count(uint64_t gates, uint32_t k, const uint8_t* __restri
 }
 
 __global__ void k_gate_fill(uint64_t gates, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
-                            const uint32_t* __restrict__ right, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
+                            const uint32_t* __restrict__ right, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list,
+                            uint32_t* __restrict__ meta) {
     const uint32_t n = 1u << k;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t l = left[g], r = right[g];
         if (l >= n || r >= n || gate_type[g] > 1) continue;
-        list[atomicAdd(cursor + l, 1u)] = (uint32_t)g;
-        list[atomicAdd(cursor + n + r, 1u)] = (uint32_t)g;
+        const uint32_t t = (uint32_t)gate_type[g] << 31, pl = atomicAdd(cursor + l, 1u), pr = atomicAdd(cursor + n + r, 1u);
+        list[pl] = (uint32_t)g;
+        meta[pl] = r | t;   // what the sums over this bucket need of the gate besides its index: the other operand, the type
+        list[pr] = (uint32_t)g;
+        meta[pr] = l | t;
     }
 }
 
@@ -1025,7 +1029,7 @@ __global__ void __launch_bounds__(256) k_gate_bucket_bounds(const uint32_t* __re
 __global__ void __launch_bounds__(256) k_gate_fill_lds(uint64_t gates, uint32_t k, uint32_t per_block,
                                                        const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
                                                        const uint32_t* __restrict__ right, const uint32_t* __restrict__ starts,
-                                                       uint32_t* __restrict__ list) {
+                                                       uint32_t* __restrict__ list, uint32_t* __restrict__ meta) {
     extern __shared__ uint32_t s_cur[];
     const uint32_t n = 1u << k, nb2 = 2u * n;
     for (uint32_t i = threadIdx.x; i < nb2; i += blockDim.x) s_cur[i] = starts[(size_t)i * gridDim.x + blockIdx.x];
@@ -1034,8 +1038,11 @@ __global__ void __launch_bounds__(256) k_gate_fill_lds(uint64_t gates, uint32_t 
     for (uint64_t g = begin + threadIdx.x; g < end; g += blockDim.x) {
         const uint32_t l = left[g], r = right[g];
         if (l >= n || r >= n || gate_type[g] > 1) continue;
-        list[atomicAdd(&s_cur[l], 1u)] = (uint32_t)g;
-        list[atomicAdd(&s_cur[n + r], 1u)] = (uint32_t)g;
+        const uint32_t t = (uint32_t)gate_type[g] << 31, pl = atomicAdd(&s_cur[l], 1u), pr = atomicAdd(&s_cur[n + r], 1u);
+        list[pl] = (uint32_t)g;
+        meta[pl] = r | t;
+        list[pr] = (uint32_t)g;
+        meta[pr] = l | t;
     }
 }
 
@@ -1046,8 +1053,8 @@ __global__ void __launch_bounds__(256) k_gate_fill_lds(uint64_t gates, uint32_t 
 // list entries index the shard's arrays, and gate_base + entry is the gate's index in the layer, which is what E
 // depends on.
 __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
-                                                 const uint32_t* __restrict__ list, const uint8_t* __restrict__ gate_type,
-                                                 const uint32_t* __restrict__ right, const Fr* __restrict__ e_hi,
+                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
+                                                 const Fr* __restrict__ e_hi,
                                                  const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                  const Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t wstride,
                                                  uint32_t gate_base) {
@@ -1056,18 +1063,25 @@ __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ of
     e_hi += (size_t)blockIdx.y << kh;
     e_lo_mont += (size_t)blockIdx.y << kl;
     W += (size_t)blockIdx.y * wstride;
+    // E[g] is a reduced product (it is an operand); E[g] W[right] only ever enters a sum, so those products are added
+    // as full 512-bit integers and reduced once per thread: 128 + 64 multiply-adds per gate instead of 2 x 128
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    Lazy17 lu = lazy_zero(), lv = lazy_zero();
     for (uint32_t i = offsets[b] + threadIdx.x; i < cursor[b]; i += blockDim.x) {
-        const uint32_t g = list[i], gg = g + gate_base;
+        // (the list entry carries the other operand and the type: gathering right[g] and gate_type[g] by gate index
+        // cost two random DRAM transactions per gate, which -- not the arithmetic -- bounded this kernel)
+        const uint32_t gg = list[i] + gate_base, mt = meta[i];
         const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
-        const Fr ew = mont_mul(e, load_fr(W + right[g]));
-        if (gate_type[g]) {
-            acc_add_fr(acc[0], ew);
+        const Fr w = load_fr(W + (mt & 0x7fffffffu));
+        if (mt >> 31) {
+            lazy_mac_v(lu, e, w);
         } else {
             acc_add_fr(acc[0], e);
-            acc_add_fr(acc[1], ew);
+            lazy_mac_v(lv, e, w);
         }
     }
+    acc_add_fr(acc[0], lazy_reduce(lu));
+    acc_add_fr(acc[1], lazy_reduce(lv));
     block_sum<9, 2>(acc, smem);
     if (threadIdx.x == 0) {
         store_fr(U + (size_t)blockIdx.y * wstride + b, acc_reduce(acc[0]));
@@ -1078,8 +1092,8 @@ __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ of
 // a_u[c] = sum over the add gates with right operand c of E[g] * eq(u, left[g]),  m_u[c] the same over its mult gates
 // (eq in Montgomery form).  grid = (2^k buckets, batch).
 __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
-                                                   const uint32_t* __restrict__ list, const uint8_t* __restrict__ gate_type,
-                                                   const uint32_t* __restrict__ left, const Fr* __restrict__ e_hi,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
+                                                   const Fr* __restrict__ e_hi,
                                                    const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                    const Fr* __restrict__ eq_mont, Fr* __restrict__ A_row, Fr* __restrict__ M_row,
                                                    uint32_t k, uint32_t wstride, uint32_t gate_base) {
@@ -1089,12 +1103,18 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
     e_lo_mont += (size_t)blockIdx.y << kl;
     eq_mont += (size_t)blockIdx.y * wstride;
     Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    Lazy17 la = lazy_zero(), lm = lazy_zero();   // unreduced sums of E[g] eq(u, left[g]), as in k_gate_uv
     for (uint32_t i = offsets[bucket] + threadIdx.x; i < cursor[bucket]; i += blockDim.x) {
-        const uint32_t g = list[i], gg = g + gate_base;
+        const uint32_t gg = list[i] + gate_base, mt = meta[i];
         const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
-        const Fr t = mont_mul(e, load_fr(eq_mont + left[g]));
-        acc_add_fr(acc[gate_type[g] ? 1 : 0], t);
+        const Fr q = load_fr(eq_mont + (mt & 0x7fffffffu));
+        if (mt >> 31)
+            lazy_mac_v(lm, e, q);
+        else
+            lazy_mac_v(la, e, q);
     }
+    acc_add_fr(acc[0], lazy_reduce(la));
+    acc_add_fr(acc[1], lazy_reduce(lm));
     block_sum<9, 2>(acc, smem);
     if (threadIdx.x == 0) {
         store_fr(A_row + (size_t)blockIdx.y * wstride + c, acc_reduce(acc[0]));
@@ -2112,7 +2132,8 @@ void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, con
         hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, starts, (uint32_t*)nullptr, sums, cells);
         hipLaunchKernelGGL(k_gate_bucket_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, starts, (uint32_t)n, lblocks, hist, offsets,
                            cursor);
-        hipLaunchKernelGGL(k_gate_fill_lds, dim3(lblocks), dim3(256), lds, s, gates, k, per_block, gate_type, left, right, starts, list);
+        hipLaunchKernelGGL(k_gate_fill_lds, dim3(lblocks), dim3(256), lds, s, gates, k, per_block, gate_type, left, right, starts, list,
+                           list + gate_list_words(gates));
         return;
     }
     const uint32_t gblocks = blocks_for(gates, 4096);
@@ -2121,23 +2142,23 @@ void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, con
     hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, counts, offsets, block_sums, n);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, sblocks);
     hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, offsets, cursor, block_sums, n);
-    hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, cursor, list);
+    hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, cursor, list, list + gate_list_words(gates));
 }
 
 static uint32_t bucket_threads(uint64_t gates, uint32_t k) { return (gates >> k) > 64u ? 256u : 64u; }   // gates per bucket on average
 
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                    const uint8_t* gate_type, const uint32_t* right, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W,
-                    Fr* U, Fr* V, LayerBatch lb, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list, gate_type,
-                       right, e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
+                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
+                       list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
 }
 
 void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                      const uint8_t* gate_type, const uint32_t* left, const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl,
-                      const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list, gate_type,
-                       left, e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride, (uint32_t)span.base);
+                      const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
+                       list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride,
+                       (uint32_t)span.base);
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
