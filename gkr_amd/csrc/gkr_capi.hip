@@ -1776,7 +1776,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     // Product passes (kernels.hip): both phases as sumchecks of W X + Y over three small tables, up to three rounds per
     // device round trip.  The default for the linear-time form over gate lists; GKR_LAYER_PER_ROUND=1: one round per trip.
     static const bool per_round = getenv("GKR_LAYER_PER_ROUND") != nullptr;
-    if (lin_b && sparse && !shard && k <= 13 && !per_round) {
+    if (lin_b && sparse && k <= 13 && !per_round) {
         gkr::ProdPassRec* prec = nullptr;
         Fr *h_pw = nullptr, *d_ppart = nullptr, *Xc = nullptr, *Yc = nullptr;
         const uint32_t max_blocks = gkr::prod_pass_blocks(1u << (k - 1));
@@ -1797,6 +1797,10 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
                     gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, s);
+                }
+                if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
+                    rc = sum_over_ranks(A, M, wlen, nullptr);
+                    if (rc) break;
                 }
                 gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
                 Tw = Wc;
