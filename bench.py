@@ -364,7 +364,8 @@ def run_layer_split(args, world):
     ctx.profile(1)
     elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
     ctx.profile(False)
-    names = ["gate_lists", "gate_uv", "gate_rows", "predicate_sorted", "layer_uv", "layer_collapse", "layer_uv_round", "layer_c_round"]
+    names = ["gate_lists", "gate_uv", "gate_rows", "predicate_sorted", "layer_uv", "layer_collapse", "layer_prod_pass", "layer_uv_round",
+             "layer_c_round"]
     prof = {n_: ctx.profile_get(n_) for n_ in names}
     if world.rank == 0:
         C, L, R = result[0]
@@ -381,12 +382,13 @@ def run_layer_split(args, world):
             "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: one GKR layer, k_i = %d, k = %d, gates split over the ranks, two "
                                    "sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" % (k_i, k),
-                       "gates_per_rank": cnt, "gates": "resident in HBM before the timed region (gkr_sumcheck_layer_device)"},
+                       "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z and W per sumcheck)"},
             "matches_golden_digest": None if want is None else digest == want, "transcript_sha256": digest,
             "roofline": {"bound": "hbm", "kernel": " + ".join(passes) + " (this rank's passes over its gates / the predicate tables)",
                          "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9 if gate_ms else None, "peak": PEAK_GBPS, "unit": "GB/s",
                          "frac": gate_bytes / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None, "traffic": None,
-                         "note": "gather / atomic bound, not a streaming kernel"},
+                         "note": "the gate passes are bound by the 254-bit multiplier (v_mad_u64_u32: 128 + 64 multiply-adds per gate), "
+                                 "not by memory: frac is reported for the contract, it is not their roofline"},
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / args.steps for n_ in names},
             "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
         if want is not None and digest != want:

@@ -1513,7 +1513,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
     if (persistent) {
         // U, V, the rounds and the row are all inside the one kernel launched below
     } else if (sparse) {
-        Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+        Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
         gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, s);
     } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
@@ -1795,7 +1795,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
                 gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
                 {
-                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
                     gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, s);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
@@ -1900,7 +1900,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
             if (sparse) {
                 {
-                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 1.0 + 4.0 + 3 * 32.0) * batch);
+                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
                     gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
                                           A, M, lb, s);
                 }

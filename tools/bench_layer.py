@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--transcript", choices=["host", "device"], default="host")
-    ap.add_argument("--resident", action="store_true", help="gate arrays uploaded once, before the timed calls (gkr_sumcheck_layer_device)")
+    ap.add_argument("--resident", action="store_true", help="gate arrays uploaded and sorted once, before the timed calls (gkr_resident_layer_*)")
     args = ap.parse_args()
     from gkr_amd import Context, multi_hash, synth
     from gkr_amd.field import MODULUS as P, from_limbs
