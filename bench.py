@@ -194,7 +194,7 @@ def run_mle(args, world):
         first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
         if first["total_ms"] > 0:
             line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
-        for rel in ("r02/l_pmc_traffic.json", "r02/d_pmc_traffic.json", "r01/d_pmc_traffic.json"):   # PMC passes are separate runs, never part of this run
+        for rel in ("r02/m_pmc_traffic.json", "r02/l_pmc_traffic.json", "r02/d_pmc_traffic.json", "r01/d_pmc_traffic.json"):   # PMC passes are separate runs, never part of this run
             traffic_file = os.path.join(REPO, "profiles", rel)
             if os.path.exists(traffic_file) and dom_name == "mle_multifold":
                 try:

@@ -19,7 +19,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_layer -- pytho
 cp $(ls /tmp/prof_layer/*/*kernel_stats.csv | head -1) $R/$OUT/kernel_stats_mode_layer_split.csv
 cd $R
 python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024 20 > $OUT/pmc_traffic.json
-cat $OUT/gpu_tests.txt
+PROBE_REPS=60 PROBE_THREADS=14,12 python tools/proof_many_probe.py 64 > $OUT/proof_many_probe_64.txt 2>/dev/null
+PROBE_REPS=60 PROBE_THREADS=14 python tools/proof_many_probe.py 3 > $OUT/proof_many_probe_3.txt 2>/dev/null
+python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split.json 2>/dev/null
+python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
+LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
+cat $OUT/gpu_tests.txt $OUT/smoke.txt
 head -c 1500 $OUT/bench_default.json
 head -12 $OUT/kernel_stats.csv
 python -c "
