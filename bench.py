@@ -99,21 +99,52 @@ class World:
             self.dist.destroy_process_group()
 
 
+def cgroup_cpu_stat():
+    """nr_throttled / throttled_usec of this container's CPU controller ({} where there is none): spinning on more
+    threads than the quota allows gets the whole process stopped for the rest of a 100 ms period."""
+    out = {}
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                k, v = line.split()
+                out[k] = int(v)
+            break
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+LAST_THROTTLE = {}
+
+
 def timed_steps(world, ctx, step, warmup, steps):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    import gc
     for _ in range(warmup):
         step()
     if ctx is not None:
         ctx.profile_reset()
     world.barrier(ctx)
     each = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        t = time.perf_counter()
-        step()
-        each.append(time.perf_counter() - t)
-    world.barrier(ctx)
-    return world.max_over_ranks(time.perf_counter() - t0), each
+    before = cgroup_cpu_stat()
+    gc.collect()
+    gc.disable()      # a collection of the interpreter inside a 12 ms step is not the prover's time
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t = time.perf_counter()
+            step()
+            each.append(time.perf_counter() - t)
+        world.barrier(ctx)
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    after = cgroup_cpu_stat()
+    LAST_THROTTLE.clear()
+    LAST_THROTTLE.update({"throttled_periods": after.get("nr_throttled", 0) - before.get("nr_throttled", 0),
+                          "throttled_ms": (after.get("throttled_usec", after.get("throttled_time", 0)) -
+                                           before.get("throttled_usec", before.get("throttled_time", 0))) / 1e3})
+    return world.max_over_ranks(elapsed), each
 
 
 # ------------------------------------------------------------------------------------------------ mode: mle
@@ -163,7 +194,7 @@ def run_mle(args, world):
             "sumchecks_per_sec": batch * args.steps * world.size / elapsed,
             "step_ms_each": [round(x * 1e3, 3) for x in each],
             "host_threads": {"usable_cpus": usable_cpus(), "GKR_HOST_THREADS": os.environ.get("GKR_HOST_THREADS"),
-                             "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE")},
+                             "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE"), "cgroup_throttling_in_timed_steps": dict(LAST_THROTTLE)},
             "roofline": {
                 "bound": "hbm", "kernel": "k_mle_multifold_mfma<5> (the 2^n -> 2^(n-5) fold pass)" if dom_name == "mle_multifold" else "k_" + dom_name,
                 "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS,
