@@ -2976,12 +2976,6 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             hW[e] = hW_big[e].data();
         }
     }
-    std::vector<std::vector<F>> hWm(L + 1);   // (A/B switch GKR_LINE_ON_HOST: the middle layers too)
-    if (getenv("GKR_LINE_ON_HOST"))
-        for (uint32_t i = 1; i <= L; ++i) {
-            hWm[i].resize((size_t)batch << c->k[i]);
-            HIP_TRY(ctx, hipMemcpyAsync(hWm[i].data(), dW[i], sizeof(Fr) * hWm[i].size(), hipMemcpyDeviceToHost, s));
-        }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
     const auto tpb0 = std::chrono::steady_clock::now();
@@ -3035,8 +3029,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         if (rc) return rc;
         const auto tl1 = std::chrono::steady_clock::now();
         std::vector<gkr_fr> z_next((size_t)batch * k);
-        static const bool line_on_host = getenv("GKR_LINE_ON_HOST") != nullptr;   // A/B: q on the host's threads, as before
-        if (!line_on_host) {
+        {
             gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
             for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
             Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
@@ -3047,13 +3040,6 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             const gkr_fr* sr = srp[b];
             const gkr_fr* b_star = sr;
             const gkr_fr* c_star = sr + k;
-            if (line_on_host) {
-                std::vector<F> vals((size_t)1 << k);
-                memcpy(vals.data(), &hWm[i + 1][(size_t)b << k], vals.size() * sizeof(F));
-                std::vector<F> co(vals);
-                mobius_msb(co, k);
-                line_restriction(vals, co, k, b_star, c_star, outs[b].q + q_off, &outs[b].q_len[i]);
-            }
             // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector and key as the
             // sumcheck's last challenge, so it is that challenge
             const gkr_fr r_star = sr[2 * k - 1];
@@ -3093,7 +3079,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         q_off += (size_t)k + 1;
         z_off += (size_t)k_i;
     }
-    if (!getenv("GKR_LINE_ON_HOST")) {
+    {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
         const F* hq = reinterpret_cast<const F*>(d_q);
