@@ -67,6 +67,42 @@ def test_gate_sharded_bad_gate_fails_every_rank():
                                                   [rng.randrange(P) for _ in range(16)], 4)
 
 
+def _decode(C, L, R, k):
+    from gkr_amd.field import from_limbs
+    proof = [from_limbs(C[j])[3 - int(L[j]):] for j in range(2 * k)]
+    return proof, from_limbs(R)
+
+
+def test_resident_layer_many_sumchecks_and_bad_gates(ctx):
+    """gkr_resident_layer_*: the gates and their sorted lists stay on the device; several (z, W) on one layer -- widths
+    with passes of one and of several blocks per proof -- equal the oracle, a second next-layer width gets its own lists,
+    a gate out of range fails the first sumcheck (and the one after it) with GKR_ERR_INVALID."""
+    from gkr_amd import GkrError
+    from gkr_amd.field import as_limbs
+    rng = random.Random(1700)
+    for k_i, k in ((9, 5), (12, 9), (3, 1), (0, 2)):
+        lay = _layer(rng, k_i, k)
+        gates = parallel.ResidentGates(ctx, k_i, 0, *lay.arrays())
+        try:
+            for trial in range(3):
+                z = [rng.randrange(P) for _ in range(k_i)]
+                w = [rng.randrange(P) for _ in range(1 << k)] if trial != 1 else [(i >> (k - 1)) + 1 for i in range(1 << k)]
+                C, L, R = gates.sumcheck_raw(k, as_limbs(z) if k_i else np.zeros((0, 4), dtype=np.uint64), as_limbs(w))
+                assert _decode(C, L, R, k) == cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w), (k_i, k, trial)
+        finally:
+            gates.close()
+    lay = _layer(rng, 8, 4)
+    lay.right[17] = 16
+    gates = parallel.ResidentGates(ctx, 8, 0, *lay.arrays())
+    try:
+        z, w = [rng.randrange(P) for _ in range(8)], [rng.randrange(P) for _ in range(16)]
+        for _ in range(2):
+            with pytest.raises(GkrError):
+                gates.sumcheck_raw(4, as_limbs(z), as_limbs(w))
+    finally:
+        gates.close()
+
+
 def test_layer_sumcheck_logical_ranks_wide(ctx):
     rng = random.Random(77)
     k_i, k = 12, 6
