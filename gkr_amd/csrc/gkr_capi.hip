@@ -346,7 +346,7 @@ struct gkr_ctx {
     std::vector<std::unique_ptr<PreparedCircuit>> circuits;   // most recently used last; bounded
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
-    hipStream_t late = nullptr;                // high-priority stream for a group's small late passes (lazy), see late_stream()
+    hipStream_t late = nullptr;                // separate stream for a group's small late passes (lazy), see late_stream()
     std::vector<hipEvent_t> aux_events;        // one per group of a batch: "the side kernel of this group is done"
     Fr* d_cts = nullptr;
     int transcript = GKR_TRANSCRIPT_HOST;
@@ -413,7 +413,7 @@ struct gkr_ctx {
     }
     // The passes of one group are ordered by the host (a pass is launched after the previous one's record has
     // landed), not by the stream.  Its LATE passes -- tables of a few thousand entries, latency-bound round trips --
-    // go to their own high-priority stream: on the main stream they would queue behind the other groups' multi-GiB
+    // go to their own stream (normal priority): on the main stream they would queue behind the other groups' multi-GiB
     // streaming passes launched earlier, and all groups' tails would pile up at the end of the call (measured: 1.9 of
     // 13.1 ms per 1024 sumchecks).
     hipError_t late_stream(hipStream_t* out) {
