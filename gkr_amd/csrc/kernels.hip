@@ -737,6 +737,65 @@ __global__ void __launch_bounds__(256) k_line_restriction(const Fr* __restrict__
     if (tid == 0) out_len[blockIdx.x] = s_maxdeg + 1u;
 }
 
+// The same for wide layers (k > 9), where one block per proof would run the 2^k (k + 1) products of a step on 256
+// threads: the Moebius part and the set-up in one block (subtractions only), then one launch per variable over
+// (blocks, batch), then the read-out.  Same buffers, same results.
+__global__ void __launch_bounds__(256) k_line_init(const Fr* __restrict__ W, uint32_t k, Fr* __restrict__ scratch, uint32_t* __restrict__ out_len) {
+    __shared__ uint32_t s_maxdeg;
+    const uint32_t n = 1u << k, tid = threadIdx.x;
+    const Fr* w = W + ((size_t)blockIdx.x << k);
+    Fr* buf0 = scratch + (size_t)blockIdx.x * 3u * n;
+    Fr* mono = buf0 + 2u * n;
+    if (tid == 0) s_maxdeg = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const Fr v = load_fr(w + i);
+        store_fr(buf0 + i, v);
+        store_fr(mono + i, v);
+    }
+    __syncthreads();
+    for (uint32_t bit = n >> 1; bit; bit >>= 1) {
+        for (uint32_t i = tid; i < n; i += blockDim.x)
+            if (i & bit) store_fr(mono + i, fr_sub(load_fr(mono + i), load_fr(mono + (i ^ bit))));
+        __syncthreads();
+    }
+    uint32_t deg = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x)
+        if (!fr_is_zero(load_fr(mono + i))) deg = max(deg, (uint32_t)__popc(i));
+    if (deg) atomicMax(&s_maxdeg, deg);
+    __syncthreads();
+    if (tid == 0) out_len[blockIdx.x] = s_maxdeg + 1u;
+}
+
+// variable j of every proof: grid = (blocks, batch)
+__global__ void __launch_bounds__(256) k_line_step(uint32_t k, uint32_t j, const Fr* __restrict__ bc, Fr* __restrict__ scratch) {
+    const uint32_t n = 1u << k, h = n >> (j + 1u);
+    const Fr* line = bc + (size_t)blockIdx.y * 2u * k;
+    Fr* base = scratch + (size_t)blockIdx.y * 3u * n;
+    const Fr* src = base + ((j & 1u) ? n : 0u);
+    Fr* dst = base + ((j & 1u) ? 0u : n);
+    const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
+    const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+    const uint32_t in_len = j + 1u, out_len_j = j + 2u;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < h * out_len_j; item += gridDim.x * blockDim.x) {
+        const uint32_t i = item / out_len_j, m = item - i * out_len_j;
+        const Fr* lo = src + (size_t)i * in_len;
+        const Fr* hi = src + (size_t)(i + h) * in_len;
+        Fr v = fr_zero();
+        if (m < in_len) {
+            const Fr l = load_fr(lo + m);
+            v = fr_add(l, mont_mul(fr_sub(load_fr(hi + m), l), cst));
+        }
+        if (m > 0) v = fr_add(v, mont_mul(fr_sub(load_fr(hi + m - 1), load_fr(lo + m - 1)), grad));
+        store_fr(dst + (size_t)i * out_len_j + m, v);
+    }
+}
+
+__global__ void k_line_out(uint32_t k, const Fr* __restrict__ scratch, Fr* __restrict__ out) {
+    const uint32_t n = 1u << k;
+    const Fr* fin = scratch + (size_t)blockIdx.x * 3u * n + ((k & 1u) ? n : 0u);
+    for (uint32_t d = threadIdx.x; d <= k; d += blockDim.x) store_fr(out + (size_t)blockIdx.x * (k + 1u) + (k - d), load_fr(fin + d));
+}
+
 // canonical -> Montgomery copy of a small table (W for the layer kernel)
 __global__ void k_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, uint32_t count) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
@@ -2046,7 +2105,17 @@ void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t
 
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
                              hipStream_t s) {
-    hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), 0, s, W, k, bc, scratch, out, out_len);
+    static const bool stepwise = getenv("GKR_LINE_STEPWISE") != nullptr;   // (test hook: the wide-layer form at every width)
+    if (k <= 9 && !stepwise) {
+        hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), 0, s, W, k, bc, scratch, out, out_len);
+        return;
+    }
+    hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
+        hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 256), batch), dim3(256), 0, s, k, j, bc, scratch);
+    }
+    hipLaunchKernelGGL(k_line_out, dim3(batch), dim3(64), 0, s, k, scratch, out);
 }
 
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s) {

@@ -25,6 +25,7 @@ def ctx(request):
     cores between launches (default) and MiMC7 on the device."""
     c = Context(0)
     c.set_transcript(N.GKR_TRANSCRIPT_HOST if request.param == "host" else N.GKR_TRANSCRIPT_DEVICE)
+    c._mode = request.param
     yield c
     c.close()
 
@@ -242,7 +243,7 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
                                  {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_LAYER_PERSISTENT": "1"},
                                  {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
                                  {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_LAYER_PER_ROUND": "1"},
-                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}],
+                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}, {"GKR_LINE_STEPWISE": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
     """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from
@@ -337,6 +338,28 @@ def test_prove_random_circuits_match_oracle(ctx, seed):
     if full:
         assert terms_as_set(pr.d) == terms_as_set(full["d"])
     assert terms_as_set(pr.input_func) == terms_as_set(dense.monomial_terms(inputs, ks[-1]))
+
+
+def test_prove_wide_layers_match_oracle(ctx):
+    """A circuit with layers of 2^9 .. 2^11 values: the line restriction q in its wide-layer form (one launch per
+    variable), product passes that span several blocks per proof; one proof and a batch of three.  Inputs with few
+    distinct values give W layers whose monomial degree -- the length of q -- is below k."""
+    rng = random.Random(4100)
+    ks = [2, 10, 11, 9]
+    layers = []
+    for i in range(len(ks) - 1):
+        g, n = 1 << ks[i], 1 << ks[i + 1]
+        layers.append(([rng.randint(0, 1) for _ in range(g)], [rng.randrange(n) for _ in range(g)],
+                       [rng.randrange(n) for _ in range(g)]))
+    witnesses = [[rng.randrange(P) for _ in range(1 << ks[-1])], [(i >> 7) + 3 for i in range(1 << ks[-1])],
+                 [rng.randrange(2) for _ in range(1 << ks[-1])]]
+    refs = [cdense.prove(layers, w) for w in witnesses]
+    circuit = _circuit(layers, 1 << ks[-1])
+    device_tx = getattr(ctx, "_mode", None) == "device"          # batched proving needs the host transcript
+    for got in ([ctx.prove(circuit, witnesses[0])],) + (() if device_tx else (ctx.prove_batch(circuit, witnesses),)):
+        for pr, ref in zip(got, refs):
+            assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"]
+            assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"]
 
 
 def test_prove_batch_equals_single_proofs_and_oracle(ctx):
