@@ -772,14 +772,15 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     gkr::SpinPool* pool = ctx->host_pool();
     const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
 
-    // Groups of ~4 GiB of tables, at least four and at most eight (1024 x 2^20: eight groups of 128).  Larger launches
+    // Groups of ~4 GiB of tables, at least four and at most eight (1024 x 2^20: eight groups of 128); sixteen for batches
+    // beyond 96 GiB (4096 x 2^20: 4.64e11 field-ops/s with sixteen groups of 256, 4.48e11 with eight of 512).  Larger launches
     // stream slightly better, smaller groups feed the host's hashing more evenly and leave a shorter exposed tail (the
     // last group's late passes); measured on MI355X, 1024 x 2^20, interleaved repeats on one box, ms per step with
     // 14 / 3 / 2 host threads: 4 groups, all pass 0s queued first 12.3-12.9 / 15.0-16.3 / 18.5-19.0; 8 groups, pass 0
     // queue depth 2 (below) 12.0-12.5 / 13.5-14.0 / 16.5-17.8; 6, 10 and 12 groups in between.
     const double batch_bytes = (double)batch * (double)len * 32.0;
     int want_groups = (int)(batch_bytes / (4.0 * 1024 * 1024 * 1024));
-    want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? 8 : want_groups);
+    want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? (batch_bytes > 96.0 * 1024 * 1024 * 1024 ? kMaxGroups : 8) : want_groups);
     int group_size = batch >= 128 ? (batch + want_groups - 1) / want_groups : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
