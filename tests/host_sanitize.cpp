@@ -218,6 +218,32 @@ static void hashes(std::mt19937_64& rng) {
             gkr::gkr_ifma_multi_hash8(hv, hl, 3, ho);
             for (int k = 0; k < lanes; ++k) CHECK(memcmp(ho[k], &r[(size_t)k * 4], 32) == 0);
         }
+        // the product pass of the layer sumcheck: records of exactly 72 values per lane, every lane count and depth
+        for (int count = 1; count <= 16; ++count) {
+            const int J = 1 + count % 3;
+            std::vector<uint64_t> recs((size_t)count * 72 * 4), w((size_t)count * 32);
+            for (size_t i = 0; i < recs.size(); ++i) recs[i] = (i % 4 == 3) ? rng() >> 4 : rng();
+            std::vector<uint64_t> c2(3 * 16 * 4), lin(3 * 16 * 4), c0(3 * 16 * 4), r(3 * 16 * 4);
+            uint32_t vl[3][16];
+            for (int t = 0; t < 3; ++t)
+                for (int k = 0; k < 16; ++k) vl[t][k] = 2 + (uint32_t)(rng() & 1);
+            gkr::gkr_ifma_prod_pass(recs.data(), 72 * 4, count, J, vl, reinterpret_cast<uint64_t(*)[16][4]>(c2.data()),
+                                    reinterpret_cast<uint64_t(*)[16][4]>(lin.data()), reinterpret_cast<uint64_t(*)[16][4]>(c0.data()),
+                                    reinterpret_cast<uint64_t(*)[16][4]>(r.data()), w.data(), 32);
+            // round 0's challenge against the plain lane hash of the same vector
+            uint64_t hv[8][3][4], ho[8][4];
+            uint32_t hl[8] = {};
+            memset(hv, 0, sizeof hv);
+            const int lanes = count < 8 ? count : 8;
+            for (int k = 0; k < lanes; ++k) {
+                memcpy(hv[k][0], &c2[(size_t)k * 4], 32);
+                memcpy(hv[k][1], &lin[(size_t)k * 4], 32);
+                memcpy(hv[k][2], &c0[(size_t)k * 4], 32);
+                hl[k] = vl[0][k];
+            }
+            gkr::gkr_ifma_multi_hash8(hv, hl, 3, ho);
+            for (int k = 0; k < lanes; ++k) CHECK(memcmp(ho[k], &r[(size_t)k * 4], 32) == 0);
+        }
     } else {
         printf("(no AVX-512 IFMA on this CPU: lane hash skipped)\n");
     }
