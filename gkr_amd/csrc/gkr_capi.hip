@@ -360,6 +360,7 @@ struct gkr_ctx {
     std::unique_ptr<gkr::SpinPool> pool;       // host transcript workers (lazy)
     std::unique_ptr<gkr::SpinPool> solo_pool;  // the empty pool a context uses while it is one of a crew (gkr_prove_many)
     bool crew_member = false;                  // one thread of several proving side by side: no workers of its own
+    int rounds_ahead = 0;                      // sumcheck rounds left in the proof being proven AFTER the current layer (help priority)
     std::unique_ptr<ProveCrew, void (*)(ProveCrew*)> crew{nullptr, nullptr};   // gkr_prove_many's threads and child contexts (lazy)
     std::map<std::string, std::pair<void*, size_t>> ws;        // grow-only device workspaces
     std::map<std::string, std::pair<void*, size_t>> pinned;    // grow-only pinned host buffers
@@ -555,7 +556,8 @@ static bool help_enabled() {
     static const bool on = getenv("GKR_NO_HELP") == nullptr;
     return on;
 }
-static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, bool several) {
+static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, bool several, int priority = 0) {
+    static const bool flat = getenv("GKR_HELP_FLAT") != nullptr;   // A/B: every posted job alike
     auto run = [&] {
         if (pool)
             pool->run_now(work);
@@ -564,7 +566,7 @@ static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, b
             }
     };
     if (several && help_enabled()) {
-        gkr::HelpBoard::Posted posted(work);
+        gkr::HelpBoard::Posted posted(work, flat ? 0 : priority);
         run();
     } else {
         run();
@@ -1852,7 +1854,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     }
                     return true;
                 };
-                run_pieces(pool, &work, batch > chunk);
+                run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
                 jp = J;
                 round0 += J;
                 rem -= J;
@@ -1979,7 +1981,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
                     return true;
                 };
-                run_pieces(pool, &work, batch > chunk);
+                run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round));
             }
             lap(t_hash);
             // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc); the linear-time
@@ -3025,8 +3027,11 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             srp[b] = outs[b].sumcheck_r + row_off;
         }
         const auto tl0 = std::chrono::steady_clock::now();
+        ctx->rounds_ahead = 0;
+        for (uint32_t later = i + 1; later < L; ++later) ctx->rounds_ahead += 2 * (int)c->k[later + 1];
         rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
                              srp.data(), nullptr, &pc->lists[i]);
+        ctx->rounds_ahead = 0;
         if (rc) return rc;
         const auto tl1 = std::chrono::steady_clock::now();
         std::vector<gkr_fr> z_next((size_t)batch * k);

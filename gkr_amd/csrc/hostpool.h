@@ -38,11 +38,14 @@ class HelpBoard {
         static HelpBoard board;
         return board;
     }
+    // priority: how much work its owner still has ahead of it after this job (any unit, e.g. sumcheck rounds left in its
+    // proof): helpers take pieces of the job whose owner is furthest from done -- the critical path of the whole step.
     // -1: no free slot (the owner then simply works alone)
-    int post(const std::function<bool()>* work) {
+    int post(const std::function<bool()>* work, int priority = 0) {
         for (int i = 0; i < kSlots; ++i) {
             const std::function<bool()>* expected = nullptr;
             if (slots_[i].job.compare_exchange_strong(expected, work, std::memory_order_seq_cst)) {
+                slots_[i].priority.store(priority, std::memory_order_relaxed);   // (a helper that still reads the old value only picks differently)
                 posted_.fetch_add(1, std::memory_order_seq_cst);
                 return i;
             }
@@ -59,23 +62,36 @@ class HelpBoard {
     }
     bool help() {
         if (posted_.load(std::memory_order_acquire) == 0) return false;
-        const int start = next_.fetch_add(1, std::memory_order_relaxed);   // helpers spread over the posted jobs
-        for (int n = 0; n < kSlots; ++n) {
-            Slot& sl = slots_[(start + n) % kSlots];
-            if (sl.job.load(std::memory_order_acquire) == nullptr) continue;
+        const int start = next_.fetch_add(1, std::memory_order_relaxed);   // equal priorities: helpers spread over the jobs
+        // posted jobs, highest priority first (at most kSlots rounds: a job whose pieces are all claimed returns false)
+        uint64_t tried = 0;
+        for (;;) {
+            int best = -1, best_prio = 0;
+            for (int n = 0; n < kSlots; ++n) {
+                const int i = (start + n) % kSlots;
+                if ((tried >> i) & 1u) continue;
+                if (slots_[i].job.load(std::memory_order_acquire) == nullptr) continue;
+                const int pr = slots_[i].priority.load(std::memory_order_relaxed);
+                if (best < 0 || pr > best_prio) {
+                    best = i;
+                    best_prio = pr;
+                }
+            }
+            if (best < 0) return false;
+            tried |= (uint64_t)1 << best;
+            Slot& sl = slots_[best];
             sl.inside.fetch_add(1, std::memory_order_seq_cst);
             const std::function<bool()>* job = sl.job.load(std::memory_order_seq_cst);
             const bool did = job && (*job)();
             sl.inside.fetch_sub(1, std::memory_order_seq_cst);
             if (did) return true;
         }
-        return false;
     }
 
     // Scope guard: the job is on the board for the lifetime of the guard
     class Posted {
        public:
-        explicit Posted(const std::function<bool()>* work) : slot_(HelpBoard::instance().post(work)) {}
+        explicit Posted(const std::function<bool()>* work, int priority = 0) : slot_(HelpBoard::instance().post(work, priority)) {}
         ~Posted() { HelpBoard::instance().retire(slot_); }
         Posted(const Posted&) = delete;
         Posted& operator=(const Posted&) = delete;
@@ -85,10 +101,11 @@ class HelpBoard {
     };
 
    private:
-    static constexpr int kSlots = 64;
+    static constexpr int kSlots = 64;   // (the `tried` mask of help() is one 64-bit word)
     struct alignas(64) Slot {
         std::atomic<const std::function<bool()>*> job{nullptr};
         std::atomic<int> inside{0};
+        std::atomic<int> priority{0};
     };
     Slot slots_[kSlots];
     std::atomic<int> posted_{0};
