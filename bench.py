@@ -418,8 +418,8 @@ def run_layer_split(args, world):
             "roofline": {"bound": "hbm", "kernel": " + ".join(passes) + " (this rank's passes over its gates / the predicate tables)",
                          "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9 if gate_ms else None, "peak": PEAK_GBPS, "unit": "GB/s",
                          "frac": gate_bytes / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None, "traffic": None,
-                         "note": "the gate passes are bound by the 254-bit multiplier (v_mad_u64_u32: 128 + 64 multiply-adds per gate), "
-                                 "not by memory: frac is reported for the contract, it is not their roofline"},
+                         "note": "the gate passes are bound by 254-bit arithmetic (1.5 product-equivalents per gate at three waves "
+                                 "per SIMD), not by memory: frac is reported for the contract, it is not their roofline"},
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / args.steps for n_ in names},
             "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
         if want is not None and digest != want:

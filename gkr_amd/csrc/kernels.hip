@@ -10,7 +10,7 @@
 // 254-bit modular integer arithmetic on v_mad_u64_u32 carry chains (fr32.h); the one exception is the multi-round
 // fold pass, whose fixed-weight products run as int8 digit products on the matrix cores (mfma_fold.h) because the
 // VALU form was instruction-issue bound.  The streaming passes are priced against HBM bandwidth; the gate passes of the
-// layer sumcheck are bound by the multiplier itself, the small kernels of a proof's rounds by latency.
+// layer sumcheck are bound by the 254-bit arithmetic, the small kernels of a proof's rounds by latency.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
