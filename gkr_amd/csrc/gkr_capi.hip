@@ -3183,10 +3183,14 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     if ((!items && n_items) || max_concurrent < 0 || n_items > (size_t)1 << 20) return ctx->fail(GKR_ERR_INVALID, "null item list or negative thread count");
     if (n_items == 0) return GKR_OK;
     if (ctx->crew_member) return ctx->fail(GKR_ERR_INVALID, "gkr_prove_many from inside a crew");
-    int want = max_concurrent ? max_concurrent : (usable_cpus() > 3 ? usable_cpus() - 2 : 1);
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) {   // ranks of one node share its CPUs
-        const int ranks = atoi(e);
-        if (!max_concurrent && ranks > 1) want = want / ranks > 1 ? want / ranks : 1;
+    int want = max_concurrent;
+    if (!want) {
+        int share = usable_cpus();
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) {   // ranks of one node share its CPUs
+            const int ranks = atoi(e);
+            if (ranks > 1) share = share / ranks > 1 ? share / ranks : 1;
+        }
+        want = share >= 6 ? share - 2 : (share >= 3 ? share - 1 : share);   // two (one, none) left to the runtime's own threads
     }
     // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
     if (!max_concurrent && (size_t)want > n_items) want = (int)n_items;
