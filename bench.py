@@ -68,9 +68,14 @@ class World:
         self.backend = os.environ.get("GKR_BENCH_BACKEND", "nccl")
         if "GKR_BENCH_DEVICE" in os.environ:
             self.local_rank = int(os.environ["GKR_BENCH_DEVICE"])
-        if self.size > 1:
+        # GKR_BENCH_FORCE_GROUP=1: a process group (and with it RCCL) also for one rank, so that the exchange path of
+        # --mode layer-split runs as it does on N GPUs (one MI355X is all a builder's box has)
+        self.grouped = self.size > 1 or os.environ.get("GKR_BENCH_FORCE_GROUP") == "1"
+        if self.grouped:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             if self.backend == "nccl":   # the process group comes first, the first GPU call after it
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
                 torch.cuda.set_device(self.local_rank)
@@ -81,7 +86,7 @@ class World:
         self.device = "cuda" if self.backend == "nccl" else "cpu"
 
     def barrier(self, ctx=None):
-        if self.size > 1:
+        if self.grouped:
             self.dist.barrier()
         self.torch.cuda.synchronize()
         if ctx is not None:
@@ -95,7 +100,7 @@ class World:
         return float(t.item())
 
     def close(self):
-        if self.size > 1:
+        if self.grouped:
             self.dist.destroy_process_group()
 
 
@@ -147,18 +152,102 @@ def timed_steps(world, ctx, step, warmup, steps):
     return world.max_over_ranks(elapsed), each
 
 
+# ------------------------------------------------------------------------------------------------ what was timed is checked
+
+def _sha(*arrays):
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def verify_mle_outputs(ctx, tables, n, batch, out, rank, sample=32, evaluations=2):
+    """Checks the (C, L, R) arrays the LAST TIMED step produced, without the oracle:
+      * against the committed digests of the reference-semantics transcripts (tests/golden/*.json, produced offline by
+        tests/golden/make_config_hashes.py): the whole batch in one digest per rank, every table of rank 0 one by one,
+        and rank 0's table 0 against config_hashes.json;
+      * the verifier's relations (python/sumcheck.py:55-70) on `sample` sumchecks spread over the whole batch (all
+        scheduling groups, first and last table included): g_1(0) + g_1(1) = the table's sum (recomputed here from the
+        downloaded table), g_j(0) + g_j(1) = g_{j-1}(r_{j-1}), r_j = MiMC7(g_j); and for `evaluations` of them the
+        final check g_n(r_n) = T(r_1 .. r_n), the table folded on the host in Python integers.
+    -> (dict for the JSON line, ok)"""
+    import numpy as np
+    from gkr_amd import multi_hash, synth
+    from gkr_amd.field import MODULUS as P, from_limbs
+    C, L, R = out
+    count = 1 << n
+    res = {"checked": "the outputs of the last timed step"}
+    ok = True
+    gold = synth.bench_batch_digests()
+    if gold and gold.get("n") == n:
+        if gold.get("batch") == batch and str(rank) in gold["whole_batch_by_rank"]:
+            res["whole_batch_digest"] = _sha(C, L, R) == gold["whole_batch_by_rank"][str(rank)]
+            res["sumchecks_in_digest"] = batch
+            ok &= res["whole_batch_digest"]
+        if rank == 0 and batch <= len(gold["rank0_tables"]):
+            bad = [b for b in range(batch) if _sha(C[b], L[b], R[b])[:16] != gold["rank0_tables"][b]]
+            res["tables_matching_their_digest"] = batch - len(bad)
+            if bad:
+                res["first_mismatching_tables"] = bad[:8]
+                ok = False
+    if rank == 0:
+        want = synth.golden_digest("mle", "n=%d,seed=%d" % (n, synth.bench_table_seed(0, 0)))
+        if want is not None:
+            res["table0_golden_digest"] = _sha(C[0], L[0], R[0]) == want
+            ok &= res["table0_golden_digest"]
+    # verifier relations
+    picks = sorted({int(round(i * (batch - 1) / max(1, sample - 1))) for i in range(min(sample, batch))})
+    evals = set(picks[:1] + picks[-1:]) if evaluations >= 2 else set(picks[:evaluations])
+    failures = []
+    for b in picks:
+        t = ctx.download(ctypes.c_void_p(tables.value + b * count * 32), (count, 4))
+        cols = t.view(np.uint32).reshape(count, 8).sum(axis=0, dtype=np.uint64)
+        claim = sum(int(cols[j]) << (32 * j) for j in range(8)) % P
+        rs = from_limbs(R[b])
+        for j in range(n):
+            ln = int(L[b, j])
+            g = from_limbs(C[b, j])[2 - ln:]        # highest degree first
+            at0 = g[-1]
+            at1 = sum(g) % P
+            if (at0 + at1) % P != claim:
+                failures.append((b, j, "sum"))
+                break
+            if multi_hash(g) != rs[j]:
+                failures.append((b, j, "challenge"))
+                break
+            claim = 0
+            for c in g:                                  # Horner at r_j
+                claim = (claim * rs[j] + c) % P
+        else:
+            if b in evals:
+                vals = np.array(from_limbs(t), dtype=object)
+                for j in range(n):
+                    h = len(vals) // 2
+                    vals = (vals[:h] + rs[j] * (vals[h:] - vals[:h])) % P
+                if int(vals[0]) != claim:
+                    failures.append((b, n, "final evaluation"))
+    res["verifier_relations"] = {"sumchecks": len(picks), "tables": picks, "with_final_evaluation": sorted(evals), "failures": failures,
+                                 "ok": not failures}
+    ok &= not failures
+    res["ok"] = bool(ok)
+    return res, bool(ok)
+
+
 # ------------------------------------------------------------------------------------------------ mode: mle
 
 def run_mle(args, world):
-    from gkr_amd import Context
+    from gkr_amd import Context, synth
     n, batch = args.n, args.batch
     count = 1 << n
     ctx = Context(world.local_rank)
     ctx.set_transcript(1 if args.transcript == "host" else 0)
     tables = ctx.alloc(batch * count * 32)
     for b in range(batch):
-        ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, 0xC0FFEE + 2 + 1000 * world.rank + b)
+        ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, synth.bench_table_seed(world.rank, b))
     ctx.synchronize()
+    ceilings = ctx.ceilings() if (world.rank == 0 and not args.no_extras) else None   # the box's own copy / product rates (~0.1 s)
     outputs = [None]   # the proof arrays of the previous step are reused (no fresh pages inside the timed call)
 
     def step():
@@ -169,6 +258,8 @@ def run_mle(args, world):
     ctx.profile(False)
     ops_per_sumcheck = 5 * (count - 1)
     value = ops_per_sumcheck * batch * args.steps * world.size / elapsed
+    verified, verified_ok = ({"skipped": "--no-verify"}, True) if args.no_verify else verify_mle_outputs(ctx, tables, n, batch, outputs[0], world.rank)
+    ranks_failed = world.max_over_ranks(0.0 if verified_ok else 1.0)
 
     names = ["mle_multifold", "mle_multifold_late", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",   # multi-round passes (default)
              "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]  # per-round paths
@@ -199,6 +290,10 @@ def run_mle(args, world):
                 "bound": "hbm", "kernel": "k_mle_multifold_mfma<5> (the 2^n -> 2^(n-5) fold pass)" if dom_name == "mle_multifold" else "k_" + dom_name,
                 "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS,
                 "traffic": None, "launches": dom["launches"],
+                "copy_GBps_measured": ceilings["copy_GBps"] if ceilings else None,
+                "read_GBps_measured": ceilings["read_GBps"] if ceilings else None,
+                "frac_of_copy": achieved / ceilings["copy_GBps"] if ceilings else None,
+                "alu_products_per_sec_measured": ceilings["modmul_per_sec"] if ceilings else None,
                 "avg_launch_us": (dom["total_ms"] * 1e3 / dom["launches"]) if dom["launches"] else None,
                 "algorithmic_bytes_per_launch": (dom["bytes"] / dom["launches"]) if dom["launches"] else None,
                 "bytes_rule": "fold pass binding J variables: (2^J + 1) * 32 B per output entry (reads 2^J source entries, "
@@ -206,6 +301,7 @@ def run_mle(args, world):
                               "fold passes run on their own stream beside other groups' streaming passes and are booked "
                               "separately (kernel_ms.mle_multifold_late): their elapsed time is not their own cost",
             },
+            "verified": dict(verified, all_ranks_ok=ranks_failed == 0.0),
             "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
             # every byte the schedule moves (pass 0 reads the tables once, every fold pass reads its source and writes
             # its output: ~66 * 2^n per sumcheck with five rounds per pass) over WALL time: the whole step as bandwidth
@@ -268,14 +364,24 @@ def run_mle(args, world):
             dt = (time.perf_counter() - t) / 5
             extras["n16"] = {"workload": "BASELINE configs[1]: 2^16 points per table, batch %d" % b16,
                              "value": 5 * ((1 << 16) - 1) * b16 / dt, "unit": "field-ops/s", "ms_per_step": dt * 1e3}
+            gold = synth.bench_batch_digests()
+            if gold and world.rank == 0 and n == gold.get("n") and b16 == gold.get("n16_tables") and not args.no_verify:
+                extras["n16"]["whole_batch_digest"] = _sha(*out16[0]) == gold["n16_whole_batch_rank0"]
+                verified_ok &= extras["n16"]["whole_batch_digest"]
     ctx.free(tables)
     ctx.close()
     # second half of the metric: every rank proves its own share of the inputs; MAX over ranks
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
+    layer24 = None
+    if not args.no_extras and args.layer_k_i > 0:
+        layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
     if world.rank == 0:
         line.update(extras)
+        if layer24:
+            line["layer24"] = layer24
+            verified_ok &= layer24["matches_golden_digest"] is not False
         if proofs:
             line["aggregated_proofs"] = proofs
         if world.size == 1 and not args.no_cpu_baseline:
@@ -283,6 +389,8 @@ def run_mle(args, world):
             line["cpu_ref_algo"] = cpu_ref_algo(args.ref_algo_seconds)
             line["cpu_pipeline"] = cpu_pipeline()
         print(json.dumps(line), flush=True)
+    if not verified_ok or ranks_failed:
+        raise SystemExit("WRONG RESULTS: the outputs of the timed steps failed their check (see \"verified\" / \"layer24\" / \"n16\")")
 
 
 def aggregated_proofs(world, n_inputs):
@@ -377,55 +485,79 @@ def run_proofs(args, world):
 
 # ------------------------------------------------------------------------------------------------ mode: layer-split
 
-def run_layer_split(args, world):
+def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
+    """BASELINE configs[4]: ONE GKR layer sumcheck (prove_sumcheck_opt, sumcheck.rs:36-156) with 2^k_i random gates
+    over a 2^k-entry next layer, gates and their sorted lists resident in HBM before the timed region, a step = one
+    sumcheck (new z, W).  split: the gates are divided over the ranks (two sum-over-ranks exchanges per sumcheck);
+    otherwise every rank proves the whole layer on its own (N = 1 work, MAX over ranks).  -> the dict of the JSON
+    line (on rank 0; None elsewhere).  The transcript is compared with the committed digest of the reference-semantics
+    transcript (tests/golden/config_hashes.json)."""
     from gkr_amd import Context, parallel, synth
-    k_i, k = args.k_i, args.k
     lay, z, W = synth.config5_layer(k_i, k)
     gt, l, r = lay.arrays()
-    first, cnt = parallel.gate_range(k_i, world.rank, world.size)
+    first, cnt = parallel.gate_range(k_i, world.rank, world.size) if split else (0, 1 << k_i)
     ctx = Context(world.local_rank)
-    # this rank's gates are resident in HBM before the timed region (the contract's "inputs already resident")
     gates = parallel.ResidentGates(ctx, k_i, first, gt[first:first + cnt], l[first:first + cnt], r[first:first + cnt])
-    coll = parallel.TorchCollective() if world.size > 1 else None
-    sum_limbs = coll.sum_limbs if coll else None   # one rank: the whole layer, no exchange
+    coll = parallel.TorchCollective() if (split and world.grouped) else None
+    exchange = coll.exchange() if coll else None   # one rank: the whole layer, no exchange
     result = [None]
 
     def step():
-        result[0] = gates.sumcheck_raw(k, z, W, sum_limbs)
+        result[0] = gates.sumcheck_raw(k, z, W, exchange)
     ctx.profile(1)
-    elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
+    elapsed, each = timed_steps(world, ctx, step, warmup, steps)
     ctx.profile(False)
-    names = ["gate_lists", "gate_uv", "gate_rows", "predicate_sorted", "layer_uv", "layer_collapse", "layer_prod_pass", "layer_uv_round",
-             "layer_c_round"]
+    names = ["gate_lists", "gate_uv", "gate_rows", "gate_combine", "predicate_sorted", "layer_uv", "layer_collapse", "layer_prod_pass",
+             "layer_uv_round", "layer_c_round"]
     prof = {n_: ctx.profile_get(n_) for n_ in names}
+    exch = ctx.profile_get("exchange")
+    own = ceilings or (ctx.ceilings(256 << 20) if world.rank == 0 else None)
+    out = None
     if world.rank == 0:
         C, L, R = result[0]
         digest = synth.transcript_digest(C, L, R)
         want = synth.golden_digest("layer", "k_i=%d,k=%d" % (k_i, k))
         N = 1 << (2 * k)
-        passes = [n_ for n_ in names[:6] if prof[n_]["launches"]]   # the passes over the gates / the dense tables that ran
-        gate_ms = sum(prof[n_]["total_ms"] for n_ in passes) / args.steps
-        gate_bytes = sum(prof[n_]["bytes"] for n_ in passes) / args.steps
-        print(json.dumps({
-            "metric": "BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" % k_i, "value": 25 * (N - 1) * args.steps / elapsed,
-            "unit": "field-ops/s", "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        passes = [n_ for n_ in ("gate_uv", "gate_rows", "gate_combine") if prof[n_]["launches"]]   # the passes over the gates
+        gate_ms = sum(prof[n_]["total_ms"] for n_ in passes) / steps
+        # what a gate pass must do, whatever the schedule: one 254-bit product per gate (eq(z, g) times W[right] resp.
+        # eq(u, left)); everything else a form spends (forming eq(z, g) from its two halves per gate, reductions) is
+        # overhead against this count -- so the fraction compares forms fairly
+        products = 2.0 * cnt
+        rate = products / (gate_ms * 1e-3) if gate_ms else None
+        peak = own["modmul_per_sec"] if own else None
+        out = {
+            "metric": "BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" % k_i, "value": 25 * (N - 1) * steps / elapsed,
+            "unit": "field-ops/s", "n_gpus": world.size if split else 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: one GKR layer, k_i = %d, k = %d, gates split over the ranks, two "
-                                   "sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" % (k_i, k),
+            "config": {"workload": "BASELINE configs[4]: one GKR layer, k_i = %d, k = %d%s" % (
+                           k_i, k, ", gates split over the ranks, two sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" if split else
+                           ", the whole layer on one GPU"),
                        "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z and W per sumcheck)"},
             "matches_golden_digest": None if want is None else digest == want, "transcript_sha256": digest,
-            "roofline": {"bound": "hbm", "kernel": " + ".join(passes) + " (this rank's passes over its gates / the predicate tables)",
-                         "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9 if gate_ms else None, "peak": PEAK_GBPS, "unit": "GB/s",
-                         "frac": gate_bytes / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None, "traffic": None,
-                         "note": "the gate passes are bound by 254-bit arithmetic (1.5 product-equivalents per gate at three waves "
-                                 "per SIMD), not by memory: frac is reported for the contract, it is not their roofline"},
-            "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / args.steps for n_ in names},
-            "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
-        if want is not None and digest != want:
-            raise SystemExit("WRONG TRANSCRIPT")
+            "roofline": {"bound": "alu", "kernel": " + ".join("k_" + p_ for p_ in passes) + " (the two passes over this rank's gates: U, V before the b rounds; the row a_u, m_u before the c rounds)",
+                         "achieved": rate, "peak": peak, "unit": "254-bit modular products/s",
+                         "frac": rate / peak if rate and peak else None, "traffic": None,
+                         "products_per_launch_pair": products, "gate_pass_ms_per_step": gate_ms,
+                         "products_rule": "one product per gate and pass (2 per gate and sumcheck); peak = the chip-wide rate of dependent "
+                                          "Montgomery products measured in this process (gkr_ubench_ceilings, 16 waves per SIMD)",
+                         "hbm_bytes_per_gate_and_pass": 8, "note": "not memory-bound: per gate one 8-byte list entry is streamed from HBM, the eq and W "
+                                          "operands are gathers from L2-resident tables"},
+            "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
+            "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},
+            "step_ms_each": [round(x * 1e3, 3) for x in each]}
     gates.close()
     ctx.close()
+    return out
+
+
+def run_layer_split(args, world):
+    out = layer_leg(world, args.k_i, args.k, args.steps, args.warmup, split=True)
+    if world.rank == 0:
+        print(json.dumps(out), flush=True)
+        if out["matches_golden_digest"] is False:
+            raise SystemExit("WRONG TRANSCRIPT")
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
@@ -524,7 +656,10 @@ def main():
     ap.add_argument("--proofs", type=int, default=64, help="inputs of the demo circuit (configs[3]); 0 = skip in mle mode")
     ap.add_argument("--k-i", type=int, default=24, help="layer-split: log2 gates")
     ap.add_argument("--k", type=int, default=12, help="layer-split: log2 entries of the next layer")
+    ap.add_argument("--layer-k-i", type=int, default=24, help="mle mode: log2 gates of the configs[4] leg on the line (0 = skip)")
+    ap.add_argument("--layer-k", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed outputs (digests + verifier relations)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--ref-algo-seconds", type=float, default=20.0)
     args = ap.parse_args()

@@ -29,13 +29,13 @@ SYMBOLS = [
     "gkr_ctx_set_transcript", "gkr_ctx_set_host_threads", "gkr_host_help_while", "gkr_prove_many", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get", "gkr_ctx_profile_samples",
     "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
     "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_host_prod_pass", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
-    "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_free", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
+    "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_free", "gkr_exchange_limbs", "gkr_resident_layer_sumcheck_dev", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
     "gkr_circom_meta", "gkr_circom_input_json", "gkr_circom_verifier_source", "gkr_circom_inject",
     "gkr_r1cs_parse", "gkr_r1cs_build", "gkr_r1cs_info", "gkr_r1cs_export", "gkr_r1cs_serialize", "gkr_r1cs_free",
     "gkr_wtns_parse", "gkr_wtns_serialize", "gkr_r1cs_compile", "gkr_layered_count", "gkr_layered_circuit",
     "gkr_layered_input_layer", "gkr_layered_input_values", "gkr_layered_free",
     "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
-    "gkr_device_fill_table", "gkr_device_synchronize",
+    "gkr_device_fill_table", "gkr_device_synchronize", "gkr_ubench_ceilings",
     "gkr_layer_session_open", "gkr_layer_session_open_tables", "gkr_layer_session_dep", "gkr_layer_session_rounds",
     "gkr_layer_session_sums", "gkr_layer_session_bind", "gkr_layer_session_tail", "gkr_layer_session_close",
     "gkr_mle_session_open", "gkr_mle_session_sums", "gkr_mle_session_bind", "gkr_mle_session_value",
@@ -61,6 +61,13 @@ class ProofBuf(ctypes.Structure):
 class ProveItem(ctypes.Structure):
     _fields_ = [("circuit", ctypes.c_void_p), ("input_values", ctypes.c_void_p), ("batch", ctypes.c_int),
                 ("require_zero_output", ctypes.c_int), ("outs", ctypes.c_void_p), ("status", ctypes.c_int)]
+
+
+ALLREDUCE_DEV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class ExchangeDev(ctypes.Structure):
+    _fields_ = [("fn", ALLREDUCE_DEV_FN), ("user", ctypes.c_void_p), ("d_limbs", ctypes.c_void_p), ("capacity", ctypes.c_size_t)]
 
 
 class R1csInfo(ctypes.Structure):
@@ -90,6 +97,8 @@ def lib():
         L.gkr_last_error.argtypes = [ctypes.c_void_p]
         L.gkr_resident_layer_free.restype = None
         L.gkr_resident_layer_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.gkr_exchange_limbs.restype = ctypes.c_size_t
+        L.gkr_exchange_limbs.argtypes = [ctypes.c_int]
         L.gkr_host_help_while.restype = ctypes.c_long
         L.gkr_host_help_while.argtypes = [ctypes.c_void_p]
         L.gkr_ctx_destroy.restype = None

@@ -49,25 +49,26 @@ struct PendingEvent {
     double bytes;
 };
 
+// The three lazily built constant tables of the host transcript are reached by up to 64 crew threads at once on the
+// first gkr_prove_many of a process: function-local statics (one thread builds, the others wait; the finished table
+// is published with the guard's release).
 const Fr* host_mimc_constants() {
-    static Fr cts[gkr::kMimcRounds];
-    static bool ready = false;
-    if (!ready) {  // idempotent; first use happens under ctx creation or a host hash call
-        gkr::mimc7_make_constants(cts);
-        ready = true;
-    }
-    return cts;
+    struct Table {
+        Fr cts[gkr::kMimcRounds];
+        Table() { gkr::mimc7_make_constants(cts); }
+    };
+    static const Table t;
+    return t.cts;
 }
 
 // the same 91 constants for the 4 x 64-bit host arithmetic (identical bytes: same Montgomery radix)
 const gkr::h64::F* host_mimc_constants64() {
-    static gkr::h64::F cts[gkr::kMimcRounds];
-    static bool ready = false;
-    if (!ready) {
-        memcpy(cts, host_mimc_constants(), sizeof cts);
-        ready = true;
-    }
-    return cts;
+    struct Table {
+        gkr::h64::F cts[gkr::kMimcRounds];
+        Table() { memcpy(cts, host_mimc_constants(), sizeof cts); }
+    };
+    static const Table t;
+    return t.cts;
 }
 
 // CPUs this process may really use: the affinity mask, capped by the cgroup CPU
@@ -108,21 +109,18 @@ int usable_cpus() {
 
 // true once the eight-lane IFMA hash is initialised (CPU has avx512ifma and GKR_NO_IFMA is unset)
 bool host_ifma_ready() {
-    static int state = -1;
-    if (state < 0) {
-        state = 0;
-        if (!getenv("GKR_NO_IFMA") && gkr::gkr_ifma_available()) {
-            const gkr::h64::F* cts = host_mimc_constants64();
-            static uint64_t canon[gkr::kMimcRounds][4];
-            for (int i = 0; i < gkr::kMimcRounds; ++i) {
-                const gkr::h64::F c = gkr::h64::from_mont(cts[i]);
-                memcpy(canon[i], &c, 32);
-            }
-            gkr::gkr_ifma_init(canon);
-            state = 1;
+    static const bool ready = [] {   // one thread initialises the 52-bit tables, the others wait at the guard
+        if (getenv("GKR_NO_IFMA") || !gkr::gkr_ifma_available()) return false;
+        const gkr::h64::F* cts = host_mimc_constants64();
+        static uint64_t canon[gkr::kMimcRounds][4];
+        for (int i = 0; i < gkr::kMimcRounds; ++i) {
+            const gkr::h64::F c = gkr::h64::from_mont(cts[i]);
+            memcpy(canon[i], &c, 32);
         }
-    }
-    return state == 1;
+        gkr::gkr_ifma_init(canon);
+        return true;
+    }();
+    return ready;
 }
 
 // up to sixteen transcripts on the IFMA code: two interleaved groups of eight fill the FMA pipes (one group is
@@ -465,6 +463,13 @@ struct gkr_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
+    // a step timed on the host clock (an exchange through host memory: not a kernel) under the same profile names
+    void add_host_sample(const char* name, double ms) {
+        ProfileRow& r = prof[name];
+        r.launches += 1;
+        r.total_ms += ms;
+        if (r.samples.size() < kMaxSamples) r.samples.emplace_back((float)ms, 0.0);
+    }
     void drain_events() {
         for (auto& p : pending) {
             (void)hipEventSynchronize(p.stop);
@@ -582,22 +587,28 @@ int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t tic
         hipError_t q = hipStreamSynchronize(ctx->stream);
         if (q != hipSuccess) return ctx->hip_fail(q, "hipStreamSynchronize");
     }
+    // The stream check and the deadline run every so often whether or not the wait was filled with other contexts'
+    // pieces (a faulted stream must be noticed also while the help board stays busy); the deadline counts from this
+    // context's last own progress -- a record of ITS round landing -- not from the entry, so time spent on others'
+    // work does not run it down.
+    auto last_progress = t0;
     for (int b = 0; b < count; ++b) {
-        uint32_t spins = 0;
+        uint32_t spins = 0, helped = 0;
         while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
             // this thread has nothing to do until its round lands: a piece of another context's posted host work
             // (a 16-lane hash call, ~30 us) instead of spinning
-            if (help && gkr::HelpBoard::instance().help()) continue;
-            GKR_CPU_RELAX();
-            if ((++spins & 0xFFFF) == 0) {
+            const bool did_help = help && gkr::HelpBoard::instance().help();
+            if (!did_help) GKR_CPU_RELAX();
+            if (did_help ? (++helped & 0x3F) == 0 : (++spins & 0xFFFF) == 0) {
                 hipError_t q = wait_mode == 2 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return ctx->hip_fail(q, "stream failed while waiting for a round");
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                if (std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(30)) {
                     if (q == hipSuccess && __atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) == ticket) break;
                     return ctx->fail(GKR_ERR_HIP, "timed out waiting for the device to publish a round");
                 }
             }
         }
+        if (spins | helped) last_progress = std::chrono::steady_clock::now();
     }
     return GKR_OK;
 }
@@ -1395,13 +1406,29 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
 // b-rounds, the row (a_u, m_u) before the c-rounds -- are completed by the caller's sum-over-ranks hook.
 struct LayerShardArgs {
     uint64_t gate_base = 0, gate_count = 0;
-    gkr_allreduce_fn allreduce = nullptr;
+    gkr_allreduce_fn allreduce = nullptr;   // host hook (field elements in host memory), or
     void* user = nullptr;
+    const gkr_exchange_dev* dev = nullptr;  // device exchange: limbs widened into the caller's device buffer, summed on the stream
 };
 
+int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                         const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                         const LayerShardArgs* shard, GateLists* cached);
+
+// Gate lists that this call built (cached->ready false on entry) count as ready only if the whole call succeeded: a bad
+// gate, a HIP error or a timeout after the sort was queued must not leave half-validated lists marked usable.
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                     const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
                     const LayerShardArgs* shard = nullptr, GateLists* cached = nullptr) {
+    const bool was_ready = cached && cached->ready;
+    const int rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached);
+    if (rc && cached && !was_ready) cached->ready = false;
+    return rc;
+}
+
+int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                         const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                         const LayerShardArgs* shard, GateLists* cached) {
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
@@ -1523,30 +1550,62 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
     }
 
-    // `count` field elements at d_vals (device) := their sums over all ranks; `flag` travels along as one more element
-    // so that every rank learns of a rank that found a bad gate (and all of them leave before the next collective)
-    auto sum_over_ranks = [&](Fr* d_a, Fr* d_b, size_t each, uint32_t* flag) -> int {
-        std::vector<gkr_fr> buf(2 * each + 1);
-        HIP_TRY(ctx, hipMemcpyAsync(buf.data(), d_a, each * sizeof(Fr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(buf.data() + each, d_b, each * sizeof(Fr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        buf[2 * each] = gkr_fr{{flag ? (uint64_t)(*flag != 0) : 0, 0, 0, 0}};
-        if (const int arc = shard->allreduce(shard->user, buf.data(), buf.size()))
-            return ctx->fail(GKR_ERR_INVALID, "the sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
-        if (!all_canonical(buf.data(), buf.size())) return ctx->fail(GKR_ERR_NON_CANONICAL, "the sum-over-ranks hook returned a value >= r");
-        if (flag) *flag = (buf[2 * each].l[0] | buf[2 * each].l[1] | buf[2 * each].l[2] | buf[2 * each].l[3]) ? 1u : 0u;
-        HIP_TRY(ctx, hipMemcpyAsync(d_a, buf.data(), each * sizeof(Fr), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(d_b, buf.data() + each, each * sizeof(Fr), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));   // buf goes out of scope
+    // The two tables d_a, d_b (`each` elements) := their sums over all ranks.  One more element travels along: "some rank
+    // failed" (a bad gate seen on the device, or `local_fail`: this rank's own error status), so that every rank enters
+    // every collective and all of them leave with an error together instead of one leaving the others inside it.
+    // Device exchange: widen -> the caller's all-reduce on this stream -> narrow, no host copy and no synchronisation;
+    // the summed flag lands in pinned memory and is looked at when the next record has landed (xflag_check).
+    uint32_t* h_xflag = nullptr;
+    if (shard && shard->dev) {
+        HIP_TRY(ctx, ctx->pinned_host("layer.xflag", 64, reinterpret_cast<void**>(&h_xflag)));
+        *h_xflag = 0;
+        if (shard->dev->capacity < gkr_exchange_limbs(k) || !shard->dev->d_limbs || !shard->dev->fn)
+            return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs(k_next) int64");
+    }
+    auto sum_over_ranks = [&](Fr* d_a, Fr* d_b, size_t each, const uint32_t* d_flag, int local_fail) -> int {
+        if (shard->dev) {
+            Timed t(ctx, "exchange", 0.0);
+            long long* limbs = reinterpret_cast<long long*>(shard->dev->d_limbs);
+            gkr::launch_exchange_widen(d_a, d_b, (uint32_t)each, d_flag, local_fail ? 1u : 0u, limbs, s);
+            const int arc = shard->dev->fn(shard->dev->user, (2 * each + 1) * 8, static_cast<void*>(s));
+            gkr::launch_exchange_narrow(limbs, d_a, d_b, (uint32_t)each, h_xflag, s);
+            if (arc) return ctx->fail(GKR_ERR_INVALID, "the device sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+            HIP_TRY(ctx, hipGetLastError());
+            return local_fail;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        gkr_fr* buf = nullptr;   // pinned, kept by the context: no pageable staging vector per exchange
+        HIP_TRY(ctx, ctx->pinned_host("layer.xbuf", sizeof(gkr_fr) * (2 * each + 1), reinterpret_cast<void**>(&buf)));
+        uint32_t hflag = local_fail ? 1u : 0u;
+        gkr::launch_copy_words(d_a, buf, each * 8, s);
+        gkr::launch_copy_words(d_b, buf + each, each * 8, s);
+        if (d_flag && !local_fail) HIP_TRY(ctx, hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, s));
+        const hipError_t se = hipStreamSynchronize(s);
+        if (se != hipSuccess) hflag = 1u;   // still enter the collective: the peers are on their way into it
+        buf[2 * each] = gkr_fr{{(uint64_t)(hflag != 0), 0, 0, 0}};
+        const int arc = shard->allreduce(shard->user, buf, 2 * each + 1);
+        if (se != hipSuccess) return ctx->hip_fail(se, "hipStreamSynchronize before the sum over ranks");
+        if (arc) return ctx->fail(GKR_ERR_INVALID, "the sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+        if (!all_canonical(buf, 2 * each + 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "the sum-over-ranks hook returned a value >= r");
+        const bool some_failed = (buf[2 * each].l[0] | buf[2 * each].l[1] | buf[2 * each].l[2] | buf[2 * each].l[3]) != 0;
+        gkr::launch_copy_words(buf, d_a, each * 8, s);
+        gkr::launch_copy_words(buf + each, d_b, each * 8, s);   // (the next exchange waits for the stream before it rewrites buf)
+        if (ctx->profile == 1)
+            ctx->add_host_sample("exchange", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (local_fail) return local_fail;
+        if (some_failed) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range, or another failure, on some rank");
+        return GKR_OK;
+    };
+    // device exchange: has the flag that travelled with the exchanges come back set?  Valid once a kernel queued after
+    // the narrow step has published something the host waited for.
+    auto xflag_check = [&]() -> int {
+        if (h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE))
+            return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range, or another failure, on some rank");
         return GKR_OK;
     };
     if (shard) {
-        uint32_t hbad = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        rc = sum_over_ranks(U, V, wlen, &hbad);
+        rc = sum_over_ranks(U, V, wlen, lists_fresh ? bad : nullptr, GKR_OK);
         if (rc) return rc;
-        if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range (on some rank)");
     }
 
     gkr::LayerHostRec* rec = nullptr;
@@ -1561,7 +1620,9 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         // h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record
         HIP_TRY(ctx, ctx->pinned_host("layer.hdep", sizeof(uint32_t) * 32 * batch, reinterpret_cast<void**>(&h_dep)));
         gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
-        if (sparse && lists_fresh) {   // lists found in the circuit cache were validated when they were built
+        // (gate-sharded with the device exchange: the flag travels with the first exchange and is looked at after the
+        // first round's record, on every rank alike -- a rank that left here would leave its peers inside a collective)
+        if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
             uint32_t hbad = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1790,6 +1851,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
+        bool second_exchange_done = false;
         for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
             Fr *Tw = Wb, *Tx = U, *Ty = V;
             if (phase == 1) {
@@ -1802,7 +1864,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, s);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
-                    rc = sum_over_ranks(A, M, wlen, nullptr);
+                    second_exchange_done = true;
+                    rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
                     if (rc) break;
                 }
                 gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
@@ -1825,6 +1888,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                 }
                 m -= jp;
                 rc = wait_records(ctx, prec, batch, ticket);
+                if (!rc) rc = xflag_check();
                 if (rc) break;
                 const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
                 std::atomic<int> next{0};
@@ -1861,12 +1925,18 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             }
         }
         session.close();
+        // a rank that failed between the exchanges still enters the second one (flag set): its peers are waiting in it.
+        // (Not when the failure is the travelling flag itself: then every rank is leaving at this very point.)
+        if (rc && shard && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
+            (void)sum_over_ranks(A, M, wlen, nullptr, rc);
         if (rc) {
             (void)hipStreamSynchronize(s);
             return rc;
         }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        rc = xflag_check();
+        if (rc) return rc;
         ctx->drain_events();
         return GKR_OK;
     }
@@ -1890,6 +1960,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         t_mark = t;
     };
     gkr::SpinPool::Session session(pool, nullptr);   // closed on every path out of the round loop
+    bool second_exchange_done = false;
     for (uint32_t round = 0; round < v; ++round) {
         cur_round = (int)round;
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
@@ -1908,7 +1979,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                                           A, M, lb, s);
                 }
                 if (shard) {
-                    rc = sum_over_ranks(A, M, wlen, nullptr);
+                    second_exchange_done = true;
+                    rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
                     if (rc) break;
                 }
             } else {
@@ -1927,6 +1999,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
             published = true;
             lap(t_launch);
             rc = wait_records(ctx, rec, batch, ticket);
+            if (!rc) rc = xflag_check();
             lap(t_wait);
             if (rc) break;
         } else if (phase == 1 && lin_b && k <= 13) {
@@ -1998,6 +2071,8 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         }
     }
     session.close();
+    if (rc && shard && lin_b && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
+        (void)sum_over_ranks(A, M, wlen, nullptr, rc);   // the peers are waiting in the second exchange
     if (dbg)
         fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us; longest single step %.0f us (%s, round %d)\n",
                 k, batch, v, t_launch, t_wait, t_hash, worst_lap, worst_kind == 0 ? "launch" : (worst_kind == 1 ? "wait" : "hash"), worst_round);
@@ -2739,6 +2814,35 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
     if (rc) {   // a failed first use may have left half-built lists behind
         layer->lists.ready = false;
     }
+    return rc;
+}
+
+size_t gkr_exchange_limbs(int k_next) {
+    if (k_next < 0 || k_next > 14) return 0;
+    return (((size_t)2 << k_next) + 1) * 8;
+}
+
+int gkr_resident_layer_sumcheck_dev(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const gkr_fr* W, const gkr_exchange_dev* exchange,
+                                    gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z) || !exchange) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    const int k_i = layer->k_i, k = layer->k;
+    if (k > 13) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs k_next <= 13");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
+    gkr_fr* hW = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
+    memcpy(hW, W, sizeof(gkr_fr) << k);
+    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    LayerShardArgs sh;
+    sh.gate_base = layer->first;
+    sh.gate_count = layer->count;
+    sh.dev = exchange;
+    const int rc = run_layer_batch(ctx, 1, k_i, k, layer->gt, layer->l, layer->r, z, dW, &out_coeffs, &out_len, &out_r, &sh, &layer->lists);
+    if (rc) layer->lists.ready = false;
     return rc;
 }
 
@@ -3666,6 +3770,55 @@ int gkr_device_fill_table(gkr_ctx* ctx, void* d_table, size_t count, uint64_t se
     gkr::launch_fill_table(static_cast<Fr*>(d_table), count, seed, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return GKR_OK;
+}
+
+int gkr_ubench_ceilings(gkr_ctx* ctx, size_t bytes, double* copy_GBps, double* read_GBps, double* modmul_per_sec) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!copy_GBps || !read_GBps || !modmul_per_sec) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (bytes < ((size_t)64 << 20)) bytes = (size_t)64 << 20;
+    bytes &= ~(size_t)4095;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    char *a = nullptr, *b = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&a), bytes));
+    if (hipMalloc(reinterpret_cast<void**>(&b), bytes) != hipSuccess) {
+        (void)hipFree(a);
+        return ctx->fail(GKR_ERR_NOMEM, "device memory for the copy probe");
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = GKR_OK;
+    auto best_ms = [&](auto&& launch, int reps) -> double {
+        double best = 1e30;
+        for (int r = 0; r < reps; ++r) {
+            if (hipEventRecord(e0, s) != hipSuccess) return -1.0;
+            launch();
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0;
+            if (r > 0 && ms < best) best = ms;   // the first repetition touches the pages
+        }
+        return best;
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = ctx->fail(GKR_ERR_HIP, "hipEventCreate");
+    if (!rc) {
+        gkr::launch_fill_table(reinterpret_cast<Fr*>(a), bytes / 32, 1, s);
+        const double c = best_ms([&] { gkr::launch_ubench_copy(a, b, bytes, s); }, 6);
+        const double rd = best_ms([&] { gkr::launch_ubench_read(a, b, bytes, s); }, 6);
+        const int waves = 16384, reps = 128;   // 16 waves per SIMD: the rate no longer grows with more
+        const double mm = best_ms([&] { gkr::launch_ubench_modmul(reinterpret_cast<Fr*>(a), 1u << 20, waves, reps, s); }, 4);
+        if (c <= 0 || rd <= 0 || mm <= 0 || hipGetLastError() != hipSuccess) {
+            rc = ctx->fail(GKR_ERR_HIP, "the ceiling probes failed");
+        } else {
+            *copy_GBps = 2.0 * (double)bytes / (c * 1e-3) / 1e9;
+            *read_GBps = (double)bytes / (rd * 1e-3) / 1e9;
+            *modmul_per_sec = (double)waves * 64.0 * reps / (mm * 1e-3);
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
 }
 
 int gkr_device_synchronize(gkr_ctx* ctx) {

@@ -2041,6 +2041,44 @@ void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_table, dim3(blocks_for(count, 4096)), dim3(256), 0, s, table, count, seed);
 }
 
+// ---- what the box itself gives (bench.py quotes these beside its roofline fractions) -----------------
+// one 16-byte element per thread, no loop: the copy shape that measured fastest on this chip (tools/ubench_copy.hip)
+__global__ void __launch_bounds__(256) k_ubench_copy(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_ubench_read(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, uint32_t per_block) {
+    const size_t base = (size_t)blockIdx.x * per_block;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (uint32_t t = threadIdx.x; t < per_block; t += 256) {
+        const size_t i = base + t;
+        if (i < n) {
+            const uint4 v = in[i];
+            acc.x ^= v.x, acc.y ^= v.y, acc.z ^= v.z, acc.w ^= v.w;
+        }
+    }
+    if (acc.x == 0x12345u && acc.y == 0x777u && acc.z == 0x1u) out[0] = acc;
+}
+// a chain of dependent 254-bit Montgomery products per lane (128 v_mad_u64_u32 + 128 v_addc each): with the chip full
+// of waves this is the arithmetic ceiling of every kernel whose work is modular products (tools/ubench_f64mont.hip)
+__global__ void __launch_bounds__(64) k_ubench_modmul(Fr* io, uint32_t mask, int reps) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    Fr x = load_fr(io + (g & mask)), y = load_fr(io + ((g + 1u) & mask));
+    for (int r = 0; r < reps; ++r) x = mont_mul(x, y);
+    if (fr_is_zero(x)) store_fr(io + (g & mask), x);   // (never: keeps the chain alive)
+}
+void launch_ubench_copy(const void* in, void* out, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_ubench_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const uint4*>(in), static_cast<uint4*>(out), n);
+}
+void launch_ubench_read(const void* in, void* out, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_ubench_read, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, static_cast<const uint4*>(in), static_cast<uint4*>(out), n, 4096u);
+}
+void launch_ubench_modmul(Fr* io, uint32_t entries_pow2, uint32_t waves, int reps, hipStream_t s) {
+    hipLaunchKernelGGL(k_ubench_modmul, dim3(waves), dim3(64), 0, s, io, entries_pow2 - 1u, reps);
+}
+
 uint32_t mle_blocks_per_table(uint32_t items, uint32_t batch) {
     // ~1024 items (4 iterations) per block, but enough blocks across the batch to fill the chip;
     // never more than one block per 256 items
@@ -2089,6 +2127,49 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
                          uint32_t batch, hipStream_t s) {
     hipLaunchKernelGGL(k_prod_c_setup, dim3(blocks_for(1u << k, 1024), batch), dim3(256), 0, s, Wb, jp, weights, A, M, X, Y, k, wstride);
+}
+
+// ---- sum over ranks on the device (gkr_exchange_dev): field elements <-> eight 32-bit limbs in int64, the form an
+// integer SUM all-reduce adds exactly (RCCL has no modular sum).  Element 2 * each is the "some rank failed" flag.
+__global__ void __launch_bounds__(256) k_exchange_widen(const Fr* __restrict__ a, const Fr* __restrict__ b, uint32_t each,
+                                                        const uint32_t* __restrict__ flag, uint32_t local_flag, long long* __restrict__ limbs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * each) {
+        const Fr v = load_fr(i < each ? a + i : b + (i - each));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) limbs[(size_t)i * 8 + j] = (long long)v.l[j];
+    } else if (i == 2 * each) {
+        limbs[(size_t)i * 8] = (long long)(((flag && *flag) || local_flag) ? 1 : 0);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) limbs[(size_t)i * 8 + j] = 0;
+    }
+}
+// limb sums of < 2^31 addends -> canonical values mod r; the summed flag goes to a word the host can read (pinned)
+__global__ void __launch_bounds__(256) k_exchange_narrow(const long long* __restrict__ limbs, Fr* __restrict__ a, Fr* __restrict__ b, uint32_t each,
+                                                         uint32_t* __restrict__ flag_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * each) {
+        Acc<10> acc = acc_zero<10>();
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long w = (unsigned long long)limbs[(size_t)i * 8 + j];
+            const unsigned long long lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            acc.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        acc.l[8] = (uint32_t)carry;
+        acc.l[9] = (uint32_t)(carry >> 32);
+        store_fr(i < each ? a + i : b + (i - each), acc_reduce(acc));
+    } else if (i == 2 * each && flag_out) {
+        *flag_out = limbs[(size_t)i * 8] ? 1u : 0u;
+    }
+}
+void launch_exchange_widen(const Fr* a, const Fr* b, uint32_t each, const uint32_t* flag, uint32_t local_flag, long long* limbs, hipStream_t s) {
+    hipLaunchKernelGGL(k_exchange_widen, dim3((2 * each + 1 + 255) / 256), dim3(256), 0, s, a, b, each, flag, local_flag, limbs);
+}
+void launch_exchange_narrow(const long long* limbs, Fr* a, Fr* b, uint32_t each, uint32_t* flag_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_exchange_narrow, dim3((2 * each + 1 + 255) / 256), dim3(256), 0, s, limbs, a, b, each, flag_out);
 }
 
 void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) {

@@ -108,6 +108,39 @@ class TorchCollective:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return t.cpu().numpy()
 
+    def exchange(self, k_max=13):
+        """What ResidentGates.sumcheck_raw takes as its sum over ranks: on RCCL the device exchange (the limbs never
+        leave the GPU, the all-reduce is queued on the library's own stream), on gloo the host transport."""
+        if self._dist.get_backend(self._group) == "nccl":
+            return DeviceExchange(self, k_max)
+        return self.sum_limbs
+
+
+class DeviceExchange:
+    """gkr_exchange_dev over torch.distributed with backend nccl (= RCCL over xGMI): the limb buffer is a CUDA int64
+    tensor the library widens into and narrows from; the hook queues ONE in-place SUM all-reduce on the library's HIP
+    stream (wrapped as torch.cuda.ExternalStream), so nothing crosses PCIe and no stream is synchronised
+    (include/gkr_amd.h, gkr_resident_layer_sumcheck_dev; the reference's counterpart is the rayon reduce of
+    sumcheck.rs:50-63, 97-124)."""
+
+    def __init__(self, coll: TorchCollective, k_max=13):
+        torch, dist, group = coll._torch, coll._dist, coll._group
+        self._buf = torch.zeros(int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max))), dtype=torch.int64, device=coll._device)
+        self.errors = []
+        self.calls = 0
+
+        def fn(_user, count, stream):
+            try:
+                self.calls += 1
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self._buf.device)):
+                    dist.all_reduce(self._buf[:count], op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception as e:   # never unwind through the C frame
+                self.errors.append(e)
+                return 1
+        self._fn = N.ALLREDUCE_DEV_FN(fn)
+        self.struct = N.ExchangeDev(self._fn, None, self._buf.data_ptr(), self._buf.numel())
+
 
 # ----------------------------------------------------------------------------- gate-sharded layer sumcheck
 
@@ -205,14 +238,21 @@ class ResidentGates:
         return self._handles[k_next]
 
     def sumcheck_raw(self, k_next, z_limbs, w_limbs, sum_limbs=None):
-        """-> (C, L, R) like Context.sumcheck_layer_raw; sum_limbs: the transport of the sum over ranks (None: the
-        arrays hold the whole layer)."""
+        """-> (C, L, R) like Context.sumcheck_layer_raw; sum_limbs: the sum over ranks -- a DeviceExchange (RCCL, on the
+        device), or the host transport `int64 limb array -> summed array` (None: the arrays hold the whole layer)."""
         v = 2 * k_next
         C = np.zeros((v, 3, 4), dtype=np.uint64)
         L = np.zeros(v, dtype=np.uint32)
         R = np.zeros((v, 4), dtype=np.uint64)
         zl = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
         wl = np.ascontiguousarray(w_limbs, dtype=np.uint64)
+        if isinstance(sum_limbs, DeviceExchange):
+            rc = N.lib().gkr_resident_layer_sumcheck_dev(self._ctx._h, self._layer(k_next), _ptr(zl), _ptr(wl), ctypes.byref(sum_limbs.struct),
+                                                         _ptr(C), _ptr(L), _ptr(R))
+            if sum_limbs.errors:
+                raise sum_limbs.errors[0]
+            self._ctx._check(rc)
+            return C, L, R
         hook, errors = make_allreduce_hook(sum_limbs) if sum_limbs is not None else (None, [])
         rc = N.lib().gkr_resident_layer_sumcheck(self._ctx._h, self._layer(k_next), _ptr(zl), _ptr(wl), hook, None, _ptr(C), _ptr(L), _ptr(R))
         if errors:
@@ -247,6 +287,90 @@ class ThreadedSum:
 
     def abort(self):
         self._barrier.abort()
+
+
+class ThreadedDeviceSum:
+    """The device exchange (gkr_exchange_dev) for P logical ranks that are P threads of one process on one GPU: every
+    rank's limb buffer is a CUDA tensor; the hook waits for its rank's stream, the last rank in adds the P buffers up on
+    the device, every rank copies the total into its own buffer on its own stream.  Same widen / narrow kernels and the
+    same flag handling as with RCCL; only the transport differs."""
+
+    def __init__(self, world, device=0, k_max=13):
+        import threading
+
+        import torch
+        self._torch = torch
+        self._barrier = threading.Barrier(world)
+        n = int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max)))
+        self._bufs = [torch.zeros(n, dtype=torch.int64, device="cuda:%d" % device) for _ in range(world)]
+        self._total = None
+        self.errors = []
+
+    def for_rank(self, rank):
+        torch = self._torch
+        buf = self._bufs[rank]
+        holder = type("Exchange", (DeviceExchange,), {})
+        ex = holder.__new__(holder)
+        ex.errors = self.errors
+        ex.calls = 0
+
+        def fn(_user, count, stream):
+            try:
+                ext = torch.cuda.ExternalStream(int(stream or 0), device=buf.device)
+                ext.synchronize()
+                if self._barrier.wait() == 0:
+                    self._total = torch.stack([b[:count] for b in self._bufs]).sum(dim=0)
+                    torch.cuda.synchronize(buf.device)
+                self._barrier.wait()
+                with torch.cuda.stream(ext):
+                    buf[:count].copy_(self._total)
+                ext.synchronize()
+                self._barrier.wait()    # nobody starts the next sum while a rank still reads this total
+                return 0
+            except Exception as e:
+                self.errors.append(e)
+                self._barrier.abort()
+                return 1
+        ex._fn = N.ALLREDUCE_DEV_FN(fn)
+        ex._buf = buf
+        ex.struct = N.ExchangeDev(ex._fn, None, buf.data_ptr(), buf.numel())
+        return ex
+
+    def abort(self):
+        self._barrier.abort()
+
+
+def prove_sumcheck_opt_logical_gates_dev(device, layer: Layer, k_next, z, W, nshards):
+    """prove_sumcheck_opt_logical_gates with the DEVICE exchange: resident gate shards, gkr_resident_layer_sumcheck_dev.
+    Returns every rank's (C, L, R)."""
+    import threading
+    gt, l, r = layer.arrays()
+    coll = ThreadedDeviceSum(nshards, device, max(k_next, 1))
+    out, errs = [None] * nshards, []
+    zl = as_limbs(z) if layer.k else np.zeros((0, 4), dtype=np.uint64)
+    wl = as_limbs(W)
+
+    def run(rank):
+        try:
+            first, count = gate_range(layer.k, rank, nshards)
+            with Context(device) as ctx:
+                gates = ResidentGates(ctx, layer.k, first, gt[first:first + count], l[first:first + count], r[first:first + count])
+                try:
+                    out[rank] = gates.sumcheck_raw(k_next, zl, wl, coll.for_rank(rank))
+                finally:
+                    gates.close()
+        except Exception as e:
+            errs.append(e)
+            coll.abort()
+    threads = [threading.Thread(target=run, args=(p,)) for p in range(nshards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
+        raise (real or errs)[0]
+    return out
 
 
 def prove_sumcheck_opt_logical_gates(device, layer: Layer, k_next, z, W, nshards):

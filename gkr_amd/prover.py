@@ -233,6 +233,12 @@ class Context:
     def synchronize(self):
         self._check(N.lib().gkr_device_synchronize(self._h))
 
+    def ceilings(self, nbytes=2 << 30):
+        """The box's own ceilings, measured now: {"copy_GBps", "read_GBps", "modmul_per_sec"} (gkr_ubench_ceilings)."""
+        c, r, m = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(N.lib().gkr_ubench_ceilings(self._h, ctypes.c_size_t(nbytes), ctypes.byref(c), ctypes.byref(r), ctypes.byref(m)))
+        return {"copy_GBps": c.value, "read_GBps": r.value, "modmul_per_sec": m.value}
+
     # -- plain multilinear sumcheck (prove_sumcheck, sumcheck.rs:158-214)
     def sumcheck_mle_raw(self, table_limbs, n):
         table_limbs = np.ascontiguousarray(table_limbs, dtype=np.uint64)

@@ -31,6 +31,23 @@ def config5_layer(k_i=24, k=12, seed=SEED + 5):
     return lay, z, W
 
 
+def bench_table_seed(rank, b):
+    """Seed of table b of rank `rank` in bench.py's default workload (1024 x 2^20 points per rank); rank 0's table 0 is
+    the table of tests/golden/config_hashes.json["mle"]["n=20,seed=12648432"]."""
+    return SEED + 2 + 1000 * rank + b
+
+
+def bench_batch_digests():
+    """tests/golden/bench_batch_hashes.json (make_config_hashes.py --bench-batch): committed digests of the
+    reference-semantics transcripts of every table bench.py times, or None."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bench_batch_hashes.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
 PROOF_BATCH_KS = [5, 6, 7, 7, 7]
 
 

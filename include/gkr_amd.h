@@ -217,6 +217,27 @@ int  gkr_resident_layer_sumcheck(gkr_ctx *ctx, gkr_resident_layer *layer, const 
                                  gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs, uint32_t *out_len,
                                  gkr_fr *out_r);
 void gkr_resident_layer_free(gkr_ctx *ctx, gkr_resident_layer *layer);
+/* The same exchange without leaving the device -- the multi-GPU twin of the rayon reduce at sumcheck.rs:50-63,
+ * 97-124 as "one RCCL reduce over xGMI": the caller owns a device buffer of `capacity` int64 (capacity >=
+ * gkr_exchange_limbs(k_next)); per exchange the library widens its partial tables into it on the device (eight
+ * 32-bit limbs per field element, each in an int64, plus one flag element), calls fn(user, count, hip_stream), which
+ * must enqueue an in-place integer SUM all-reduce of d_limbs[0 .. count) ON THAT STREAM (ncclAllReduce(buf, buf, count,
+ * ncclInt64, ncclSum, comm, stream); torch.distributed.all_reduce under torch.cuda.ExternalStream(stream)), and
+ * reduces the sums mod r on the device.  No host copy, no stream synchronisation: the host next touches the stream
+ * when the first round's record lands.  fn is called on every rank the same number of times even when a rank has
+ * failed locally (the flag element carries "some rank failed", and all ranks then return an error together); fn
+ * itself must not fail on one rank only. */
+typedef int (*gkr_allreduce_dev_fn)(void *user, size_t count, void *hip_stream);
+typedef struct {
+    gkr_allreduce_dev_fn fn;
+    void *user;
+    int64_t *d_limbs;   /* device memory owned by the caller */
+    size_t capacity;    /* in int64 elements */
+} gkr_exchange_dev;
+size_t gkr_exchange_limbs(int k_next);
+int  gkr_resident_layer_sumcheck_dev(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const gkr_fr *W,
+                                     const gkr_exchange_dev *exchange, gkr_fr *out_coeffs, uint32_t *out_len,
+                                     gkr_fr *out_r);
 /* host only: count field elements <-> count x 8 int64 (32-bit limbs, least significant first); narrow reduces
  * limb sums of up to 2^31 addends mod r */
 int  gkr_fr_widen(const gkr_fr *values, size_t count, int64_t *limbs);
@@ -432,6 +453,12 @@ int  gkr_device_download(gkr_ctx *ctx, void *h_dst, const void *d_src, size_t by
  * top limb masked to 61 bits; mix64 = splitmix64's finaliser) */
 int  gkr_device_fill_table(gkr_ctx *ctx, void *d_table, size_t count, uint64_t seed);
 int  gkr_device_synchronize(gkr_ctx *ctx);
+/* What this box itself gives, measured now (SURVEY section 8d asks bench.py to quote them beside the vendor
+ * peaks): a plain device-to-device copy of `bytes` (>= 64 MiB; read + write counted) and a read-only stream, in
+ * GB/s, and the chip-wide rate of 254-bit Montgomery products (dependent chains, 16 waves per SIMD) -- the
+ * arithmetic ceiling of the gate passes of prove_sumcheck_opt (sumcheck.rs:50-63, 97-124).  No reference
+ * counterpart: measurement only. */
+int  gkr_ubench_ceilings(gkr_ctx *ctx, size_t bytes, double *copy_GBps, double *read_GBps, double *modmul_per_sec);
 
 #ifdef __cplusplus
 }

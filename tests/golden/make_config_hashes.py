@@ -2,6 +2,7 @@
 """Golden digests of the oracle's transcripts at BASELINE config sizes (too large to commit as vectors).
 
     python tests/golden/make_config_hashes.py      # rewrites tests/golden/config_hashes.json (~1 min of CPU)
+    python tests/golden/make_config_hashes.py --bench-batch   # rewrites tests/golden/bench_batch_hashes.json (~6 min, 8 cores)
 
 For each workload of gkr_amd.synth the C oracle (oracle/c, pinned against the reference-generated fixtures by
 tests/test_oracle_*.py) produces the transcript; what is committed is sha256 over the raw output arrays
@@ -28,8 +29,54 @@ def digest(*arrays):
     return h.hexdigest()
 
 
+def _bench_table_transcript(seed):
+    """One table of bench.py's default workload: fill_table(2^20, seed) -> the oracle's (C, L, R) as bytes, and the
+    transcripts of its sixteen 2^16-point slices (what the n16 leg proves on the same memory)."""
+    table = cdense.fill_table(1 << 20, seed)
+    C, L, R = cdense.sumcheck_mle_raw(table, 20, 1)
+    slices = [cdense.sumcheck_mle_raw(table[j << 16:(j + 1) << 16], 16, 1) for j in range(16)]
+    return seed, (C.tobytes(), L.tobytes(), R.tobytes()), [(c.tobytes(), l.tobytes(), r.tobytes()) for c, l, r in slices]
+
+
+def bench_batch_digests(ranks=8, batch=1024, n16_tables=4096):
+    """Digests of everything bench.py's default line times (gkr_amd.synth.bench_table_seed): per rank the whole batch of
+    1024 x 2^20 transcripts (sha256 over the C | L | R output arrays as the C ABI lays them out for the batch), rank 0's
+    tables one by one (first 16 hex digits), and rank 0's 4096 x 2^16 leg."""
+    import multiprocessing
+    seeds = sorted({synth.bench_table_seed(r, b) for r in range(ranks) for b in range(batch)})
+    with multiprocessing.Pool(min(8, os.cpu_count() or 1)) as pool:
+        done = {}
+        n16 = {}
+        for seed, t20, t16 in pool.imap_unordered(_bench_table_transcript, seeds, chunksize=4):
+            done[seed] = t20
+            if seed < synth.bench_table_seed(0, 0) + n16_tables // 16:
+                n16[seed] = t16
+    out = {"batch": batch, "n": 20, "whole_batch_by_rank": {}, "rank0_tables": [], "n16_whole_batch_rank0": None, "n16_tables": n16_tables}
+    for r in range(ranks):
+        hc, hl, hr = [], [], []
+        for b in range(batch):
+            c, l, rr = done[synth.bench_table_seed(r, b)]
+            hc.append(c), hl.append(l), hr.append(rr)
+        out["whole_batch_by_rank"][str(r)] = hashlib.sha256(b"".join(hc) + b"".join(hl) + b"".join(hr)).hexdigest()
+    for b in range(batch):
+        out["rank0_tables"].append(hashlib.sha256(b"".join(done[synth.bench_table_seed(0, b)])).hexdigest()[:16])
+    hc, hl, hr = [], [], []
+    for j in range(n16_tables):
+        c, l, rr = n16[synth.bench_table_seed(0, j >> 4)][j & 15]
+        hc.append(c), hl.append(l), hr.append(rr)
+    out["n16_whole_batch_rank0"] = hashlib.sha256(b"".join(hc) + b"".join(hl) + b"".join(hr)).hexdigest()
+    return out
+
+
 def main():
     out = {"what": "sha256(coeffs | lens | challenges) of the C oracle's transcript; inputs: gkr_amd.synth", "layer": {}, "mle": {}}
+    if "--bench-batch" in sys.argv:   # ~6 min on 8 cores: kept in its own file, regenerated only when asked
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_batch_hashes.json")
+        with open(path, "w") as f:
+            json.dump(bench_batch_digests(), f, indent=0, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        return
     for k_i, k in ((16, 8), (20, 10), (24, 12)):
         lay, z, W = synth.config5_layer(k_i, k)
         C, L, R = cdense.sumcheck_layer_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)

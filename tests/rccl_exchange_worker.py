@@ -1,0 +1,45 @@
+"""Child process of test_device_exchange_over_rccl_single_rank: process group (backend nccl = RCCL) first, GPU second;
+a gate-sharded layer sumcheck whose two exchanges run as torch.distributed all-reduces on the library's own stream."""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    torch.cuda.set_device(0)
+    from gkr_amd import Context, parallel
+    from gkr_amd.field import to_limbs
+    from oracle import cdense
+    from oracle.field import P
+    rng = random.Random(77)
+    coll = parallel.TorchCollective()
+    ex = coll.exchange()
+    assert isinstance(ex, parallel.DeviceExchange)
+    with Context(0) as ctx:
+        for k_i, k in ((10, 6), (16, 8)):
+            g = 1 << k_i
+            gt = np.array([rng.randint(0, 1) for _ in range(g)], dtype=np.uint8)
+            l = np.array([rng.randrange(1 << k) for _ in range(g)], dtype=np.uint32)
+            r = np.array([rng.randrange(1 << k) for _ in range(g)], dtype=np.uint32)
+            gates = parallel.ResidentGates(ctx, k_i, 0, gt, l, r)
+            for _ in range(3):
+                z = to_limbs([rng.randrange(P) for _ in range(k_i)])
+                w = to_limbs([rng.randrange(P) for _ in range(1 << k)])
+                C, L, R = gates.sumcheck_raw(k, z, w, ex)
+                c2, l2, r2 = cdense.sumcheck_layer_raw(k_i, k, gt, l, r, z, w)
+                assert np.array_equal(C, c2) and np.array_equal(L, l2) and np.array_equal(R, r2), (k_i, k)
+            gates.close()
+    assert ex.calls == 12, ex.calls
+    dist.destroy_process_group()
+    print("OK")
+
+
+if __name__ == "__main__":
+    main()

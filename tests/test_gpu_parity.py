@@ -167,6 +167,37 @@ def test_mle_batch_is_independent_sumchecks(ctx):
         ctx.free(d)
 
 
+def test_mle_headline_workload_shape_matches_oracle():
+    """What bench.py times, at a size the oracle can follow: 2^20-point tables in a batch of 256 (two scheduling
+    groups of 128, the late stream on, all hashing threads racing for records) -- 24 tables spread over both groups,
+    first and last included, byte for byte against the C oracle; every other table against the committed digests
+    (tests/golden/bench_batch_hashes.json: the same seeds as the bench)."""
+    import hashlib
+    from gkr_amd import synth
+    n, batch = 20, 256
+    count = 1 << n
+    with Context(0) as c:
+        d = c.alloc(batch * count * 32)
+        try:
+            for b in range(batch):
+                c.fill_table(N.ctypes.c_void_p(d.value + b * count * 32), count, synth.bench_table_seed(0, b))
+            C, L, R = c.sumcheck_mle_batch_device(d, n, batch)
+            C2, L2, R2 = c.sumcheck_mle_batch_device(d, n, batch, out=(np.zeros_like(C), np.zeros_like(L), np.zeros_like(R)))
+        finally:
+            c.free(d)
+    assert np.array_equal(C, C2) and np.array_equal(L, L2) and np.array_equal(R, R2)   # a second step gives the same bytes
+    picks = sorted({0, 1, 63, 64, 127, 128, 129, 191, 192, 254, 255} | {int(i * 255 / 12) for i in range(13)})
+    assert len(picks) >= 16
+    for b in picks:
+        c2, l2, r2 = cdense.sumcheck_mle_raw(cdense.fill_table(count, synth.bench_table_seed(0, b)), n)
+        assert np.array_equal(C[b], c2) and np.array_equal(L[b], l2) and np.array_equal(R[b], r2), b
+    gold = synth.bench_batch_digests()
+    assert gold is not None and gold["n"] == n
+    for b in range(batch):
+        h = hashlib.sha256(C[b].tobytes() + L[b].tobytes() + R[b].tobytes()).hexdigest()[:16]
+        assert h == gold["rank0_tables"][b], b
+
+
 def test_mle_verifier_relation_at_full_size(ctx):
     """size-independent property at 2^20: g_j(0)+g_j(1) = g_{j-1}(r_{j-1}), r_j = MiMC(g_j)."""
     n = 20

@@ -56,6 +56,44 @@ def test_layer_sumcheck_gate_sharded_logical_ranks(nshards):
             assert len(got) == nshards and all(g == want for g in got), (nshards, k_i, k)
 
 
+@pytest.mark.parametrize("nshards", [1, 2, 3, 8])
+def test_layer_sumcheck_gate_sharded_device_exchange(nshards):
+    """The same split with the DEVICE exchange (gkr_resident_layer_sumcheck_dev): partial tables widened, summed and
+    narrowed on the GPU, no host copy; every rank's transcript equals the unsharded oracle's."""
+    rng = random.Random(1700 + nshards)
+    for k_i, k in ((7, 4), (0, 3), (10, 6), (16, 8)):
+        lay = _layer(rng, k_i, k)
+        z = to_limbs([rng.randrange(P) for _ in range(k_i)])
+        w = to_limbs([rng.randrange(P) for _ in range(1 << k)] if k_i != 10 else [(i & 1) + 5 for i in range(1 << k)])
+        want = cdense.sumcheck_layer_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, w)
+        got = parallel.prove_sumcheck_opt_logical_gates_dev(0, lay, k, z, w, nshards)
+        assert len(got) == nshards
+        for C, L, R in got:
+            assert np.array_equal(C, want[0]) and np.array_equal(L, want[1]) and np.array_equal(R, want[2]), (nshards, k_i, k)
+
+
+def test_device_exchange_bad_gate_fails_every_rank():
+    from gkr_amd import GkrError
+    rng = random.Random(1601)
+    lay = _layer(rng, 6, 4)
+    lay.right[-1] = 1 << 4
+    with pytest.raises(GkrError):
+        parallel.prove_sumcheck_opt_logical_gates_dev(0, lay, 4, [rng.randrange(P) for _ in range(6)],
+                                                      [rng.randrange(P) for _ in range(16)], 4)
+
+
+def test_device_exchange_over_rccl_single_rank():
+    """RCCL itself in the loop: a process group with backend nccl (world of one rank -- one MI355X is what this box
+    has), the all-reduce queued on the library's stream through torch.distributed; transcript = the oracle's."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_exchange_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_gate_sharded_bad_gate_fails_every_rank():
     """A bad gate on ONE rank: every rank must come back with an error (none may stay inside the collective)."""
     from gkr_amd import GkrError
