@@ -615,6 +615,45 @@ GKR_HD void lazy_mac_v(Lazy17& acc, const Fr& a, const Fr& b) {
     acc.l[16] = (uint32_t)col;
 }
 
+// One product, added to ONE of two accumulators chosen per lane -- without a branch: a wave whose lanes pick different
+// accumulators would otherwise run the 64 multiply-adds twice (once per side of the branch).  Three selects per column.
+GKR_HD void lazy_mac_sel(Lazy17& A, Lazy17& B, bool toA, const Fr& a, const Fr& b) {
+    uint64_t col = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        col += toA ? A.l[c] : B.l[c];
+#pragma unroll
+        for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96(col, ex, a.l[i], b.l[c - i]);
+        const uint32_t lo = (uint32_t)col;
+        A.l[c] = toA ? lo : A.l[c];
+        B.l[c] = toA ? B.l[c] : lo;
+        col = (col >> 32) | ((uint64_t)ex << 32);
+        ex = 0;
+    }
+#pragma unroll
+    for (int c = 15; c < 17; ++c) {
+        col += toA ? A.l[c] : B.l[c];
+        const uint32_t lo = (uint32_t)col;
+        A.l[c] = toA ? lo : A.l[c];
+        B.l[c] = toA ? B.l[c] : lo;
+        col >>= 32;
+    }
+}
+
+// acc += x * 2^256 (x where `on`, else nothing): after the Montgomery reduction of the accumulator this is "+ x" --
+// how a term that carries no second factor joins a lazy sum of products for nine additions instead of a product by one.
+GKR_HD void lazy_add_hi(Lazy17& acc, const Fr& x, bool on) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t t = (uint64_t)acc.l[8 + i] + (on ? x.l[i] : 0u) + carry;
+        acc.l[8 + i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    acc.l[16] += (uint32_t)carry;
+}
+
 // two independent dot products advanced together (see mac96x2_s)
 GKR_HD void lazy_mac2_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub) {
     uint64_t cA = 0, cB = 0;
@@ -866,6 +905,58 @@ GKR_HD Fr lazy_reduce_k8(const Lazy17& x) {
     for (int i = 0; i < 8; ++i) r8[i] = t[8 + i];   // < 2.6 r < 2^256: t[16] == 0
     const Fr once = cond_sub_mod(r8);
     return cond_sub_mod(once.l);
+}
+
+// The same eight Montgomery steps for a sum of at most 32 terms, each a product of two values below r or a value
+// below r times 2^256 (lazy_add_hi), WITHOUT the final canonical reduction: the result is some 256-bit representative
+// of x / 2^256 mod r, which is all a value needs to be that goes on as an operand of another lazy product.
+// (x + M p) / 2^256 < 32 r + p < 7.2 * 2^256, so the ninth limb is at most 7; since 2^256 = R1 (mod r) with
+// R1 < 2^252, replacing top * 2^256 by top * R1 twice brings the value below 2^256.
+GKR_HD Fr lazy_reduce_partial32(const Lazy17& x) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    constexpr uint32_t r1[8] = GKR_R1_LIMBS;
+    uint32_t t[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = x.l[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t m = t[k] * GKR_INV32;
+        uint64_t a2 = t[k];
+        uint32_t e2 = 0;
+        mac96_s(a2, e2, m, p[0]);
+        a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+        e2 = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            a2 += t[k + j];
+            mac96_s(a2, e2, m, p[j]);
+            t[k + j] = (uint32_t)a2;
+            a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+            e2 = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 17; ++j) {
+            a2 += t[j];
+            t[j] = (uint32_t)a2;
+            a2 >>= 32;
+        }
+    }
+    uint32_t top = t[16];
+    Fr out;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.l[i] = t[8 + i];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c += (uint64_t)out.l[i] + (uint64_t)top * r1[i];   // top <= 7: no overflow of the 64-bit column
+            out.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        top = (uint32_t)c;
+    }
+    return out;   // top == 0 now
 }
 
 GKR_HD Fr lazy_reduce(const Lazy17& x) {

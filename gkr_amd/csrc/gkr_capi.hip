@@ -25,6 +25,7 @@
 #include "fr64.h"
 #include "hostpool.h"
 #include "kernels.h"
+#include "gate_seg.h"
 #include "keccak.h"
 #include "mimc7.h"
 #include "mimc_ifma.h"
@@ -312,7 +313,17 @@ bool all_canonical(const gkr_fr* v, size_t n) {
 // the circuit, and an aggregation step proves the same <= 20 circuits for input after input.
 struct GateLists {
     uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
+    gkr::GateSegs segs;   // the lists' segments (large layers; segs.words is one more device allocation)
     bool ready = false;
+    void release() {
+        if (offsets) (void)hipFree(offsets);
+        if (cursor) (void)hipFree(cursor);
+        if (list) (void)hipFree(list);
+        if (segs.words) (void)hipFree(segs.words);
+        offsets = cursor = list = nullptr;
+        segs = gkr::GateSegs();
+        ready = false;
+    }
 };
 struct PreparedCircuit {
     uint64_t h1 = 0, h2 = 0;
@@ -324,11 +335,7 @@ struct PreparedCircuit {
         for (auto p : gt) (void)hipFree(p);
         for (auto p : l) (void)hipFree(p);
         for (auto p : r) (void)hipFree(p);
-        for (auto& g : lists) {
-            if (g.offsets) (void)hipFree(g.offsets);
-            if (g.cursor) (void)hipFree(g.cursor);
-            if (g.list) (void)hipFree(g.list);
-        }
+        for (auto& g : lists) g.release();
         gt.clear();
         l.clear();
         r.clear();
@@ -1331,8 +1338,9 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
 // d_A / d_M hold batch tables of N entries each.
 // E[g] = eq(z, g) = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the device from the points
 // the host left in pinned memory (k_eq_table), E_lo in Montgomery form so that the product of the two is canonical.
-static int upload_eq_tables(gkr_ctx* ctx, int k_i, const gkr_fr* z, int batch, Fr** e_hi_out, Fr** e_lo_out) {
-    const int kl = k_i / 2, kh = k_i - kl;
+static int upload_eq_tables(gkr_ctx* ctx, int k_i, const gkr_fr* z, int batch, Fr** e_hi_out, Fr** e_lo_out, int kl = -1) {
+    if (kl < 0) kl = k_i / 2;
+    const int kh = k_i - kl;
     Fr *e_hi = nullptr, *e_lo = nullptr;
     WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
     WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
@@ -1483,7 +1491,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr;
-    const uint32_t kl = (uint32_t)(k_i / 2);
+    // where eq(z, g) is split into E_hi, E_lo: in the middle, or -- large layers, whose gate passes run over segments
+    // of the sorted lists (gate_seg.h) -- where the segments are cut
+    const uint32_t kl = gkr::gate_seg_shift(span, (uint32_t)k_i, (uint32_t)k);
+    gkr::GateSegs local_segs;
+    gkr::GateSegs* segs = cached ? &cached->segs : &local_segs;
+    Fr* seg_partials = nullptr;
     if (lin_b) {
         WS(ctx, "layer.U", Fr, wlen * batch, U);
         WS(ctx, "layer.V", Fr, wlen * batch, V);
@@ -1499,9 +1512,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         uint32_t *g_counts = nullptr, *g_bsums = nullptr;
         const size_t nb2 = (size_t)2 << k;
         WS(ctx, "pred.bad", uint32_t, 1, bad);
-        rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
+        rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo, (int)kl);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+        if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
         if (cached && cached->ready) {
             lists_fresh = false;
             g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
@@ -1523,10 +1537,19 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 WS(ctx, "gates.list", uint32_t, 2 * gkr::gate_list_words(span.count), g_list);
             }
             HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
-            uint32_t* lds_scratch = nullptr;
+            uint32_t *lds_scratch = nullptr, *seg_scratch = nullptr;
             if (const size_t words = gkr::gate_lists_lds_scratch_words(span.count, (uint32_t)k)) WS(ctx, "gates.lds", uint32_t, words, lds_scratch);
+            if (const size_t words = gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k)) {
+                if (cached) {
+                    if (!cached->segs.words) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->segs.words), words * sizeof(uint32_t)));
+                } else {
+                    WS(ctx, "gates.segs", uint32_t, words, local_segs.words);
+                }
+                WS(ctx, "gates.segscratch", uint32_t, gkr::gate_segs_scratch_words(span, (uint32_t)k_i, (uint32_t)k), seg_scratch);
+            }
             Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
-            gkr::launch_gate_lists(span.count, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch, s);
+            gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch,
+                                   segs, seg_scratch, s);
             if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
         }
     } else {
@@ -1543,8 +1566,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     if (persistent) {
         // U, V, the rounds and the row are all inside the one kernel launched below
     } else if (sparse) {
-        Timed t(ctx, "gate_uv", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
-        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, s);
+        Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
+        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
     } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
@@ -1860,8 +1883,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
                 gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
                 {
-                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
-                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, s);
+                    Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
+                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, segs, seg_partials, s);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
                     second_exchange_done = true;
@@ -1974,9 +1997,9 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
             if (sparse) {
                 {
-                    Timed t(ctx, "gate_rows", (double)span.count * (4.0 + 4.0 + 3 * 32.0) * batch);
+                    Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
-                                          A, M, lb, s);
+                                          A, M, lb, segs, seg_partials, s);
                 }
                 if (shard) {
                     second_exchange_done = true;
@@ -2560,6 +2583,29 @@ int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
     return GKR_OK;
 }
 
+// One item of a gate-list segment and its bucket's combine step, on the host twins of the device code (gate_seg.h):
+// out0 / out1 = E_hi * sum over the item's gates, canonical.
+int gkr_selftest_seg_item(const gkr_fr* e_lo, const gkr_fr* t, const uint8_t* is_mult, size_t n, const gkr_fr* e_hi, int rows,
+                          gkr_fr* out0, gkr_fr* out1) {
+    if (!e_lo || !t || !is_mult || !e_hi || !out0 || !out1 || n > gkr::kSegCap) return GKR_ERR_INVALID;
+    if (!all_canonical(e_lo, n) || !all_canonical(t, n) || !all_canonical(e_hi, 1)) return GKR_ERR_NON_CANONICAL;
+    gkr::Lazy17 L0 = gkr::lazy_zero(), L1 = gkr::lazy_zero();
+    for (size_t i = 0; i < n; ++i) {
+        const Fr e = gkr::to_mont(to_dev(e_lo[i])), w = gkr::to_mont(to_dev(t[i]));
+        if (rows)
+            gkr::seg_gate<true>(L0, L1, e, w, is_mult[i] != 0);
+        else
+            gkr::seg_gate<false>(L0, L1, e, w, is_mult[i] != 0);
+    }
+    const Fr x = gkr::lazy_reduce_partial32(L0), y = gkr::lazy_reduce_partial32(L1);
+    gkr::Lazy17 A = gkr::lazy_zero(), B = gkr::lazy_zero();
+    gkr::lazy_mac_v(A, x, to_dev(*e_hi));
+    gkr::lazy_mac_v(B, y, to_dev(*e_hi));
+    *out0 = to_abi(gkr::lazy_reduce(A));
+    *out1 = to_abi(gkr::lazy_reduce(B));
+    return GKR_OK;
+}
+
 // q(t) = W(b + t (c - b)) the way gkr_prove computes it on the host (Moebius transform for the length, variable-by-
 // variable binding for the coefficients); out: k + 1 slots right-aligned
 int gkr_selftest_line_restriction(int k, const gkr_fr* W, const gkr_fr* b, const gkr_fr* c, gkr_fr* out, uint32_t* out_len) {
@@ -2750,9 +2796,7 @@ void gkr_resident_layer_free(gkr_ctx* ctx, gkr_resident_layer* layer) {
     if (layer->gt) (void)hipFree(layer->gt);
     if (layer->l) (void)hipFree(layer->l);
     if (layer->r) (void)hipFree(layer->r);
-    if (layer->lists.offsets) (void)hipFree(layer->lists.offsets);
-    if (layer->lists.cursor) (void)hipFree(layer->lists.cursor);
-    if (layer->lists.list) (void)hipFree(layer->lists.list);
+    layer->lists.release();
     delete layer;
 }
 

@@ -118,14 +118,49 @@ size_t gate_lists_lds_scratch_words(uint64_t gates, uint32_t k);
 // buckets), and after them, entry for entry, what the sums over a bucket need of the gate besides its index: the OTHER
 // operand in the low bits, the gate type in bit 31 (read in list order instead of gathered by gate index)
 inline size_t gate_list_words(uint64_t gates) { return 2 * (size_t)gates + 1; }
-void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+// Segments of the sorted lists (gate_seg.h): the bucket lists cut where gate >> shift changes, so that E_hi is a common
+// factor of a segment; segments cut into items of <= kSegCap gates, both halves (left-operand buckets, right-operand
+// buckets) in one item array, `order` = the items of each half by decreasing length.  Built once per circuit by
+// launch_gate_lists right after the block-private sort (whose per-block starts ARE the segment bounds).
+struct GateSegs {
+    uint32_t shift = 0;      // log2 gates per run; 0: no segments (small layer, unaligned shard): the bucket kernels run
+    uint32_t runs = 0;       // runs the span covers
+    uint32_t run_base = 0;   // the span's first run in the layer (index into E_hi)
+    uint32_t bound = 0;      // capacity of items / order (both halves together)
+    uint32_t half_bound = 0; // most items one half can have
+    uint32_t groups = 0;     // most groups (64 items, one wave's work) one half can have
+    uint32_t nb = 0;         // 2^k buckets per half
+    uint64_t packed_half = 0;   // capacity of one half of `packed`, in entries
+    uint32_t* words = nullptr;  // one allocation of gate_segs_words()
+    // items | order | bucket_begin | group_len | group_off | packed
+    uint2* items() const { return reinterpret_cast<uint2*>(words); }      // {first list entry, len | run << 8}
+    uint32_t* order() const { return words + 2 * (size_t)bound; }          // the items of each half by decreasing length
+    uint32_t* bucket_begin() const { return order() + bound; }             // 2 nb + 1 item offsets (+ 1 pad)
+    uint32_t* group_len() const { return bucket_begin() + 2 * (size_t)nb + 2; }   // 2 * groups: gates of a group's longest item
+    uint32_t* group_off() const { return group_len() + 2 * (size_t)groups; }      // 2 * groups + 1: first entry / 64 of the group in `packed`
+    // The list entries once more, in the order the pass reads them: group after group, inside a group step-major --
+    // entry (step j, lane l) = gate j of the group's item l -- so that a wave's load of one step is 256 contiguous bytes
+    // (per-lane walks through list / meta cost one cache line per gate and array).
+    // entry = (gate & mask) | other operand << shift | type << 31   (shift + k <= 31)
+    uint32_t* packed() const { return group_off() + 2 * (size_t)groups + 2; }
+};
+// the split point of eq(z, g) = E_hi[g >> shift] * E_lo[g & mask] the gate passes of this span use: k_i / 2 for the
+// bucket kernels, the segment shift where segments apply (a function of the span and the widths only)
+uint32_t gate_seg_shift(GateSpan span, uint32_t k_i, uint32_t k);
+size_t gate_segs_words(GateSpan span, uint32_t k_i, uint32_t k);           // u32 words of GateSegs::words (0: no segments)
+size_t gate_segs_scratch_words(GateSpan span, uint32_t k_i, uint32_t k);   // u32 words of build scratch
+size_t gate_seg_partial_elems(GateSpan span, uint32_t k_i, uint32_t k);    // Fr elements of pass scratch per proof
+void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
-                       uint32_t* lds_scratch, hipStream_t s);
+                       uint32_t* lds_scratch, GateSegs* segs, uint32_t* seg_scratch, hipStream_t s);
+// e_hi / e_lo_mont split at `kl` = gate_seg_shift() when segs->shift != 0 (partials: gate_seg_partial_elems() * batch
+// elements of scratch), else at any kl
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, hipStream_t s);
+                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, const GateSegs* segs,
+                    Fr* partials, hipStream_t s);
 void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      hipStream_t s);
+                      const GateSegs* segs, Fr* partials, hipStream_t s);
 // One launch per layer (small layers): the whole layer sumcheck of `batch` proofs as one resident kernel, one block
 // per proof, tables in LDS; rounds are handed to the host and challenges taken back through pinned memory, no
 // launch per round (kernels.hip, k_layer_persistent).

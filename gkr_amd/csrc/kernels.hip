@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "gate_seg.h"
 #include "mfma_fold.h"
 #include "mimc7.h"
 
@@ -1182,6 +1183,212 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Segments of the sorted gate lists (gate_seg.h).
+// The block-private sort leaves bucket b's gates as blocks-many runs in ascending block order, run j = the gates of
+// sort block j, and `starts[b * blocks + j]` is where it begins: `m` consecutive sort blocks make one segment.
+// ---------------------------------------------------------------------------
+// items per segment; segment s = bucket2 * runs + run over both halves (bucket2 < 2 * 2^k); cnt has nseg + 1 entries
+__global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ hist, uint32_t blocks,
+                                                   uint32_t m, uint32_t runs, uint32_t nseg, uint32_t* __restrict__ cnt) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseg) return;
+    if (s == nseg) {
+        cnt[s] = 0;
+        return;
+    }
+    const uint32_t b2 = s / runs, run = s - b2 * runs;
+    const uint32_t first = run * m, last = (first + m < blocks ? first + m : blocks) - 1;
+    const size_t row = (size_t)b2 * blocks;
+    const uint32_t len = starts[row + last] + hist[row + last] - starts[row + first];
+    cnt[s] = (len + kSegCap - 1) / kSegCap;
+}
+__global__ void __launch_bounds__(256) k_seg_fill(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ hist, uint32_t blocks,
+                                                  uint32_t m, uint32_t runs, uint32_t nseg, const uint32_t* __restrict__ off,
+                                                  uint2* __restrict__ items, uint32_t* __restrict__ bucket_begin) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseg) return;
+    const uint32_t b2 = s / runs, run = s - b2 * runs;
+    if (run == 0) bucket_begin[b2] = off[s];   // (s == nseg: b2 = 2 * 2^k, the total)
+    if (s == nseg) return;
+    const uint32_t first = run * m, last = (first + m < blocks ? first + m : blocks) - 1;
+    const size_t row = (size_t)b2 * blocks;
+    const uint32_t begin = starts[row + first], len = starts[row + last] + hist[row + last] - begin;
+    uint32_t o = off[s];
+    for (uint32_t done = 0; done < len; done += kSegCap, ++o)
+        items[o] = make_uint2(begin + done, (len - done < kSegCap ? len - done : kSegCap) | (run << 8));
+}
+// counting sort of the items by (half, decreasing length): block-private histograms in LDS, bin-major global layout,
+// one scan, block-private cursors (the scheme of k_gate_count_lds / k_gate_fill_lds with 2 * kSegCap bins)
+constexpr uint32_t kSegBins = 2 * kSegCap;
+__device__ __forceinline__ uint32_t seg_bin(uint32_t i, uint32_t half1_begin, uint32_t len) {
+    return (i >= half1_begin ? kSegCap : 0u) + (kSegCap - len);   // len in 1 .. kSegCap
+}
+__global__ void __launch_bounds__(256) k_seg_len_hist(const uint2* __restrict__ items, const uint32_t* __restrict__ bucket_begin, uint32_t nb,
+                                                      uint32_t per_block, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[kSegBins];
+    if (threadIdx.x < kSegBins) s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t half1 = bucket_begin[nb], total = bucket_begin[2 * nb];
+    const uint32_t begin = blockIdx.x * per_block, end = begin + per_block < total ? begin + per_block : total;
+    for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&s_h[seg_bin(i, half1, items[i].y & 0xffu)], 1u);
+    __syncthreads();
+    if (threadIdx.x < kSegBins) hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_h[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_seg_len_fill(const uint2* __restrict__ items, const uint32_t* __restrict__ bucket_begin, uint32_t nb,
+                                                      uint32_t per_block, const uint32_t* __restrict__ starts, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_c[kSegBins];
+    if (threadIdx.x < kSegBins) s_c[threadIdx.x] = starts[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const uint32_t half1 = bucket_begin[nb], total = bucket_begin[2 * nb];
+    const uint32_t begin = blockIdx.x * per_block, end = begin + per_block < total ? begin + per_block : total;
+    for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) order[atomicAdd(&s_c[seg_bin(i, half1, items[i].y & 0xffu)], 1u)] = i;
+}
+
+// Groups: 64 consecutive items of a half's length-sorted order = one wave's work.  group_len = the gates of its first
+// (longest) item; slot = half * groups + w.
+__global__ void __launch_bounds__(256) k_seg_group_len(const uint2* __restrict__ items, const uint32_t* __restrict__ order,
+                                                       const uint32_t* __restrict__ bucket_begin, uint32_t nb, uint32_t groups,
+                                                       uint32_t* __restrict__ group_len) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot > 2 * groups) return;
+    if (slot == 2 * groups) {
+        group_len[slot] = 0;
+        return;
+    }
+    const uint32_t half = slot >= groups ? 1u : 0u, w = slot - half * groups;
+    const uint32_t begin = bucket_begin[half ? nb : 0], end = bucket_begin[half ? 2 * nb : nb];
+    const uint32_t pos = begin + 64u * w;
+    group_len[slot] = pos < end ? (items[order[pos]].y & 0xffu) : 0u;
+}
+// one wave per group: the entries of its items, step-major (see GateSegs::packed)
+__global__ void __launch_bounds__(64) k_seg_pack(const uint2* __restrict__ items, const uint32_t* __restrict__ order,
+                                                 const uint32_t* __restrict__ bucket_begin, uint32_t nb, uint32_t groups,
+                                                 const uint32_t* __restrict__ group_len, const uint32_t* __restrict__ group_off,
+                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta, uint32_t gate_base,
+                                                 uint32_t shift, uint32_t* __restrict__ packed) {
+    const uint32_t slot = blockIdx.x, half = slot >= groups ? 1u : 0u, w = slot - half * groups;
+    const uint32_t n = group_len[slot];
+    if (!n) return;
+    const uint32_t begin = bucket_begin[half ? nb : 0], end = bucket_begin[half ? 2 * nb : nb];
+    const uint32_t pos = begin + 64u * w + threadIdx.x;
+    uint32_t first = 0, len = 0;
+    if (pos < end) {
+        const uint2 it = items[order[pos]];
+        first = it.x;
+        len = it.y & 0xffu;
+    }
+    uint32_t* dst = packed + (size_t)group_off[slot] * 64u + threadIdx.x;
+    const uint32_t lmask = (1u << shift) - 1u;
+    for (uint32_t j = 0; j < n; ++j) {
+        uint32_t v = 0u;
+        if (j < len) {
+            const uint32_t mt = meta[first + j];
+            v = ((list[first + j] + gate_base) & lmask) | ((mt & 0x7fffffffu) << shift) | (mt & 0x80000000u);
+        }
+        dst[(size_t)j * 64u] = v;
+    }
+}
+
+// One item per lane, longest items first (the lanes of a wave run the same number of steps): the unreduced sums of
+// E_lo[g & mask] * T[other operand] over the item's gates (gate_seg.h, seg_gate), left as 256-bit representatives for
+// k_seg_combine.  ROWS = false: the left-operand buckets with T = W (U, V); true: the right-operand buckets with
+// T = eq(u, .) (the row).  Per gate a wave streams 8 bytes (one coalesced load per step), gathers E_lo from L2 and
+// T from LDS (LDS_T: the 2^k-entry table copied into the block's LDS once; the blocks are resident and take groups
+// until none is left) -- the passes' first form gathered three operands per gate from L2 and was bound by those
+// cache-line transfers, not by its arithmetic.  The operands of step j + 1 are loaded before step j's products.
+// grid = (resident blocks, batch), block = 1024 (LDS_T) / 256
+template <bool ROWS, bool LDS_T>
+__global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __restrict__ items, const uint32_t* __restrict__ order,
+                                                                  const uint32_t* __restrict__ bucket_begin, uint32_t nb, uint32_t groups,
+                                                                  const uint32_t* __restrict__ group_len, const uint32_t* __restrict__ group_off,
+                                                                  const uint32_t* __restrict__ packed, const Fr* __restrict__ e_lo_mont, uint32_t shift,
+                                                                  const Fr* __restrict__ T, uint32_t tlen, uint32_t tstride, Fr* __restrict__ X,
+                                                                  Fr* __restrict__ Y, uint32_t pstride, uint32_t dbg_mask, uint32_t dbg_nomac) {
+    extern __shared__ uint4 s_raw[];
+    e_lo_mont += (size_t)blockIdx.y << shift;
+    T += (size_t)blockIdx.y * tstride;
+    const Fr* Tt = T;
+    if (LDS_T) {
+        const uint4* src = reinterpret_cast<const uint4*>(T);
+        for (uint32_t i = threadIdx.x; i < 2 * tlen; i += blockDim.x) s_raw[i] = src[i];
+        __syncthreads();
+        Tt = reinterpret_cast<const Fr*>(s_raw);
+    }
+    const uint32_t half = ROWS ? 1u : 0u;
+    const uint32_t begin = bucket_begin[half ? nb : 0], end = bucket_begin[half ? 2 * nb : nb];
+    const uint32_t lane = threadIdx.x & 63u, waves = blockDim.x >> 6, lmask = (1u << shift) - 1u;
+    const uint32_t ngroups = (end - begin + 63u) / 64u;
+    for (uint32_t w = blockIdx.x * waves + (threadIdx.x >> 6); w < ngroups; w += gridDim.x * waves) {
+        const uint32_t slot = half * groups + w, n = group_len[slot];
+        const uint32_t pos = begin + 64u * w + lane;
+        uint32_t idx = 0, len = 0;
+        if (pos < end) {
+            idx = order[pos];
+            len = items[idx].y & 0xffu;
+        }
+        if (dbg_nomac) len = 0;
+        const uint32_t* src = packed + (size_t)group_off[slot] * 64u + lane;
+        Lazy17 L0 = lazy_zero(), L1 = lazy_zero();
+        // Entries are requested four steps ahead and E_lo one step ahead: a step's two dependent loads (the entry from
+        // HBM, then the gather it addresses) would otherwise cost ~2 us per step with nothing to hide behind.
+        const uint32_t last = n - 1u, omask = (1u << (31u - shift)) - 1u;
+        uint32_t ent = src[0] & dbg_mask;
+        uint32_t p1 = src[(size_t)(1u < last ? 1u : last) * 64u], p2 = src[(size_t)(2u < last ? 2u : last) * 64u],
+                 p3 = src[(size_t)(3u < last ? 3u : last) * 64u];
+        Fr e = load_fr(e_lo_mont + (ent & lmask)), t;
+        if (!LDS_T) t = load_fr(Tt + ((ent >> shift) & omask));
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t p4 = src[(size_t)(j + 4u < last ? j + 4u : last) * 64u];
+            const uint32_t ent_n = p1 & dbg_mask;
+            const Fr e_n = load_fr(e_lo_mont + (ent_n & lmask));   // in flight while this step's products run
+            Fr t_n;
+            if (LDS_T)
+                t = load_fr(Tt + ((ent >> shift) & omask));   // LDS: no need to look ahead
+            else
+                t_n = load_fr(Tt + ((ent_n >> shift) & omask));
+            if (j < len) seg_gate<ROWS>(L0, L1, e, t, (ent >> 31) != 0u);
+            ent = ent_n;
+            e = e_n;
+            if (!LDS_T) t = t_n;
+            p1 = p2;
+            p2 = p3;
+            p3 = p4;
+        }
+        if (pos < end) {
+            const size_t o = (size_t)blockIdx.y * pstride + (idx - begin);
+            store_fr(X + o, lazy_reduce_partial32(L0));
+            store_fr(Y + o, lazy_reduce_partial32(L1));
+        }
+    }
+}
+// out0[bucket] = sum over the bucket's items of E_hi[run] * X[item], out1 likewise with Y: one wave per bucket.
+// grid = (2^k, batch), block = 64
+__global__ void __launch_bounds__(64) k_seg_combine(const uint2* __restrict__ items, const uint32_t* __restrict__ bucket_begin, uint32_t b_first,
+                                                    const Fr* __restrict__ X, const Fr* __restrict__ Y, uint32_t pstride,
+                                                    const Fr* __restrict__ e_hi, uint32_t kh, uint32_t run_base, Fr* __restrict__ out0,
+                                                    Fr* __restrict__ out1, uint32_t wstride) {
+    const uint32_t half_begin = bucket_begin[b_first], lo = bucket_begin[b_first + blockIdx.x], hi = bucket_begin[b_first + blockIdx.x + 1];
+    e_hi += ((size_t)blockIdx.y << kh) + run_base;
+    X += (size_t)blockIdx.y * pstride;
+    Y += (size_t)blockIdx.y * pstride;
+    Lazy17 A = lazy_zero(), B = lazy_zero();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 64) {
+        const Fr eh = load_fr(e_hi + (items[i].y >> 8));
+        lazy_mac_v(A, load_fr(X + (i - half_begin)), eh);
+        lazy_mac_v(B, load_fr(Y + (i - half_begin)), eh);
+    }
+    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
+    acc_add_fr(acc[0], lazy_reduce(A));
+    acc_add_fr(acc[1], lazy_reduce(B));
+    acc[0] = wave_sum(acc[0]);
+    acc[1] = wave_sum(acc[1]);
+    if (threadIdx.x == 0) {
+        store_fr(out0 + (size_t)blockIdx.y * wstride + blockIdx.x, acc_reduce(acc[0]));
+        store_fr(out1 + (size_t)blockIdx.y * wstride + blockIdx.x, acc_reduce(acc[1]));
+    }
+}
+
 // widened cell -> canonical Fr.  limb sums < 2^32 * 2^32; value < 2^32 r.
 __global__ void k_predicate_normalise(const unsigned long long* __restrict__ wide, Fr* __restrict__ out, size_t cells) {
     for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
@@ -2266,11 +2473,78 @@ size_t gate_lists_lds_scratch_words(uint64_t gates, uint32_t k) {
     return 2 * n + (n + kScanPerBlock - 1) / kScanPerBlock + 1;
 }
 
-void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+// ---- segments: where they apply and what they need ---------------------------------------------------------------------
+static uint32_t log2_exact(uint64_t x) {   // log2 of a power of two, else 64
+    if (!x || (x & (x - 1))) return 64;
+    uint32_t l = 0;
+    while ((x >> l) != 1) ++l;
+    return l;
+}
+struct SegPlan {
+    uint32_t shift = 0, runs = 0, run_base = 0, m = 0, blocks = 0, nseg = 0, bound = 0, half_bound = 0, len_blocks = 0, groups = 0;
+    uint64_t packed_half = 0;
+};
+static SegPlan seg_plan(GateSpan span, uint32_t k_i, uint32_t k) {
+    SegPlan p;
+    static const bool off = getenv("GKR_GATE_SEGMENTS_OFF") != nullptr;
+    static const uint32_t min_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENTS_MIN_LOG2"); return e ? (uint32_t)atoi(e) : 19u; }();
+    static const uint32_t mean_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENT_LOG2"); return e && atoi(e) >= 2 && atoi(e) <= 8 ? (uint32_t)atoi(e) : kSegMeanLog2; }();
+    const uint32_t blocks = gate_lists_lds_blocks(span.count, k);
+    if (off || !blocks || span.count < ((uint64_t)1 << min_log2) || span.count > ((uint64_t)1 << 31)) return p;
+    const uint64_t per_block = (span.count + blocks - 1) / blocks;
+    const uint32_t pb = log2_exact(per_block);
+    if (pb == 64 || span.count % per_block) return p;              // blocks of a power of two of gates, all full
+    uint32_t shift = k + mean_log2 > pb ? k + mean_log2 : pb;       // segments of 2^mean_log2 gates on average
+    if (shift > k_i) shift = k_i;
+    if (shift < pb || shift > 20 || shift + k > 31 || (span.base & (((uint64_t)1 << shift) - 1))) return p;   // E_lo: at most 2^20 entries; a packed entry is 32 bits; aligned span
+    p.shift = shift;
+    p.m = 1u << (shift - pb);
+    p.blocks = blocks;
+    p.runs = (blocks + p.m - 1) / p.m;
+    p.run_base = (uint32_t)(span.base >> shift);
+    p.nseg = (2u << k) * p.runs;
+    const uint64_t half = ((uint64_t)p.runs << k) + span.count / kSegCap + 1;
+    if (2 * half > ((uint64_t)1 << 31) || p.runs >= (1u << 24)) return SegPlan();
+    p.half_bound = (uint32_t)half;
+    p.bound = (uint32_t)(2 * half);
+    p.len_blocks = (p.bound + 16383) / 16384;
+    if (p.len_blocks > 1024) p.len_blocks = 1024;
+    p.groups = p.half_bound / 64 + 1;
+    // a half's groups, each padded to its longest item: sorted by length, the padding telescopes to < 64 * kSegCap
+    // entries, plus a last partial group
+    p.packed_half = span.count + 2 * 64 * (uint64_t)kSegCap + 64;
+    return p;
+}
+uint32_t gate_seg_shift(GateSpan span, uint32_t k_i, uint32_t k) {
+    const SegPlan p = seg_plan(span, k_i, k);
+    return p.shift ? p.shift : k_i / 2;
+}
+size_t gate_segs_words(GateSpan span, uint32_t k_i, uint32_t k) {
+    const SegPlan p = seg_plan(span, k_i, k);
+    if (!p.shift) return 0;
+    return 3 * (size_t)p.bound + ((size_t)2 << k) + 2 + 2 * (size_t)p.groups + (2 * (size_t)p.groups + 2) + 2 * (size_t)p.packed_half;
+}
+size_t gate_segs_scratch_words(GateSpan span, uint32_t k_i, uint32_t k) {
+    const SegPlan p = seg_plan(span, k_i, k);
+    if (!p.shift) return 0;
+    const size_t a = (size_t)p.nseg + 1, b = (size_t)kSegBins * p.len_blocks, c = 2 * (size_t)p.groups + 1;
+    return 2 * a + (a + kScanPerBlock - 1) / kScanPerBlock + 1 + 2 * b + (b + kScanPerBlock - 1) / kScanPerBlock + 1 +
+           (c + kScanPerBlock - 1) / kScanPerBlock + 1;
+}
+size_t gate_seg_partial_elems(GateSpan span, uint32_t k_i, uint32_t k) {
+    const SegPlan p = seg_plan(span, k_i, k);
+    return p.shift ? 2 * (size_t)p.half_bound : 0;
+}
+
+void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
-                       uint32_t* lds_scratch, hipStream_t s) {
+                       uint32_t* lds_scratch, GateSegs* segs, uint32_t* seg_scratch, hipStream_t s) {
+    const uint64_t gates = span.count;
     const size_t n = (size_t)2 << k;
     const uint32_t lblocks = lds_scratch ? gate_lists_lds_blocks(gates, k) : 0;
+    if (segs) {
+        segs->shift = 0;
+    }
     if (lblocks) {
         const size_t cells = n * lblocks;
         uint32_t *hist = lds_scratch, *starts = lds_scratch + cells, *sums = lds_scratch + 2 * cells;
@@ -2285,6 +2559,45 @@ void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, con
                            cursor);
         hipLaunchKernelGGL(k_gate_fill_lds, dim3(lblocks), dim3(256), lds, s, gates, k, per_block, gate_type, left, right, starts, list,
                            list + gate_list_words(gates));
+        const SegPlan p = seg_plan(span, k_i, k);
+        if (segs && segs->words && seg_scratch && p.shift) {
+            // the segments of both halves: count the items, scan, fill; then the items of each half by decreasing length
+            const size_t a = (size_t)p.nseg + 1, b = (size_t)kSegBins * p.len_blocks;
+            const uint32_t ablocks = (uint32_t)((a + kScanPerBlock - 1) / kScanPerBlock), bblocks = (uint32_t)((b + kScanPerBlock - 1) / kScanPerBlock);
+            uint32_t *cnt = seg_scratch, *off = cnt + a, *asums = off + a, *lh = asums + ablocks + 1, *ls = lh + b, *bsums = ls + b,
+                     *csums = bsums + bblocks + 1;
+            segs->shift = p.shift;
+            segs->runs = p.runs;
+            segs->run_base = p.run_base;
+            segs->bound = p.bound;
+            segs->half_bound = p.half_bound;
+            segs->groups = p.groups;
+            segs->nb = 1u << k;
+            segs->packed_half = p.packed_half;
+            const dim3 sg((unsigned)((a + 255) / 256));
+            hipLaunchKernelGGL(k_seg_count, sg, dim3(256), 0, s, starts, hist, lblocks, p.m, p.runs, p.nseg, cnt);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(ablocks), dim3(256), 0, s, cnt, off, asums, a);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, asums, ablocks);
+            hipLaunchKernelGGL(k_scan_add, dim3(ablocks), dim3(256), 0, s, off, (uint32_t*)nullptr, asums, a);
+            hipLaunchKernelGGL(k_seg_fill, sg, dim3(256), 0, s, starts, hist, lblocks, p.m, p.runs, p.nseg, off, segs->items(), segs->bucket_begin());
+            const uint32_t per = (p.bound + p.len_blocks - 1) / p.len_blocks;
+            hipLaunchKernelGGL(k_seg_len_hist, dim3(p.len_blocks), dim3(256), 0, s, segs->items(), segs->bucket_begin(), 1u << k, per, lh);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(bblocks), dim3(256), 0, s, lh, ls, bsums, b);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, bsums, bblocks);
+            hipLaunchKernelGGL(k_scan_add, dim3(bblocks), dim3(256), 0, s, ls, (uint32_t*)nullptr, bsums, b);
+            hipLaunchKernelGGL(k_seg_len_fill, dim3(p.len_blocks), dim3(256), 0, s, segs->items(), segs->bucket_begin(), 1u << k, per, ls, segs->order());
+            // the groups of 64 items, where each begins in the step-major copy of the entries, and that copy
+            const size_t c = 2 * (size_t)p.groups + 1;
+            const uint32_t cblocks = (uint32_t)((c + kScanPerBlock - 1) / kScanPerBlock);
+            hipLaunchKernelGGL(k_seg_group_len, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, s, segs->items(), segs->order(), segs->bucket_begin(),
+                               1u << k, p.groups, segs->group_len());
+            hipLaunchKernelGGL(k_scan_blocks, dim3(cblocks), dim3(256), 0, s, segs->group_len(), segs->group_off(), csums, c);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, csums, cblocks);
+            hipLaunchKernelGGL(k_scan_add, dim3(cblocks), dim3(256), 0, s, segs->group_off(), (uint32_t*)nullptr, csums, c);
+            hipLaunchKernelGGL(k_seg_pack, dim3(2 * p.groups), dim3(64), 0, s, segs->items(), segs->order(), segs->bucket_begin(), 1u << k, p.groups,
+                               segs->group_len(), segs->group_off(), list, list + gate_list_words(gates), (uint32_t)span.base, p.shift,
+                               segs->packed());
+        }
         return;
     }
     const uint32_t gblocks = blocks_for(gates, 4096);
@@ -2296,17 +2609,69 @@ void launch_gate_lists(uint64_t gates, uint32_t k, const uint8_t* gate_type, con
     hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, cursor, list, list + gate_list_words(gates));
 }
 
+static uint32_t device_cus() {
+    static const uint32_t n = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256u;
+        return (uint32_t)prop.multiProcessorCount;
+    }();
+    return n;
+}
+template <bool ROWS, bool LDS_T>
+static void launch_seg_pass_t(const GateSegs& g, uint32_t k, const Fr* e_lo_mont, const Fr* T, Fr* X, Fr* Y, LayerBatch lb, hipStream_t s) {
+    const uint32_t tlen = 1u << k;
+    const size_t lds = LDS_T ? (size_t)tlen * sizeof(Fr) : 0;
+    static bool attr_set = false;   // (idempotent; a race sets it twice)
+    if (LDS_T && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_pass<ROWS, LDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    // resident blocks: one 1024-thread block per CU with the table in LDS; 256-thread blocks, four per CU, without
+    const uint32_t blocks = LDS_T ? device_cus() : 4 * device_cus();
+    // (experiments only -- wrong results: E_lo indices masked so that the gather always hits L1; no arithmetic)
+    static const uint32_t dbg_lo = [] { const char* e = getenv("GKR_DEBUG_SEG_ELO_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
+    const uint32_t dbg_mask = dbg_lo | ~((1u << g.shift) - 1u);
+    static const uint32_t dbg_nomac = getenv("GKR_DEBUG_SEG_NO_MAC") ? 1u : 0u;
+    hipLaunchKernelGGL((k_seg_pass<ROWS, LDS_T>), dim3(blocks, lb.batch), dim3(LDS_T ? 1024 : 256), lds, s, g.items(), g.order(), g.bucket_begin(),
+                       g.nb, g.groups, g.group_len(), g.group_off(), g.packed(), e_lo_mont, g.shift, T, tlen,
+                       (uint32_t)lb.wstride, X, Y, g.half_bound, dbg_mask, dbg_nomac);
+}
+static void launch_seg_pass(bool rows, const GateSegs& g, uint32_t k, const Fr* e_lo_mont, const Fr* T, Fr* X, Fr* Y, LayerBatch lb, hipStream_t s) {
+    static const bool no_lds = getenv("GKR_GATE_SEGMENTS_NO_LDS") != nullptr;
+    const bool lds_t = !no_lds && ((size_t)sizeof(Fr) << k) <= 128 * 1024;
+    if (rows)
+        lds_t ? launch_seg_pass_t<true, true>(g, k, e_lo_mont, T, X, Y, lb, s) : launch_seg_pass_t<true, false>(g, k, e_lo_mont, T, X, Y, lb, s);
+    else
+        lds_t ? launch_seg_pass_t<false, true>(g, k, e_lo_mont, T, X, Y, lb, s) : launch_seg_pass_t<false, false>(g, k, e_lo_mont, T, X, Y, lb, s);
+}
+
 static uint32_t bucket_threads(uint64_t gates, uint32_t k) { return (gates >> k) > 64u ? 256u : 64u; }   // gates per bucket on average
 
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, hipStream_t s) {
+                    const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, const GateSegs* segs,
+                    Fr* partials, hipStream_t s) {
+    if (segs && segs->shift && partials) {
+        Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
+        launch_seg_pass(false, *segs, k, e_lo_mont, W, X, Y, lb, s);
+        hipLaunchKernelGGL(k_seg_combine, dim3(1u << k, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 0u, X, Y, segs->half_bound,
+                           e_hi, k_i - segs->shift, segs->run_base, U, V, (uint32_t)lb.wstride);
+        return;
+    }
     hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
                        list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
 }
 
 void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      hipStream_t s) {
+                      const GateSegs* segs, Fr* partials, hipStream_t s) {
+    if (segs && segs->shift && partials) {
+        Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
+        launch_seg_pass(true, *segs, k, e_lo_mont, eq_mont, X, Y, lb, s);
+        hipLaunchKernelGGL(k_seg_combine, dim3(1u << k, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 1u << k, X, Y,
+                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, A_row, M_row, (uint32_t)lb.wstride);
+        return;
+    }
     hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
                        list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride,
                        (uint32_t)span.base);

@@ -117,7 +117,9 @@ class TorchCollective:
 
 
 class DeviceExchange:
-    """gkr_exchange_dev over torch.distributed with backend nccl (= RCCL over xGMI): the limb buffer is a CUDA int64
+    """(Order of initialisation in a process: torch's GPU runtime first -- init_process_group / torch.cuda.init() -- then
+    the first gkr Context; the other way round torch finds no device on this image.)
+    gkr_exchange_dev over torch.distributed with backend nccl (= RCCL over xGMI): the limb buffer is a CUDA int64
     tensor the library widens into and narrows from; the hook queues ONE in-place SUM all-reduce on the library's HIP
     stream (wrapped as torch.cuda.ExternalStream), so nothing crosses PCIe and no stream is synchronised
     (include/gkr_amd.h, gkr_resident_layer_sumcheck_dev; the reference's counterpart is the rayon reduce of

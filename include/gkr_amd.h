@@ -149,6 +149,11 @@ int  gkr_selftest_pass_schedule(int n, int mfma, uint32_t *rounds, size_t capaci
 /* q(t) = W(b + t (c - b)) (reduce_multiple_polynomial, poly.rs:469-500) as gkr_prove computes it on the host: W = 2^k
  * evaluations; out = k + 1 slots right-aligned, highest degree first; *out_len = 1 + largest monomial degree of W */
 int  gkr_selftest_line_restriction(int k, const gkr_fr *W, const gkr_fr *b, const gkr_fr *c, gkr_fr *out, uint32_t *out_len);
+/* one item (<= 32 gates) of a gate-list segment and its combine step, on the host twins of the device code
+ * (csrc/gate_seg.h): rows = 0: out0 = e_hi * sum_i e_lo[i] (is_mult[i] ? t[i] : 1), out1 = e_hi * sum_{!is_mult} e_lo[i] t[i]
+ * (the U, V sums of sumcheck.rs:50-63); rows = 1: out0 over the add gates, out1 over the mult gates (:97-124) */
+int  gkr_selftest_seg_item(const gkr_fr *e_lo, const gkr_fr *t, const uint8_t *is_mult, size_t n, const gkr_fr *e_hi, int rows,
+                           gkr_fr *out0, gkr_fr *out1);
 /* lo + r (hi - lo) through the fixed-multiplier table the fold kernels use */
 int  gkr_selftest_fold(const gkr_fr *lo, const gkr_fr *hi, const gkr_fr *r, gkr_fr *out);
 

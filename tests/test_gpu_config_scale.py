@@ -34,15 +34,47 @@ def config5_expected(tmp_path_factory):
     return path, (C, L, R)
 
 
-@pytest.mark.parametrize("env", [{}, {"GKR_GATE_SORT_GLOBAL": "1", "GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"},
+@pytest.mark.parametrize("env", [{}, {"GKR_GATE_SEGMENTS_OFF": "1"}, {"GKR_GATE_SEGMENT_LOG2": "6"},
+                                 {"GKR_GATE_SORT_GLOBAL": "1", "GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"},
                                  {"GKR_LAYER_DENSE_B": "1"}],
-                         ids=["default(gate lists, block-private sort)", "gate lists, global-atomic sort",
-                              "dense tables, linear-time rounds", "dense b-phase passes"])
+                         ids=["default(gate lists, block-private sort, segment passes)", "bucket passes (no segments)", "segments of 64 gates",
+                              "gate lists, global-atomic sort", "dense tables, linear-time rounds", "dense b-phase passes"])
 def test_config5_layer_every_form_matches_oracle(config5_expected, env):
     path, _ = config5_expected
     out = subprocess.run([sys.executable, os.path.join(HERE, "config_scale_worker.py"), str(K_I), str(K), path],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("k_i,k,env", [(16, 8, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}), (18, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}),
+                                       (19, 12, {}), (20, 10, {}), (21, 9, {"GKR_GATE_SEGMENT_LOG2": "3"}), (22, 11, {})])
+def test_segment_passes_at_other_widths_match_oracle(tmp_path, k_i, k, env):
+    """The segment form of the gate passes (csrc/gate_seg.h) where the split of eq(z, .) and the number of sort blocks
+    per segment take other values than at configs[4]'s size (one block per segment, many, segments of 8 gates)."""
+    lay, z, W = synth.config5_layer(k_i, k)
+    C, L, R = cdense.sumcheck_layer_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+    path = str(tmp_path / "expected.npz")
+    np.savez(path, C=C, L=L, R=R)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "config_scale_worker.py"), str(k_i), str(k), path],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_segment_passes_with_skewed_buckets_match_oracle():
+    """Segments far from the average: every gate of the first quarter of the layer wired to ONE left operand (segments
+    of 2^16 gates, cut into items of 32), a bucket nobody uses, all gates of one type in a stretch."""
+    k_i, k = 20, 10
+    lay, z, W = synth.config5_layer(k_i, k, seed=77)
+    gt, l, r = (a.copy() for a in lay.arrays())
+    l[: 1 << 18] = 5
+    r[1 << 18: 1 << 19] = 1023
+    l[l == 7] = 8
+    gt[3 << 18:] = 1
+    want = cdense.sumcheck_layer_raw(k_i, k, gt, l, r, z, W)
+    from gkr_amd import Layer
+    with Context(0) as ctx:
+        got = ctx.sumcheck_layer_raw(Layer(k_i, gt, l, r), k, z, W)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
 
 
 def test_config5_layer_eight_logical_ranks_match_oracle(config5_expected):

@@ -96,6 +96,37 @@ def test_lazy_dot_product_on_host_matches_bigints():
         assert from_limbs(O)[0] == sum(x * y for x, y in zip(a, b)) % P
 
 
+def test_gate_segment_item_on_host_matches_bigints():
+    """One item of a sorted gate list's segment (csrc/gate_seg.h) on the host twins of the device code: the selected
+    lazy accumulate, the "no second factor" term added at 2^256, the partial reduction with its two top-limb folds (worst
+    case: 32 add gates of p - 1), the combine step with E_hi."""
+    lib = N.lib()
+    rng = random.Random(66)
+    for trial in range(40):
+        n = [0, 1, 32, 32, 32, 17][trial] if trial < 6 else rng.randint(1, 32)
+        e = [rng.randrange(P) for _ in range(n)]
+        t = [rng.randrange(P) for _ in range(n)]
+        m = [rng.randint(0, 1) for _ in range(n)]
+        if trial == 2:
+            e, t, m = [P - 1] * n, [P - 1] * n, [0] * n
+        if trial == 3:
+            e, t, m = [P - 1] * n, [P - 1] * n, [1] * n
+        eh = rng.randrange(P) if trial != 4 else P - 1
+        E = to_limbs(e) if n else np.zeros((0, 4), dtype=np.uint64)
+        T = to_limbs(t) if n else np.zeros((0, 4), dtype=np.uint64)
+        M = np.asarray(m, dtype=np.uint8)
+        for rows in (0, 1):
+            O0, O1 = np.zeros((1, 4), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64)
+            assert lib.gkr_selftest_seg_item(_p(E), _p(T), _p(M), ctypes.c_size_t(n), _p(to_limbs([eh])), ctypes.c_int(rows), _p(O0), _p(O1)) == 0
+            if rows:
+                want0 = eh * sum(x * y for x, y, mm in zip(e, t, m) if not mm) % P
+                want1 = eh * sum(x * y for x, y, mm in zip(e, t, m) if mm) % P
+            else:
+                want0 = eh * sum(x * (y if mm else 1) for x, y, mm in zip(e, t, m)) % P
+                want1 = eh * sum(x * y for x, y, mm in zip(e, t, m) if not mm) % P
+            assert from_limbs(O0)[0] == want0 and from_limbs(O1)[0] == want1, (trial, rows)
+
+
 def test_batched_transcript_hash_matches_oracle():
     """the eight-lane (AVX-512 IFMA where available) MiMC7 of the host transcript, every length mix"""
     lib = N.lib()
