@@ -104,6 +104,30 @@ class World:
             self.dist.destroy_process_group()
 
 
+def transcript_threads():
+    """Host threads a context's transcript uses by default (gkr_capi.hip, default_host_threads): the rank's share of the
+    usable CPUs, two (one, none) of them left to the runtime's own threads."""
+    if os.environ.get("GKR_HOST_THREADS", "").isdigit() and int(os.environ["GKR_HOST_THREADS"]) >= 1:
+        return int(os.environ["GKR_HOST_THREADS"])
+    share = usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(64, share - 2 if share >= 6 else (share - 1 if share >= 3 else share)))
+
+
+def transcript_floor(hashed_elements, vector_len, threads, achieved_ms):
+    """The bound of a leg whose step time is the host's MiMC7 hashing: every round vector of every sumcheck is hashed
+    once (Mimc7::multi_hash, sumcheck.rs:84,129,152: 91 rounds per element), the hashes of one sumcheck are a serial
+    chain, those of different sumchecks are independent.  floor = hashed elements x the measured time per element on
+    one thread (sixteen transcripts in IFMA lanes, measured now on this host) / threads."""
+    from gkr_amd.prover import host_hash_us
+    lanes16, scalar = host_hash_us(vector_len)
+    per_elem = (lanes16 if lanes16 > 0 else scalar) / vector_len
+    floor_ms = hashed_elements * per_elem / threads / 1e3
+    return {"bound": "host transcript (MiMC7 hashing throughput of the host cores)", "hashed_elements_per_step": int(hashed_elements),
+            "us_per_hash_16_lanes": lanes16, "us_per_hash_scalar": scalar, "vector_len_timed": vector_len, "threads": threads,
+            "floor_ms": floor_ms, "achieved_ms": achieved_ms, "achieved_over_floor": achieved_ms / floor_ms if floor_ms else None,
+            "frac": floor_ms / achieved_ms if achieved_ms else None}
+
+
 def cgroup_cpu_stat():
     """nr_throttled / throttled_usec of this container's CPU controller ({} where there is none): spinning on more
     threads than the quota allows gets the whole process stopped for the rest of a 100 ms period."""
@@ -302,6 +326,8 @@ def run_mle(args, world):
                               "separately (kernel_ms.mle_multifold_late): their elapsed time is not their own cost",
             },
             "verified": dict(verified, all_ranks_ok=ranks_failed == 0.0),
+            # the step's other resource: the host hashes batch x n round vectors per step
+            "host_transcript": transcript_floor(int(outputs[0][1].sum()), 2, transcript_threads(), elapsed / args.steps * 1e3),
             "kernel_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
             # every byte the schedule moves (pass 0 reads the tables once, every fold pass reads its source and writes
             # its output: ~66 * 2^n per sumcheck with five rounds per pass) over WALL time: the whole step as bandwidth
@@ -364,6 +390,8 @@ def run_mle(args, world):
             dt = (time.perf_counter() - t) / 5
             extras["n16"] = {"workload": "BASELINE configs[1]: 2^16 points per table, batch %d" % b16,
                              "value": 5 * ((1 << 16) - 1) * b16 / dt, "unit": "field-ops/s", "ms_per_step": dt * 1e3}
+            extras["n16"]["roofline"] = transcript_floor(int(out16[0][1].sum()), 2, transcript_threads(), dt * 1e3)
+            extras["n16"]["roofline"]["hbm_GBps_whole_step"] = (66.0 * (1 << 16) * b16) / dt / 1e9   # ~66 * 2^n bytes per sumcheck over wall time
             gold = synth.bench_batch_digests()
             if gold and world.rank == 0 and n == gold.get("n") and b16 == gold.get("n16_tables") and not args.no_verify:
                 extras["n16"]["whole_batch_digest"] = _sha(*out16[0]) == gold["n16_whole_batch_rank0"]
@@ -444,6 +472,8 @@ def aggregated_proofs(world, n_inputs):
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt,
                       "ms_each_rank0": each}
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
+    hashed = sum(int(arrs[1].sum()) for arrs in step._prepared["outs"])   # lengths of all round vectors of the last step
+    out["config3"]["roofline"] = transcript_floor(hashed, 3, threads, dt * 1e3)
     ctx.close()
     step.close()
     return out

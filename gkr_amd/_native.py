@@ -35,7 +35,7 @@ SYMBOLS = [
     "gkr_wtns_parse", "gkr_wtns_serialize", "gkr_r1cs_compile", "gkr_layered_count", "gkr_layered_circuit",
     "gkr_layered_input_layer", "gkr_layered_input_values", "gkr_layered_free",
     "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
-    "gkr_device_fill_table", "gkr_device_synchronize", "gkr_ubench_ceilings",
+    "gkr_device_fill_table", "gkr_device_synchronize", "gkr_ubench_ceilings", "gkr_ubench_host_hash",
     "gkr_layer_session_open", "gkr_layer_session_open_tables", "gkr_layer_session_dep", "gkr_layer_session_rounds",
     "gkr_layer_session_sums", "gkr_layer_session_bind", "gkr_layer_session_tail", "gkr_layer_session_close",
     "gkr_mle_session_open", "gkr_mle_session_sums", "gkr_mle_session_bind", "gkr_mle_session_value",

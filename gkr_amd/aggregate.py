@@ -200,11 +200,21 @@ class ProvingStep:
 
     def prove_raw_many(self, ctx, inputs, max_concurrent=0):
         """The same step through gkr_prove_many: one call, the library's own threads and child contexts instead of
-        interpreter threads (no GIL hand-offs, no thread start per call).  -> the challenge arrays, as prove_raw."""
-        key = tuple(x.ctypes.data for x in inputs) + tuple(x.shape[0] for x in inputs)
-        if getattr(self, "_prepared_key", None) != (id(ctx), key):
+        interpreter threads (no GIL hand-offs, no thread start per call).  -> the challenge arrays, as prove_raw.
+
+        `inputs` must be C-contiguous uint64 arrays (what inputs_for returns): the prepared item list points INTO them,
+        so that a caller proving step after step updates them in place; the list is kept for as long as the same array
+        objects and the same (open) context come back.  The returned arrays are the prepared list's output buffers:
+        the next call overwrites them -- copy what must outlive it."""
+        for x in inputs:
+            if not (isinstance(x, np.ndarray) and x.dtype == np.uint64 and x.flags["C_CONTIGUOUS"]):
+                raise ValueError("prove_raw_many needs C-contiguous uint64 input arrays (a converted copy would not see later updates)")
+        handle = getattr(ctx, "_h", None)
+        key = (id(ctx), handle.value if handle else None) + tuple(id(x) for x in inputs) + tuple(x.shape for x in inputs)
+        if getattr(self, "_prepared_key", None) != key or handle is None or not handle.value:
             self._prepared = ctx.prepare_many(list(zip(self.circuits, inputs)))
-            self._prepared_key = (id(ctx), key)
+            self._prepared_inputs = list(inputs)   # the key holds ids: keep the objects alive so that no id is reused
+            self._prepared_key = key
         return [arrs[2] for arrs in ctx.prove_many_raw(self._prepared, max_concurrent)]
 
     @staticmethod

@@ -1429,7 +1429,17 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
                     const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
                     const LayerShardArgs* shard = nullptr, GateLists* cached = nullptr) {
     const bool was_ready = cached && cached->ready;
-    const int rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached);
+    int rc = GKR_OK;
+    if (ctx->transcript != GKR_TRANSCRIPT_HOST && batch > 1 && !shard) {
+        // The device transcript hashes on one lane per sumcheck and its round kernels take one proof: the proofs of a
+        // batch go through one after the other (complete and host-free, not fast: ~1 ms per round and proof).
+        const size_t wlen = (size_t)1 << k;
+        for (int b = 0; b < batch && rc == GKR_OK; ++b)
+            rc = run_layer_batch_impl(ctx, 1, k_i, k, d_gt, d_l, d_r, z + (size_t)b * k_i, d_W + (size_t)b * wlen, out_coeffs + b, out_len + b,
+                                      out_r + b, nullptr, cached);
+    } else {
+        rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached);
+    }
     if (rc && cached && !was_ready) cached->ready = false;
     return rc;
 }
@@ -2542,6 +2552,47 @@ int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int
     return GKR_OK;
 }
 
+// the transcript's own ceiling on this host: microseconds per MiMC7 multi_hash of a `len`-element round vector (len 2:
+// plain sumcheck; 3: layer sumcheck) on one thread -- sixteen transcripts side by side in IFMA lanes (per hash, i.e.
+// call time / 16; 0 where the CPU has no IFMA) and one transcript on the scalar 4 x 64-bit code
+int gkr_ubench_host_hash(int len, double* us_per_hash_lanes16, double* us_per_hash_scalar) {
+    if (len < 1 || len > 3 || !us_per_hash_lanes16 || !us_per_hash_scalar) return GKR_ERR_INVALID;
+    uint64_t v16[16][3][4], o16[16][4];
+    uint32_t len16[16];
+    for (int k = 0; k < 16; ++k) {
+        len16[k] = (uint32_t)len;
+        for (int e = 0; e < 3; ++e)
+            for (int j = 0; j < 4; ++j) v16[k][e][j] = j == 3 ? 0x0123456789abcdefull >> 4 : 0x9E3779B97F4A7C15ull * (uint64_t)(k * 12 + e * 4 + j + 1);
+    }
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    *us_per_hash_lanes16 = 0.0;
+    if (host_ifma_ready()) {
+        double best = 1e30;
+        for (int rep = 0; rep < 5; ++rep) {
+            const auto t0 = now();
+            for (int i = 0; i < 64; ++i) {
+                gkr::gkr_ifma_multi_hash16(v16, len16, 3, o16);
+                memcpy(v16[i & 15][2], o16[(i + 1) & 15], 32);   // (keeps the calls dependent)
+            }
+            const double us = std::chrono::duration<double, std::micro>(now() - t0).count() / (64.0 * 16.0);
+            if (us < best) best = us;
+        }
+        *us_per_hash_lanes16 = best;
+    }
+    const gkr::h64::F* cts = host_mimc_constants64();
+    gkr::h64::F v[3];
+    memcpy(v, v16[0], 96);
+    double best = 1e30;
+    for (int rep = 0; rep < 5; ++rep) {
+        const auto t0 = now();
+        for (int i = 0; i < 32; ++i) v[2] = gkr::h64::mimc7_multi_hash(v + (3 - len), len, cts, nullptr);
+        const double us = std::chrono::duration<double, std::micro>(now() - t0).count() / 32.0;
+        if (us < best) best = us;
+    }
+    *us_per_hash_scalar = best;
+    return GKR_OK;
+}
+
 int gkr_selftest_dot(const gkr_fr* a, const gkr_fr* b, size_t n, gkr_fr* out) {
     if ((!a || !b) && n) return GKR_ERR_INVALID;
     if (!out) return GKR_ERR_INVALID;
@@ -3180,7 +3231,10 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
                              srp.data(), nullptr, &pc->lists[i]);
         ctx->rounds_ahead = 0;
-        if (rc) return rc;
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->aux);   // earlier layers' line restrictions still write the pinned q buffers the next call reuses
+            return rc;
+        }
         const auto tl1 = std::chrono::steady_clock::now();
         std::vector<gkr_fr> z_next((size_t)batch * k);
         {

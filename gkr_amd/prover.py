@@ -101,6 +101,15 @@ def multi_hash(values, key=0):
     return from_limbs(out)[0]
 
 
+def host_hash_us(length):
+    """(us per hash in sixteen IFMA lanes, us per scalar hash) of a `length`-element round vector on one host thread."""
+    a, b = ctypes.c_double(), ctypes.c_double()
+    rc = N.lib().gkr_ubench_host_hash(ctypes.c_int(length), ctypes.byref(a), ctypes.byref(b))
+    if rc:
+        raise GkrError(rc)
+    return a.value, b.value
+
+
 def _proof_bufs(arrays, B):
     """The B gkr_proof_buf structures (nine pointers each) over arrays whose first axis is the proof: one address
     matrix, base + b * stride per array, built in numpy -- not B x 9 ctypes objects (0.5 - 1 ms of interpreter time per

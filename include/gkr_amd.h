@@ -463,6 +463,10 @@ int  gkr_device_synchronize(gkr_ctx *ctx);
  * GB/s, and the chip-wide rate of 254-bit Montgomery products (dependent chains, 16 waves per SIMD) -- the
  * arithmetic ceiling of the gate passes of prove_sumcheck_opt (sumcheck.rs:50-63, 97-124).  No reference
  * counterpart: measurement only. */
+/* host only: microseconds per Mimc7::multi_hash (sumcheck.rs:84,129,152) of a len-element round vector on ONE thread
+ * of this host: sixteen transcripts side by side in AVX-512 IFMA lanes (time per hash; 0 without IFMA), and one
+ * transcript on the scalar code.  The legs of the bench that are bound by the transcript quote their floor from it. */
+int  gkr_ubench_host_hash(int len, double *us_per_hash_lanes16, double *us_per_hash_scalar);
 int  gkr_ubench_ceilings(gkr_ctx *ctx, size_t bytes, double *copy_GBps, double *read_GBps, double *modmul_per_sec);
 
 #ifdef __cplusplus

@@ -115,6 +115,29 @@ def test_wtns_container_round_trip_and_byte_equality_with_the_oracle_writer():
             product.read_wtns(bad)
 
 
+# ---------------------------------------------------------------------------------------------- both compilers vs circuits derived by hand
+
+def test_compilers_match_the_circuits_derived_by_hand_from_convert_rs():
+    """tests/golden/convert_hand_derived.json: three systems whose layered circuits were worked out by hand from
+    rust/src/convert.rs (neg flag, odd merge_nodes, relay gates with the lazily allocated zero slot, the relay / op-node
+    dedupe asymmetry, the width-limit merge after the stable depth sort).  Both the oracle's restatement and the
+    product's C++ compiler must reproduce them -- until now the two only checked each other."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convert_hand_derived.json")))
+    assert len(gold["cases"]) == 3
+    for case in gold["cases"]:
+        cons = [tuple([(int(c), int(w)) for c, w in part] for part in con) for con in case["constraints"]]
+        r = dict(n_wires=case["n_wires"], n_pub_out=case["n_pub_out"], n_pub_in=case["n_pub_in"], n_prv_in=case["n_prv_in"], constraints=cons)
+        want = [dict(k=c["k"], layers=[tuple(map(list, l)) for l in c["layers"]], inputs=[tuple(x) for x in c["inputs"]]) for c in case["circuits"]]
+        got_oracle = _oracle_compiled(r)
+        got_oracle = [dict(k=c["k"], layers=[tuple(map(list, l)) for l in c["layers"]], inputs=[tuple(x) for x in c["inputs"]]) for c in got_oracle]
+        assert got_oracle == want, case["name"]
+        got_product = _compiled(_build(r))
+        got_product = [dict(k=c["k"], layers=[tuple(map(list, l)) for l in c["layers"]], inputs=[tuple(x) for x in c["inputs"]]) for c in got_product]
+        assert got_product == want, case["name"]
+
+
 # ---------------------------------------------------------------------------------------------- compiler vs oracle
 
 @pytest.mark.parametrize("style", ["plain", "negated"])

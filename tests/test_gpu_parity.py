@@ -386,17 +386,15 @@ def test_prove_wide_layers_match_oracle(ctx):
                  [rng.randrange(2) for _ in range(1 << ks[-1])]]
     refs = [cdense.prove(layers, w) for w in witnesses]
     circuit = _circuit(layers, 1 << ks[-1])
-    device_tx = getattr(ctx, "_mode", None) == "device"          # batched proving needs the host transcript
-    for got in ([ctx.prove(circuit, witnesses[0])],) + (() if device_tx else (ctx.prove_batch(circuit, witnesses),)):
+    for got in ([ctx.prove(circuit, witnesses[0])], ctx.prove_batch(circuit, witnesses)):
         for pr, ref in zip(got, refs):
             assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"]
             assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"]
 
 
 def test_prove_batch_equals_single_proofs_and_oracle(ctx):
-    """gkr_prove_batch: proofs of one circuit for many witnesses advanced together (host transcript)."""
-    if ctx.device_name() and getattr(ctx, "_mode", None) == "device":
-        pytest.skip("batched proving needs the host transcript")
+    """gkr_prove_batch: proofs of one circuit for many witnesses advanced together (host transcript), or layer by
+    layer one after the other with no host in the loop (device transcript)."""
     rng = random.Random(4242)
     ks = [3, 4, 5, 4]
     layers = []
@@ -409,12 +407,7 @@ def test_prove_batch_equals_single_proofs_and_oracle(ctx):
     inputs = [[rng.randrange(P) for _ in range(1 << ks[-1])] for _ in range(B)]
     inputs[3] = [7] * (1 << ks[-1])                       # constant inputs: short round vectors
     inputs[5] = [i & 1 for i in range(1 << ks[-1])]       # depends on the last variable only
-    try:
-        got = ctx.prove_batch(circ, inputs)
-    except GkrError as e:
-        if "host transcript" in str(e):
-            pytest.skip("batched proving needs the host transcript")
-        raise
+    got = ctx.prove_batch(circ, inputs)
     for b in (0, 3, 5, 11, 18):
         ref = cdense.prove(layers, inputs[b])
         pr = got[b]
