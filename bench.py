@@ -267,7 +267,11 @@ def run_mle(args, world):
     count = 1 << n
     ctx = Context(world.local_rank)
     ctx.set_transcript(1 if args.transcript == "host" else 0)
-    tables = ctx.alloc(batch * count * 32)
+    # (experiment: GKR_BENCH_ALIGN_LOG2=30 puts the tables on a 1 GiB boundary of the virtual address space inside a larger
+    # allocation -- does the fold pass's bandwidth follow the alignment?  profiles/r03: it does not)
+    align_log2 = int(os.environ.get("GKR_BENCH_ALIGN_LOG2", "0") or 0)
+    raw_tables = ctx.alloc(batch * count * 32 + ((1 << align_log2) if align_log2 else 0))
+    tables = ctypes.c_void_p((raw_tables.value + (1 << align_log2) - 1) >> align_log2 << align_log2) if align_log2 else raw_tables
     for b in range(batch):
         ctx.fill_table(ctypes.c_void_p(tables.value + b * count * 32), count, synth.bench_table_seed(world.rank, b))
     ctx.synchronize()
@@ -307,6 +311,7 @@ def run_mle(args, world):
                        "transcript": "MiMC7-91 on %s, included in the timed region" % args.transcript,
                        "parallelism": "independent sumchecks per rank, no collective"},
             "sumchecks_per_sec": batch * args.steps * world.size / elapsed,
+            "tables_device_address": hex(tables.value),
             "step_ms_each": [round(x * 1e3, 3) for x in each],
             "host_threads": {"usable_cpus": usable_cpus(), "GKR_HOST_THREADS": os.environ.get("GKR_HOST_THREADS"),
                              "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE"), "cgroup_throttling_in_timed_steps": dict(LAST_THROTTLE)},
@@ -344,6 +349,16 @@ def run_mle(args, world):
             rates = sorted(by / (ms * 1e-3) / 1e9 for ms, by in big if ms > 0)
             line["roofline"]["first_fold_pass_GBps"] = {"min": rates[0], "median": statistics.median(rates), "max": rates[-1],
                                                         "launches": len(rates)}
+            # The launches of a step go out in group order; a step's FIRST fold launch is the only one that has the chip to
+            # itself (the later ones share it with earlier groups' late passes on the second stream, whose bytes are not booked
+            # to this kernel): what round 2 called a placement lottery (profiles/r03/e_lottery_*: per-group medians 6.45, 6.0,
+            # 6.0, 6.2 ... TB/s in every process, 6.5 - 6.6 for ALL groups with GKR_NO_LATE_STREAM=1)
+            per_step = len(big) // max(1, args.steps)
+            if per_step >= 1 and len(big) == per_step * args.steps:
+                first = [by / (ms * 1e-3) / 1e9 for ms, by in big[::per_step] if ms > 0]
+                if first:
+                    line["roofline"]["first_fold_pass_GBps"]["unshared_median"] = statistics.median(first)
+                    line["roofline"]["first_fold_pass_GBps"]["unshared_frac_of_peak"] = statistics.median(first) / PEAK_GBPS
         first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
         if first["total_ms"] > 0:
             line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
@@ -396,7 +411,7 @@ def run_mle(args, world):
             if gold and world.rank == 0 and n == gold.get("n") and b16 == gold.get("n16_tables") and not args.no_verify:
                 extras["n16"]["whole_batch_digest"] = _sha(*out16[0]) == gold["n16_whole_batch_rank0"]
                 verified_ok &= extras["n16"]["whole_batch_digest"]
-    ctx.free(tables)
+    ctx.free(raw_tables)
     ctx.close()
     # second half of the metric: every rank proves its own share of the inputs; MAX over ranks
     proofs = None
