@@ -128,6 +128,24 @@ def transcript_floor(hashed_elements, vector_len, threads, achieved_ms):
             "frac": floor_ms / achieved_ms if achieved_ms else None}
 
 
+def guarded(fn, seconds):
+    """fn() on a worker thread with a deadline -> (result, error text or None, still running)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["out"] = fn()
+        except BaseException as e:   # noqa: BLE001 -- reported on the line
+            box["err"] = "%s: %s" % (type(e).__name__, e)
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, "no result after %d s (a rank may be stuck in a collective)" % seconds, True
+    return box.get("out"), box.get("err"), False
+
+
 def cgroup_cpu_stat():
     """nr_throttled / throttled_usec of this container's CPU controller ({} where there is none): spinning on more
     threads than the quota allows gets the whole process stopped for the rest of a 100 ms period."""
@@ -362,9 +380,11 @@ def run_mle(args, world):
         first = prof["mle_sub_sums"] if prof["mle_sub_sums"]["launches"] else prof["mle_sum_first"]
         if first["total_ms"] > 0:
             line["roofline"]["first_pass_GBps"] = first["bytes"] / (first["total_ms"] * 1e-3) / 1e9
-        for rel in ("r02/m_pmc_traffic.json", "r02/l_pmc_traffic.json", "r02/d_pmc_traffic.json", "r01/d_pmc_traffic.json"):   # PMC passes are separate runs, never part of this run
-            traffic_file = os.path.join(REPO, "profiles", rel)
-            if os.path.exists(traffic_file) and dom_name == "mle_multifold":
+        import glob
+        # PMC passes are separate runs (counters slow the kernels 2.5x), never part of this run: the newest committed one
+        for traffic_file in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "*pmc_traffic.json")), reverse=True):
+            rel = os.path.relpath(traffic_file, os.path.join(REPO, "profiles"))
+            if dom_name == "mle_multifold":
                 try:
                     tj = json.load(open(traffic_file))
                     if tj.get("batch") == batch and tj.get("n") == n:
@@ -417,21 +437,36 @@ def run_mle(args, world):
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
-    layer24 = None
+    layer24 = layer24_split = None
+    split_hung = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
+        if world.size > 1:
+            # configs[4] as BASELINE words it: the layer's gates split over the ranks, two RCCL all-reduces per sumcheck
+            # (device exchange).  Under a watchdog: a rank stuck in a collective must not cost the whole line.
+            def split_leg():
+                world.torch.cuda.set_device(world.local_rank)
+                return layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=True, ceilings=ceilings)
+            layer24_split, err, split_hung = guarded(split_leg, 180)
+            if err:
+                layer24_split = {"error": err}
     if world.rank == 0:
         line.update(extras)
         if layer24:
             line["layer24"] = layer24
             verified_ok &= layer24["matches_golden_digest"] is not False
+        if layer24_split:
+            line["layer24_split"] = layer24_split
+            verified_ok &= layer24_split.get("matches_golden_digest") is not False and "error" not in layer24_split
         if proofs:
             line["aggregated_proofs"] = proofs
         if world.size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_dense(n, args.cpu_seconds)
             line["cpu_ref_algo"] = cpu_ref_algo(args.ref_algo_seconds)
             line["cpu_pipeline"] = cpu_pipeline()
-        print(json.dumps(line), flush=True)
+        emit(line)
+    if split_hung:
+        os._exit(4)    # a thread of this process sits in a collective that will not return: no orderly shutdown possible
     if not verified_ok or ranks_failed:
         raise SystemExit("WRONG RESULTS: the outputs of the timed steps failed their check (see \"verified\" / \"layer24\" / \"n16\")")
 
@@ -514,7 +549,7 @@ def run_proofs(args, world):
             step_obj.prove_raw_many(ctx, inputs, threads)
     elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
     if world.rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "aggregated proofs/sec", "value": args.proofs * subs * args.steps / elapsed, "unit": "proofs/s",
             "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
@@ -523,7 +558,7 @@ def run_proofs(args, world):
                        "inputs_per_rank": [len(parallel.shard_units(args.proofs, r, world.size)) for r in range(world.size)],
                        "proof": "one prover::prove call (one sub-circuit of one input)",
                        "how": "gkr_prove_many, %d threads / child contexts per rank" % threads, "cpus_per_rank": cpus},
-            "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]}), flush=True)
+            "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]})
     ctx.close()
     step_obj.close()
 
@@ -600,7 +635,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
 def run_layer_split(args, world):
     out = layer_leg(world, args.k_i, args.k, args.steps, args.warmup, split=True)
     if world.rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
         if out["matches_golden_digest"] is False:
             raise SystemExit("WRONG TRANSCRIPT")
 
@@ -686,7 +721,26 @@ def cpu_pipeline():
             "sample": "%d proofs (3 example inputs x 12 sub-circuits of the t.circom-equivalent R1CS), compile included, %.2f s" % (proofs, dt)}
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, on the process's real stdout (see main)."""
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
+    # Libraries below write banners to stdout (RCCL: version / hostname lines at start-up and shutdown; gloo: "Rank n is
+    # connected ..."): file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to the saved one.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

@@ -620,7 +620,7 @@ int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t tic
     return GKR_OK;
 }
 
-constexpr int kMaxGroups = 16;
+constexpr int kMaxGroups = 32;
 
 #define WS(ctx, slot, type, count, ptr) \
     HIP_TRY(ctx, (ctx)->workspace(slot, (size_t)(count) * sizeof(type), reinterpret_cast<void**>(&(ptr))))
@@ -800,7 +800,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // queue depth 2 (below) 12.0-12.5 / 13.5-14.0 / 16.5-17.8; 6, 10 and 12 groups in between.
     const double batch_bytes = (double)batch * (double)len * 32.0;
     int want_groups = (int)(batch_bytes / (4.0 * 1024 * 1024 * 1024));
-    want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? (batch_bytes > 96.0 * 1024 * 1024 * 1024 ? kMaxGroups : 8) : want_groups);
+    want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? (batch_bytes > 96.0 * 1024 * 1024 * 1024 ? 16 : 8) : want_groups);
+    // Small tables (BASELINE configs[1]: 4096 x 2^16) are bound by the host's hashing, not by the stream: sixteen groups
+    // with pass 0 of four of them queued ahead keep the hashing threads fed from start to end (MI355X, 14 threads, ms per
+    // 4096 x 2^16: 4 groups 8.1 - 8.2, 8 groups 8.1, 16 groups 7.2, 16 groups / depth 4 7.0 - 7.2, 32 groups / depth 8 7.1;
+    // profiles/r03/f_n16_groups*.jsonl)
+    const bool small_tables = n <= 17 && batch >= 256;
+    if (small_tables) want_groups = 16;
     int group_size = batch >= 128 ? (batch + want_groups - 1) / want_groups : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
@@ -998,10 +1004,11 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // (P0 P0 F0 P0 F1 P0 F2 F3 with four groups), and the host's hashing -- which with few threads takes as long as the
     // GPU's work -- is fed from the first millisecond to the last instead of in one burst after all the pass 0s.
     // (All pass 0s first: 2 host threads 19.0 ms per 1024 x 2^20 at 77 % hashing occupancy, 3 threads 15.6 ms at 63 %.)
-    static const int depth = [] {
+    static const int depth_env = [] {
         const char* e = getenv("GKR_PASS_QUEUE_DEPTH");
-        return e && atoi(e) > 0 ? atoi(e) : 2;
+        return e && atoi(e) > 0 ? atoi(e) : 0;
     }();
+    const int depth = depth_env ? depth_env : (small_tables ? 4 : 2);
     int next_first = 0;   // groups [next_first, groups): pass 0 still to launch
     while (next_first < groups && next_first < depth) launch_first(grp[next_first++]);
     dbg_b = dbg_us();

@@ -8,11 +8,11 @@ timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $OUT/gpu_tests
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --proofs 0 > /tmp/stats_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-verify --proofs 0 > /tmp/stats_bench.json 2>/dev/null
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) $R/$OUT/kernel_stats.csv
 cp /tmp/stats_bench.json $R/$OUT/stats_bench.json
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile --proofs 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile --proofs 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify --no-profile --proofs 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify --no-profile --proofs 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_proofs -- python3 $R/bench.py --mode proofs --steps 3 --warmup 1 > /tmp/proofs_bench.json 2>/dev/null
 cp $(ls /tmp/prof_proofs/*/*kernel_stats.csv | head -1) $R/$OUT/kernel_stats_mode_proofs.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_layer -- python3 $R/bench.py --mode layer-split --steps 3 --warmup 1 > /tmp/layer_bench.json 2>/dev/null
@@ -22,8 +22,9 @@ python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024 20 > $OUT/pmc_tra
 PROBE_REPS=60 PROBE_THREADS=14,12 python tools/proof_many_probe.py 64 > $OUT/proof_many_probe_64.txt 2>/dev/null
 PROBE_REPS=60 PROBE_THREADS=14 python tools/proof_many_probe.py 3 > $OUT/proof_many_probe_3.txt 2>/dev/null
 python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split.json 2>/dev/null
+GKR_BENCH_FORCE_GROUP=1 python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split_rccl_one_rank.json 2>/dev/null
 python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
-LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
+LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --no-verify --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
 cat $OUT/gpu_tests.txt $OUT/smoke.txt
 head -c 1500 $OUT/bench_default.json
