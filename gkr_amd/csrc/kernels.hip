@@ -1261,33 +1261,40 @@ __global__ void __launch_bounds__(256) k_seg_group_len(const uint2* __restrict__
     const uint32_t pos = begin + 64u * w;
     group_len[slot] = pos < end ? (items[order[pos]].y & 0xffu) : 0u;
 }
-// one wave per group: the entries of its items, step-major (see GateSegs::packed)
-__global__ void __launch_bounds__(64) k_seg_pack(const uint2* __restrict__ items, const uint32_t* __restrict__ order,
-                                                 const uint32_t* __restrict__ bucket_begin, uint32_t nb, uint32_t groups,
-                                                 const uint32_t* __restrict__ group_len, const uint32_t* __restrict__ group_off,
-                                                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta, uint32_t gate_base,
-                                                 uint32_t shift, uint32_t* __restrict__ packed) {
-    const uint32_t slot = blockIdx.x, half = slot >= groups ? 1u : 0u, w = slot - half * groups;
+// one wave per group: the entries of its items, step-major (see GateSegs::packed).  An item's entries are contiguous in
+// list / meta, so the wave reads item after item with its lanes (one or two cache lines per load instead of 64 per
+// step), transposes in LDS and writes whole 256-byte steps.  grid = ceil(2 * groups / 4), block = 256
+__global__ void __launch_bounds__(256) k_seg_pack(const uint2* __restrict__ items, const uint32_t* __restrict__ order,
+                                                  const uint32_t* __restrict__ bucket_begin, uint32_t nb, uint32_t groups,
+                                                  const uint32_t* __restrict__ group_len, const uint32_t* __restrict__ group_off,
+                                                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta, uint32_t gate_base,
+                                                  uint32_t shift, uint32_t* __restrict__ packed) {
+    __shared__ uint32_t tile[4][kSegCap][65];   // [wave][step][lane], rows padded: the column writes hit 32 banks
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * 4u + wave;
+    if (slot >= 2 * groups) return;
+    const uint32_t half = slot >= groups ? 1u : 0u, w = slot - half * groups;
     const uint32_t n = group_len[slot];
     if (!n) return;
     const uint32_t begin = bucket_begin[half ? nb : 0], end = bucket_begin[half ? 2 * nb : nb];
-    const uint32_t pos = begin + 64u * w + threadIdx.x;
+    const uint32_t pos = begin + 64u * w + lane;
     uint32_t first = 0, len = 0;
     if (pos < end) {
         const uint2 it = items[order[pos]];
         first = it.x;
         len = it.y & 0xffu;
     }
-    uint32_t* dst = packed + (size_t)group_off[slot] * 64u + threadIdx.x;
     const uint32_t lmask = (1u << shift) - 1u;
-    for (uint32_t j = 0; j < n; ++j) {
-        uint32_t v = 0u;
-        if (j < len) {
-            const uint32_t mt = meta[first + j];
-            v = ((list[first + j] + gate_base) & lmask) | ((mt & 0x7fffffffu) << shift) | (mt & 0x80000000u);
+    for (uint32_t j = 0; j < n; ++j) tile[wave][j][lane] = 0u;
+    for (uint32_t q = 0; q < 64u; ++q) {
+        const uint32_t fq = __shfl(first, (int)q, 64), lq = __shfl(len, (int)q, 64);
+        if (lane < lq) {
+            const uint32_t mt = meta[fq + lane];
+            tile[wave][lane][q] = ((list[fq + lane] + gate_base) & lmask) | ((mt & 0x7fffffffu) << shift) | (mt & 0x80000000u);
         }
-        dst[(size_t)j * 64u] = v;
     }
+    uint32_t* dst = packed + (size_t)group_off[slot] * 64u + lane;
+    for (uint32_t j = 0; j < n; ++j) dst[(size_t)j * 64u] = tile[wave][j][lane];
 }
 
 // One item per lane, longest items first (the lanes of a wave run the same number of steps): the unreduced sums of
@@ -2594,7 +2601,7 @@ void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* g
             hipLaunchKernelGGL(k_scan_blocks, dim3(cblocks), dim3(256), 0, s, segs->group_len(), segs->group_off(), csums, c);
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, csums, cblocks);
             hipLaunchKernelGGL(k_scan_add, dim3(cblocks), dim3(256), 0, s, segs->group_off(), (uint32_t*)nullptr, csums, c);
-            hipLaunchKernelGGL(k_seg_pack, dim3(2 * p.groups), dim3(64), 0, s, segs->items(), segs->order(), segs->bucket_begin(), 1u << k, p.groups,
+            hipLaunchKernelGGL(k_seg_pack, dim3((2 * p.groups + 3) / 4), dim3(256), 0, s, segs->items(), segs->order(), segs->bucket_begin(), 1u << k, p.groups,
                                segs->group_len(), segs->group_off(), list, list + gate_list_words(gates), (uint32_t)span.base, p.shift,
                                segs->packed());
         }
