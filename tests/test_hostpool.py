@@ -39,6 +39,19 @@ def test_worker_pool_under_thread_sanitizer():
         assert out.returncode == 0 and "bad=0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
 
 
+def test_first_use_of_the_transcript_tables_under_thread_sanitizer():
+    """`make tsan` also builds the library's whole host side with -fsanitize=thread (libgkr_tsan.so) and
+    tests/first_use_race.cpp: 32 threads make the FIRST call into the MiMC7 constant tables and the IFMA initialisation
+    at the same instant, as gkr_prove_many's crew does in a fresh process.  No race report, known answers everywhere."""
+    build = subprocess.run(["make", "-C", os.path.join(REPO, "gkr_amd", "csrc"), "tsan"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("no ThreadSanitizer build of the host side here: " + build.stderr[-300:])
+    exe = os.path.join(REPO, "gkr_amd", "build_san", "first_use_race_tsan")
+    for _ in range(3):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+        assert out.returncode == 0 and "bad=0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
+
+
 def test_host_only_units_under_address_and_ub_sanitizers():
     """`make asan`: the R1CS / witness containers and compiler, the circom text generators, keccak and the IFMA hash
     driven through the C ABI with valid, truncated and bit-flipped inputs (tests/host_sanitize.cpp)."""
