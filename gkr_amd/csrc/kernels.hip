@@ -1134,12 +1134,10 @@ __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ of
         const uint32_t gg = list[i] + gate_base, mt = meta[i];
         const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
         const Fr w = load_fr(W + (mt & 0x7fffffffu));
-        if (mt >> 31) {
-            lazy_mac_v(lu, e, w);
-        } else {
-            acc_add_fr(acc[0], e);
-            lazy_mac_v(lv, e, w);
-        }
+        // (the accumulator is chosen per lane without a branch: a divergent one ran the 64 multiply-adds twice)
+        const bool mult = (mt >> 31) != 0u;
+        lazy_mac_sel(lu, lv, mult, e, w);
+        if (!mult) acc_add_fr(acc[0], e);
     }
     acc_add_fr(acc[0], lazy_reduce(lu));
     acc_add_fr(acc[1], lazy_reduce(lv));
@@ -1169,10 +1167,7 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
         const uint32_t gg = list[i] + gate_base, mt = meta[i];
         const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
         const Fr q = load_fr(eq_mont + (mt & 0x7fffffffu));
-        if (mt >> 31)
-            lazy_mac_v(lm, e, q);
-        else
-            lazy_mac_v(la, e, q);
+        lazy_mac_sel(lm, la, (mt >> 31) != 0u, e, q);
     }
     acc_add_fr(acc[0], lazy_reduce(la));
     acc_add_fr(acc[1], lazy_reduce(lm));
@@ -1318,7 +1313,17 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
     const Fr* Tt = T;
     if (LDS_T) {
         const uint4* src = reinterpret_cast<const uint4*>(T);
-        for (uint32_t i = threadIdx.x; i < 2 * tlen; i += blockDim.x) s_raw[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 2 * tlen; i += 4 * blockDim.x) {   // four loads in flight per thread
+            uint4 v0 = src[i], v1, v2, v3;
+            const bool h1 = i + blockDim.x < 2 * tlen, h2 = i + 2 * blockDim.x < 2 * tlen, h3 = i + 3 * blockDim.x < 2 * tlen;
+            if (h1) v1 = src[i + blockDim.x];
+            if (h2) v2 = src[i + 2 * blockDim.x];
+            if (h3) v3 = src[i + 3 * blockDim.x];
+            s_raw[i] = v0;
+            if (h1) s_raw[i + blockDim.x] = v1;
+            if (h2) s_raw[i + 2 * blockDim.x] = v2;
+            if (h3) s_raw[i + 3 * blockDim.x] = v3;
+        }
         __syncthreads();
         Tt = reinterpret_cast<const Fr*>(s_raw);
     }
