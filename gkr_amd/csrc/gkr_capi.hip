@@ -790,7 +790,22 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     const bool scalar_book = getenv("GKR_HOST_PASS_SCALAR") != nullptr;   // A/B switch: host_pass_scalar even where the CPU has IFMA
     std::vector<uint32_t> dep_last(batch, 0);
     gkr::SpinPool* pool = ctx->host_pool();
-    const uint32_t chunk_tables = (uint32_t)hash_chunk_size(batch, pool->workers() + 1);
+    // Sumchecks a hashing thread takes at a time, per group: sixteen (full IFMA calls: throughput) when the group has plenty
+    // for every thread; otherwise ONE chunk per thread where that fits the sixteen lanes -- a pass's J hashes of a sumcheck
+    // are a serial chain, so a group of 128 on 14 threads is done in one chain of 16-lane calls filled to 10 (J x 20 us)
+    // instead of two chains of 8-lane calls (2 x J x 16 us), at the same cost per hash; GKR_HASH_CHUNK forces 8 or 16
+    const int hash_threads = pool->workers() + 1;
+    auto group_chunk = [hash_threads](int nb) -> uint32_t {
+        static const int forced = [] {
+            const char* e = getenv("GKR_HASH_CHUNK");
+            const int v = e ? atoi(e) : 0;
+            return v == 8 || v == 16 ? v : 0;
+        }();
+        if (forced) return (uint32_t)forced;
+        if (nb >= 32 * hash_threads) return 16u;
+        const int per = (nb + hash_threads - 1) / hash_threads;
+        return (uint32_t)(per <= 8 ? 8 : (per <= 16 ? per : 16));
+    };
 
     // Groups of ~4 GiB of tables, at least four and at most eight (1024 x 2^20: eight groups of 128); sixteen for batches
     // beyond 96 GiB (4096 x 2^20: 4.64e11 field-ops/s with sixteen groups of 256, 4.48e11 with eight of 512).  Larger launches
@@ -982,6 +997,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             Group& G = grp[best];
             const uint32_t first = (uint32_t)best_c;
             const uint32_t left = (uint32_t)G.nb - first;
+            const uint32_t chunk_tables = group_chunk(G.nb);
             const uint32_t take = left < chunk_tables ? left : chunk_tables;
             if (!G.claim.compare_exchange_strong(best_c, best_c + take, std::memory_order_acq_rel)) continue;   // lost a race: look again
             const double t_in = dbg ? dbg_us() : 0.0;
