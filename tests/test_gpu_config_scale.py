@@ -77,6 +77,28 @@ def test_segment_passes_with_skewed_buckets_match_oracle():
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
 
 
+def test_segment_passes_in_a_batch_of_proofs_match_oracle():
+    """gkr_prove_batch over a circuit whose first layer is large enough for the segment passes (2^19 gates over 2^9
+    values): three witnesses advanced together -- every proof's own eq tables, partial sums and outputs (the batch index
+    of k_seg_pass / k_seg_combine) -- each equal to the oracle's proof."""
+    from gkr_amd import GKRCircuit, Layer
+    rng = np.random.default_rng(4242)
+    ks = [19, 9, 7]
+    layers = []
+    for i in range(2):
+        g, m = 1 << ks[i], 1 << ks[i + 1]
+        layers.append((rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, m, g, dtype=np.uint32), rng.integers(0, m, g, dtype=np.uint32)))
+    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(2)], ks[-1])
+    witnesses = [from_limbs(synth.rand_fr(np.random.default_rng(900 + b), 1 << ks[-1])) for b in range(3)]
+    with Context(0) as ctx:
+        proofs = ctx.prove_batch(circuit, witnesses)
+    plain = [(list(map(int, t)), list(map(int, l)), list(map(int, r))) for t, l, r in layers]
+    for pr, w in zip(proofs, witnesses):
+        ref = cdense.prove(plain, w)
+        assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"]
+        assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"]
+
+
 def test_config5_layer_eight_logical_ranks_match_oracle(config5_expected):
     """configs[4] as BASELINE states it: the layer split over 8 ranks.  Eight logical ranks (threads, one context
     each) on the one visible GPU run the gate-sharded form; every rank must hold the oracle's transcript."""
