@@ -1635,7 +1635,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         uint32_t hflag = local_fail ? 1u : 0u;
         gkr::launch_copy_words(d_a, buf, each * 8, s);
         gkr::launch_copy_words(d_b, buf + each, each * 8, s);
-        if (d_flag && !local_fail) HIP_TRY(ctx, hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, s));
+        // (no early return between here and the hook: the peers are on their way into the collective)
+        if (d_flag && !local_fail && hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) hflag = 1u;
         const hipError_t se = hipStreamSynchronize(s);
         if (se != hipSuccess) hflag = 1u;   // still enter the collective: the peers are on their way into it
         buf[2 * each] = gkr_fr{{(uint64_t)(hflag != 0), 0, 0, 0}};
@@ -2143,6 +2144,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         HIP_TRY(ctx, hipMemcpyAsync(out_r[0], d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (const int xr = xflag_check()) return xr;
     ctx->drain_events();
     return GKR_OK;
 }
