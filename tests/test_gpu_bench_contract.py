@@ -1,0 +1,53 @@
+"""bench.py's output contract, on a small instance of every leg: stdout is exactly ONE JSON line with the driver's
+keys, the roofline and cpu_baseline objects, the check of the timed outputs, and all five BASELINE configs."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, env=None):
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(args), capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d:\n%s" % (len(lines), out.stdout[:2000])
+    return json.loads(lines[0])
+
+
+def test_default_mode_line():
+    d = _run("--batch", "64", "--steps", "2", "--warmup", "1", "--proofs", "4", "--cpu-seconds", "0.5", "--ref-algo-seconds", "1",
+             "--layer-k-i", "20", "--layer-k", "10")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["unit"] == "field-ops/s" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["copy_GBps_measured"] > 1000 and r["alu_products_per_sec_measured"] > 1e10
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # what was timed was checked: digests of rank 0's tables (the seeds are the full run's) and the verifier's relations
+    v = d["verified"]
+    assert v["ok"] is True and v["tables_matching_their_digest"] == 64 and v["table0_golden_digest"] is True and v["verifier_relations"]["ok"] is True
+    # the other configs on the line
+    assert d["n16"]["value"] > 0 and d["n16"]["roofline"]["floor_ms"] > 0
+    assert d["layer24"]["matches_golden_digest"] is True and d["layer24"]["roofline"]["bound"] == "alu"
+    assert d["aggregated_proofs"]["config0_three_inputs"]["proofs"] == 36 and d["aggregated_proofs"]["config3"]["proofs"] == 4 * 12
+    assert d["host_transcript"]["floor_ms"] > 0
+
+
+def test_layer_split_mode_with_a_process_group_of_one_rank():
+    """--mode layer-split under GKR_BENCH_FORCE_GROUP=1: backend nccl (RCCL) initialised before the first GPU call, both
+    exchanges of every sumcheck as all-reduces on the library's stream; golden transcript."""
+    d = _run("--mode", "layer-split", "--k-i", "20", "--k", "10", "--steps", "3", "--warmup", "1",
+             env={"GKR_BENCH_FORCE_GROUP": "1", "MASTER_PORT": "29633", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["matches_golden_digest"] is True and d["exchange"]["calls_per_step"] == 2.0 and d["exchange"]["us_per_call"] > 0
+    assert d["roofline"]["bound"] == "alu" and d["scaling"] == "strong"
