@@ -2499,7 +2499,10 @@ struct SegPlan {
 static SegPlan seg_plan(GateSpan span, uint32_t k_i, uint32_t k) {
     SegPlan p;
     static const bool off = getenv("GKR_GATE_SEGMENTS_OFF") != nullptr;
-    static const uint32_t min_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENTS_MIN_LOG2"); return e ? (uint32_t)atoi(e) : 19u; }();
+    // (measured, MI355X, gate passes of a layer with k = k_i / 2, ms per pass segment / bucket form: 2^16 gates 0.089 / 0.024,
+    // 2^20 0.090 / 0.052, 2^22 0.104 / 0.125, 2^24 0.245 / 0.43 -- the segment form has ~85 us of fixed latency (resident
+    // blocks, the one-wave-per-bucket combine); profiles/r03/q_segment_threshold.jsonl)
+    static const uint32_t min_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENTS_MIN_LOG2"); return e ? (uint32_t)atoi(e) : 22u; }();
     static const uint32_t mean_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENT_LOG2"); return e && atoi(e) >= 2 && atoi(e) <= 8 ? (uint32_t)atoi(e) : kSegMeanLog2; }();
     const uint32_t blocks = gate_lists_lds_blocks(span.count, k);
     if (off || !blocks || span.count < ((uint64_t)1 << min_log2) || span.count > ((uint64_t)1 << 31)) return p;

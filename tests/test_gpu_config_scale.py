@@ -47,7 +47,8 @@ def test_config5_layer_every_form_matches_oracle(config5_expected, env):
 
 
 @pytest.mark.parametrize("k_i,k,env", [(16, 8, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}), (18, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}),
-                                       (19, 12, {}), (20, 10, {}), (21, 9, {"GKR_GATE_SEGMENT_LOG2": "3"}), (22, 11, {})])
+                                       (19, 12, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}), (20, 10, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}),
+                                       (21, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16", "GKR_GATE_SEGMENT_LOG2": "3"}), (22, 11, {})])
 def test_segment_passes_at_other_widths_match_oracle(tmp_path, k_i, k, env):
     """The segment form of the gate passes (csrc/gate_seg.h) where the split of eq(z, .) and the number of sort blocks
     per segment take other values than at configs[4]'s size (one block per segment, many, segments of 8 gates)."""
@@ -60,43 +61,17 @@ def test_segment_passes_at_other_widths_match_oracle(tmp_path, k_i, k, env):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_segment_passes_with_skewed_buckets_match_oracle():
-    """Segments far from the average: every gate of the first quarter of the layer wired to ONE left operand (segments
-    of 2^16 gates, cut into items of 32), a bucket nobody uses, all gates of one type in a stretch."""
-    k_i, k = 20, 10
-    lay, z, W = synth.config5_layer(k_i, k, seed=77)
-    gt, l, r = (a.copy() for a in lay.arrays())
-    l[: 1 << 18] = 5
-    r[1 << 18: 1 << 19] = 1023
-    l[l == 7] = 8
-    gt[3 << 18:] = 1
-    want = cdense.sumcheck_layer_raw(k_i, k, gt, l, r, z, W)
-    from gkr_amd import Layer
-    with Context(0) as ctx:
-        got = ctx.sumcheck_layer_raw(Layer(k_i, gt, l, r), k, z, W)
-    assert all(np.array_equal(a, b) for a, b in zip(got, want))
-
-
-def test_segment_passes_in_a_batch_of_proofs_match_oracle():
-    """gkr_prove_batch over a circuit whose first layer is large enough for the segment passes (2^19 gates over 2^9
-    values): three witnesses advanced together -- every proof's own eq tables, partial sums and outputs (the batch index
-    of k_seg_pass / k_seg_combine) -- each equal to the oracle's proof."""
-    from gkr_amd import GKRCircuit, Layer
-    rng = np.random.default_rng(4242)
-    ks = [19, 9, 7]
-    layers = []
-    for i in range(2):
-        g, m = 1 << ks[i], 1 << ks[i + 1]
-        layers.append((rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, m, g, dtype=np.uint32), rng.integers(0, m, g, dtype=np.uint32)))
-    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(2)], ks[-1])
-    witnesses = [from_limbs(synth.rand_fr(np.random.default_rng(900 + b), 1 << ks[-1])) for b in range(3)]
-    with Context(0) as ctx:
-        proofs = ctx.prove_batch(circuit, witnesses)
-    plain = [(list(map(int, t)), list(map(int, l)), list(map(int, r))) for t, l, r in layers]
-    for pr, w in zip(proofs, witnesses):
-        ref = cdense.prove(plain, w)
-        assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"]
-        assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"]
+@pytest.mark.parametrize("scenario", ["skewed", "batch"])
+def test_segment_passes_scenarios_match_oracle(scenario):
+    """tests/segment_scenarios_worker.py (a child: the size from which layers take the segment passes is read once per
+    process, and these layers are below the default):
+      skewed  segments far from the average -- every gate of the first quarter of a 2^20-gate layer wired to ONE left
+              operand (segments of 2^16 gates, cut into items of 32), a bucket nobody uses, all gates of one type in a stretch;
+      batch   gkr_prove_batch over a circuit whose first layer has 2^19 gates: three witnesses advanced together -- every
+              proof's own eq tables, partial sums and outputs (the batch index of k_seg_pass / k_seg_combine)."""
+    out = subprocess.run([sys.executable, os.path.join(HERE, "segment_scenarios_worker.py"), scenario],
+                         env=dict(os.environ, GKR_GATE_SEGMENTS_MIN_LOG2="16"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_config5_layer_eight_logical_ranks_match_oracle(config5_expected):
