@@ -198,6 +198,19 @@ def test_mle_headline_workload_shape_matches_oracle():
         assert h == gold["rank0_tables"][b], b
 
 
+@pytest.mark.parametrize("n", [24, 27, 30])
+def test_mle_largest_tables(n):
+    """Maximum sizes of the plain sumcheck: one table of 2^24 and 2^27 points (every byte against the oracle) and of
+    2^30 points = 32 GiB, the ABI's limit (two runs agree; the verifier's sum / challenge relations over all 30 rounds).
+    In a child process: tests/big_table_worker.py."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "big_table_worker.py"), str(n)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_mle_verifier_relation_at_full_size(ctx):
     """size-independent property at 2^20: g_j(0)+g_j(1) = g_{j-1}(r_{j-1}), r_j = MiMC(g_j)."""
     n = 20
