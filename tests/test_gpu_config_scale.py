@@ -48,7 +48,8 @@ def test_config5_layer_every_form_matches_oracle(config5_expected, env):
 
 @pytest.mark.parametrize("k_i,k,env", [(16, 8, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}), (18, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}),
                                        (19, 12, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}), (20, 10, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16"}),
-                                       (21, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16", "GKR_GATE_SEGMENT_LOG2": "3"}), (22, 11, {})])
+                                       (21, 9, {"GKR_GATE_SEGMENTS_MIN_LOG2": "16", "GKR_GATE_SEGMENT_LOG2": "3"}), (22, 11, {}),
+                                       (26, 12, {}), (25, 13, {})])
 def test_segment_passes_at_other_widths_match_oracle(tmp_path, k_i, k, env):
     """The segment form of the gate passes (csrc/gate_seg.h) where the split of eq(z, .) and the number of sort blocks
     per segment take other values than at configs[4]'s size (one block per segment, many, segments of 8 gates)."""
