@@ -40,10 +40,14 @@ def test_worker_pool_under_thread_sanitizer():
 
 
 def test_first_use_of_the_transcript_tables_under_thread_sanitizer():
-    """`make tsan` also builds the library's whole host side with -fsanitize=thread (libgkr_tsan.so) and
+    """tests/build_host_tsan.sh builds the library's whole host side with -fsanitize=thread (libgkr_tsan.so) and
     tests/first_use_race.cpp: 32 threads make the FIRST call into the MiMC7 constant tables and the IFMA initialisation
-    at the same instant, as gkr_prove_many's crew does in a fresh process.  No race report, known answers everywhere."""
-    build = subprocess.run(["make", "-C", os.path.join(REPO, "gkr_amd", "csrc"), "tsan"], capture_output=True, text=True)
+    at the same instant, as gkr_prove_many's crew does in a fresh process.  No race report, known answers everywhere.
+    (CPU only: the script does not travel to the GPU box.)"""
+    script = os.path.join(HERE, "build_host_tsan.sh")
+    if not os.path.exists(script):
+        pytest.skip("tests/build_host_tsan.sh is not here (GPU box)")
+    build = subprocess.run(["bash", script], capture_output=True, text=True)
     if build.returncode != 0:
         pytest.skip("no ThreadSanitizer build of the host side here: " + build.stderr[-300:])
     exe = os.path.join(REPO, "gkr_amd", "build_san", "first_use_race_tsan")
