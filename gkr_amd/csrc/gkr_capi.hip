@@ -564,6 +564,13 @@ struct DevBuf {
 // Host work in pieces (`work` claims and runs one per call): this thread, this context's pool workers if a session is
 // open, and -- while the job is on the process-wide board -- threads of OTHER contexts that are waiting for their GPU
 // (wait_records).  Returns when every piece has been run to its end.  GKR_NO_HELP=1: no sharing between contexts.
+// GKR_DEBUG_TIMING: where a proving thread's time goes (per thread, summed over a gkr_prove_batch call)
+struct ThreadTimeAccount {
+    double own_pieces_us = 0, helped_us = 0, spin_us = 0;
+};
+static thread_local ThreadTimeAccount t_account;
+static inline double now_us_dbg() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static bool help_enabled() {
     static const bool on = getenv("GKR_NO_HELP") == nullptr;
     return on;
@@ -577,12 +584,15 @@ static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, b
             while ((*work)()) {
             }
     };
+    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const double t0 = dbg ? now_us_dbg() : 0.0;
     if (several && help_enabled()) {
         gkr::HelpBoard::Posted posted(work, flat ? 0 : priority);
         run();
     } else {
         run();
     }
+    if (dbg) t_account.own_pieces_us += now_us_dbg() - t0;
 }
 
 template <typename Rec>
@@ -604,8 +614,11 @@ int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t tic
         while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
             // this thread has nothing to do until its round lands: a piece of another context's posted host work
             // (a 16-lane hash call, ~30 us) instead of spinning
+            static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+            const double th0 = dbg ? now_us_dbg() : 0.0;
             const bool did_help = help && gkr::HelpBoard::instance().help();
             if (!did_help) GKR_CPU_RELAX();
+            if (dbg) (did_help ? t_account.helped_us : t_account.spin_us) += now_us_dbg() - th0;
             if (did_help ? (++helped & 0x3F) == 0 : (++spins & 0xFFFF) == 0) {
                 hipError_t q = wait_mode == 2 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return ctx->hip_fail(q, "stream failed while waiting for a round");
@@ -3206,6 +3219,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     HIP_TRY(ctx, hipStreamSynchronize(s));
     static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
     const auto tpb0 = std::chrono::steady_clock::now();
+    if (dbg_pb) t_account = ThreadTimeAccount();
     if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
     for (int b = 0; b < batch; ++b) {
         if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
@@ -3332,6 +3346,9 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "[gkr timing] prove batch=%d depth=%u: %.0f us before the layers (circuit lookup, forward evaluation, readback), "
                         "%.0f us layers + q readback, since entry %.0f us\n", batch, L, us(t_entry, tpb0), us(tpb0, t_end), us(t_entry, t_end));
+        fprintf(stderr, "[gkr timing] this thread: own hashing pieces (incl. waiting for helpers) %.0f us, others' pieces %.0f us, spinning with nothing to take %.0f us, "
+                        "the rest (launches, set-up, copies) %.0f us\n", t_account.own_pieces_us, t_account.helped_us, t_account.spin_us,
+                us(t_entry, t_end) - t_account.own_pieces_us - t_account.helped_us - t_account.spin_us);
     }
     if (fresh && !no_cache) {
         constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
