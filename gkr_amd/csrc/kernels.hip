@@ -617,11 +617,19 @@ __global__ void __launch_bounds__(256) k_prod_c_setup(const Fr* __restrict__ Wb,
                                                       Fr* __restrict__ Y, uint32_t k, uint32_t wstride) {
     __shared__ Fr s_wu;
     const size_t base = (size_t)blockIdx.y * wstride;
-    if (threadIdx.x == 0) {
-        // W(u): the last b pass's variables bound in what is left of Wb (Montgomery in, Montgomery out)
-        Fr wu = mont_mul(load_fr(Wb + base), load_fr(weights + (size_t)blockIdx.y * 8));
-        for (uint32_t b = 1; b < (1u << jp); ++b) wu = fr_add(wu, mont_mul(load_fr(Wb + base + b), load_fr(weights + (size_t)blockIdx.y * 8 + b)));
-        s_wu = wu;
+    if (threadIdx.x < 64) {
+        // W(u): the last b pass's variables bound in what is left of Wb (Montgomery in, Montgomery out) -- one product per
+        // lane (at most eight), summed across lanes: one product deep instead of eight on every layer's set-up path
+        Fr wu = fr_zero();
+        if (threadIdx.x < (1u << jp)) wu = mont_mul(load_fr(Wb + base + threadIdx.x), load_fr(weights + (size_t)blockIdx.y * 8 + threadIdx.x));
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.l[j] = __shfl_down(wu.l[j], off, 64);
+            wu = fr_add(wu, o);
+        }
+        if (threadIdx.x == 0) s_wu = wu;
     }
     __syncthreads();
     const Fr wu = s_wu;
@@ -660,18 +668,29 @@ __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points,
         s_f[0][threadIdx.x] = to_mont(fr_sub(one, x));
     }
     __syncthreads();
-    const uint32_t n = 1u << nvars;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
-        Fr p = fr_zero();
-        p.l[0] = 1u;
-        if (nvars) {
-            p = s_f[(g >> (nvars - 1u)) & 1u][0];
-            for (uint32_t i = 1; i < nvars; ++i) p = mont_mul(p, s_f[(g >> (nvars - 1u - i)) & 1u][i]);
-            if (!montgomery) p = from_mont(p);
-        } else if (montgomery) {
-            p = to_mont(p);
+    // Four lanes per entry: lane q of a quad multiplies the factors i = q, q + 4, ... (a 254-bit product is a ~1.2 us
+    // dependent chain on one lane, and these kernels sit on every layer's set-up path: 16 variables = 4 + 2 products deep
+    // instead of 15), then the quad's four partial products are multiplied together across lanes.
+    const uint32_t n = 1u << nvars, q = threadIdx.x & 3u;
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; g < n; g += (gridDim.x * blockDim.x) >> 2) {
+        Fr p = fr_mont_one();
+        bool any = false;
+        for (uint32_t i = q; i < nvars; i += 4) {
+            const Fr f = s_f[(g >> (nvars - 1u - i)) & 1u][i];
+            p = any ? mont_mul(p, f) : f;
+            any = true;
         }
-        store_fr(out + ((size_t)blockIdx.y << nvars) + g, p);
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {
+            Fr o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.l[j] = __shfl_xor(p.l[j], step, 64);
+            p = mont_mul(p, o);
+        }
+        if (q == 0) {
+            if (!montgomery) p = from_mont(p);
+            store_fr(out + ((size_t)blockIdx.y << nvars) + g, p);
+        }
     }
 }
 
@@ -2399,7 +2418,7 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) 
 
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
                      hipStream_t s) {
-    hipLaunchKernelGGL(k_eq_table, dim3(blocks_for(1u << nvars, 1024), batch), dim3(256), 0, s, points, stride, first, nvars, out,
+    hipLaunchKernelGGL(k_eq_table, dim3(blocks_for((size_t)4 << nvars, 4096), batch), dim3(256), 0, s, points, stride, first, nvars, out,
                        montgomery ? 1u : 0u);
 }
 
