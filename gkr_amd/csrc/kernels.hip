@@ -566,8 +566,11 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
         const uint32_t idx = a * S + i0 + i;
         Fr v;
         if (jp) {
-            v = mont_mul(load_fr(T[t] + idx), s_w[0]);
-            for (uint32_t b = 1; b < (1u << jp); ++b) v = fr_add(v, mont_mul(load_fr(T[t] + ((size_t)b << m) + idx), s_w[b]));
+            // at most eight products: added unreduced, one short reduction (a pass is a latency chain on the round path:
+            // 8 x 64 + 64 multiply-adds deep instead of 8 x 128)
+            Lazy17 acc = lazy_zero();
+            for (uint32_t b = 0; b < (1u << jp); ++b) lazy_mac_v(acc, load_fr(T[t] + ((size_t)b << m) + idx), s_w[b]);
+            v = lazy_reduce_k8(acc);
             store_fr(T[t] + idx, v);
         } else {
             v = load_fr(T[t] + idx);
@@ -577,8 +580,11 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     __syncthreads();
     const uint32_t p = tid & 63u, sub = tid >> 6, a = p >> 3, b = p & 7u;
     Fr acc = fr_zero(), accy = fr_zero();
-    if (a < nsub && b < nsub)
-        for (uint32_t i = sub; i < ti; i += 4) acc = fr_add(acc, mont_mul(s_t[1][b][i], s_t[0][a][i]));
+    if (a < nsub && b < nsub) {
+        Lazy17 la = lazy_zero();   // kProdTile / 4 = at most four products per thread
+        for (uint32_t i = sub; i < ti; i += 4) lazy_mac_v(la, s_t[1][b][i], s_t[0][a][i]);
+        acc = lazy_reduce_k8(la);
+    }
     if (p < nsub)
         for (uint32_t i = sub; i < ti; i += 4) accy = fr_add(accy, s_t[2][p][i]);
     s_red[sub][p] = acc;
