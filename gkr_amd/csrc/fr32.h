@@ -643,6 +643,28 @@ GKR_HD void lazy_mac_sel(Lazy17& A, Lazy17& B, bool toA, const Fr& a, const Fr& 
 
 // acc += x * 2^256 (x where `on`, else nothing): after the Montgomery reduction of the accumulator this is "+ x" --
 // how a term that carries no second factor joins a lazy sum of products for nine additions instead of a product by one.
+#if defined(__HIP_DEVICE_COMPILE__)
+// (device: the addend masked with eight selects, then one padded carry chain over limbs 8..16 -- the portable form
+// below compiles to ~45 instructions, and the segment pass is bound by its instruction count)
+__device__ inline __attribute__((always_inline)) void lazy_add_hi(Lazy17& acc, const Fr& x, bool on) {
+    uint32_t m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = on ? x.l[i] : 0u;
+    asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %4, %13, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %5, %14, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %6, %15, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %16, vcc\n\ts_nop 1\n\t"
+        "v_addc_co_u32_e32 %8, vcc, 0, %8, vcc"
+        : "+v"(acc.l[8]), "+v"(acc.l[9]), "+v"(acc.l[10]), "+v"(acc.l[11]), "+v"(acc.l[12]), "+v"(acc.l[13]), "+v"(acc.l[14]),
+          "+v"(acc.l[15]), "+v"(acc.l[16])
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7])
+        : "vcc");
+}
+#else
 GKR_HD void lazy_add_hi(Lazy17& acc, const Fr& x, bool on) {
     uint64_t carry = 0;
 #pragma unroll
@@ -653,6 +675,7 @@ GKR_HD void lazy_add_hi(Lazy17& acc, const Fr& x, bool on) {
     }
     acc.l[16] += (uint32_t)carry;
 }
+#endif
 
 // two independent dot products advanced together (see mac96x2_s)
 GKR_HD void lazy_mac2_s(Lazy17& A, const Fr& a, const Fr& ua, Lazy17& B, const Fr& b, const Fr& ub) {

@@ -1399,30 +1399,40 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
         }
     }
 }
-// out0[bucket] = sum over the bucket's items of E_hi[run] * X[item], out1 likewise with Y: one wave per bucket.
-// grid = (2^k, batch), block = 64
+// out0[bucket] = sum over the bucket's items of E_hi[run] * X[item], out1 likewise with Y: half a wave (32 lanes) per
+// bucket -- the two unreduced sums are added up across the lanes as they are (17-limb adds over DPP shuffles) and reduced
+// once, so the fixed cost of a wave (the reductions) is shared by two buckets.  grid = (2^k / 2, batch), block = 64
 __global__ void __launch_bounds__(64) k_seg_combine(const uint2* __restrict__ items, const uint32_t* __restrict__ bucket_begin, uint32_t b_first,
-                                                    const Fr* __restrict__ X, const Fr* __restrict__ Y, uint32_t pstride,
+                                                    uint32_t nb, const Fr* __restrict__ X, const Fr* __restrict__ Y, uint32_t pstride,
                                                     const Fr* __restrict__ e_hi, uint32_t kh, uint32_t run_base, Fr* __restrict__ out0,
                                                     Fr* __restrict__ out1, uint32_t wstride) {
-    const uint32_t half_begin = bucket_begin[b_first], lo = bucket_begin[b_first + blockIdx.x], hi = bucket_begin[b_first + blockIdx.x + 1];
+    const uint32_t lane = threadIdx.x & 31u, bucket = 2u * blockIdx.x + (threadIdx.x >> 5);
+    const bool live = bucket < nb;
+    const uint32_t half_begin = bucket_begin[b_first], lo = live ? bucket_begin[b_first + bucket] : 0u, hi = live ? bucket_begin[b_first + bucket + 1] : 0u;
     e_hi += ((size_t)blockIdx.y << kh) + run_base;
     X += (size_t)blockIdx.y * pstride;
     Y += (size_t)blockIdx.y * pstride;
     Lazy17 A = lazy_zero(), B = lazy_zero();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 64) {
+    for (uint32_t i = lo + lane; i < hi; i += 32) {
         const Fr eh = load_fr(e_hi + (items[i].y >> 8));
         lazy_mac_v(A, load_fr(X + (i - half_begin)), eh);
         lazy_mac_v(B, load_fr(Y + (i - half_begin)), eh);
     }
-    Acc<9> acc[2] = {acc_zero<9>(), acc_zero<9>()};
-    acc_add_fr(acc[0], lazy_reduce(A));
-    acc_add_fr(acc[1], lazy_reduce(B));
-    acc[0] = wave_sum(acc[0]);
-    acc[1] = wave_sum(acc[1]);
-    if (threadIdx.x == 0) {
-        store_fr(out0 + (size_t)blockIdx.y * wstride + blockIdx.x, acc_reduce(acc[0]));
-        store_fr(out1 + (size_t)blockIdx.y * wstride + blockIdx.x, acc_reduce(acc[1]));
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        Lazy17 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) {
+            oa.l[j] = __shfl_xor(A.l[j], off, 64);
+            ob.l[j] = __shfl_xor(B.l[j], off, 64);
+        }
+        lazy_add(A, oa);
+        lazy_add(B, ob);
+    }
+    const Fr r0 = lazy_reduce(A), r1 = lazy_reduce(B);
+    if (live && lane == 0) {
+        store_fr(out0 + (size_t)blockIdx.y * wstride + bucket, r0);
+        store_fr(out1 + (size_t)blockIdx.y * wstride + bucket, r1);
     }
 }
 
@@ -2694,8 +2704,8 @@ void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* off
     if (segs && segs->shift && partials) {
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(false, *segs, k, e_lo_mont, W, X, Y, lb, s);
-        hipLaunchKernelGGL(k_seg_combine, dim3(1u << k, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 0u, X, Y, segs->half_bound,
-                           e_hi, k_i - segs->shift, segs->run_base, U, V, (uint32_t)lb.wstride);
+        hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 0u, 1u << k, X, Y,
+                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, U, V, (uint32_t)lb.wstride);
         return;
     }
     hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
@@ -2708,7 +2718,7 @@ void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* o
     if (segs && segs->shift && partials) {
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(true, *segs, k, e_lo_mont, eq_mont, X, Y, lb, s);
-        hipLaunchKernelGGL(k_seg_combine, dim3(1u << k, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 1u << k, X, Y,
+        hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 1u << k, 1u << k, X, Y,
                            segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, A_row, M_row, (uint32_t)lb.wstride);
         return;
     }
