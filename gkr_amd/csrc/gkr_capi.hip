@@ -835,6 +835,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // profiles/r03/f_n16_groups*.jsonl)
     const bool small_tables = n <= 17 && batch >= 256;
     if (small_tables) want_groups = 16;
+    // A rank with two or three host threads (eight ranks on a 16-core host) is bound by its hashing: smaller groups shorten
+    // the stretch before the first hashes and after the last fold (1024 x 2^20, two threads: 16.3 - 16.7 ms with eight
+    // groups, 16.0 with sixteen; profiles/r03/w_two_host_threads_group_size.jsonl)
+    if (hash_threads <= 3 && batch >= 256 && want_groups < 16) want_groups = 16;
     int group_size = batch >= 128 ? (batch + want_groups - 1) / want_groups : (batch >= 16 ? (batch + 1) / 2 : batch);
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
     int groups = (batch + group_size - 1) / group_size;
