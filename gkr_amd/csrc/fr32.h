@@ -203,6 +203,15 @@ __device__ inline __attribute__((always_inline)) void mac96(uint64_t& acc, uint3
         : "+v"(acc), "+v"(ex), "=&s"(carry)
         : "v"(x), "v"(y));
 }
+// the first product of a column: ex is SET to the carry (saves clearing it between columns)
+__device__ inline __attribute__((always_inline)) void mac96_first(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
+    uint64_t carry;
+    uint32_t e;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2"
+        : "+v"(acc), "=v"(e), "=&s"(carry)
+        : "v"(x), "v"(y));
+    ex = e;
+}
 // y wave-uniform (an SGPR or a constant the compiler puts in one)
 __device__ inline __attribute__((always_inline)) void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y_uniform) {
     uint64_t carry;
@@ -301,6 +310,11 @@ __device__ inline __attribute__((always_inline)) void sub256(uint32_t (&o)[8], u
 GKR_HD void mac96(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
     const uint64_t p = (uint64_t)x * y, s = acc + p;
     ex += (s < acc) ? 1u : 0u;
+    acc = s;
+}
+GKR_HD void mac96_first(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
+    const uint64_t p = (uint64_t)x * y, s = acc + p;
+    ex = (s < acc) ? 1u : 0u;
     acc = s;
 }
 GKR_HD void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) { mac96(acc, ex, x, y); }
@@ -601,12 +615,13 @@ GKR_HD void lazy_mac_v(Lazy17& acc, const Fr& a, const Fr& b) {
     uint32_t ex = 0;
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
-        col += acc.l[c];
+        col += acc.l[c];   // col < 2^35 after the shift: cannot overflow
+        const int i0 = c > 7 ? c - 7 : 0, i1 = c < 7 ? c : 7;
+        mac96_first(col, ex, a.l[i0], b.l[c - i0]);
 #pragma unroll
-        for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96(col, ex, a.l[i], b.l[c - i]);
+        for (int i = i0 + 1; i <= i1; ++i) mac96(col, ex, a.l[i], b.l[c - i]);
         acc.l[c] = (uint32_t)col;
         col = (col >> 32) | ((uint64_t)ex << 32);
-        ex = 0;
     }
     col += acc.l[15];
     acc.l[15] = (uint32_t)col;
@@ -623,13 +638,14 @@ GKR_HD void lazy_mac_sel(Lazy17& A, Lazy17& B, bool toA, const Fr& a, const Fr& 
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
         col += toA ? A.l[c] : B.l[c];
+        const int i0 = c > 7 ? c - 7 : 0, i1 = c < 7 ? c : 7;
+        mac96_first(col, ex, a.l[i0], b.l[c - i0]);
 #pragma unroll
-        for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96(col, ex, a.l[i], b.l[c - i]);
+        for (int i = i0 + 1; i <= i1; ++i) mac96(col, ex, a.l[i], b.l[c - i]);
         const uint32_t lo = (uint32_t)col;
         A.l[c] = toA ? lo : A.l[c];
         B.l[c] = toA ? B.l[c] : lo;
         col = (col >> 32) | ((uint64_t)ex << 32);
-        ex = 0;
     }
 #pragma unroll
     for (int c = 15; c < 17; ++c) {
