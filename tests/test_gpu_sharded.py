@@ -82,6 +82,43 @@ def test_device_exchange_bad_gate_fails_every_rank():
                                                       [rng.randrange(P) for _ in range(16)], 4)
 
 
+def test_device_exchange_argument_errors_are_statuses(ctx):
+    """gkr_resident_layer_sumcheck_dev: a buffer smaller than gkr_exchange_limbs(k_next), a null hook, and a hook that
+    reports failure come back as error statuses (the hook's failure after both kernels of the exchange were queued)."""
+    import torch
+    from gkr_amd import GkrError
+    from gkr_amd import _native as N
+    rng = random.Random(1702)
+    k_i, k = 6, 4
+    lay = _layer(rng, k_i, k)
+    gt, l, r = lay.arrays()
+    z = to_limbs([rng.randrange(P) for _ in range(k_i)])
+    w = to_limbs([rng.randrange(P) for _ in range(1 << k)])
+    need = int(N.lib().gkr_exchange_limbs(ctypes.c_int(k)))
+    assert need == ((2 << k) + 1) * 8 and N.lib().gkr_exchange_limbs(ctypes.c_int(99)) == 0
+    buf = torch.zeros(need, dtype=torch.int64, device="cuda:0")
+    calls = []
+
+    def failing(_user, count, stream):
+        calls.append(count)
+        return 7
+    gates = parallel.ResidentGates(ctx, k_i, 0, gt, l, r)
+    try:
+        for fn, capacity in ((N.ALLREDUCE_DEV_FN(failing), need - 1), (N.ALLREDUCE_DEV_FN(0), need), (N.ALLREDUCE_DEV_FN(failing), need)):
+            ex = parallel.DeviceExchange.__new__(parallel.DeviceExchange)
+            ex.errors, ex.calls, ex._buf, ex._fn = [], 0, buf, fn
+            ex.struct = N.ExchangeDev(fn, None, buf.data_ptr(), capacity)
+            with pytest.raises(GkrError):
+                gates.sumcheck_raw(k, z, w, ex)
+        assert calls == [need]      # only the last case reaches the hook
+        # and the layer still proves afterwards (whole layer, no exchange)
+        want = cdense.sumcheck_layer_raw(k_i, k, gt, l, r, z, w)
+        got = gates.sumcheck_raw(k, z, w)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    finally:
+        gates.close()
+
+
 def test_device_exchange_over_rccl_single_rank():
     """RCCL itself in the loop: a process group with backend nccl (world of one rank -- one MI355X is what this box
     has), the all-reduce queued on the library's stream through torch.distributed; transcript = the oracle's."""
