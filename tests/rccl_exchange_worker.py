@@ -37,6 +37,19 @@ def main():
                 assert np.array_equal(C, c2) and np.array_equal(L, l2) and np.array_equal(R, r2), (k_i, k)
             gates.close()
     assert ex.calls == 12, ex.calls
+    # the plain sumcheck's trailing-variable form: one all-reduce of the round's two sums per round through RCCL
+    # (gkr_mle_session_* shards, parallel.prove_sumcheck_distributed), against the oracle's transcript
+    with Context(0) as ctx:
+        n = 12
+        table = cdense.fill_table(1 << n, 4321)
+        d = ctx.alloc((1 << n) * 32)
+        ctx.upload(d, table)
+        shard = parallel.MleSession(ctx, d, n)
+        proof, rs = parallel.prove_sumcheck_distributed(shard, coll, n, None, None)
+        shard.close()
+        ctx.free(d)
+        from gkr_amd.field import from_limbs
+        assert (proof, rs) == cdense.sumcheck_mle(from_limbs(table), n)
     dist.destroy_process_group()
     print("OK")
 

@@ -121,7 +121,8 @@ def test_device_exchange_argument_errors_are_statuses(ctx):
 
 def test_device_exchange_over_rccl_single_rank():
     """RCCL itself in the loop: a process group with backend nccl (world of one rank -- one MI355X is what this box
-    has), the all-reduce queued on the library's stream through torch.distributed; transcript = the oracle's."""
+    has), the layer's two exchanges as all-reduces queued on the library's stream through torch.distributed, and the plain
+    sumcheck's per-round all-reduce of the trailing-variable form; transcripts = the oracle's."""
     import os
     import subprocess
     import sys
