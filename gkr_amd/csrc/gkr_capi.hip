@@ -28,6 +28,7 @@
 #include "gate_seg.h"
 #include "keccak.h"
 #include "mimc7.h"
+#include "mimc_adx.h"
 #include "mimc_ifma.h"
 
 using gkr::Fr;
@@ -122,6 +123,16 @@ bool host_ifma_ready() {
         return true;
     }();
     return ready;
+}
+
+// ONE transcript's hash of a round vector (canonical in, canonical out) on the calling thread: the mulx / adcx / adox
+// code of mimc_adx.cpp where the CPU has it (GKR_NO_ADX unset), the portable 4 x 64-bit code of fr64.h otherwise
+inline gkr::h64::F host_multi_hash(const gkr::h64::F* arr, int n, const gkr::h64::F* cts) {
+    static const bool adx = !getenv("GKR_NO_ADX") && gkr::gkr_adx_available();
+    if (!adx) return gkr::h64::mimc7_multi_hash(arr, n, cts, nullptr);
+    gkr::h64::F out;
+    gkr::gkr_adx_multi_hash(reinterpret_cast<const uint64_t(*)[4]>(arr), n, reinterpret_cast<const uint64_t(*)[4]>(cts), out.l);
+    return out;
 }
 
 // up to sixteen transcripts on the IFMA code: two interleaved groups of eight fill the FMA pipes (one group is
@@ -674,7 +685,7 @@ static void host_pass_scalar(const uint64_t* sums, size_t sums_row_words, int co
             const F d = gkr::h64::sub(hi, lo);
             const uint32_t ln = (final_len && t == J - 1) ? final_len[k] : (gkr::h64::is_zero(d) ? 1u : 2u);
             const F vec[2] = {d, lo};
-            const F rc = gkr::h64::mimc7_multi_hash(vec + (2 - ln), (int)ln, cts, nullptr);
+            const F rc = host_multi_hash(vec + (2 - ln), (int)ln, cts);
             memcpy(c0[t][k], &lo, 32);
             memcpy(c1[t][k], &d, 32);
             memcpy(r[t][k], &rc, 32);
@@ -736,7 +747,7 @@ static void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, in
             const F vlin = sub(sub(g1, vc0), vc2);
             const uint32_t ln = vec_len[t][k];
             const F vec[3] = {vc2, vlin, vc0};
-            const F rc = mimc7_multi_hash(vec + (3 - ln), (int)ln, cts, nullptr);
+            const F rc = host_multi_hash(vec + (3 - ln), (int)ln, cts);
             memcpy(c2[t][k], &vc2, 32);
             memcpy(lin[t][k], &vlin, 32);
             memcpy(c0[t][k], &vc0, 32);
@@ -1238,7 +1249,7 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
             } else {
                 for (int i = 0; i < count; ++i) {
                     gkr::h64::F vec[2] = {c1[i], c0[i]};
-                    const gkr::h64::F r = gkr::h64::mimc7_multi_hash(vec + (2 - ln[i]), (int)ln[i], cts, nullptr);
+                    const gkr::h64::F r = host_multi_hash(vec + (2 - ln[i]), (int)ln[i], cts);
                     publish(b_first + i, round, c0[i], c1[i], ln[i], r);
                 }
             }
@@ -1810,7 +1821,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 } else {
                     for (int j = 0; j < nr; ++j) {
                         gkr::h64::F vec[3] = {c2[j], lin[j], c0[j]};
-                        r[j] = gkr::h64::mimc7_multi_hash(vec + (3 - ln[j]), (int)ln[j], cts64, nullptr);
+                        r[j] = host_multi_hash(vec + (3 - ln[j]), (int)ln[j], cts64);
                     }
                 }
                 if (dbg_r) lap_us(us_hash);
@@ -1896,7 +1907,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         } else {
             for (int i = 0; i < count; ++i) {
                 gkr::h64::F vec[3] = {c2[i], lin[i], c0[i]};
-                r[i] = gkr::h64::mimc7_multi_hash(vec + (3 - ln[i]), (int)ln[i], cts64, nullptr);
+                r[i] = host_multi_hash(vec + (3 - ln[i]), (int)ln[i], cts64);
             }
         }
         for (int i = 0; i < count; ++i) {
@@ -2587,7 +2598,7 @@ int gkr_selftest_hash8(const gkr_fr* vecs, const uint32_t* len, gkr_fr* out, int
         for (int k = 0; k < 8; ++k) {
             gkr::h64::F v[3];
             memcpy(v, vecs + 3 * k, 96);
-            const gkr::h64::F r = gkr::h64::mimc7_multi_hash(v + (3 - len[k]), (int)len[k], cts, nullptr);
+            const gkr::h64::F r = host_multi_hash(v + (3 - len[k]), (int)len[k], cts);
             memcpy(&out[k], &r, 32);
         }
     }
@@ -2627,7 +2638,7 @@ int gkr_ubench_host_hash(int len, double* us_per_hash_lanes16, double* us_per_ha
     double best = 1e30;
     for (int rep = 0; rep < 5; ++rep) {
         const auto t0 = now();
-        for (int i = 0; i < 32; ++i) v[2] = gkr::h64::mimc7_multi_hash(v + (3 - len), len, cts, nullptr);
+        for (int i = 0; i < 32; ++i) v[2] = host_multi_hash(v + (3 - len), len, cts);
         const double us = std::chrono::duration<double, std::micro>(now() - t0).count() / 32.0;
         if (us < best) best = us;
     }

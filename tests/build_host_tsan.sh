@@ -13,7 +13,7 @@ CLANGXX=${CLANGXX:-/opt/rocm/lib/llvm/bin/clang++}
 SAN="-fsanitize=thread"
 $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-function -Xarch_host $SAN -c gkr_capi.hip -o $OUT/gkr_capi_tsan.o
 $CLANGXX -O1 -g -std=c++17 -fPIC $SAN -Wno-unknown-pragmas -mavx512f -mavx512ifma -mavx512vl -c mimc_ifma.cpp -o $OUT/mimc_ifma_tsan.o
-for u in keccak circom_input r1cs; do $CLANGXX -O1 -g -std=c++17 -fPIC $SAN -Wno-unknown-pragmas -c $u.cpp -o $OUT/${u}_tsan.o; done
+for u in keccak circom_input r1cs mimc_adx; do $CLANGXX -O1 -g -std=c++17 -fPIC $SAN -Wno-unknown-pragmas -c $u.cpp -o $OUT/${u}_tsan.o; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -o $OUT/libgkr_tsan.so $OUT/gkr_capi_tsan.o kernels.o $OUT/mimc_ifma_tsan.o $OUT/keccak_tsan.o \
-    $OUT/circom_input_tsan.o $OUT/r1cs_tsan.o
+    $OUT/circom_input_tsan.o $OUT/r1cs_tsan.o $OUT/mimc_adx_tsan.o
 $CLANGXX -O1 -g -std=c++17 $SAN -pthread ../../tests/first_use_race.cpp -L$OUT -lgkr_tsan -Wl,-rpath,'$ORIGIN' -o $OUT/first_use_race_tsan

@@ -16,6 +16,7 @@
 #include "../gkr_amd/csrc/fr64.h"
 #include "../gkr_amd/csrc/keccak.h"
 #include "../gkr_amd/csrc/mimc7.h"
+#include "../gkr_amd/csrc/mimc_adx.h"
 #include "../gkr_amd/csrc/mimc_ifma.h"
 
 static int failures = 0;
@@ -172,6 +173,25 @@ static void hashes(std::mt19937_64& rng) {
     for (size_t n = 0; n < msg.size(); n += 17) gkr::keccak256(msg.data(), n, out);
     gkr::Fr cts[gkr::kMimcRounds];
     gkr::mimc7_make_constants(cts);
+    if (gkr::gkr_adx_available()) {
+        // one transcript on mulx / adcx / adox against the portable 4 x 64-bit code, edge values included
+        gkr::h64::F c64[gkr::kMimcRounds];
+        memcpy(c64, cts, sizeof c64);
+        for (int it = 0; it < 200; ++it) {
+            gkr::h64::F v[3];
+            for (auto& e : v) {
+                e = gkr::h64::F{{rng(), rng(), rng(), rng() >> 4}};
+                if (it % 7 == 0) e = gkr::h64::F{{0, 0, 0, 0}};
+                if (it % 11 == 0) e = gkr::h64::F{{gkr::h64::kMod[0] - 1, gkr::h64::kMod[1], gkr::h64::kMod[2], gkr::h64::kMod[3]}};
+            }
+            for (int n = 0; n <= 3; ++n) {
+                const gkr::h64::F want = gkr::h64::mimc7_multi_hash(v, n, c64, nullptr);
+                gkr::h64::F got;
+                gkr::gkr_adx_multi_hash(reinterpret_cast<const uint64_t(*)[4]>(v), n, reinterpret_cast<const uint64_t(*)[4]>(c64), got.l);
+                CHECK(memcmp(&want, &got, 32) == 0);
+            }
+        }
+    }
     if (gkr::gkr_ifma_available()) {
         static uint64_t canon[gkr::kMimcRounds][4];
         for (int i = 0; i < gkr::kMimcRounds; ++i) {

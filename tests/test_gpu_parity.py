@@ -117,7 +117,7 @@ def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
 
 @pytest.mark.parametrize("env", [{"GKR_NO_MFMA_FOLD": "1"}, {"GKR_ROUNDS_PER_PASS": "1"}, {"GKR_ROUNDS_PER_PASS": "3"},
                                  {"GKR_ROUNDS_PER_PASS": "4"}, {"GKR_HASH_CHUNK": "16", "GKR_HOST_THREADS": "2"},
-                                 {"GKR_NO_IFMA": "1"}, {"GKR_HOST_PASS_SCALAR": "1"}, {"GKR_PLAN_MAIN": "1", "GKR_FOLD_BLOCKS": "8192"},
+                                 {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_HOST_PASS_SCALAR": "1"}, {"GKR_PLAN_MAIN": "1", "GKR_FOLD_BLOCKS": "8192"},
                                  {"GKR_PASS_QUEUE_DEPTH": "1", "GKR_GROUP_SIZE": "3"}, {"GKR_PASS_QUEUE_DEPTH": "16", "GKR_GROUP_SIZE": "2"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_fold_pass_variants_match_oracle(env):
@@ -287,7 +287,7 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
                                  {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_LAYER_PERSISTENT": "1"},
                                  {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
                                  {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_LAYER_PER_ROUND": "1"},
-                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}, {"GKR_LINE_STEPWISE": "1"}],
+                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_LINE_STEPWISE": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
     """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from

@@ -149,6 +149,48 @@ def test_batched_transcript_hash_matches_oracle():
             assert got[k] == mimc7.multi_hash(vals[k][3 - lens[k]:]), (trial, k, lens[k])
 
 
+_HASH8_CHILD = r"""
+import ctypes, random, sys
+import numpy as np
+sys.path.insert(0, %r)
+from gkr_amd import _native as N
+from gkr_amd.field import MODULUS as P, to_limbs, from_limbs
+lib = N.lib()
+rng = random.Random(11)
+for trial in range(6):
+    lens = [rng.randint(0, 3) for _ in range(8)]
+    vals = [[rng.randrange(P) for _ in range(3)] for _ in range(8)]
+    if trial == 0:
+        vals[0], vals[1], lens[0], lens[1] = [0, 0, 0], [P - 1, P - 1, P - 1], 3, 3
+    V = to_limbs([x for row in vals for x in row])
+    L = np.asarray(lens, dtype=np.uint32)
+    O = np.zeros((8, 4), dtype=np.uint64)
+    used = ctypes.c_int(-1)
+    assert lib.gkr_selftest_hash8(V.ctypes.data_as(ctypes.c_void_p), L.ctypes.data_as(ctypes.c_void_p), O.ctypes.data_as(ctypes.c_void_p), ctypes.byref(used)) == 0
+    assert used.value == 0
+    print(lens, [row for row in vals], [int(x) for x in from_limbs(O)])
+"""
+
+
+@pytest.mark.parametrize("env", [{"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}], ids=["mulx_adx", "portable"])
+def test_single_transcript_hash_matches_oracle(env):
+    """one transcript's MiMC7 on the calling thread (batch 1 and chunk tails): the mulx / adcx / adox code of
+    mimc_adx.cpp where the CPU has it, and the portable 4 x 64-bit code -- the knobs are read once per process"""
+    import ast
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _HASH8_CHILD % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("[")]
+    assert len(lines) == 6
+    for line in lines:
+        lens, vals, got = ast.literal_eval("(" + line.replace("] [", "], [") + ")")
+        for k in range(8):
+            assert got[k] == mimc7.multi_hash(vals[k][3 - lens[k]:]), (env, k)
+
+
 def test_host_pass_matches_big_integers():
     """the host's share of a multi-round pass (round coefficients from the sub-block sums, vector lengths, MiMC7
     challenges, binding, the next fold's weights): scalar and IFMA-lane forms against Python integers and the
