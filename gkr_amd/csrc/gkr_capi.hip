@@ -1568,14 +1568,26 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     }
     int rc = GKR_OK;
     uint32_t* bad = nullptr;
+    uint32_t* h_dep = nullptr;   // pinned: which variables W depends on, per proof; the device leaves it there before round 0
+    if (host_tx) HIP_TRY(ctx, ctx->pinned_host("layer.hdep", sizeof(uint32_t) * 32 * batch, reinterpret_cast<void**>(&h_dep)));
     bool lists_fresh = true;   // the gate lists are built (and the gates validated) in this call
     if (sparse) {
         uint32_t *g_counts = nullptr, *g_bsums = nullptr;
         const size_t nb2 = (size_t)2 << k;
         WS(ctx, "pred.bad", uint32_t, 1, bad);
-        rc = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo, (int)kl);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+        {
+            // the eq tables of z (built on the device from the points in pinned memory), the Montgomery copies of W and the
+            // dependence flags: one launch (k_layer_prologue)
+            const int kh = k_i - (int)kl;
+            WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
+            WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
+            gkr_fr* hz = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz)));
+            memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
+            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, persistent ? nullptr : Wb,
+                                       persistent ? nullptr : Wc, (uint32_t)k, dep, h_dep, (uint32_t)batch, s);
+        }
+        if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)
         if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
         if (cached && cached->ready) {
             lists_fresh = false;
@@ -1618,12 +1630,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         if (rc) return rc;
     }
     gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, tlen, wlen};
-    HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
-    if (!persistent) {
+    if (!sparse) {   // (the gate-list form did all of this in its prologue launch above)
+        HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
         gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
         gkr::launch_to_mont(d_W, Wc, (uint32_t)(wlen * batch), s);
+        gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
     }
-    gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
     if (persistent) {
         // U, V, the rounds and the row are all inside the one kernel launched below
     } else if (sparse) {
@@ -1695,7 +1707,6 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
 
     gkr::LayerHostRec* rec = nullptr;
     gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
-    uint32_t* h_dep = nullptr;   // pinned: which variables W depends on, per proof; the device leaves it there before round 0
     const gkr::h64::F* cts64 = host_mimc_constants64();
     const bool ifma = host_ifma_ready();
     gkr::SpinPool* pool = nullptr;
@@ -1703,8 +1714,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
         // h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record
-        HIP_TRY(ctx, ctx->pinned_host("layer.hdep", sizeof(uint32_t) * 32 * batch, reinterpret_cast<void**>(&h_dep)));
-        gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
+        // (the gate-list form's prologue launch wrote it)
+        if (!sparse) gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
         // (gate-sharded with the device exchange: the flag travels with the first exchange and is looked at after the
         // first round's record, on every rank alike -- a rank that left here would leave its peers inside a collective)
         if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built

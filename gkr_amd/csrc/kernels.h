@@ -210,6 +210,11 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s);
 // out[proof][g] = eq(points[proof * stride + first ..+nvars), g), nvars <= 28; points may be pinned host memory
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
                      hipStream_t s);
+// one launch for a layer's set-up: E_hi (canonical, kh leading coordinates of the proof's point), E_lo (Montgomery, kl
+// trailing ones), the two Montgomery copies of W (Wb null: none) and the 32 dependence flags per proof, in dep and -- when not null -- in
+// pinned host memory host_dep (k_layer_prologue)
+void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,
+                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
 // q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, out batch x (k + 1)
 // highest degree first, out_len batch
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,

@@ -602,17 +602,21 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     }
 }
 
-// grid = (batch), block = 128: totals of the blocks' partials -> the pinned record
-__global__ void __launch_bounds__(128) k_prod_publish(const Fr* __restrict__ partials, uint32_t blocks, ProdPassRec* __restrict__ rec,
+// grid = (batch), block = 288: totals of the blocks' partials -> the pinned record.  Four threads per value, each a
+// quarter of the blocks (the kernel sits between two hashes of the round path: 32 dependent additions took 12 us)
+__global__ void __launch_bounds__(320) k_prod_publish(const Fr* __restrict__ partials, uint32_t blocks, ProdPassRec* __restrict__ rec,
                                                       uint32_t ticket) {
-    const uint32_t tid = threadIdx.x;
+    __shared__ Fr s_q[4][kProdRecValues];
+    const uint32_t tid = threadIdx.x, q = tid / (uint32_t)kProdRecValues, val = tid % (uint32_t)kProdRecValues;
     ProdPassRec* r = rec + blockIdx.x;
-    if (tid < (uint32_t)kProdRecValues) {
-        const Fr* p = partials + (size_t)blockIdx.x * blocks * kProdRecValues + tid;
-        Fr v = load_fr(p);
-        for (uint32_t k = 1; k < blocks; ++k) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
-        store_fr(&r->v[tid], v);
+    if (q < 4) {
+        const Fr* p = partials + (size_t)blockIdx.x * blocks * kProdRecValues + val;
+        Fr v = fr_zero();
+        for (uint32_t k = q; k < blocks; k += 4) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
+        s_q[q][val] = v;
     }
+    __syncthreads();
+    if (tid < (uint32_t)kProdRecValues) store_fr(&r->v[tid], fr_add(fr_add(s_q[0][tid], s_q[1][tid]), fr_add(s_q[2][tid], s_q[3][tid])));
     __syncthreads();   // every record store is issued and waited for before the release below
     if (tid == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -662,10 +666,10 @@ __global__ void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restr
 // read where the host wrote them (pinned memory): no copy engine, no transfer call on the round path.  Every entry is
 // its own product of nvars factors (the host's doubling construction gives the same field elements).
 // grid = (blocks over 2^nvars, batch), block = 256
-__global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
-                                                  Fr* __restrict__ out, uint32_t montgomery) {
+__device__ __forceinline__ void eq_table_part(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
+                                              Fr* __restrict__ out, uint32_t montgomery, uint32_t bx, uint32_t nbx, uint32_t proof) {
     __shared__ Fr s_f[2][32];   // Montgomery forms of 1 - x_i and x_i
-    const Fr* pt = points + (size_t)blockIdx.y * stride + first;
+    const Fr* pt = points + (size_t)proof * stride + first;
     if (threadIdx.x < nvars) {
         const Fr x = load_fr(pt + threadIdx.x);
         Fr one = fr_zero();
@@ -678,7 +682,7 @@ __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points,
     // dependent chain on one lane, and these kernels sit on every layer's set-up path: 16 variables = 4 + 2 products deep
     // instead of 15), then the quad's four partial products are multiplied together across lanes.
     const uint32_t n = 1u << nvars, q = threadIdx.x & 3u;
-    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; g < n; g += (gridDim.x * blockDim.x) >> 2) {
+    for (uint32_t g = (bx * blockDim.x + threadIdx.x) >> 2; g < n; g += (nbx * blockDim.x) >> 2) {
         Fr p = fr_mont_one();
         bool any = false;
         for (uint32_t i = q; i < nvars; i += 4) {
@@ -695,7 +699,60 @@ __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points,
         }
         if (q == 0) {
             if (!montgomery) p = from_mont(p);
-            store_fr(out + ((size_t)blockIdx.y << nvars) + g, p);
+            store_fr(out + ((size_t)proof << nvars) + g, p);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
+                                                  Fr* __restrict__ out, uint32_t montgomery) {
+    eq_table_part(points, stride, first, nvars, out, montgomery, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Everything a layer's sumcheck needs before its first gate pass, in ONE launch (seven launches of 5 - 20 us each sat
+// on every layer's set-up path: the two eq tables, two memsets, two Montgomery copies of W, the dependence flags):
+//   blocks [0, nb_hi):   E_hi = eq(z[0 .. kh), .)   canonical
+//   next nb_lo blocks:   E_lo = eq(z[kh .. k_i), .) Montgomery
+//   next nb_mont blocks: Wb = Wc = Montgomery form of W (skipped when Wb is null)
+//   last block:          dep[b] = 1 iff W differs somewhere across bit (k-1-b)  (k_depends; no memset, no global atomics),
+//                        also left in pinned host memory (host_dep, may be null) for the host transcript's length rule
+// grid = (nb_hi + nb_lo + nb_mont + 1, batch), block = 256
+__global__ void __launch_bounds__(256) k_layer_prologue(const Fr* __restrict__ points, uint32_t k_i, uint32_t kh, uint32_t kl,
+                                                        Fr* __restrict__ e_hi, Fr* __restrict__ e_lo, const Fr* __restrict__ W,
+                                                        Fr* __restrict__ Wb, Fr* __restrict__ Wc, uint32_t k, uint32_t* __restrict__ dep,
+                                                        uint32_t* __restrict__ host_dep, uint32_t nb_hi, uint32_t nb_lo, uint32_t nb_mont) {
+    const uint32_t bx = blockIdx.x, proof = blockIdx.y, n = 1u << k;
+    if (bx < nb_hi) {
+        eq_table_part(points, k_i, 0u, kh, e_hi, 0u, bx, nb_hi, proof);
+    } else if (bx < nb_hi + nb_lo) {
+        eq_table_part(points, k_i, kh, kl, e_lo, 1u, bx - nb_hi, nb_lo, proof);
+    } else if (bx < nb_hi + nb_lo + nb_mont) {
+        if (!Wb) return;
+        const size_t base = (size_t)proof << k;
+        for (uint32_t i = (bx - nb_hi - nb_lo) * blockDim.x + threadIdx.x; i < n; i += nb_mont * blockDim.x) {
+            const Fr m = to_mont(load_fr(W + base + i));
+            store_fr(Wb + base + i, m);
+            store_fr(Wc + base + i, m);
+        }
+    } else {
+        __shared__ uint32_t s_dep;
+        if (threadIdx.x == 0) s_dep = 0;
+        __syncthreads();
+        const Fr* w = W + ((size_t)proof << k);
+        uint32_t bits = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const Fr a = load_fr(w + i);
+            for (uint32_t b = 0; b < k; ++b) {
+                const uint32_t bit = 1u << (k - 1 - b);
+                if (!(bits >> b & 1u) && !(i & bit) && !fr_eq(a, load_fr(w + (i ^ bit)))) bits |= 1u << b;
+            }
+        }
+        if (bits) atomicOr(&s_dep, bits);
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const uint32_t f = (s_dep >> threadIdx.x) & 1u;
+            dep[(size_t)proof * 32 + threadIdx.x] = f;
+            if (host_dep) host_dep[(size_t)proof * 32 + threadIdx.x] = f;   // pinned: the host reads it once a later kernel has released round 0's record
         }
     }
 }
@@ -2375,7 +2432,7 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
     const uint32_t blocks = prod_pass_blocks(1u << (m_in - jp - J));
     hipLaunchKernelGGL(k_prod_cross, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
-    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(128), 0, s, partials, blocks, rec, ticket);
+    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(4 * kProdRecValues), 0, s, partials, blocks, rec, ticket);
 }
 
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
@@ -2436,6 +2493,14 @@ void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t
                      hipStream_t s) {
     hipLaunchKernelGGL(k_eq_table, dim3(blocks_for((size_t)4 << nvars, 4096), batch), dim3(256), 0, s, points, stride, first, nvars, out,
                        montgomery ? 1u : 0u);
+}
+
+void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,
+                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s) {
+    const uint32_t nb_hi = blocks_for((size_t)4 << kh, 4096), nb_lo = blocks_for((size_t)4 << kl, 4096);
+    const uint32_t nb_mont = Wb ? blocks_for((size_t)1 << k, 1024) : 0u;
+    hipLaunchKernelGGL(k_layer_prologue, dim3(nb_hi + nb_lo + nb_mont + 1, batch), dim3(256), 0, s, points, k_i, kh, kl, e_hi, e_lo, W, Wb,
+                       Wc, k, dep, host_dep, nb_hi, nb_lo, nb_mont);
 }
 
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
