@@ -1955,16 +1955,19 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
                 for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
                 gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
+                bool c_tables_done = false;   // (one rank holds all gates and the rows come from segments: the row pass writes X, Y too)
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
-                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, segs, seg_partials, s);
+                    const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
+                    c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
+                                                          segs, seg_partials, s, shard ? nullptr : &fuse);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
                     second_exchange_done = true;
                     rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
                     if (rc) break;
                 }
-                gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
+                if (!c_tables_done) gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
                 Tw = Wc;
                 Tx = Xc;
                 Ty = Yc;

@@ -158,9 +158,19 @@ void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* g
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, const GateSegs* segs,
                     Fr* partials, hipStream_t s);
-void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+// the c-phase's set-up done by the row pass itself (launch_prod_c_setup's arguments; Wb null: not fused)
+struct CPhaseFuse {
+    const Fr* Wb = nullptr;
+    const Fr* weights = nullptr;
+    Fr* X = nullptr;
+    Fr* Y = nullptr;
+    uint32_t jp = 0;
+};
+// fuse (may be null): also write X = a_u + W(u) m_u, Y = W(u) a_u; returns true when it did (the segment form), false when
+// the caller still has to launch_prod_c_setup (the bucket form)
+bool launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      const GateSegs* segs, Fr* partials, hipStream_t s);
+                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse = nullptr);
 // One launch per layer (small layers): the whole layer sumcheck of `batch` proofs as one resident kernel, one block
 // per proof, tables in LDS; rounds are handed to the host and challenges taken back through pinned memory, no
 // launch per round (kernels.hip, k_layer_persistent).

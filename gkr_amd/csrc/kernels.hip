@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
 __global__ void __launch_bounds__(64) k_seg_combine(const uint2* __restrict__ items, const uint32_t* __restrict__ bucket_begin, uint32_t b_first,
                                                     uint32_t nb, const Fr* __restrict__ X, const Fr* __restrict__ Y, uint32_t pstride,
                                                     const Fr* __restrict__ e_hi, uint32_t kh, uint32_t run_base, Fr* __restrict__ out0,
-                                                    Fr* __restrict__ out1, uint32_t wstride) {
+                                                    Fr* __restrict__ out1, uint32_t wstride, CPhaseFuse fuse) {
     const uint32_t lane = threadIdx.x & 31u, bucket = 2u * blockIdx.x + (threadIdx.x >> 5);
     const bool live = bucket < nb;
     const uint32_t half_begin = bucket_begin[b_first], lo = live ? bucket_begin[b_first + bucket] : 0u, hi = live ? bucket_begin[b_first + bucket + 1] : 0u;
@@ -1490,6 +1490,27 @@ __global__ void __launch_bounds__(64) k_seg_combine(const uint2* __restrict__ it
     if (live && lane == 0) {
         store_fr(out0 + (size_t)blockIdx.y * wstride + bucket, r0);
         store_fr(out1 + (size_t)blockIdx.y * wstride + bucket, r1);
+    }
+    if (fuse.Wb) {
+        // the rows are a_u, m_u: the c-phase's tables X = a_u + W(u) m_u, Y = W(u) a_u straight from here (k_prod_c_setup's
+        // arithmetic; one launch less between the row pass and the c-phase's first product pass)
+        const size_t base = (size_t)blockIdx.y * wstride;
+        Fr wu = fr_zero();
+        if (threadIdx.x < (1u << fuse.jp)) wu = mont_mul(load_fr(fuse.Wb + base + threadIdx.x), load_fr(fuse.weights + (size_t)blockIdx.y * 8 + threadIdx.x));
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.l[j] = __shfl_down(wu.l[j], off, 64);
+            wu = fr_add(wu, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wu.l[j] = __shfl(wu.l[j], 0, 64);
+        const Fr x = fr_add(r0, mont_mul(r1, wu)), y = mont_mul(r0, wu);
+        if (live && lane == 0) {
+            store_fr(fuse.X + base + bucket, x);
+            store_fr(fuse.Y + base + bucket, y);
+        }
     }
 }
 
@@ -2770,26 +2791,27 @@ void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* off
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(false, *segs, k, e_lo_mont, W, X, Y, lb, s);
         hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 0u, 1u << k, X, Y,
-                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, U, V, (uint32_t)lb.wstride);
+                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, U, V, (uint32_t)lb.wstride, CPhaseFuse{});
         return;
     }
     hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
                        list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
 }
 
-void launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+bool launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      const GateSegs* segs, Fr* partials, hipStream_t s) {
+                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse) {
     if (segs && segs->shift && partials) {
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(true, *segs, k, e_lo_mont, eq_mont, X, Y, lb, s);
         hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 1u << k, 1u << k, X, Y,
-                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, A_row, M_row, (uint32_t)lb.wstride);
-        return;
+                           segs->half_bound, e_hi, k_i - segs->shift, segs->run_base, A_row, M_row, (uint32_t)lb.wstride, fuse ? *fuse : CPhaseFuse{});
+        return fuse != nullptr;
     }
     hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
                        list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride,
                        (uint32_t)span.base);
+    return false;
 }
 
 void launch_predicate_normalise(const unsigned long long* wide, Fr* out, size_t cells, hipStream_t s) {
