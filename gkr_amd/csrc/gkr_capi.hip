@@ -956,8 +956,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         if (gkr::mle_multifold_uses_mfma((uint32_t)S, nblk)) {
             // the digit matrices only depend on the weights the host just wrote: built on the side stream, so the
             // main stream (busy with another group's pass) pays one event wait, not a launch round trip
+            // (one group: nothing else is streaming, and the event between the two streams costs the round path ~10 us
+            // more than a second launch on the same stream -- 15 us against 5 between the plan and the fold)
             static const bool plan_inline = getenv("GKR_PLAN_MAIN") != nullptr;
-            if (plan_inline || st != s) {
+            if (plan_inline || st != s || groups == 1) {
                 gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, st);
             } else {
                 {
