@@ -26,6 +26,9 @@ GKR_BENCH_FORCE_GROUP=1 python bench.py --mode layer-split --steps 10 --warmup 3
 python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
 LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --no-verify --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
+bash tools/trace_layer_timeline.sh > $OUT/layer24_kernel_timeline.txt 2>&1
+bash tools/trace_mle_latency_timeline.sh > $OUT/mle_batch1_kernel_timeline.txt 2>&1
+cd $R
 cat $OUT/gpu_tests.txt $OUT/smoke.txt
 head -c 1500 $OUT/bench_default.json
 head -12 $OUT/kernel_stats.csv
