@@ -1,3 +1,6 @@
+// One MiMC7-91 permutation on one host thread, six forms (see README.md here); the last one became gkr_amd/csrc/mimc_adx.cpp.
+//   clang++ -O3 -std=c++17 -DGKR_HD= -I../../gkr_amd/csrc '-DTGT=__attribute__((target("bmi2,adx")))' scalar_hash.cpp \
+//       ../../gkr_amd/csrc/keccak.o -o /tmp/scalar_hash && /tmp/scalar_hash        (-DXREG: left operand in registers)
 #include "fr64.h"
 #include "keccak.h"
 #include "mimc7.h"
