@@ -1363,11 +1363,18 @@ __global__ void __launch_bounds__(256) k_seg_pack(const uint2* __restrict__ item
     }
     const uint32_t lmask = (1u << shift) - 1u;
     for (uint32_t j = 0; j < n; ++j) tile[wave][j][lane] = 0u;
+    // inside an item the add gates come first (any order gives the same sums): the pass then changes the accumulator
+    // its products go to once per item instead of selecting it per gate
+    const uint64_t below = ((uint64_t)1 << lane) - 1u;
     for (uint32_t q = 0; q < 64u; ++q) {
         const uint32_t fq = __shfl(first, (int)q, 64), lq = __shfl(len, (int)q, 64);
-        if (lane < lq) {
-            const uint32_t mt = meta[fq + lane];
-            tile[wave][lane][q] = ((list[fq + lane] + gate_base) & lmask) | ((mt & 0x7fffffffu) << shift) | (mt & 0x80000000u);
+        const bool have = lane < lq;
+        const uint32_t mt = have ? meta[fq + lane] : 0u;
+        const bool is_add = have && !(mt >> 31);
+        const uint64_t valid = __ballot(have), addm = __ballot(is_add);
+        if (have) {
+            const uint32_t at = is_add ? (uint32_t)__popcll(addm & below) : (uint32_t)(__popcll(addm) + __popcll(valid & ~addm & below));
+            tile[wave][at][q] = ((list[fq + lane] + gate_base) & lmask) | ((mt & 0x7fffffffu) << shift) | (mt & 0x80000000u);
         }
     }
     uint32_t* dst = packed + (size_t)group_off[slot] * 64u + lane;
@@ -1423,7 +1430,10 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
         }
         if (dbg_nomac) len = 0;
         const uint32_t* src = packed + (size_t)group_off[slot] * 64u + lane;
-        Lazy17 L0 = lazy_zero(), L1 = lazy_zero();
+        // R0: the accumulator this lane's products go to -- its add gates' sum first, its mult gates' sum after the one
+        // exchange at the item's first mult gate (k_seg_pack puts an item's add gates first); R1: the other one
+        Lazy17 R0 = lazy_zero(), R1 = lazy_zero();
+        bool sw = false;
         // Entries are requested four steps ahead and E_lo one step ahead: a step's two dependent loads (the entry from
         // HBM, then the gather it addresses) would otherwise cost ~2 us per step with nothing to hide behind.
         const uint32_t last = n - 1u, omask = (1u << (31u - shift)) - 1u;
@@ -1441,7 +1451,19 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
                 t = load_fr(Tt + ((ent >> shift) & omask));   // LDS: no need to look ahead
             else
                 t_n = load_fr(Tt + ((ent_n >> shift) & omask));
-            if (j < len) seg_gate<ROWS>(L0, L1, e, t, (ent >> 31) != 0u);
+            const bool live = j < len, go = live && (ent >> 31) != 0u && !sw;
+            if (__any(go)) {
+                if (go) {
+#pragma unroll
+                    for (int c = 0; c < 17; ++c) asm("v_swap_b32 %0, %1" : "+v"(R0.l[c]), "+v"(R1.l[c]));
+                }
+                sw = sw || go;
+            }
+            if (live) {
+                lazy_mac_v(R0, e, t);
+                // (U, V: an add gate's term without a second factor joins the mult gates' sum, which is R1 until the exchange)
+                if (!ROWS) lazy_add_hi(R1, e, !sw);
+            }
             ent = ent_n;
             e = e_n;
             if (!LDS_T) t = t_n;
@@ -1451,6 +1473,14 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
         }
         if (pos < end) {
             const size_t o = (size_t)blockIdx.y * pstride + (idx - begin);
+            // ROWS: add gates -> X, mult gates -> Y;  U, V: mult gates (+ the add gates' plain terms) -> X, add gates -> Y
+            const bool r0_is_x = ROWS ? !sw : sw;
+            Lazy17 L0, L1;
+#pragma unroll
+            for (int c = 0; c < 17; ++c) {
+                L0.l[c] = r0_is_x ? R0.l[c] : R1.l[c];
+                L1.l[c] = r0_is_x ? R1.l[c] : R0.l[c];
+            }
             store_fr(X + o, lazy_reduce_partial32(L0));
             store_fr(Y + o, lazy_reduce_partial32(L1));
         }
