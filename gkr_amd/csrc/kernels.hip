@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
             if (live) {
                 lazy_mac_v(R0, e, t);
                 // (U, V: an add gate's term without a second factor joins the mult gates' sum, which is R1 until the exchange)
-                if (!ROWS) lazy_add_hi(R1, e, !sw);
+                if (!ROWS && !sw) lazy_add_hi(R1, e, true);
             }
             ent = ent_n;
             e = e_n;
