@@ -29,4 +29,26 @@ GKR_HD void seg_gate(Lazy17& L0, Lazy17& L1, const Fr& e, const Fr& t, bool is_m
     if (!ROWS) lazy_add_hi(L0, e, !is_mult);
 }
 
+// The form k_seg_pass runs since the items keep their add gates first (k_seg_pack): no select per gate.  R0 is the
+// accumulator the products go to, R1 the other one; at the item's first mult gate the two are exchanged (`sw`), once.
+//   one gate:   seg_gate_ordered<ROWS>(R0, R1, sw, e, t, is_mult)      (an add gate after a mult gate is a caller's error)
+//   at the end: seg_item_sums<ROWS>(R0, R1, sw, L0, L1)                 L0, L1 as seg_gate leaves them
+template <bool ROWS>
+GKR_HD void seg_gate_ordered(Lazy17& R0, Lazy17& R1, bool& sw, const Fr& e, const Fr& t, bool is_mult) {
+    if (is_mult && !sw) {
+        const Lazy17 x = R0;
+        R0 = R1;
+        R1 = x;
+        sw = true;
+    }
+    lazy_mac_v(R0, e, t);
+    if (!ROWS && !sw) lazy_add_hi(R1, e, true);   // U: the add gate's term without a second factor joins the mult gates' sum
+}
+template <bool ROWS>
+GKR_HD void seg_item_sums(const Lazy17& R0, const Lazy17& R1, bool sw, Lazy17& L0, Lazy17& L1) {
+    const bool r0_first = ROWS ? !sw : sw;   // ROWS: add gates -> L0, mult -> L1;  U, V: mult (+ plain add terms) -> L0, add -> L1
+    L0 = r0_first ? R0 : R1;
+    L1 = r0_first ? R1 : R0;
+}
+
 }  // namespace gkr

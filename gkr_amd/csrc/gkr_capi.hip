@@ -2709,14 +2709,32 @@ int gkr_selftest_seg_item(const gkr_fr* e_lo, const gkr_fr* t, const uint8_t* is
                           gkr_fr* out0, gkr_fr* out1) {
     if (!e_lo || !t || !is_mult || !e_hi || !out0 || !out1 || n > gkr::kSegCap) return GKR_ERR_INVALID;
     if (!all_canonical(e_lo, n) || !all_canonical(t, n) || !all_canonical(e_hi, 1)) return GKR_ERR_NON_CANONICAL;
-    gkr::Lazy17 L0 = gkr::lazy_zero(), L1 = gkr::lazy_zero();
-    for (size_t i = 0; i < n; ++i) {
-        const Fr e = gkr::to_mont(to_dev(e_lo[i])), w = gkr::to_mont(to_dev(t[i]));
-        if (rows)
-            gkr::seg_gate<true>(L0, L1, e, w, is_mult[i] != 0);
-        else
-            gkr::seg_gate<false>(L0, L1, e, w, is_mult[i] != 0);
-    }
+    // both forms of the item arithmetic (gate_seg.h): a select per gate in the order given, and -- what k_seg_pass runs -- the
+    // add gates first with one exchange of the accumulators; they must leave the same two sums
+    gkr::Lazy17 L0 = gkr::lazy_zero(), L1 = gkr::lazy_zero(), R0 = gkr::lazy_zero(), R1 = gkr::lazy_zero(), O0, O1;
+    bool sw = false;
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t i = 0; i < n; ++i) {
+            const Fr e = gkr::to_mont(to_dev(e_lo[i])), w = gkr::to_mont(to_dev(t[i]));
+            const bool m = is_mult[i] != 0;
+            if (pass == 0) {
+                if (rows)
+                    gkr::seg_gate<true>(L0, L1, e, w, m);
+                else
+                    gkr::seg_gate<false>(L0, L1, e, w, m);
+            }
+            if (m != (pass == 1)) continue;   // pass 0: the add gates, pass 1: the mult gates
+            if (rows)
+                gkr::seg_gate_ordered<true>(R0, R1, sw, e, w, m);
+            else
+                gkr::seg_gate_ordered<false>(R0, R1, sw, e, w, m);
+        }
+    if (rows)
+        gkr::seg_item_sums<true>(R0, R1, sw, O0, O1);
+    else
+        gkr::seg_item_sums<false>(R0, R1, sw, O0, O1);
+    for (int c = 0; c < 17; ++c)
+        if (O0.l[c] != L0.l[c] || O1.l[c] != L1.l[c]) return GKR_ERR_INVALID;
     const Fr x = gkr::lazy_reduce_partial32(L0), y = gkr::lazy_reduce_partial32(L1);
     gkr::Lazy17 A = gkr::lazy_zero(), B = gkr::lazy_zero();
     gkr::lazy_mac_v(A, x, to_dev(*e_hi));

@@ -1451,6 +1451,7 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
                 t = load_fr(Tt + ((ent >> shift) & omask));   // LDS: no need to look ahead
             else
                 t_n = load_fr(Tt + ((ent_n >> shift) & omask));
+            // seg_gate_ordered (gate_seg.h), with the exchange skipped by the whole wave when no lane is at its first mult gate
             const bool live = j < len, go = live && (ent >> 31) != 0u && !sw;
             if (__any(go)) {
                 if (go) {
@@ -1474,13 +1475,8 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
         if (pos < end) {
             const size_t o = (size_t)blockIdx.y * pstride + (idx - begin);
             // ROWS: add gates -> X, mult gates -> Y;  U, V: mult gates (+ the add gates' plain terms) -> X, add gates -> Y
-            const bool r0_is_x = ROWS ? !sw : sw;
             Lazy17 L0, L1;
-#pragma unroll
-            for (int c = 0; c < 17; ++c) {
-                L0.l[c] = r0_is_x ? R0.l[c] : R1.l[c];
-                L1.l[c] = r0_is_x ? R1.l[c] : R0.l[c];
-            }
+            seg_item_sums<ROWS>(R0, R1, sw, L0, L1);
             store_fr(X + o, lazy_reduce_partial32(L0));
             store_fr(Y + o, lazy_reduce_partial32(L1));
         }
