@@ -568,8 +568,16 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
         if (jp) {
             // at most eight products: added unreduced, one short reduction (a pass is a latency chain on the round path:
             // 8 x 64 + 64 multiply-adds deep instead of 8 x 128)
+            // (all operands requested before the first product: eight dependent-looking loads in a row cost the round path
+            // ~1 us each)
+            Fr in[8];
+#pragma unroll
+            for (uint32_t b = 0; b < 8u; ++b)
+                if (b < (1u << jp)) in[b] = load_fr(T[t] + ((size_t)b << m) + idx);
             Lazy17 acc = lazy_zero();
-            for (uint32_t b = 0; b < (1u << jp); ++b) lazy_mac_v(acc, load_fr(T[t] + ((size_t)b << m) + idx), s_w[b]);
+#pragma unroll
+            for (uint32_t b = 0; b < 8u; ++b)
+                if (b < (1u << jp)) lazy_mac_v(acc, in[b], s_w[b]);
             v = lazy_reduce_k8(acc);
             store_fr(T[t] + idx, v);
         } else {
