@@ -55,7 +55,7 @@ struct ProdPassRec {
 };
 static_assert(sizeof(ProdPassRec) == kProdRecValues * 32 + 32, "product-pass record layout");
 // entries per block of a pass (one tile) and blocks per proof for tables whose sub-blocks have S entries
-constexpr uint32_t kProdTile = 16;
+constexpr uint32_t kProdTile = 8;
 inline uint32_t prod_pass_blocks(uint32_t S) { return S <= kProdTile ? 1u : S / kProdTile; }
 // One pass on the tables W (Montgomery), X, Y (canonical) of 2^m_in entries per proof (stride wstride): bind the jp
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then

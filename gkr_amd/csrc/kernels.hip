@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     const uint32_t p = tid & 63u, sub = tid >> 6, a = p >> 3, b = p & 7u;
     Fr acc = fr_zero(), accy = fr_zero();
     if (a < nsub && b < nsub) {
-        Lazy17 la = lazy_zero();   // kProdTile / 4 = at most four products per thread
+        Lazy17 la = lazy_zero();   // kProdTile / 4 = two products per thread
         for (uint32_t i = sub; i < ti; i += 4) lazy_mac_v(la, s_t[1][b][i], s_t[0][a][i]);
         acc = lazy_reduce_k8(la);
     }
