@@ -778,13 +778,25 @@ __global__ void __launch_bounds__(256) k_layer_prologue(const Fr* __restrict__ p
 __global__ void __launch_bounds__(256) k_line_restriction(const Fr* __restrict__ W, uint32_t k, const Fr* __restrict__ bc,
                                                           Fr* __restrict__ scratch, Fr* __restrict__ out,
                                                           uint32_t* __restrict__ out_len) {
+    // (the tables live in LDS -- 3 * 2^k elements, 48 KB at k = 9 -- and the line's coefficients are converted once, up
+    // front: through global scratch, with b_j, c_j fetched from pinned memory and converted inside every step, the
+    // 2k dependent steps took ~60 us of every layer's path to the next layer's z)
+    extern __shared__ uint4 s_line_raw[];
     __shared__ uint32_t s_maxdeg;
+    __shared__ Fr s_cst[16], s_grad[16];
     const uint32_t n = 1u << k, tid = threadIdx.x;
     const Fr* w = W + ((size_t)blockIdx.x << k);
     const Fr* line = bc + (size_t)blockIdx.x * 2u * k;
-    Fr* buf[2] = {scratch + (size_t)blockIdx.x * 3u * n, scratch + (size_t)blockIdx.x * 3u * n + n};
-    Fr* mono = scratch + (size_t)blockIdx.x * 3u * n + 2u * n;
+    Fr* const base = reinterpret_cast<Fr*>(s_line_raw);
+    Fr* buf[2] = {base, base + n};
+    Fr* mono = base + 2u * n;
+    (void)scratch;
     if (tid == 0) s_maxdeg = 0;
+    if (tid < k) {
+        const Fr bj = load_fr(line + tid), cj = load_fr(line + k + tid);
+        s_cst[tid] = to_mont(bj);
+        s_grad[tid] = to_mont(fr_sub(cj, bj));
+    }
     for (uint32_t i = tid; i < n; i += blockDim.x) {
         const Fr v = load_fr(w + i);
         store_fr(buf[0] + i, v);
@@ -806,8 +818,7 @@ __global__ void __launch_bounds__(256) k_line_restriction(const Fr* __restrict__
     for (uint32_t j = 0; j < k; ++j, h >>= 1) {
         const Fr* src = buf[j & 1];
         Fr* dst = buf[(j & 1) ^ 1];
-        const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
-        const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+        const Fr cst = s_cst[j], grad = s_grad[j];
         const uint32_t in_len = j + 1, out_len_j = j + 2;
         for (uint32_t item = tid; item < h * out_len_j; item += blockDim.x) {
             const uint32_t i = item / out_len_j, m = item - i * out_len_j;
@@ -2562,7 +2573,7 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
                              hipStream_t s) {
     static const bool stepwise = getenv("GKR_LINE_STEPWISE") != nullptr;   // (test hook: the wide-layer form at every width)
     if (k <= 9 && !stepwise) {
-        hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), 0, s, W, k, bc, scratch, out, out_len);
+        hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), (size_t)3 * sizeof(Fr) << k, s, W, k, bc, scratch, out, out_len);
         return;
     }
     hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
