@@ -501,6 +501,181 @@ int ogkr_sumcheck_layer(int k_i, int k_next, const uint8_t *gate_type, const uin
     return 0;
 }
 
+/* ---------------------------------------- the layer sumcheck in linear time
+ * The same transcript as ogkr_sumcheck_layer (prove_sumcheck_opt, rust/src/gkr/sumcheck.rs:36-156) without the
+ * 2^{2k}-entry tables, so that it can follow layers of 2^15 .. 2^24 values: the C twin of oracle/gatesum.py.
+ *     sum_c f(b, c) = W(b) U(b) + V(b),  U(b) = sum_c [a(b,c) + m(b,c) W(c)],  V(b) = sum_c a(b,c) W(c)
+ * are sums over the gate list (sumcheck.rs:50-63 reduces over the same list); with b bound to u the rounds over c
+ * run on the single row a_u(c) = sum_b eq(u,b) a(b,c), m_u(c) (sumcheck.rs:97-124).  Field arithmetic is exact, so
+ * the round vectors are the field elements the dense form gives: tests/test_oracle_c.py holds the two against each
+ * other for every k the dense form can reach. */
+static void depends_on_wide(int k, const ogkr_fr *W, int *dep, int nt) {
+    size_t n = (size_t)1 << k;
+    (void)nt;
+    for (int b = 0; b < k; ++b) {
+        size_t bit = (size_t)1 << (k - 1 - b);
+        int d = 0;
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(| : d)
+        for (size_t i = 0; i < n; ++i)
+            if (!(i & bit) && memcmp(W[i].l, W[i ^ bit].l, 32)) d |= 1;
+        dep[b] = d;
+    }
+}
+
+static void publish_round(int j, int dep_j, const u64 c2[4], const u64 g1[4], const u64 c0[4], ogkr_fr *out_coeffs,
+                          uint32_t *out_len, ogkr_fr *out_r) {
+    const ogkr_fr zero = {{0, 0, 0, 0}};
+    u64 c1[4];
+    fr_sub(g1, c0, c1);
+    fr_sub(c1, c2, c1);
+    int length = 2 + (dep_j ? 1 : 0);
+    out_len[j] = (uint32_t)length;
+    memcpy(out_coeffs[3 * j].l, c2, 32);
+    memcpy(out_coeffs[3 * j + 1].l, c1, 32);
+    memcpy(out_coeffs[3 * j + 2].l, c0, 32);
+    if (length == 2) out_coeffs[3 * j] = zero;
+    ogkr_multi_hash(&out_coeffs[3 * j + (3 - length)], (size_t)length, &zero, &out_r[j]);
+}
+
+int ogkr_sumcheck_layer_lin(int k_i, int k_next, const uint8_t *gate_type, const uint32_t *left,
+                            const uint32_t *right, const ogkr_fr *z, const ogkr_fr *W,
+                            ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads) {
+    if (k_i < 0 || k_i > 30 || k_next < 1 || k_next > 28) return -1;
+    if (!cts_ready) init_constants();
+    int nt = set_threads(threads);
+    const int k = k_next;
+    const size_t G = (size_t)1 << k_i, n = (size_t)1 << k;
+    for (size_t g = 0; g < G; ++g)
+        if (left[g] >> k || right[g] >> k || gate_type[g] > 1) return -1;
+    u64(*e)[4] = malloc(G * 32), (*eu)[4] = malloc(n * 32);
+    u64(*Wm)[4] = malloc(n * 32), (*Wt)[4] = malloc(n * 32);
+    u64(*X)[4] = calloc(n, 32), (*Y)[4] = calloc(n, 32);
+    if (!e || !eu || !Wm || !Wt || !X || !Y) return -2;
+    eq_table(k_i, z, e);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (size_t i = 0; i < n; ++i) {
+        to_mont(W[i].l, Wm[i]);
+        memcpy(Wt[i], Wm[i], 32);
+    }
+    int dep[32];
+    depends_on_wide(k, W, dep, nt);
+    /* U = X, V = Y: one pass over the gates (serial: the cells collide) */
+    for (size_t g = 0; g < G; ++g) {
+        u64 t[4];
+        mont_mul(e[g], Wm[right[g]], t);                 /* eq(z, g) W(right) */
+        if (gate_type[g]) {
+            fr_add(X[left[g]], t, X[left[g]]);
+        } else {
+            fr_add(X[left[g]], e[g], X[left[g]]);
+            fr_add(Y[left[g]], t, Y[left[g]]);
+        }
+    }
+    /* the k rounds that bind b: g(x) = sum_i W_i(x) U_i(x) + V_i(x) */
+    for (int j = 0; j < k; ++j) {
+        size_t h = n >> (j + 1);
+        u64 c0[4] = {0}, g1[4] = {0}, c2[4] = {0};
+#pragma omp parallel num_threads(nt)
+        {
+            u64 l0[4] = {0}, l1[4] = {0}, l2[4] = {0};
+#pragma omp for schedule(static) nowait
+            for (size_t i = 0; i < h; ++i) {
+                u64 t[4], dw[4], du[4];
+                mont_mul(X[i], Wt[i], t);
+                fr_add(l0, t, l0);
+                fr_add(l0, Y[i], l0);
+                mont_mul(X[i + h], Wt[i + h], t);
+                fr_add(l1, t, l1);
+                fr_add(l1, Y[i + h], l1);
+                fr_sub(Wt[i + h], Wt[i], dw);
+                fr_sub(X[i + h], X[i], du);
+                mont_mul(du, dw, t);
+                fr_add(l2, t, l2);
+            }
+#pragma omp critical(ogkr_lin_b)
+            {
+                fr_add(c0, l0, c0);
+                fr_add(g1, l1, g1);
+                fr_add(c2, l2, c2);
+            }
+        }
+        publish_round(j, dep[j], c2, g1, c0, out_coeffs, out_len, out_r);
+        u64 rm[4];
+        to_mont(out_r[j].l, rm);
+        fold_table(X, h, rm, nt);
+        fold_table(Y, h, rm, nt);
+        fold_table(Wt, h, rm, nt);
+    }
+    u64 wu[4];                       /* W(u), Montgomery form */
+    memcpy(wu, Wt[0], 32);
+    /* the rows a_u (X), m_u (Y) */
+    eq_table(k, out_r, eu);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (size_t i = 0; i < n; ++i) {
+        to_mont(eu[i], eu[i]);
+        memset(X[i], 0, 32);
+        memset(Y[i], 0, 32);
+        memcpy(Wt[i], Wm[i], 32);
+    }
+    for (size_t g = 0; g < G; ++g) {
+        u64 t[4];
+        mont_mul(e[g], eu[left[g]], t);                  /* eq(z, g) eq(u, left) */
+        u64 *dst = gate_type[g] ? Y[right[g]] : X[right[g]];
+        fr_add(dst, t, dst);
+    }
+    /* the k rounds that bind c on the row at b = u */
+    for (int j = 0; j < k; ++j) {
+        size_t h = n >> (j + 1);
+        u64 c0[4] = {0}, g1[4] = {0}, c2[4] = {0};
+#pragma omp parallel num_threads(nt)
+        {
+            u64 l0[4] = {0}, l1[4] = {0}, l2[4] = {0};
+#pragma omp for schedule(static) nowait
+            for (size_t i = 0; i < h; ++i) {
+                u64 s0[4], s1[4], pq0[4], pq1[4], da[4], dm[4], ds[4], dpq[4], t[4];
+                fr_add(wu, Wt[i], s0);
+                fr_add(wu, Wt[i + h], s1);
+                mont_mul(wu, Wt[i], pq0);
+                mont_mul(wu, Wt[i + h], pq1);
+                mont_mul(X[i], s0, t);
+                fr_add(l0, t, l0);
+                mont_mul(Y[i], pq0, t);
+                fr_add(l0, t, l0);
+                mont_mul(X[i + h], s1, t);
+                fr_add(l1, t, l1);
+                mont_mul(Y[i + h], pq1, t);
+                fr_add(l1, t, l1);
+                fr_sub(X[i + h], X[i], da);
+                fr_sub(Y[i + h], Y[i], dm);
+                fr_sub(s1, s0, ds);
+                fr_sub(pq1, pq0, dpq);
+                mont_mul(da, ds, t);
+                fr_add(l2, t, l2);
+                mont_mul(dm, dpq, t);
+                fr_add(l2, t, l2);
+            }
+#pragma omp critical(ogkr_lin_c)
+            {
+                fr_add(c0, l0, c0);
+                fr_add(g1, l1, g1);
+                fr_add(c2, l2, c2);
+            }
+        }
+        publish_round(k + j, dep[j], c2, g1, c0, out_coeffs, out_len, out_r);
+        u64 rm[4];
+        to_mont(out_r[k + j].l, rm);
+        fold_table(X, h, rm, nt);
+        fold_table(Y, h, rm, nt);
+        fold_table(Wt, h, rm, nt);
+    }
+    free(e);
+    free(eu);
+    free(Wm);
+    free(Wt);
+    free(X);
+    free(Y);
+    return 0;
+}
+
 void ogkr_layer_eval(size_t gates, const uint8_t *gate_type, const uint32_t *left,
                      const uint32_t *right, const ogkr_fr *prev, ogkr_fr *out) {
 #pragma omp parallel for schedule(static)
@@ -516,19 +691,20 @@ void ogkr_mobius(ogkr_fr *vals, int k) {
     size_t n = (size_t)1 << k;
     for (int b = 0; b < k; ++b) {
         size_t bit = (size_t)1 << (k - 1 - b);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i)
-            if (i & bit) fr_sub(vals[i].l, vals[i ^ bit].l, vals[i].l);
+            if (i & bit) fr_sub(vals[i].l, vals[i ^ bit].l, vals[i].l);   /* (reads only entries without the bit) */
     }
 }
 
 int ogkr_line_restriction(int k, const ogkr_fr *b, const ogkr_fr *c, const ogkr_fr *W,
                           ogkr_fr *out, uint32_t *out_len) {
-    if (k < 0 || k > 20) return -1;
+    if (k < 0 || k > 24) return -1;
     size_t n = (size_t)1 << k;
     ogkr_fr *co = malloc(n * 32);
-    u64(*poly)[4] = malloc((size_t)(k + 2) * 32), (*res)[4] = calloc((size_t)(k + 1), 32);
+    u64(*res)[4] = calloc((size_t)(k + 1), 32);
     u64(*grad)[4] = malloc((size_t)(k + 1) * 32), (*cst)[4] = malloc((size_t)(k + 1) * 32);
-    if (!co || !poly || !res || !grad || !cst) return -2;
+    if (!co || !res || !grad || !cst) return -2;
     memcpy(co, W, n * 32);
     ogkr_mobius(co, k);
     for (int j = 0; j < k; ++j) {
@@ -537,35 +713,47 @@ int ogkr_line_restriction(int k, const ogkr_fr *b, const ogkr_fr *c, const ogkr_
         to_mont(g, grad[j]);
         to_mont(b[j].l, cst[j]);
     }
-    /* res[d] = coefficient of t^d (ascending while accumulating) */
+    /* res[d] = coefficient of t^d (ascending while accumulating); every monomial expanded along the line, as the
+     * reference does (poly.rs:476-497); the monomials are independent, so they are dealt over the threads */
     int maxdeg = 0;
-    for (size_t mono = 0; mono < n; ++mono) {
-        const u64 *cf = co[mono].l;
-        if (!(cf[0] | cf[1] | cf[2] | cf[3])) continue;
-        int deg = 0;
-        memcpy(poly[0], cf, 32);
-        for (int j = 0; j < k; ++j) {
-            if (!((mono >> (k - 1 - j)) & 1)) continue;
-            /* poly *= (grad_j t + cst_j) */
-            memset(poly[deg + 1], 0, 32);
-            for (int d = deg + 1; d >= 1; --d) {
-                u64 x[4], y[4];
-                mont_mul(poly[d - 1], grad[j], x);
-                mont_mul(poly[d], cst[j], y);
-                fr_add(x, y, poly[d]);
+#pragma omp parallel
+    {
+        u64 poly[32][4], lres[32][4];
+        int lmax = 0;
+        memset(lres, 0, sizeof lres);
+#pragma omp for schedule(dynamic, 1024) nowait
+        for (size_t mono = 0; mono < n; ++mono) {
+            const u64 *cf = co[mono].l;
+            if (!(cf[0] | cf[1] | cf[2] | cf[3])) continue;
+            int deg = 0;
+            memcpy(poly[0], cf, 32);
+            for (int j = 0; j < k; ++j) {
+                if (!((mono >> (k - 1 - j)) & 1)) continue;
+                /* poly *= (grad_j t + cst_j) */
+                memset(poly[deg + 1], 0, 32);
+                for (int d = deg + 1; d >= 1; --d) {
+                    u64 x[4], y[4];
+                    mont_mul(poly[d - 1], grad[j], x);
+                    mont_mul(poly[d], cst[j], y);
+                    fr_add(x, y, poly[d]);
+                }
+                u64 y0[4];
+                mont_mul(poly[0], cst[j], y0);
+                memcpy(poly[0], y0, 32);
+                ++deg;
             }
-            u64 y0[4];
-            mont_mul(poly[0], cst[j], y0);
-            memcpy(poly[0], y0, 32);
-            ++deg;
+            if (deg > lmax) lmax = deg;
+            for (int d = 0; d <= deg; ++d) fr_add(lres[d], poly[d], lres[d]);
         }
-        if (deg > maxdeg) maxdeg = deg;
-        for (int d = 0; d <= deg; ++d) fr_add(res[d], poly[d], res[d]);
+#pragma omp critical(ogkr_line)
+        {
+            if (lmax > maxdeg) maxdeg = lmax;
+            for (int d = 0; d <= k; ++d) fr_add(res[d], lres[d], res[d]);
+        }
     }
     *out_len = (uint32_t)(maxdeg + 1);
     for (int d = 0; d <= k; ++d) memcpy(out[k - d].l, res[d], 32);   /* highest first, right-aligned */
     free(co);
-    free(poly);
     free(res);
     free(grad);
     free(cst);

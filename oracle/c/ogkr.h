@@ -59,6 +59,12 @@ int ogkr_sumcheck_layer(int k_i, int k_next, const uint8_t *gate_type, const uin
                         const uint32_t *right, const ogkr_fr *z, const ogkr_fr *W,
                         ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads);
 
+/* The same transcript in time linear in the gates (no 2^{2 k_next}-entry tables; k_next up to 28): U, V and the
+ * c-phase row summed over the gate list -- the C twin of oracle/gatesum.py, the checker for wide layers. */
+int ogkr_sumcheck_layer_lin(int k_i, int k_next, const uint8_t *gate_type, const uint32_t *left,
+                            const uint32_t *right, const ogkr_fr *z, const ogkr_fr *W,
+                            ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads);
+
 /* eq(z, .) weights scattered into the dense predicate tables A, M (2^{2 k_next} each). */
 int ogkr_predicate_tables(int k_i, int k_next, const uint8_t *gate_type, const uint32_t *left,
                           const uint32_t *right, const ogkr_fr *z, ogkr_fr *A, ogkr_fr *M);

@@ -142,6 +142,30 @@ def sumcheck_layer_raw(k_i, k_next, gate_type, left, right, z_limbs, w_limbs, th
     return C, L, R
 
 
+def sumcheck_layer_lin_raw(k_i, k_next, gate_type, left, right, z_limbs, w_limbs, threads=0):
+    """The linear-time twin (ogkr_sumcheck_layer_lin): same outputs as sumcheck_layer_raw, any k_next <= 28."""
+    gt, l, r = _gates(gate_type, left, right)
+    v = 2 * k_next
+    C = np.zeros((v, 3, 4), dtype=np.uint64)
+    L = np.zeros(v, dtype=np.uint32)
+    R = np.zeros((v, 4), dtype=np.uint64)
+    z_limbs = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
+    w_limbs = np.ascontiguousarray(w_limbs, dtype=np.uint64)
+    assert w_limbs.shape == (1 << k_next, 4) and len(gt) == 1 << k_i
+    rc = lib().ogkr_sumcheck_layer_lin(ctypes.c_int(k_i), ctypes.c_int(k_next), _p(gt), _p(l), _p(r), _p(z_limbs),
+                                       _p(w_limbs), _p(C), _p(L), _p(R), ctypes.c_int(threads if threads > 0 else usable_threads()))
+    if rc:
+        raise ValueError("ogkr_sumcheck_layer_lin rc=%d" % rc)
+    return C, L, R
+
+
+def sumcheck_layer_lin(k_i, k_next, gate_type, left, right, z, w, threads=0):
+    zl = to_limbs(z) if len(z) else np.zeros((0, 4), dtype=np.uint64)
+    C, L, R = sumcheck_layer_lin_raw(k_i, k_next, gate_type, left, right, zl, to_limbs(w), threads)
+    proof = [from_limbs(C[j])[3 - int(L[j]):] for j in range(2 * k_next)]
+    return proof, from_limbs(R)
+
+
 def sumcheck_layer(k_i, k_next, gate_type, left, right, z, w, threads=0):
     zl = to_limbs(z) if len(z) else np.zeros((0, 4), dtype=np.uint64)
     C, L, R = sumcheck_layer_raw(k_i, k_next, gate_type, left, right, zl, to_limbs(w), threads)
@@ -167,6 +191,54 @@ def layer_eval_raw(gate_type, left, right, prev_limbs):
     out = np.zeros((len(gt), 4), dtype=np.uint64)
     lib().ogkr_layer_eval(ctypes.c_size_t(len(gt)), _p(gt), _p(l), _p(r), _p(prev_limbs), _p(out))
     return out
+
+
+def line_restriction_raw(b_limbs, c_limbs, w_limbs, k):
+    """-> (q (k+1,4) right-aligned highest first, length)."""
+    O = np.zeros((k + 1, 4), dtype=np.uint64)
+    ln = ctypes.c_uint32(0)
+    B = np.ascontiguousarray(b_limbs, dtype=np.uint64).reshape(-1, 4)
+    Cc = np.ascontiguousarray(c_limbs, dtype=np.uint64).reshape(-1, 4)
+    Wl = np.ascontiguousarray(w_limbs, dtype=np.uint64)
+    rc = lib().ogkr_line_restriction(ctypes.c_int(k), _p(B), _p(Cc), _p(Wl), _p(O), ctypes.byref(ln))
+    if rc:
+        raise ValueError("ogkr_line_restriction rc=%d" % rc)
+    return O, int(ln.value)
+
+
+def mobius_raw(w_limbs, k):
+    """evaluation table -> monomial coefficients (get_multi_ext, poly.rs:502-536), limbs in, limbs out."""
+    out = np.array(w_limbs, dtype=np.uint64, copy=True).reshape(1 << k, 4)
+    lib().ogkr_mobius(_p(out), ctypes.c_int(k))
+    return out
+
+
+def prove_raw(layers, input_limbs, threads=0):
+    """prover.rs:6-96 on limb arrays only (no Python integers per table entry): for circuits with wide layers, where
+    the dense layer form cannot follow.  Uses the linear-time layer prover.  z[0] = 0 (prover.rs:16-21).
+    -> dict of numpy arrays: per layer C (2k,3,4), L (2k,), R (2k,4), q (k+1,4), q_len; z list of (k_i,4); r (depth,4);
+    values list of (2^k_i,4)."""
+    vals = [np.ascontiguousarray(input_limbs, dtype=np.uint64).reshape(-1, 4)]
+    for gt, l, r in reversed(layers):
+        vals.append(layer_eval_raw(gt, l, r, vals[-1]))
+    vals.reverse()
+    ks = [max(0, (v.shape[0] - 1).bit_length()) for v in vals]
+    z = [np.zeros((ks[0], 4), dtype=np.uint64)]
+    Cs, Ls, Rs, qs, qlens, rstars = [], [], [], [], [], []
+    for i, (gt, l, r) in enumerate(layers):
+        kn = ks[i + 1]
+        C, L, R = sumcheck_layer_lin_raw(ks[i], kn, gt, l, r, z[i], vals[i + 1], threads)
+        Cs.append(C)
+        Ls.append(L)
+        Rs.append(R)
+        q, qlen = line_restriction_raw(R[:kn], R[kn:], vals[i + 1], kn)
+        qs.append(q)
+        qlens.append(qlen)
+        r_star = from_limbs(R[2 * kn - 1:2 * kn])[0]   # multi_hash(last round vector) = the last challenge (prover.rs:74-78)
+        bs, cs = from_limbs(R[:kn]), from_limbs(R[kn:])
+        z.append(to_limbs([(bi + (ci - bi) * r_star) % P for bi, ci in zip(bs, cs)]))
+        rstars.append(r_star)
+    return dict(C=Cs, L=Ls, R=Rs, q=qs, q_len=qlens, z=z, r=to_limbs(rstars), k=ks, values=vals)
 
 
 def line_restriction(b, c, w, k):
