@@ -138,6 +138,8 @@ inline gkr::h64::F host_multi_hash(const gkr::h64::F* arr, int n, const gkr::h64
 // up to sixteen transcripts on the IFMA code: two interleaved groups of eight fill the FMA pipes (one group is
 // a dependent chain), so chunks of sixteen cost ~1.3x a chunk of eight
 constexpr int kHashChunkMax = 16;
+// the size limits of include/gkr_amd.h
+constexpr int kMaxLayerK = GKR_MAX_K_NEXT, kMaxLayerKi = GKR_MAX_K_I, kMaxDenseK = GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT;
 inline void ifma_hash_chunk(const uint64_t (*vec)[3][4], const uint32_t* ln, int count, uint64_t (*out)[4]) {
     if (count > 8)
         gkr::gkr_ifma_multi_hash16(vec, ln, 3, out);
@@ -324,14 +326,16 @@ bool all_canonical(const gkr_fr* v, size_t n) {
 // the circuit, and an aggregation step proves the same <= 20 circuits for input after input.
 struct GateLists {
     uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
+    uint32_t* heavy = nullptr;   // wide layers: the work lists of the buckets too long for a lane group (kernels_wide.hip)
     gkr::GateSegs segs;   // the lists' segments (large layers; segs.words is one more device allocation)
     bool ready = false;
     void release() {
         if (offsets) (void)hipFree(offsets);
         if (cursor) (void)hipFree(cursor);
         if (list) (void)hipFree(list);
+        if (heavy) (void)hipFree(heavy);
         if (segs.words) (void)hipFree(segs.words);
-        offsets = cursor = list = nullptr;
+        offsets = cursor = list = heavy = nullptr;
         segs = gkr::GateSegs();
         ready = false;
     }
@@ -1506,8 +1510,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     const double t_entry_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
-    if (shard && (!host_tx || batch != 1 || k > 13))
-        return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript, one proof and k_next <= 13");
+    if (shard && (!host_tx || batch != 1)) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript and one proof");
+    if (k > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "layer wider than the library's limits (gkr_amd.h: GKR_MAX_K_NEXT, GKR_MAX_K_I)");
+    if (!host_tx && k > kMaxDenseK)
+        return ctx->fail(GKR_ERR_INVALID, "the device transcript works on dense 2^(2 k_next)-entry predicate tables: k_next <= 14 (GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT)");
     const gkr::GateSpan span{shard ? shard->gate_base : 0, shard ? shard->gate_count : (uint64_t)1 << k_i};
     hipStream_t s = ctx->stream;
     Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr, *d_coeffs = nullptr, *d_r_out = nullptr;
@@ -1515,7 +1521,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     uint32_t *d_len = nullptr, *dep = nullptr;
     gkr::LayerPartial* partials = nullptr;
     // Three forms of the b-phase (all the same transcript):
-    //   gate lists (default with the host transcript, k <= 13): no 2^{2k}-entry tables at all -- U, V and the
+    //   gate lists (default with the host transcript; the only form for k > 13): no 2^{2k}-entry tables at all -- U, V and the
     //     c-phase row are summed straight from the gates grouped by left / right operand (kernels.hip, k_gate_*);
     //   dense predicate tables, U, V and the row from two passes over them (layers with more than 2^{2k-2} gates;
     //     GKR_LAYER_DENSE_TABLES forces it, GKR_LAYER_GATE_LISTS forces the gate lists);
@@ -1538,7 +1544,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     // gate lists also for dense layers when the block-private sort applies (k <= 12, >= 2^16 gates: 2^24 gates sort in
     // ~0.5 ms, against 2.7 ms for the dense tables' cell sort)
     const bool lds_sort = gkr::gate_lists_lds_blocks(span.count, (uint32_t)k) != 0;
-    const bool sparse = shard || persistent || (lin_b && !dense_tables && k <= 13 && (gate_lists_always || lds_sort || k_i + 2 <= 2 * k));
+    const bool sparse = shard || persistent || (lin_b && (k > 13 || (!dense_tables && (gate_lists_always || lds_sort || k_i + 2 <= 2 * k))));
+    // Wide layers (2^13 buckets and more per half, each with a few gates): the gate passes run with a group of lanes per
+    // bucket and the rare long buckets in units (kernels_wide.hip) -- a block per bucket would be 2^20 blocks for a gate apiece.
+    // GKR_GATE_GROUPS_MIN_K moves the switch (tests run the form on small layers too).
+    static const int wide_min_k = [] { const char* e = getenv("GKR_GATE_GROUPS_MIN_K"); return e ? atoi(e) : (int)gkr::kWideMinK; }();
+    const bool wide = sparse && !persistent && k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -1553,7 +1564,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
     gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
     Fr *e_hi = nullptr, *e_lo = nullptr;
-    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr;
+    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_heavy = nullptr;
+    Fr* heavy_partials = nullptr;
     // where eq(z, g) is split into E_hi, E_lo: in the middle, or -- large layers, whose gate passes run over segments
     // of the sorted lists (gate_seg.h) -- where the segments are cut
     const uint32_t kl = gkr::gate_seg_shift(span, (uint32_t)k_i, (uint32_t)k);
@@ -1586,9 +1598,17 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             gkr_fr* hz = nullptr;
             HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz)));
             memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
+            // (the dependence flags of a table beyond 2^13 values are found over a grid, not by the prologue's one block)
+            const bool dep_wide = k > 13;
             gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, persistent ? nullptr : Wb,
-                                       persistent ? nullptr : Wc, (uint32_t)k, dep, h_dep, (uint32_t)batch, s);
+                                       persistent ? nullptr : Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s);
+            if (dep_wide) {
+                uint32_t* dep_bits = nullptr;
+                WS(ctx, "layer.depbits", uint32_t, (size_t)batch, dep_bits);
+                gkr::launch_depends_wide(d_W, (uint32_t)k, dep_bits, dep, h_dep, (uint32_t)batch, s);
+            }
         }
+        if (wide) WS(ctx, "gates.heavypart", Fr, gkr::gate_heavy_partial_elems(span.count, (uint32_t)k) * batch, heavy_partials);
         if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)
         if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
         if (cached && cached->ready) {
@@ -1596,6 +1616,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
             g_cursor = cached->cursor;
             g_list = cached->list;
+            g_heavy = cached->heavy;
+            if (wide && !g_heavy) return ctx->fail(GKR_ERR_INVALID, "cached gate lists were built without the wide layer's work lists");
         } else {
             WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
             WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
@@ -1603,13 +1625,17 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
                 if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
                 if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
+                if (wide && !cached->heavy)
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->heavy), gkr::gate_heavy_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
                 g_offsets = cached->offsets;
                 g_cursor = cached->cursor;
                 g_list = cached->list;
+                g_heavy = cached->heavy;
             } else {
                 WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
                 WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
                 WS(ctx, "gates.list", uint32_t, 2 * gkr::gate_list_words(span.count), g_list);
+                if (wide) WS(ctx, "gates.heavy", uint32_t, gkr::gate_heavy_words(span.count, (uint32_t)k), g_heavy);
             }
             HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
             uint32_t *lds_scratch = nullptr, *seg_scratch = nullptr;
@@ -1625,6 +1651,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
             gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch,
                                    segs, seg_scratch, s);
+            if (wide) gkr::launch_gate_heavy_lists(span, (uint32_t)k, g_offsets, g_cursor, g_heavy, s);
             if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
         }
     } else {
@@ -1642,7 +1669,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         // U, V, the rounds and the row are all inside the one kernel launched below
     } else if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
-        gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
+        if (wide)
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s);
+        else
+            gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
     } else if (lin_b) {
         Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
         gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
@@ -1938,10 +1968,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     // Product passes (kernels.hip): both phases as sumchecks of W X + Y over three small tables, up to three rounds per
     // device round trip.  The default for the linear-time form over gate lists; GKR_LAYER_PER_ROUND=1: one round per trip.
     static const bool per_round = getenv("GKR_LAYER_PER_ROUND") != nullptr;
-    if (lin_b && sparse && k <= 13 && !per_round) {
+    if (lin_b && sparse && (k > 13 || !per_round)) {   // (the per-round kernels' c-phase keeps a row in one block: k <= 13)
         gkr::ProdPassRec* prec = nullptr;
         Fr *h_pw = nullptr, *d_ppart = nullptr, *Xc = nullptr, *Yc = nullptr;
-        const uint32_t max_blocks = gkr::prod_pass_blocks(1u << (k - 1));
+        const uint32_t max_blocks = gkr::prod_pass_max_blocks((uint32_t)k);
         HIP_TRY(ctx, ctx->pinned_host("layer.prec", sizeof(gkr::ProdPassRec) * batch, reinterpret_cast<void**>(&prec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.pw", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_pw)));
         WS(ctx, "layer.ppart", Fr, (size_t)batch * max_blocks * gkr::kProdRecValues, d_ppart);
@@ -1961,8 +1991,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
-                    c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
-                                                          segs, seg_partials, s, shard ? nullptr : &fuse);
+                    if (wide)
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
+                                                   heavy_partials, s);
+                    else
+                        c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
+                                                              segs, seg_partials, s, shard ? nullptr : &fuse);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
                     second_exchange_done = true;
@@ -2076,8 +2110,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             if (sparse) {
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
-                    gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
-                                          A, M, lb, segs, seg_partials, s);
+                    if (wide)
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
+                                                   heavy_partials, s);
+                    else
+                        gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
+                                              A, M, lb, segs, seg_partials, s);
                 }
                 if (shard) {
                     second_exchange_done = true;
@@ -2258,11 +2296,13 @@ void line_restriction(const std::vector<gkr::h64::F>& vals, const std::vector<gk
 int check_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c) {
     if (!c || !c->k || c->depth < 1 || !c->gate_type || !c->left || !c->right)
         return ctx ? ctx->fail(GKR_ERR_INVALID, "null circuit description") : GKR_ERR_INVALID;
-    for (uint32_t i = 0; i <= c->depth; ++i)
-        if (c->k[i] > 28) return ctx ? ctx->fail(GKR_ERR_INVALID, "layer wider than 2^28") : GKR_ERR_INVALID;
+    if (c->k[0] > (uint32_t)kMaxLayerKi) return ctx ? ctx->fail(GKR_ERR_INVALID, "output layer wider than 2^GKR_MAX_K_I") : GKR_ERR_INVALID;
     for (uint32_t i = 1; i <= c->depth; ++i) {
         if (c->k[i] == 0) return ctx ? ctx->fail(GKR_ERR_DEGENERATE, "k[i+1] == 0: v = 0 (sumcheck.rs:49)") : GKR_ERR_DEGENERATE;
-        if (c->k[i] > 14) return ctx ? ctx->fail(GKR_ERR_INVALID, "dense predicate tables need k[i+1] <= 14") : GKR_ERR_INVALID;
+        if (c->k[i] > (uint32_t)kMaxLayerK)
+            return ctx ? ctx->fail(GKR_ERR_INVALID, "layer of more than 2^GKR_MAX_K_NEXT values (gkr_amd.h, limits)") : GKR_ERR_INVALID;
+        if (ctx && ctx->transcript != GKR_TRANSCRIPT_HOST && c->k[i] > (uint32_t)kMaxDenseK)
+            return ctx->fail(GKR_ERR_INVALID, "the device transcript needs k[i+1] <= GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT (dense predicate tables)");
     }
     return GKR_OK;
 }
@@ -2819,7 +2859,7 @@ static int check_layer_args(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gt
     if (!gt || !l || !r || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
     if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
-    if (k_next < 0 || k_next > 14) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, 14] (dense predicate tables)");
+    if (k_next < 0 || k_next > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT], k_i in [0, GKR_MAX_K_I]");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     // every gate is validated on the device by the scatter kernel; small layers are also checked here
     // so that the error names the cause
@@ -2859,7 +2899,7 @@ int gkr_sumcheck_layer_sharded(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_
     if (gate_count && (!gate_type || !left || !right)) return ctx->fail(GKR_ERR_INVALID, "null gate array");
     if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
     if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
-    if (k_next < 0 || k_next > 13) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, 13] for a gate-sharded layer");
+    if (k_next < 0 || k_next > kMaxLayerK) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT]");
     if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
@@ -2946,7 +2986,7 @@ int gkr_resident_layer_create(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_f
     if ((!gate_type || !left || !right) && gate_count) return ctx->fail(GKR_ERR_INVALID, "null gate array");
     if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
     if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
-    if (k_next < 0 || k_next > 14) return ctx->fail(GKR_ERR_INVALID, "k_next out of range");
+    if (k_next < 0 || k_next > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT], k_i in [0, GKR_MAX_K_I]");
     if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<gkr_resident_layer, void (*)(gkr_resident_layer*)> L(new gkr_resident_layer(), [](gkr_resident_layer* p) {
@@ -2976,7 +3016,6 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
     const int k_i = layer->k_i, k = layer->k;
     if (!allreduce && (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)))
         return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the layer must be whole");
-    if (allreduce && k > 13) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs k_next <= 13");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3000,7 +3039,7 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
 }
 
 size_t gkr_exchange_limbs(int k_next) {
-    if (k_next < 0 || k_next > 14) return 0;
+    if (k_next < 0 || k_next > kMaxLayerK) return 0;
     return (((size_t)2 << k_next) + 1) * 8;
 }
 
@@ -3009,7 +3048,6 @@ int gkr_resident_layer_sumcheck_dev(gkr_ctx* ctx, gkr_resident_layer* layer, con
     if (!ctx) return GKR_ERR_INVALID;
     if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z) || !exchange) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     const int k_i = layer->k_i, k = layer->k;
-    if (k > 13) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs k_next <= 13");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3251,9 +3289,26 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
     const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
     std::vector<F> hW_big[2];
+    // d and input_func are the monomial forms of W_0 and W_L (get_multi_ext, poly.rs:502-536): tables beyond 2^12 values are
+    // transformed on the device (k launches over a grid) and land in the proof buffers directly; small ones on the host
+    constexpr uint32_t kDeviceMobiusMinK = 13;
+    bool coeffs_done[2] = {false, false};
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t i = e ? L : 0;
+        if (c->k[i] < kDeviceMobiusMinK) continue;
+        const size_t n = (size_t)1 << c->k[i];
+        Fr* mono = nullptr;
+        HIP_TRY(ctx, ctx->workspace(e ? "prove.monoL" : "prove.mono0", n * batch * sizeof(Fr), reinterpret_cast<void**>(&mono)));
+        HIP_TRY(ctx, hipMemcpyAsync(mono, dW[i], n * batch * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+        gkr::launch_mobius(mono, c->k[i], n, (uint32_t)batch, s);
+        for (int b = 0; b < batch; ++b)
+            HIP_TRY(ctx, hipMemcpyAsync(e ? outs[b].input_coeffs : outs[b].d_coeffs, mono + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        coeffs_done[e] = true;
+    }
     for (int e = 0; e < 2; ++e) {
         const uint32_t i = e ? L : 0;
         const size_t bytes = ((size_t)batch << c->k[i]) * sizeof(Fr);
+        if (coeffs_done[e] && e == 1) continue;   // (W_0 is still read below: output 0 must be zero)
         if (bytes <= kKernelCopyLimit) {
             F* dst = nullptr;
             HIP_TRY(ctx, ctx->pinned_host(e ? "prove.hWL" : "prove.hW0", bytes, reinterpret_cast<void**>(&dst)));
@@ -3274,12 +3329,17 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
             return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
         // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
-        std::vector<F> co(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
-        mobius_msb(co, c->k[0]);
-        memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
-        co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
-        mobius_msb(co, c->k[L]);
-        memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
+        std::vector<F> co;
+        if (!coeffs_done[0]) {
+            co.assign(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
+            mobius_msb(co, c->k[0]);
+            memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
+        }
+        if (!coeffs_done[1]) {
+            co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
+            mobius_msb(co, c->k[L]);
+            memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
+        }
         // z[0] = 0 (prover.rs:16-21)
         for (uint32_t j = 0; j < c->k[0]; ++j) memset(&outs[b].z[j], 0, sizeof(gkr_fr));
     }
@@ -3305,6 +3365,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     HIP_TRY(ctx, ctx->pinned_host("prove.q", q_total * batch * sizeof(Fr), reinterpret_cast<void**>(&d_q)));
     HIP_TRY(ctx, ctx->pinned_host("prove.qlen", (size_t)L * batch * sizeof(uint32_t), reinterpret_cast<void**>(&d_qlen)));
     WS(ctx, "prove.lr", Fr, (size_t)batch * 3 * ((size_t)1 << kmax), d_lr);
+    uint32_t* d_lrdeg = nullptr;
+    WS(ctx, "prove.lrdeg", uint32_t, (size_t)batch, d_lrdeg);
     HIP_TRY(ctx, ctx->aux_stream(0));
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = c->k[i], k = c->k[i + 1];
@@ -3329,7 +3391,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
             for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
             Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
-            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_q + q_off * batch,
+            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, d_q + q_off * batch,
                                          d_qlen + (size_t)i * batch, (uint32_t)batch, ctx->aux);
         }
         auto finish = [&](int b) {

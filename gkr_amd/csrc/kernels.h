@@ -55,8 +55,15 @@ struct ProdPassRec {
 };
 static_assert(sizeof(ProdPassRec) == kProdRecValues * 32 + 32, "product-pass record layout");
 // entries per block of a pass (one tile) and blocks per proof for tables whose sub-blocks have S entries
-constexpr uint32_t kProdTile = 8;
-inline uint32_t prod_pass_blocks(uint32_t S) { return S <= kProdTile ? 1u : S / kProdTile; }
+constexpr uint32_t kProdTile = 8, kProdTileWide = 32;
+inline uint32_t prod_pass_tile(uint32_t S) { return S >= 1024u ? kProdTileWide : kProdTile; }
+inline uint32_t prod_pass_blocks(uint32_t S) { return S <= kProdTile ? 1u : S / prod_pass_tile(S); }
+// most blocks per proof any pass over tables of 2^k entries takes (sub-blocks of 1 .. 2^(k-1) entries)
+inline uint32_t prod_pass_max_blocks(uint32_t k) {
+    uint32_t m = 1;
+    for (uint32_t l = 0; l < k; ++l) m = prod_pass_blocks(1u << l) > m ? prod_pass_blocks(1u << l) : m;
+    return m;
+}
 // One pass on the tables W (Montgomery), X, Y (canonical) of 2^m_in entries per proof (stride wstride): bind the jp
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
 // the cross sums for the next J rounds -> the pinned records (seq = ticket, system-scope release); partials: scratch of
@@ -225,10 +232,33 @@ void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t
 // pinned host memory host_dep (k_layer_prologue)
 void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,
                            uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
-// q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, out batch x (k + 1)
-// highest degree first, out_len batch
-void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
-                             hipStream_t s);
+// q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, deg_scratch batch
+// words (device), out batch x (k + 1) highest degree first, out_len batch
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* out, uint32_t* out_len,
+                             uint32_t batch, hipStream_t s);
+
+// ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------
+// The gate passes with a group of 2^lg lanes per bucket; buckets longer than gate_heavy_threshold() gates are cut into
+// units of kHeavyUnit gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
+constexpr uint32_t kHeavyPerLane = 32;    // a lane of a group walks at most this many gates
+constexpr uint32_t kHeavyUnit = 256;      // gates per unit of a heavy bucket (one wave, four gates per lane)
+constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the lane-group passes
+uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k);
+uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k);
+size_t gate_heavy_words(uint64_t gates, uint32_t k);            // u32 words of the work lists (both halves)
+size_t gate_heavy_partial_elems(uint64_t gates, uint32_t k);    // Fr elements of pass scratch per proof
+void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, uint32_t* heavy_words, hipStream_t s);
+void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+                         const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
+                         Fr* heavy_partials, hipStream_t s);
+void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
+                           const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s);
+// dependence flags over a grid: bits = batch zeroed-by-the-launcher words of scratch; dep / host_dep as launch_layer_prologue
+void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
+// in-place Moebius transform (evaluations -> monomial coefficients, MSB-first) of `batch` tables of 2^k, `stride` apart
+void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStream_t s);
+void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t* out_len, uint32_t batch, hipStream_t s);
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, uint32_t batch, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,

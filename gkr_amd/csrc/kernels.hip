@@ -15,60 +15,12 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "dev_util.h"
 #include "gate_seg.h"
 #include "mfma_fold.h"
 #include "mimc7.h"
 
 namespace gkr {
-
-// ---------------------------------------------------------------------------
-// wave64 / block reductions of wide accumulators
-// ---------------------------------------------------------------------------
-
-template <int NL>
-__device__ __forceinline__ Acc<NL> wave_sum(Acc<NL> a) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Acc<NL> o;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) o.l[i] = __shfl_down(a.l[i], off, 64);
-        acc_add_acc(a, o);
-    }
-    return a;  // lane 0 holds the wave total
-}
-
-// Sum NA accumulators over the block; thread 0 gets the totals.  smem must hold
-// (blockDim.x / 64) * NA accumulators.
-template <int NL, int NA>
-__device__ __forceinline__ void block_sum(Acc<NL> (&acc)[NA], Acc<NL>* smem) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-        acc[k] = wave_sum(acc[k]);
-        if (lane == 0) smem[wave * NA + k] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < nwaves; ++w)
-#pragma unroll
-            for (int k = 0; k < NA; ++k) acc_add_acc(acc[k], smem[w * NA + k]);
-    }
-}
-
-__device__ __forceinline__ Fr load_fr(const Fr* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1];
-    Fr f;
-    f.l[0] = a.x; f.l[1] = a.y; f.l[2] = a.z; f.l[3] = a.w;
-    f.l[4] = b.x; f.l[5] = b.y; f.l[6] = b.z; f.l[7] = b.w;
-    return f;
-}
-
-__device__ __forceinline__ void store_fr(Fr* p, const Fr& f) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(f.l[0], f.l[1], f.l[2], f.l[3]);
-    q[1] = make_uint4(f.l[4], f.l[5], f.l[6], f.l[7]);
-}
 
 // device-side build of the round's fixed-multiplier table (device transcript only):
 // R_i = r * 2^(32 i) * 2^64 mod p, canonical
@@ -547,17 +499,20 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
 // Same round polynomials as the per-round kernels: bit-exact.
 // ---------------------------------------------------------------------------
 
-// grid = (blocks, batch), block = 256: this block's tile of i, all 2^J sub-blocks
+// grid = (blocks, batch), block = 256: this block's tile of i, all 2^J sub-blocks.  TILE = kProdTile entries of every
+// sub-block per block for the tables of a circom-sized layer (latency: many small blocks), kProdTileWide for wide layers
+// (sub-blocks of >= 1024 entries: fewer partials to total on the round path).
+template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
                                                     const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
                                                     ProdPassRec* __restrict__ rec, uint32_t ticket) {
     __shared__ Fr s_w[8];
-    __shared__ Fr s_t[3][8][kProdTile];          // folded tile: table, sub-block, i
+    __shared__ Fr s_t[3][8][TILE];               // folded tile: table, sub-block, i
     __shared__ Fr s_red[4][kProdRecValues];
     const uint32_t tid = threadIdx.x, proof = blockIdx.y;
     Fr* T[3] = {Wt + (size_t)proof * wstride, Xt + (size_t)proof * wstride, Yt + (size_t)proof * wstride};
     const uint32_t m = m_in - jp, nsub = 1u << J, S = 1u << (m - J);
-    const uint32_t ti = S < kProdTile ? S : kProdTile, i0 = blockIdx.x * kProdTile;
+    const uint32_t ti = S < TILE ? S : TILE, i0 = blockIdx.x * TILE;
     if (tid < (1u << jp)) s_w[tid] = load_fr(weights + (size_t)proof * 8 + tid);
     __syncthreads();
     // the tile of the tables with the previous pass's variables bound (written back: later passes read it)
@@ -589,7 +544,7 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     const uint32_t p = tid & 63u, sub = tid >> 6, a = p >> 3, b = p & 7u;
     Fr acc = fr_zero(), accy = fr_zero();
     if (a < nsub && b < nsub) {
-        Lazy17 la = lazy_zero();   // kProdTile / 4 = two products per thread
+        Lazy17 la = lazy_zero();   // TILE / 4 products per thread
         for (uint32_t i = sub; i < ti; i += 4) lazy_mac_v(la, s_t[1][b][i], s_t[0][a][i]);
         acc = lazy_reduce_k8(la);
     }
@@ -610,21 +565,27 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     }
 }
 
-// grid = (batch), block = 288: totals of the blocks' partials -> the pinned record.  Four threads per value, each a
-// quarter of the blocks (the kernel sits between two hashes of the round path: 32 dependent additions took 12 us)
-__global__ void __launch_bounds__(320) k_prod_publish(const Fr* __restrict__ partials, uint32_t blocks, ProdPassRec* __restrict__ rec,
-                                                      uint32_t ticket) {
-    __shared__ Fr s_q[4][kProdRecValues];
-    const uint32_t tid = threadIdx.x, q = tid / (uint32_t)kProdRecValues, val = tid % (uint32_t)kProdRecValues;
+// grid = (batch), block = Q * 72 (Q = 4, or 14 for the many blocks of a wide layer): totals of the blocks' partials -> the
+// pinned record.  Q threads per value, each a Q-th of the blocks (the kernel sits between two hashes of the round path: 32
+// dependent additions took 12 us)
+__global__ void __launch_bounds__(1024) k_prod_publish(const Fr* __restrict__ partials, uint32_t blocks, ProdPassRec* __restrict__ rec,
+                                                       uint32_t ticket) {
+    __shared__ Fr s_q[14][kProdRecValues];
+    const uint32_t tid = threadIdx.x, Q = blockDim.x / (uint32_t)kProdRecValues, q = tid / (uint32_t)kProdRecValues,
+                   val = tid % (uint32_t)kProdRecValues;
     ProdPassRec* r = rec + blockIdx.x;
-    if (q < 4) {
+    if (q < Q) {
         const Fr* p = partials + (size_t)blockIdx.x * blocks * kProdRecValues + val;
         Fr v = fr_zero();
-        for (uint32_t k = q; k < blocks; k += 4) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
+        for (uint32_t k = q; k < blocks; k += Q) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
         s_q[q][val] = v;
     }
     __syncthreads();
-    if (tid < (uint32_t)kProdRecValues) store_fr(&r->v[tid], fr_add(fr_add(s_q[0][tid], s_q[1][tid]), fr_add(s_q[2][tid], s_q[3][tid])));
+    if (tid < (uint32_t)kProdRecValues) {
+        Fr v = s_q[0][tid];
+        for (uint32_t j = 1; j < Q; ++j) v = fr_add(v, s_q[j][tid]);
+        store_fr(&r->v[tid], v);
+    }
     __syncthreads();   // every record store is issued and waited for before the release below
     if (tid == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -743,6 +704,7 @@ __global__ void __launch_bounds__(256) k_layer_prologue(const Fr* __restrict__ p
             store_fr(Wc + base + i, m);
         }
     } else {
+        if (!dep) return;   // (a wide table's flags are found over a grid: launch_depends_wide)
         __shared__ uint32_t s_dep;
         if (threadIdx.x == 0) s_dep = 0;
         __syncthreads();
@@ -2407,13 +2369,6 @@ __global__ void __launch_bounds__(256) k_fold_small(Fr* __restrict__ W, uint32_t
 // host-callable launchers
 // ---------------------------------------------------------------------------
 
-static inline uint32_t blocks_for(uint64_t items, uint32_t cap) {
-    uint64_t b = (items + 255) / 256;
-    if (b < 1) b = 1;
-    if (b > cap) b = cap;
-    return (uint32_t)b;
-}
-
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_table, dim3(blocks_for(count, 4096)), dim3(256), 0, s, table, count, seed);
 }
@@ -2496,9 +2451,12 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
-    const uint32_t blocks = prod_pass_blocks(1u << (m_in - jp - J));
-    hipLaunchKernelGGL(k_prod_cross, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
-    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(4 * kProdRecValues), 0, s, partials, blocks, rec, ticket);
+    const uint32_t S = 1u << (m_in - jp - J), blocks = prod_pass_blocks(S);
+    if (prod_pass_tile(S) == kProdTileWide)
+        hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
+    else
+        hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
+    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((blocks > 256 ? 14 : 4) * kProdRecValues), 0, s, partials, blocks, rec, ticket);
 }
 
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
@@ -2569,17 +2527,22 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
                        Wc, k, dep, host_dep, nb_hi, nb_lo, nb_mont);
 }
 
-void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, Fr* out, uint32_t* out_len, uint32_t batch,
-                             hipStream_t s) {
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* out, uint32_t* out_len,
+                             uint32_t batch, hipStream_t s) {
     static const bool stepwise = getenv("GKR_LINE_STEPWISE") != nullptr;   // (test hook: the wide-layer form at every width)
     if (k <= 9 && !stepwise) {
         hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), (size_t)3 * sizeof(Fr) << k, s, W, k, bc, scratch, out, out_len);
         return;
     }
-    hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
+    // (the set-up -- copy, Moebius transform, largest monomial degree -- in one block per proof up to 2^12 values, over a
+    // grid beyond: kernels_wide.hip)
+    if (k <= 12)
+        hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
+    else
+        launch_line_setup_wide(W, k, scratch, deg_scratch, out_len, batch, s);
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
-        hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 256), batch), dim3(256), 0, s, k, j, bc, scratch);
+        hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bc, scratch);
     }
     hipLaunchKernelGGL(k_line_out, dim3(batch), dim3(64), 0, s, k, scratch, out);
 }

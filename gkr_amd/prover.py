@@ -407,9 +407,11 @@ class Context:
         outs = self.prove_many_raw(prepared, max_concurrent)
         return [_decode_proofs(arrs, circuit.get_k_list()) for arrs, (circuit, _) in zip(outs, work)]
 
-    def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs):
-        """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg).
-        inputs_limbs: (B, 2^input_k, 4) uint64.  Returns the challenge arrays (B, rounds, 4)."""
+    def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs, all_arrays=False):
+        """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg; circuits with wide
+        layers, whose d / input_func tables have 2^18 and more entries).
+        inputs_limbs: (B, 2^input_k, 4) uint64.  Returns the challenge arrays (B, rounds, 4), or with all_arrays the nine
+        output arrays [coeffs, lens, challenges, q, q_len, z, r, d, input] (first axis = proof)."""
         L = circuit.depth()
         B = inputs_limbs.shape[0]
         ks = circuit.get_k_list()
@@ -429,7 +431,7 @@ class Context:
                 np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
         bufs = _proof_bufs(arrs, B)
         self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B), ctypes.c_int(0), bufs))
-        return arrs[2]
+        return arrs if all_arrays else arrs[2]
 
 
 _default_ctx = None

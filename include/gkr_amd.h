@@ -58,6 +58,23 @@ typedef struct { uint64_t l[4]; } gkr_fr;
 
 typedef struct gkr_ctx gkr_ctx;
 
+/* ---- limits (every size limit of the library; tests/test_host_library.py checks this table against the code) ----
+ * The reference proves any GKRCircuit its compiler emits (prover.rs:6-96; layers padded to whatever 2^k they need,
+ * convert.rs:209-214).  The library's limits are those of 32-bit gate indices and device memory, not of a table form:
+ *   GKR_MAX_K_NEXT   widest next layer of a layer sumcheck (2^k_next values W; k[i+1] of gkr_prove): U, V, W, the
+ *                    c-phase row and eq(u, .) are 2^k_next-entry tables in HBM (9 x 32 B per value and proof);
+ *   GKR_MAX_K_I      most gates of a layer, 2^k_i (also the output layer k[0]); sorted gate lists cost 16 B per gate;
+ *   GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT   with GKR_TRANSCRIPT_DEVICE the layer sumcheck works on dense 2^(2 k_next)-entry
+ *                    predicate tables (the host-free form is complete, not fast): k_next <= 14;
+ *   GKR_MAX_MLE_N    plain sumcheck: tables of 2^n values, batch * 2^n <= 2^30 values (32 GiB) per call;
+ *   GKR_MAX_BATCH    proofs per gkr_prove_batch call.
+ * A call beyond a limit returns GKR_ERR_INVALID and names the limit in gkr_last_error. */
+#define GKR_MAX_K_NEXT 24
+#define GKR_MAX_K_I 28
+#define GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT 14
+#define GKR_MAX_MLE_N 30
+#define GKR_MAX_BATCH 4096
+
 enum {
     GKR_OK = 0,
     GKR_ERR_INVALID = 1,      /* bad sizes / null pointers / operand index out of range */
@@ -188,7 +205,7 @@ int  gkr_sumcheck_layer(gkr_ctx *ctx, int k_i, int k_next, const uint8_t *gate_t
  *
  * This rank holds gates gate_first .. gate_first + gate_count - 1 of the layer's 2^k_i (the three arrays have
  * gate_count entries; gate_count may be 0).  z, W and the outputs are as for gkr_sumcheck_layer and identical on
- * all ranks.  Needs the host transcript and k_next <= 13.
+ * all ranks.  Needs the host transcript; k_next <= GKR_MAX_K_NEXT as everywhere.
  *
  * allreduce: called twice per layer (three times never), each time with `count` canonical field elements in host
  * memory that it must replace by their sums over all ranks mod r (the same on every rank); 0 = success.  RCCL has

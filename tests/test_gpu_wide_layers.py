@@ -1,0 +1,155 @@
+"""GPU parity for WIDE layers: next-layer tables of 2^14 .. 2^20 values and more, which prover::prove accepts like any
+other GKRCircuit (rust/src/gkr/prover.rs:23-83; layers are padded to whatever 2^k the compiler needs,
+rust/src/convert.rs:209-214).  The checker is the C oracle's linear-time layer prover (oracle/c/ogkr.c,
+ogkr_sumcheck_layer_lin), which tests/test_oracle_c.py pins against the dense forms and the reference's fixtures for
+every width those reach.  Bit-exact: every byte of (coefficients, lengths, challenges) and of q, z, r, d, input_func."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gkr_amd import Context, GKRCircuit, GkrError, Layer, synth
+from oracle import cdense
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _same(got, want):
+    return all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("k_i,k", [(20, 15), (22, 16), (24, 18), (20, 20), (14, 14), (10, 17), (21, 13)])
+def test_wide_layer_sumcheck_matches_oracle(ctx, k_i, k):
+    lay, z, W = synth.config5_layer(k_i, k, seed=synth.SEED + 100 * k_i + k)
+    want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+    got = ctx.sumcheck_layer_raw(lay, k, z, W)
+    assert _same(got, want)
+
+
+def _circom_like_layer(k_i, k, seed):
+    """What a compiled layer looks like (convert.rs:278-343): half of the gates are relay gates Add(x, zero) that all read
+    the zero slot as their right operand -- ONE bucket with 2^(k_i - 1) gates --, a few hot wires feed thousands of gates,
+    the rest is scattered; a stretch of one gate type; a slot nobody reads."""
+    rng = np.random.default_rng(seed)
+    g = 1 << k_i
+    gt = rng.integers(0, 2, g, dtype=np.uint8)
+    l = rng.integers(0, 1 << k, g, dtype=np.uint32)
+    r = rng.integers(0, 1 << k, g, dtype=np.uint32)
+    relay = rng.random(g) < 0.5
+    gt[relay] = 0
+    r[relay] = 2                                   # the lazily allocated zero slot
+    hot = rng.random(g) < 0.05
+    l[hot] = rng.integers(0, 4, int(hot.sum()), dtype=np.uint32) * 1000 + 17   # four wires with ~1 % of the gates each
+    l[l == 5] = 6                                  # bucket 5 empty
+    gt[: g >> 3] = 1
+    return Layer(k_i, gt, l, r)
+
+
+@pytest.mark.parametrize("k_i,k", [(18, 18), (20, 19), (16, 14)])
+def test_wide_layer_with_heavy_buckets_matches_oracle(ctx, k_i, k):
+    lay = _circom_like_layer(k_i, k, 31 * k_i + k)
+    rng = np.random.default_rng(5)
+    z, W = synth.rand_fr(rng, k_i), synth.rand_fr(rng, 1 << k)
+    want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+    assert _same(ctx.sumcheck_layer_raw(lay, k, z, W), want)
+
+
+def test_wide_layer_short_round_vectors(ctx):
+    """W without some of its variables (get_univariate_coeff, poly.rs:388-420: the round vector then has two entries): the
+    dependence flags of a wide table are found over a grid (k_depends_wide)."""
+    k_i, k = 16, 15
+    lay, z, _ = synth.config5_layer(k_i, k, seed=9)
+    rng = np.random.default_rng(10)
+    base = synth.rand_fr(rng, 1 << 5)
+    idx = np.arange(1 << k)
+    for W in (base[(idx >> 3) & 31],                     # depends on variables 8 .. 12 only
+              base[idx & 31],                             # the last five
+              np.repeat(base[:1], 1 << k, axis=0)):       # constant
+        W = np.ascontiguousarray(W)
+        want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+        assert set(want[1].tolist()) <= {2, 3} and (want[1] == 2).any()
+        assert _same(ctx.sumcheck_layer_raw(lay, k, z, W), want)
+
+
+def _random_circuit(ks, seed):
+    rng = np.random.default_rng(seed)
+    layers = []
+    for i in range(len(ks) - 1):
+        g, m = 1 << ks[i], 1 << ks[i + 1]
+        layers.append((rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, m, g, dtype=np.uint32), rng.integers(0, m, g, dtype=np.uint32)))
+    return layers
+
+
+def _check_proofs(arrs, layers, ks, witnesses):
+    sc, sl, sr, q, ql, z, rr, dco, ico = arrs
+    for b in range(witnesses.shape[0]):
+        ref = cdense.prove_raw(layers, witnesses[b])
+        ro = qo = 0
+        zo = ks[0]
+        assert not z[b, :ks[0]].any()                    # z[0] = 0 (prover.rs:16-21)
+        for i in range(len(layers)):
+            k = ks[i + 1]
+            assert np.array_equal(sc[b, ro:ro + 2 * k], ref["C"][i]), (b, i)
+            assert np.array_equal(sl[b, ro:ro + 2 * k], ref["L"][i]), (b, i)
+            assert np.array_equal(sr[b, ro:ro + 2 * k], ref["R"][i]), (b, i)
+            assert int(ql[b, i]) == ref["q_len"][i] and np.array_equal(q[b, qo:qo + k + 1], ref["q"][i]), (b, i)
+            assert np.array_equal(z[b, zo:zo + k], ref["z"][i + 1]), (b, i)
+            ro += 2 * k
+            qo += k + 1
+            zo += k
+        assert np.array_equal(rr[b], ref["r"])
+        assert np.array_equal(dco[b], cdense.mobius_raw(ref["values"][0], ks[0]))
+        assert np.array_equal(ico[b], cdense.mobius_raw(ref["values"][-1], ks[-1]))
+
+
+def test_prove_with_an_input_layer_of_2pow18_values(ctx):
+    """A whole proof (prover::prove, prover.rs:6-96) through layers of 2^16 and 2^18 values: sumchecks, q (the stepwise line
+    restriction with its grid set-up), z, r, and d / input_func from the device's Moebius transform."""
+    ks = [12, 16, 18]
+    layers = _random_circuit(ks, 71)
+    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(len(layers))], ks[-1])
+    wit = synth.rand_fr(np.random.default_rng(72), 1 << ks[-1])[None]
+    _check_proofs(ctx.prove_batch_raw(circuit, wit, all_arrays=True), layers, ks, wit)
+
+
+def test_prove_batch_of_three_through_wide_layers(ctx):
+    ks = [13, 15, 14, 16]
+    layers = _random_circuit(ks, 81)
+    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(len(layers))], ks[-1])
+    wit = np.stack([synth.rand_fr(np.random.default_rng(820 + b), 1 << ks[-1]) for b in range(3)])
+    arrs = ctx.prove_batch_raw(circuit, wit, all_arrays=True)
+    _check_proofs(arrs, layers, ks, wit)
+    # and again from the circuit cache (sorted lists and heavy-bucket work lists kept per circuit)
+    arrs2 = ctx.prove_batch_raw(circuit, wit[:2], all_arrays=True)
+    assert all(np.array_equal(a[:2], b) for a, b in zip(arrs, arrs2))
+
+
+@pytest.mark.parametrize("scenario", ["small", "heavy-batch", "per-round"])
+def test_lane_group_passes_on_small_layers(scenario):
+    """tests/wide_scenarios_worker.py (a child: GKR_GATE_GROUPS_MIN_K is read once per process): the lane-group form of the
+    gate passes and its heavy-bucket units forced onto layers the dense C oracle reaches, also in a batch of proofs and
+    with the per-round kernels after them."""
+    env = dict(os.environ, GKR_GATE_GROUPS_MIN_K="1")
+    if scenario == "per-round":
+        env["GKR_LAYER_PER_ROUND"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(HERE, "wide_scenarios_worker.py"), scenario], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_limits_are_reported(ctx):
+    lay = Layer(2, [0, 1, 0, 1], [0, 1, 2, 3], [3, 2, 1, 0])
+    with pytest.raises(GkrError) as e:
+        ctx.sumcheck_layer_raw(lay, 25, np.zeros((2, 4), dtype=np.uint64), np.zeros((1 << 25, 4), dtype=np.uint64))
+    assert "GKR_MAX_K_NEXT" in str(e.value)
