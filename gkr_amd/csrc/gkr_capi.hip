@@ -649,6 +649,7 @@ int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t tic
 }
 
 constexpr int kMaxGroups = 32;
+constexpr int kMleShardTailLog2 = 6;   // entries (log2) every shard keeps for the gathered tail of a sumcheck split over ranks
 
 #define WS(ctx, slot, type, count, ptr) \
     HIP_TRY(ctx, (ctx)->workspace(slot, (size_t)(count) * sizeof(type), reinterpret_cast<void**>(&(ptr))))
@@ -783,9 +784,18 @@ static void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, in
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
 // eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
 // variables at once.  Length rules as in run_mle_batch.
+// `tail` (may be null): the tables are the TAIL of longer sumchecks (gkr_sumcheck_mle_sharded_dev: what is left of a table
+// split over ranks, gathered) -- round j of a tail is round round_offset + j of a sumcheck with n_total rounds (row stride
+// of the outputs), and the last round's length follows the ORIGINAL table's dependence on its last variable (dep_last,
+// null: the tail is the whole table), not the folded tail's.
+struct MleTailArgs {
+    int n_total = 0, round_offset = 0;
+    const uint32_t* dep_last = nullptr;
+};
 int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len,
-                         gkr_fr* out_r) {
+                         gkr_fr* out_r, const MleTailArgs* tail = nullptr) {
     using gkr::h64::F;
+    const int n_out = tail ? tail->n_total : n, r_off = tail ? tail->round_offset : 0;
     static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
     const auto dbg_t0 = std::chrono::steady_clock::now();
     auto dbg_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
@@ -991,7 +1001,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         uint32_t ln[gkr::kMlePassMaxRounds][16], final_len[16];
         const bool final_pass = G.round0 + J == n;
         for (int i = 0; i < count; ++i) {
-            if (G.round0 == 0) dep_last[b_first + i] = rec[b_first + i].dep;
+            if (G.round0 == 0) dep_last[b_first + i] = tail && tail->dep_last ? tail->dep_last[b_first + i] : rec[b_first + i].dep;
             final_len[i] = dep_last[b_first + i] ? 2u : 1u;
         }
         static_assert(sizeof(gkr::MleHostRecSub) % 8 == 0, "hand-off records are addressed in 64-bit words");
@@ -1002,13 +1012,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         for (int i = 0; i < count; ++i) {
             const int b = b_first + i;
             for (int t = 0; t < J; ++t) {
-                const int round = G.round0 + t;
-                gkr_fr* oc = out_coeffs + ((size_t)b * n + round) * 2;
+                const int round = r_off + G.round0 + t;
+                gkr_fr* oc = out_coeffs + ((size_t)b * n_out + round) * 2;
                 memset(&oc[0], 0, 32);
                 if (ln[t][i] == 2) memcpy(&oc[0], c1[t][i], 32);
                 memcpy(&oc[1], c0[t][i], 32);
-                out_len[(size_t)b * n + round] = ln[t][i];
-                memcpy(&out_r[(size_t)b * n + round], r[t][i], 32);
+                out_len[(size_t)b * n_out + round] = ln[t][i];
+                memcpy(&out_r[(size_t)b * n_out + round], r[t][i], 32);
             }
         }
     };
@@ -2839,6 +2849,194 @@ int gkr_sumcheck_mle(gkr_ctx* ctx, const gkr_fr* table, int n, gkr_fr* out_coeff
     HIP_TRY(ctx, d.alloc(len));
     HIP_TRY(ctx, hipMemcpyAsync(d.p, table, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     return run_mle_batch(ctx, d.p, n, 1, out_coeffs, out_len, out_r);
+}
+
+// ---- one plain sumcheck split over ranks, on the multi-round schedule -----------------------------------------------
+// prove_sumcheck (sumcheck.rs:158-214) with the reduce over the hypercube (the rayon reduce of :62) split over P = 2^lp
+// ranks.  Rank p holds, of every table T (2^n entries, variable 1 = most significant index bit), the shard
+//     T_p[h * 2 + x_n] = T[h * 2P + 2p + x_n],   h < 2^(n - lp - 1):
+// the index bits lp .. 1 are the rank, the last variable stays inside every shard.  Rounds bind the leading variable,
+// so every pair (i, i + half) is rank-local while bits of h are bound; the sub-block sums a pass hands the host are
+// linear in the table, so the whole table's 2^J sums are the sums over ranks of the shards' -- ONE all-reduce of
+// 2^J (+ 2 flags) field elements per pass of J <= 5 rounds (n = 20 on 8 ranks: 3 exchanges + the gather, not 20), queued
+// on the library's stream through the caller's gkr_exchange_dev; every rank then runs the same J rounds on the same
+// sums and derives the same weights, no broadcast.  When 2^6 entries per shard are left they are gathered (one more
+// all-reduce, of zero-padded buffers) into a tail table of 2^(6 + lp) entries on which every rank finishes the last
+// rounds redundantly.  "Does T depend on x_n" (the last round's length, sumcheck.rs:206-207) is the OR over ranks of
+// a neighbour compare inside each shard -- exact, no shard is compared across ranks.
+size_t gkr_exchange_limbs_mle(int n, int log2_shards, int batch) {
+    if (n < 2 || log2_shards < 0 || log2_shards > 16 || n - log2_shards < 1 || n - log2_shards > GKR_MAX_MLE_N || batch < 1) return 0;
+    const int nl = n - log2_shards, t = nl < kMleShardTailLog2 ? nl : kMleShardTailLog2;
+    const size_t per_pass = (size_t)batch * (gkr::kMleMaxSub + 2) * 8, gather = ((size_t)batch << (t + log2_shards)) * 8 + 8;
+    return per_pass > gather ? per_pass : gather;
+}
+
+int gkr_sumcheck_mle_sharded_dev(gkr_ctx* ctx, const void* d_shards, int n, int log2_shards, int shard, int batch,
+                                 const gkr_exchange_dev* exchange, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r,
+                                 uint32_t* out_exchanges) {
+    using gkr::h64::F;
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!d_shards || !exchange || !exchange->fn || !exchange->d_limbs || !out_coeffs || !out_len || !out_r || batch < 1 || batch > 65535)
+        return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of range [1, 65535]");
+    const int lp = log2_shards, nl = n - lp;
+    if (lp < 0 || lp > 16 || shard < 0 || shard >= (1 << lp)) return ctx->fail(GKR_ERR_INVALID, "shard must be in [0, 2^log2_shards), log2_shards in [0, 16]");
+    if (n < 2 || nl < 1 || nl > GKR_MAX_MLE_N) return ctx->fail(GKR_ERR_INVALID, "n >= 2 and 1 <= n - log2_shards <= GKR_MAX_MLE_N needed");
+    if (ctx->transcript != GKR_TRANSCRIPT_HOST) return ctx->fail(GKR_ERR_INVALID, "a sumcheck split over ranks needs the host transcript");
+    if (exchange->capacity < gkr_exchange_limbs_mle(n, lp, batch)) return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs_mle(n, log2_shards, batch) int64");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const Fr* shards = static_cast<const Fr*>(d_shards);
+    const size_t len = (size_t)1 << nl;
+    const int t_stop = nl < kMleShardTailLog2 ? nl : kMleShardTailLog2;   // variables every shard keeps for the gathered tail
+    static const int jmax = getenv("GKR_NO_MFMA_FOLD") ? 3 : gkr::kMlePassMaxRounds;
+    auto rounds_for = [&](int m) {
+        int j = mle_pass_rounds(m, nl, jmax);
+        if (m - j < t_stop) j = m - t_stop;
+        return j;
+    };
+    long long* limbs = reinterpret_cast<long long*>(exchange->d_limbs);
+    // everything that can fail locally is set up BEFORE the first exchange; from there on a failure is carried through the
+    // remaining exchanges as a flag, so that no rank is left waiting inside a collective
+    Fr *work = nullptr, *d_tail = nullptr;
+    gkr::MleSubPartial* partials = nullptr;
+    gkr::MleHostRecSub *rec = nullptr, *d_rec = nullptr;
+    Fr* h_w = nullptr;
+    unsigned char* plans = nullptr;
+    uint32_t* h_fail = nullptr;
+    const int j_first = nl > t_stop ? rounds_for(nl) : 0;
+    const size_t work_len = j_first ? len >> j_first : 1;
+    WS(ctx, "mlex.work", Fr, (size_t)batch * work_len, work);
+    WS(ctx, "mlex.tail", Fr, (size_t)batch << (t_stop + lp), d_tail);
+    WS(ctx, "mlex.partials", gkr::MleSubPartial, (size_t)batch * gkr::kMaxBlocksPerTable, partials);
+    WS(ctx, "mlex.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
+    WS(ctx, "mlex.drec", gkr::MleHostRecSub, (size_t)batch, d_rec);
+    HIP_TRY(ctx, ctx->pinned_host("mlex.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
+    HIP_TRY(ctx, ctx->pinned_host("mlex.w", sizeof(Fr) * gkr::kMleMaxSub * batch, reinterpret_cast<void**>(&h_w)));
+    HIP_TRY(ctx, ctx->pinned_host("mlex.fail", 64, reinterpret_cast<void**>(&h_fail)));
+    *h_fail = 0;
+    std::vector<uint32_t> dep_last(batch, 0);
+    const bool ifma = host_ifma_ready();
+    gkr::SpinPool* pool = batch >= 32 ? ctx->host_pool() : nullptr;
+    int rc = GKR_OK;          // this rank's own failure, carried through the remaining exchanges
+    uint32_t exchanges = 0;
+    auto exchange_sums = [&](int J, uint32_t ticket) {
+        Timed t(ctx, "exchange", 0.0);
+        gkr::launch_mle_xwiden(d_rec, (uint32_t)J, (uint32_t)batch, rc ? 1u : 0u, limbs, s);
+        const int arc = exchange->fn(exchange->user, (size_t)batch * (((size_t)1 << J) + 2) * 8, static_cast<void*>(s));
+        gkr::launch_mle_xnarrow(limbs, (uint32_t)J, (uint32_t)batch, rec, ticket, h_fail, s);
+        ++exchanges;
+        if (arc && !rc) rc = ctx->fail(GKR_ERR_INVALID, "the device sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+    };
+    auto some_rank_failed = [&]() { return __atomic_load_n(h_fail, __ATOMIC_ACQUIRE) != 0; };
+    // the J rounds of every table on the summed sub-block sums (the same on every rank), and the fold weights
+    auto host_rounds = [&](int J, int round0) {
+        const int chunk = 16;
+        std::atomic<int> next{0};
+        const std::function<bool()> work_fn = [&]() -> bool {
+            const int first = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (first >= batch) return false;
+            const int count = batch - first < chunk ? batch - first : chunk;
+            uint64_t c0[gkr::kMlePassMaxRounds][16][4], c1[gkr::kMlePassMaxRounds][16][4], r[gkr::kMlePassMaxRounds][16][4];
+            uint32_t ln[gkr::kMlePassMaxRounds][16];
+            (ifma && count >= 3 ? gkr::gkr_ifma_pass : host_pass_scalar)(reinterpret_cast<const uint64_t*>(rec[first].sums), sizeof(gkr::MleHostRecSub) / 8, count, J,
+                                                                          nullptr, c0, c1, r, ln, reinterpret_cast<uint64_t*>(h_w + (size_t)first * gkr::kMleMaxSub),
+                                                                          4 * gkr::kMleMaxSub);
+            for (int i = 0; i < count; ++i) {
+                const int b = first + i;
+                if (round0 == 0) dep_last[b] = rec[b].dep;
+                for (int tt = 0; tt < J; ++tt) {
+                    const size_t row = (size_t)b * n + round0 + tt;
+                    memset(&out_coeffs[row * 2], 0, 32);
+                    if (ln[tt][i] == 2) memcpy(&out_coeffs[row * 2], c1[tt][i], 32);
+                    memcpy(&out_coeffs[row * 2 + 1], c0[tt][i], 32);
+                    out_len[row] = ln[tt][i];
+                    memcpy(&out_r[row], r[tt][i], 32);
+                }
+            }
+            return true;
+        };
+        gkr::SpinPool::Session session(pool, nullptr);
+        run_pieces(pool, &work_fn, batch > chunk);
+    };
+    // ---- the rank-local rounds: n - lp - t_stop of them, in passes
+    int m = nl, round0 = 0, jin = 0;
+    while (m - jin > t_stop) {
+        m -= jin;
+        const int J = rounds_for(m);
+        const uint32_t ticket = ++ctx->ticket;
+        if (!rc) {
+            const size_t src_len = (size_t)1 << (m + jin), S = (size_t)1 << m;
+            const bool from_input = round0 == jin;   // pass 0 (sums only) and the first fold read the input shards
+            const Fr* src = from_input ? shards : work;
+            const size_t src_stride = from_input ? len : work_len;
+            if (jin == 0) {
+                if (len <= gkr::kSmallPassEntries) {
+                    gkr::launch_mle_multifold_small(0, shards, len, nullptr, 0, (uint32_t)len, (uint32_t)J, batch, h_w, d_rec, ticket, s);
+                } else {
+                    const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)len, (uint32_t)J, batch);
+                    {
+                        Timed t(ctx, "mle_sub_sums", (double)batch * len * 32.0);
+                        gkr::launch_mle_sub_sums(shards, len, (uint32_t)len, batch, nblk, partials, s);
+                    }
+                    gkr::launch_mle_sub_reduce(partials, nblk, (uint32_t)J, batch, d_rec, ticket, s);
+                }
+            } else if (S <= gkr::kSmallPassEntries) {
+                gkr::launch_mle_multifold_small(jin, src, src_stride, work, work_len, (uint32_t)S, (uint32_t)J, batch, h_w, d_rec, ticket, s);
+            } else {
+                const uint32_t nblk = gkr::mle_multifold_blocks((uint32_t)S, (uint32_t)J, batch);
+                if (gkr::mle_multifold_uses_mfma((uint32_t)S, nblk)) gkr::launch_mle_fold_plan(jin, h_w, plans, batch, s);
+                {
+                    Timed t(ctx, "mle_multifold", (double)batch * ((double)src_len + (double)S) * 32.0);
+                    gkr::launch_mle_multifold(jin, src, src_stride, work, work_len, (uint32_t)S, batch, nblk, h_w, plans, partials, s);
+                }
+                gkr::launch_mle_sub_reduce(partials, nblk, (uint32_t)J, batch, d_rec, ticket, s);
+            }
+            if (hipError_t le = hipGetLastError(); le != hipSuccess) rc = ctx->hip_fail(le, "launch of a sumcheck pass");
+        }
+        exchange_sums(J, ticket);
+        if (!rc) rc = wait_records(ctx, rec, batch, ticket);
+        if (!rc && some_rank_failed()) rc = ctx->fail(GKR_ERR_HIP, "another rank failed during the sumcheck");
+        if (!rc) host_rounds(J, round0);
+        round0 += J;
+        jin = J;
+    }
+    // ---- bind the last pass's variables (2^t_stop entries per shard are left), gather the tail
+    m -= jin;
+    const Fr* rest = shards;
+    size_t rest_stride = len;
+    if (jin && !rc) {
+        const uint32_t ticket = ++ctx->ticket;
+        const size_t S = (size_t)1 << m;
+        const bool from_input = round0 == jin;   // one pass so far: its sums came from the input shards
+        gkr::launch_mle_multifold_small(jin, from_input ? shards : work, from_input ? len : work_len, work, work_len, (uint32_t)S, 1u, batch, h_w, d_rec,
+                                        ticket, s);
+        rest = work;
+        rest_stride = work_len;
+        if (hipError_t le = hipGetLastError(); le != hipSuccess) rc = ctx->hip_fail(le, "launch of the last rank-local fold");
+    }
+    {
+        Timed t(ctx, "exchange", 0.0);
+        gkr::launch_mle_gather_widen(rest, rest_stride, (uint32_t)m, (uint32_t)lp, (uint32_t)shard, rc ? 1u : 0u, (uint32_t)batch, limbs, s);
+        const int arc = exchange->fn(exchange->user, ((size_t)batch << (m + lp)) * 8 + 8, static_cast<void*>(s));
+        gkr::launch_mle_gather_narrow(limbs, (uint32_t)(m + lp), (uint32_t)batch, d_tail, h_fail, s);
+        ++exchanges;
+        if (arc && !rc) rc = ctx->fail(GKR_ERR_INVALID, "the device sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+    }
+    if (out_exchanges) *out_exchanges = exchanges;
+    {
+        const hipError_t se = hipStreamSynchronize(s);   // the tail is complete, the flag has landed
+        if (se != hipSuccess && !rc) rc = ctx->hip_fail(se, "hipStreamSynchronize after the gather");
+    }
+    if (!rc && some_rank_failed()) rc = ctx->fail(GKR_ERR_HIP, "another rank failed during the sumcheck");
+    if (rc) return rc;
+    ctx->drain_events();
+    // ---- the last t_stop + lp rounds on the gathered tail, the same on every rank
+    MleTailArgs tail;
+    tail.n_total = n;
+    tail.round_offset = round0;
+    tail.dep_last = round0 ? dep_last.data() : nullptr;   // (no rank-local round: the tail is the whole table, its own neighbour compare decides)
+    const int n_tail = m + lp;
+    return run_mle_batch_passes(ctx, d_tail, n_tail, batch, out_coeffs, out_len, out_r, &tail);
 }
 
 // ---- layer sumcheck / predicates / layer eval -------------------------------------

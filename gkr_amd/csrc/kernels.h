@@ -259,6 +259,16 @@ void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep,
 // in-place Moebius transform (evaluations -> monomial coefficients, MSB-first) of `batch` tables of 2^k, `stride` apart
 void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStream_t s);
 void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t* out_len, uint32_t batch, hipStream_t s);
+
+// ---- one plain sumcheck split over ranks (kernels_wide.hip): the per-pass exchange of the sub-block sums and the final gather
+// rec: the pass's records in DEVICE memory; limbs: batch x (2^J + 2) x 8 int64 (sums | dep | fail per table)
+void launch_mle_xwiden(const MleHostRecSub* rec, uint32_t J, uint32_t batch, uint32_t local_fail, long long* limbs, hipStream_t s);
+void launch_mle_xnarrow(const long long* limbs, uint32_t J, uint32_t batch, MleHostRecSub* host_rec, uint32_t ticket, uint32_t* fail_out,
+                        hipStream_t s);
+// the 2^t entries every shard has left -> the tail table of 2^(t + lp) entries (limbs: batch x 2^(t+lp) x 8 + 8 int64)
+void launch_mle_gather_widen(const Fr* src, size_t stride, uint32_t t, uint32_t lp, uint32_t shard, uint32_t local_fail, uint32_t batch,
+                             long long* limbs, hipStream_t s);
+void launch_mle_gather_narrow(const long long* limbs, uint32_t tn, uint32_t batch, Fr* tail, uint32_t* fail_out, hipStream_t s);
 void launch_to_mont(const Fr* in, Fr* out, uint32_t count, hipStream_t s);
 void launch_depends(const Fr* W, uint32_t k, uint32_t* dep, uint32_t batch, hipStream_t s);
 void launch_predicate_scatter(uint32_t k_i, uint32_t k_next, const uint8_t* gate_type, const uint32_t* left,

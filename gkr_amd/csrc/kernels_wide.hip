@@ -329,4 +329,118 @@ void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxd
     hipLaunchKernelGGL(k_line_len_out, dim3(batch), dim3(1), 0, s, maxdeg_scratch, out_len);
 }
 
+// ---------------------------------------------------------------------------
+// One plain sumcheck split over ranks (gkr_sumcheck_mle_sharded_dev): what crosses the ranks is, per pass, the 2^J
+// sub-block sums of every table -- they are linear in the table, so the sums of the whole table are the sums over ranks
+// of the shards' sums (the multi-GPU twin of the rayon reduce, sumcheck.rs:62 applied to prove_sumcheck :158-214) --
+// and once, at the end, the few entries every shard has left.  Field elements travel as eight 32-bit limbs in int64 (an
+// integer SUM all-reduce of those is exact; RCCL has no modular sum).
+//   per table: 2^J sums | dep ("the shard depends on the last variable") | fail   ->  (2^J + 2) x 8 int64
+// ---------------------------------------------------------------------------
+// grid = (batch), block = 64: records in DEVICE memory (written by k_mle_sub_reduce / k_mle_multifold_small) -> limbs
+__global__ void __launch_bounds__(64) k_mle_xwiden(const MleHostRecSub* __restrict__ rec, uint32_t J, uint32_t local_fail, long long* __restrict__ limbs) {
+    const uint32_t b = blockIdx.x, n = (1u << J) + 2u, e = threadIdx.x;
+    if (e >= n) return;
+    long long* out = limbs + ((size_t)b * n + e) * 8;
+    if (e < (1u << J)) {
+        const Fr v = load_fr(&rec[b].sums[e]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = local_fail ? 0 : (long long)v.l[j];
+    } else {
+        const uint32_t f = e == (1u << J) ? (local_fail ? 0u : rec[b].dep) : local_fail;
+        out[0] = (long long)(f ? 1 : 0);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) out[j] = 0;
+    }
+}
+// limb sums -> the pinned host record of every table (sums mod r, dep = some rank's shard depends on the last variable),
+// seq = ticket last; *fail_out (pinned, may be null) = some rank failed
+__global__ void __launch_bounds__(64) k_mle_xnarrow(const long long* __restrict__ limbs, uint32_t J, MleHostRecSub* __restrict__ host_rec,
+                                                    uint32_t ticket, uint32_t* __restrict__ fail_out) {
+    const uint32_t b = blockIdx.x, n = (1u << J) + 2u, e = threadIdx.x;
+    const long long* in = limbs + ((size_t)b * n + e) * 8;
+    MleHostRecSub* r = host_rec + b;
+    if (e < (1u << J)) {
+        Acc<10> acc = acc_zero<10>();
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long w = (unsigned long long)in[j];
+            const unsigned long long lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            acc.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        acc.l[8] = (uint32_t)carry;
+        acc.l[9] = (uint32_t)(carry >> 32);
+        store_fr(&r->sums[e], acc_reduce(acc));
+    } else if (e == (1u << J)) {
+        r->dep = in[0] ? 1u : 0u;
+    } else if (e == (1u << J) + 1u) {
+        if (in[0] && fail_out) __hip_atomic_store(fail_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();   // every record store is issued and waited for before the release below
+    if (e == 0) __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_mle_xwiden(const MleHostRecSub* rec, uint32_t J, uint32_t batch, uint32_t local_fail, long long* limbs, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_xwiden, dim3(batch), dim3(64), 0, s, rec, J, local_fail, limbs);
+}
+void launch_mle_xnarrow(const long long* limbs, uint32_t J, uint32_t batch, MleHostRecSub* host_rec, uint32_t ticket, uint32_t* fail_out,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_xnarrow, dim3(batch), dim3(64), 0, s, limbs, J, host_rec, ticket, fail_out);
+}
+
+// The shards' last entries gathered into the tail table every rank finishes on.  Shard p of P = 2^lp holds, of the table
+// with the leading variables bound, the entries whose index bits lp .. 1 are p (the last variable -- bit 0 -- stays
+// inside every shard: "does T depend on x_n" is then a local neighbour compare, exact without comparing shards across
+// ranks): local entry (h, x_n) is tail entry h * 2P + 2p + x_n.  An all-gather as a SUM all-reduce of zero-padded
+// buffers: per table 2^(t + lp) elements x 8 int64, then one more element: the fail flag.
+// grid = (blocks, batch), block = 256
+__global__ void __launch_bounds__(256) k_mle_gather_widen(const Fr* __restrict__ src, size_t stride, uint32_t t, uint32_t lp, uint32_t shard,
+                                                          uint32_t local_fail, uint32_t batch, long long* __restrict__ limbs) {
+    const uint32_t total = 1u << (t + lp), b = blockIdx.y;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        long long* out = limbs + ((size_t)b * total + g) * 8;
+        const bool mine = ((g >> 1) & ((1u << lp) - 1u)) == shard && !local_fail;
+        Fr v = fr_zero();
+        if (mine) v = load_fr(src + (size_t)b * stride + (((g >> (lp + 1u)) << 1) | (g & 1u)));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = (long long)v.l[j];
+    }
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        long long* f = limbs + (size_t)batch * total * 8;
+        f[0] = local_fail ? 1 : 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) f[j] = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_mle_gather_narrow(const long long* __restrict__ limbs, uint32_t tn, uint32_t batch, Fr* __restrict__ tail,
+                                                           uint32_t* __restrict__ fail_out) {
+    const uint32_t total = 1u << tn, b = blockIdx.y;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        const long long* in = limbs + ((size_t)b * total + g) * 8;
+        Acc<10> acc = acc_zero<10>();
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long w = (unsigned long long)in[j];
+            const unsigned long long lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            acc.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        acc.l[8] = (uint32_t)carry;
+        acc.l[9] = (uint32_t)(carry >> 32);
+        store_fr(tail + (size_t)b * total + g, acc_reduce(acc));
+    }
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && fail_out && limbs[(size_t)batch * total * 8])
+        __hip_atomic_store(fail_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_mle_gather_widen(const Fr* src, size_t stride, uint32_t t, uint32_t lp, uint32_t shard, uint32_t local_fail, uint32_t batch,
+                             long long* limbs, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_gather_widen, dim3(blocks_for((uint64_t)1 << (t + lp), 64), batch), dim3(256), 0, s, src, stride, t, lp, shard, local_fail,
+                       batch, limbs);
+}
+void launch_mle_gather_narrow(const long long* limbs, uint32_t tn, uint32_t batch, Fr* tail, uint32_t* fail_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mle_gather_narrow, dim3(blocks_for((uint64_t)1 << tn, 64), batch), dim3(256), 0, s, limbs, tn, batch, tail, fail_out);
+}
+
 }  // namespace gkr

@@ -108,12 +108,20 @@ class TorchCollective:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return t.cpu().numpy()
 
-    def exchange(self, k_max=13):
+    def exchange(self, k_max=13, limbs=0):
         """What ResidentGates.sumcheck_raw takes as its sum over ranks: on RCCL the device exchange (the limbs never
         leave the GPU, the all-reduce is queued on the library's own stream), on gloo the host transport."""
         if self._dist.get_backend(self._group) == "nccl":
-            return DeviceExchange(self, k_max)
+            return DeviceExchange(self, k_max, limbs)
         return self.sum_limbs
+
+    def device_exchange(self, limbs):
+        """A gkr_exchange_dev of `limbs` int64 whatever the backend (what sumcheck_mle_sharded_raw takes): RCCL queues the
+        all-reduce on the library's stream; gloo -- ranks sharing a GPU in the tests, hosts without RCCL -- waits for the
+        stream, sums on the host and copies back (StagedDeviceExchange)."""
+        if self._dist.get_backend(self._group) == "nccl":
+            return DeviceExchange(self, 1, limbs)
+        return StagedDeviceExchange(self, limbs)
 
 
 class DeviceExchange:
@@ -125,11 +133,13 @@ class DeviceExchange:
     (include/gkr_amd.h, gkr_resident_layer_sumcheck_dev; the reference's counterpart is the rayon reduce of
     sumcheck.rs:50-63, 97-124)."""
 
-    def __init__(self, coll: TorchCollective, k_max=13):
+    def __init__(self, coll: TorchCollective, k_max=13, limbs=0):
         torch, dist, group = coll._torch, coll._dist, coll._group
-        self._buf = torch.zeros(int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max))), dtype=torch.int64, device=coll._device)
+        self._buf = torch.zeros(max(int(limbs), int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max)))), dtype=torch.int64, device=coll._device)
         self.errors = []
         self.calls = 0
+        self.backend = "nccl"
+        self.world = coll.world
 
         def fn(_user, count, stream):
             try:
@@ -142,6 +152,58 @@ class DeviceExchange:
                 return 1
         self._fn = N.ALLREDUCE_DEV_FN(fn)
         self.struct = N.ExchangeDev(self._fn, None, self._buf.data_ptr(), self._buf.numel())
+
+
+class StagedDeviceExchange(DeviceExchange):
+    """The same contract over a backend that cannot reduce device memory (gloo): the hook waits for the library's stream,
+    sums the limbs on the host and copies them back before it returns -- correct, not fast; RCCL is the product path."""
+
+    def __init__(self, coll: TorchCollective, limbs):
+        import torch
+        dist, group = coll._dist, coll._group
+        self._buf = torch.zeros(int(limbs), dtype=torch.int64, device="cuda:%d" % torch.cuda.current_device())
+        self.errors = []
+        self.calls = 0
+        self.backend = dist.get_backend(group)
+        self.world = coll.world
+
+        def fn(_user, count, stream):
+            try:
+                self.calls += 1
+                ext = torch.cuda.ExternalStream(int(stream or 0), device=self._buf.device)
+                ext.synchronize()
+                host = self._buf[:count].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                with torch.cuda.stream(ext):
+                    self._buf[:count].copy_(host.to(self._buf.device))
+                ext.synchronize()
+                return 0
+            except Exception as e:
+                self.errors.append(e)
+                return 1
+        self._fn = N.ALLREDUCE_DEV_FN(fn)
+        self.struct = N.ExchangeDev(self._fn, None, self._buf.data_ptr(), self._buf.numel())
+
+
+class NoExchange:
+    """gkr_exchange_dev for ONE rank (log2_shards = 0): a device buffer and a hook that has nothing to add."""
+
+    def __init__(self, ctx: Context, limbs):
+        self._ctx = ctx
+        self._d = ctx.alloc(8 * int(limbs))
+        self.errors = []
+        self.calls = 0
+
+        def fn(_user, count, stream):
+            self.calls += 1
+            return 0
+        self._fn = N.ALLREDUCE_DEV_FN(fn)
+        self.struct = N.ExchangeDev(self._fn, None, self._d.value, int(limbs))
+
+    def close(self):
+        if self._d is not None:
+            self._ctx.free(self._d)
+            self._d = None
 
 
 # ----------------------------------------------------------------------------- gate-sharded layer sumcheck
@@ -251,8 +313,10 @@ class ResidentGates:
         if isinstance(sum_limbs, DeviceExchange):
             rc = N.lib().gkr_resident_layer_sumcheck_dev(self._ctx._h, self._layer(k_next), _ptr(zl), _ptr(wl), ctypes.byref(sum_limbs.struct),
                                                          _ptr(C), _ptr(L), _ptr(R))
-            if sum_limbs.errors:
-                raise sum_limbs.errors[0]
+            if sum_limbs.errors:   # (taken off the list: a later call with the same exchange object starts clean)
+                errs = list(sum_limbs.errors)
+                del sum_limbs.errors[:]
+                raise errs[0]
             self._ctx._check(rc)
             return C, L, R
         hook, errors = make_allreduce_hook(sum_limbs) if sum_limbs is not None else (None, [])
@@ -297,13 +361,13 @@ class ThreadedDeviceSum:
     the device, every rank copies the total into its own buffer on its own stream.  Same widen / narrow kernels and the
     same flag handling as with RCCL; only the transport differs."""
 
-    def __init__(self, world, device=0, k_max=13):
+    def __init__(self, world, device=0, k_max=13, limbs=0):
         import threading
 
         import torch
         self._torch = torch
         self._barrier = threading.Barrier(world)
-        n = int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max)))
+        n = max(int(limbs), int(N.lib().gkr_exchange_limbs(ctypes.c_int(k_max))))
         self._bufs = [torch.zeros(n, dtype=torch.int64, device="cuda:%d" % device) for _ in range(world)]
         self._total = None
         self.errors = []
@@ -688,6 +752,110 @@ def prove_sumcheck_distributed(shard, coll, n, dep_rank_bit, open_tail, hasher=m
                                     dep_rank_bit, hasher)
     values = [v[0] for v in coll.all_gather_fr([shard.value()])] if log_p else []
     return _finish_mle(open_tail, values, n, log_p, dep_rank_bit, proof, rs, hasher)
+
+
+# ----------------------------------------------------------------------------- one plain sumcheck split over ranks, multi-round passes
+
+def mle_shard(table_limbs, n, log_p, p):
+    """Shard p of 2^log_p of a table of 2^n entries as gkr_sumcheck_mle_sharded_dev wants it: index bits log_p .. 1 of an
+    entry are its rank, the last variable stays inside the shard -- T_p[h * 2 + x_n] = T[h * 2P + 2p + x_n]."""
+    t = np.ascontiguousarray(table_limbs, dtype=np.uint64).reshape(1 << (n - log_p - 1), 1 << log_p, 2, 4)
+    return np.ascontiguousarray(t[:, p]).reshape(-1, 4)
+
+
+def exchange_limbs_mle(n, log_p, batch=1):
+    N.lib().gkr_exchange_limbs_mle.restype = ctypes.c_size_t
+    return int(N.lib().gkr_exchange_limbs_mle(ctypes.c_int(n), ctypes.c_int(log_p), ctypes.c_int(batch)))
+
+
+def sumcheck_mle_sharded_raw(ctx: Context, d_shards, n, log_p, shard, exchange, batch=1):
+    """gkr_sumcheck_mle_sharded_dev: this rank's `batch` shards (device memory, 2^(n - log_p) entries each) of `batch`
+    tables of 2^n entries -> the whole transcript (C (batch, n, 2, 4), L (batch, n), R (batch, n, 4)) and the number of
+    exchanges.  exchange: a DeviceExchange / StagedDeviceExchange / NoExchange / ThreadedDeviceSum.for_rank()."""
+    C = np.zeros((batch, n, 2, 4), dtype=np.uint64)
+    L = np.zeros((batch, n), dtype=np.uint32)
+    R = np.zeros((batch, n, 4), dtype=np.uint64)
+    nx = ctypes.c_uint32(0)
+    rc = N.lib().gkr_sumcheck_mle_sharded_dev(ctx._h, d_shards, ctypes.c_int(n), ctypes.c_int(log_p), ctypes.c_int(shard),
+                                              ctypes.c_int(batch), ctypes.byref(exchange.struct), _ptr(C), _ptr(L), _ptr(R), ctypes.byref(nx))
+    if exchange.errors:
+        errs = list(exchange.errors)
+        del exchange.errors[:]
+        raise errs[0]
+    ctx._check(rc)
+    return C, L, R, int(nx.value)
+
+
+def prove_sumcheck_logical_dev(device, tables_limbs, n, nshards):
+    """`batch` tables (batch, 2^n, 4) split over `nshards` logical ranks on ONE GPU -- a thread and a context per rank, as
+    one process per GPU would have, the all-reduce an in-process device sum -- through gkr_sumcheck_mle_sharded_dev.
+    Returns every rank's (C, L, R, exchanges)."""
+    import threading
+    log_p = _log2(nshards)
+    tables = np.ascontiguousarray(tables_limbs, dtype=np.uint64).reshape(-1, 1 << n, 4)
+    batch = tables.shape[0]
+    limbs = exchange_limbs_mle(n, log_p, batch)
+    coll = ThreadedDeviceSum(nshards, device, 1, limbs)
+    out, errs = [None] * nshards, []
+
+    def run(rank):
+        try:
+            mine = np.stack([mle_shard(tables[b], n, log_p, rank) for b in range(batch)]) if log_p else tables
+            with Context(device) as ctx:
+                d = ctx.alloc(mine.nbytes)
+                try:
+                    ctx.upload(d, mine)
+                    out[rank] = sumcheck_mle_sharded_raw(ctx, d, n, log_p, rank, coll.for_rank(rank), batch)
+                finally:
+                    ctx.free(d)
+        except Exception as e:
+            errs.append(e)
+            coll.abort()
+    threads = [threading.Thread(target=run, args=(p,)) for p in range(nshards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
+        raise (real or errs)[0]
+    return out
+
+
+def prove_sumcheck_split_model(shard_values, n, log_p, rank, coll, hasher=multi_hash):
+    """The split of gkr_sumcheck_mle_sharded_dev restated on Python integers over a collective (CPU: gloo in the tests): the
+    partition, the linearity of the sums, "depends on x_n" as the OR of the shards' neighbour compares, the gather order of
+    the tail.  One all-reduce per round here (the library sends the sums of up to five rounds at once -- the same
+    transcript).  shard_values: this rank's 2^(n - log_p) integers, mle_shard layout.  -> (proof, r), the same on every rank."""
+    P_ = 1 << log_p
+    t = [v % MODULUS for v in shard_values]
+    dep_last = coll.all_reduce_or(any(t[2 * h] != t[2 * h + 1] for h in range(len(t) // 2)))
+    proof, rs = [], []
+    keep = min(n - log_p, 6)
+    for j in range(n - log_p - keep):
+        h = len(t) // 2
+        c0, s1 = coll.all_reduce_fr([sum(t[:h]) % MODULUS, sum(t[h:]) % MODULUS])
+        c1 = (s1 - c0) % MODULUS
+        g = [c1, c0] if c1 else [c0]
+        r = hasher(g, 0)
+        proof.append(g)
+        rs.append(r)
+        t = [(t[i] + r * (t[i + h] - t[i])) % MODULUS for i in range(h)]
+    # gather: local entry (h, x) is tail entry h * 2P + 2 rank + x
+    tail = [0] * (len(t) * P_)
+    for i, v in enumerate(t):
+        tail[(i >> 1) * 2 * P_ + 2 * rank + (i & 1)] = v
+    tail = coll.all_reduce_fr(tail)
+    done = len(proof)
+    for j in range(done, n):
+        h = len(tail) // 2
+        c0, c1 = sum(tail[:h]) % MODULUS, (sum(tail[h:]) - sum(tail[:h])) % MODULUS
+        g = ([c1, c0] if dep_last else [c0]) if j == n - 1 else ([c1, c0] if c1 else [c0])
+        r = hasher(g, 0)
+        proof.append(g)
+        rs.append(r)
+        tail = [(tail[i] + r * (tail[i + h] - tail[i])) % MODULUS for i in range(h)]
+    return proof, rs
 
 
 def tables_differ(ctx: Context, d_a, d_b, count):

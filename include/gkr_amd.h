@@ -260,6 +260,28 @@ size_t gkr_exchange_limbs(int k_next);
 int  gkr_resident_layer_sumcheck_dev(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const gkr_fr *W,
                                      const gkr_exchange_dev *exchange, gkr_fr *out_coeffs, uint32_t *out_len,
                                      gkr_fr *out_r);
+/* ---- one plain sumcheck split over GPUs: prove_sumcheck (sumcheck.rs:158-214), its reduce over the hypercube (the rayon
+ * reduce of sumcheck.rs:62) as one RCCL all-reduce per PASS ------------------------------------------------------------
+ * A table T of 2^n values is split over P = 2^log2_shards ranks; rank p holds the shard
+ *     T_p[h * 2 + x_n] = T[h * 2P + 2p + x_n],   h < 2^(n - log2_shards - 1)
+ * (index bits log2_shards .. 1 of an entry are its rank; the last variable stays inside every shard), `batch` shards
+ * of 2^(n - log2_shards) values each, contiguous in device memory.  Rounds bind the leading variable, so every pair is
+ * rank-local until 2^6 entries per shard are left: the library runs its multi-round passes on the shard (the kernels of
+ * gkr_sumcheck_mle_batch_device), and per pass of J <= 5 rounds ONE in-place SUM all-reduce of batch * (2^J + 2) * 8
+ * int64 through `exchange` completes the 2^J sub-block sums (they are linear in the table), on the library's stream;
+ * every rank then hashes the same round vectors and binds the same challenges.  One more all-reduce gathers the 2^6
+ * entries every shard has left, and all ranks finish the last 6 + log2_shards rounds on that tail.  n = 20 on 8 ranks:
+ * 3 exchanges + 1 gather instead of 20 per-round reduces.  Every rank returns the whole transcript (outputs as
+ * gkr_sumcheck_mle_batch_device: batch x n rows), bit-exact with the unsharded sumcheck.  "Does T depend on x_n" (the
+ * last round's length) is a neighbour compare inside the shards, OR-ed over the ranks with the sums.
+ * exchange: as for gkr_resident_layer_sumcheck_dev; capacity >= gkr_exchange_limbs_mle(n, log2_shards, batch).  A rank
+ * that fails still enters every exchange (the flag travels with the sums) and all ranks return an error together.
+ * *out_exchanges (may be NULL): how many times fn was called.  log2_shards = 0 is allowed (one rank; fn may then be a
+ * no-op).  Needs the host transcript; 1 <= n - log2_shards <= GKR_MAX_MLE_N. */
+size_t gkr_exchange_limbs_mle(int n, int log2_shards, int batch);
+int  gkr_sumcheck_mle_sharded_dev(gkr_ctx *ctx, const void *d_shards, int n, int log2_shards, int shard, int batch,
+                                  const gkr_exchange_dev *exchange, gkr_fr *out_coeffs, uint32_t *out_len, gkr_fr *out_r,
+                                  uint32_t *out_exchanges);
 /* host only: count field elements <-> count x 8 int64 (32-bit limbs, least significant first); narrow reduces
  * limb sums of up to 2^31 addends mod r */
 int  gkr_fr_widen(const gkr_fr *values, size_t count, int64_t *limbs);

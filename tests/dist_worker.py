@@ -175,6 +175,23 @@ def main():
     got = parallel.prove_sumcheck_distributed(local, coll, n, dep_rank_bit, lambda v: OracleMleShard(v), hasher=oracle_hash)
     out["mle_ok"] = got == dense.sumcheck_mle(table, n)
 
+    # the split of gkr_sumcheck_mle_sharded_dev (rank = index bits log2 P .. 1, the last variable inside every shard,
+    # sums linear over ranks, gathered tail) restated on Python integers over this gloo group, against the oracle:
+    # tables with and without rank-local rounds, one that does not depend on its last variable, one constant
+    ok = True
+    lp = world.bit_length() - 1
+    for n2, kind in ((9, "random"), (9, "no-last"), (8, "constant"), (5, "random"), (7, "no-last")):
+        if kind == "random":
+            tb = [rng.randrange(P) for _ in range(1 << n2)]
+        elif kind == "no-last":
+            half = [rng.randrange(P) for _ in range(1 << (n2 - 1))]
+            tb = [half[i >> 1] for i in range(1 << n2)]
+        else:
+            tb = [11] * (1 << n2)
+        mine = [tb[h * 2 * world + 2 * rank + x] for h in range(1 << (n2 - lp - 1)) for x in (0, 1)]
+        ok = ok and parallel.prove_sumcheck_split_model(mine, n2, lp, rank, coll, hasher=oracle_hash) == dense.sumcheck_mle(tb, n2)
+    out["mle_split_ok"] = ok
+
     with open(os.path.join(os.environ["GKR_TEST_OUT"], "rank%d.json" % rank), "w") as f:
         json.dump(out, f)
     dist.destroy_process_group()

@@ -50,6 +50,21 @@ def main():
         ctx.free(d)
         from gkr_amd.field import from_limbs
         assert (proof, rs) == cdense.sumcheck_mle(from_limbs(table), n)
+    # the plain sumcheck split over ranks on the multi-round schedule (gkr_sumcheck_mle_sharded_dev): its per-pass
+    # all-reduces and the gather queued on the library's stream through RCCL; one rank = the whole table
+    with Context(0) as ctx:
+        for n, batch in ((20, 1), (14, 3), (5, 2)):
+            tables = np.stack([cdense.fill_table(1 << n, 555 + 7 * b + n) for b in range(batch)])
+            ex2 = coll.device_exchange(parallel.exchange_limbs_mle(n, 0, batch))
+            assert isinstance(ex2, parallel.DeviceExchange) and ex2.backend == "nccl"
+            d = ctx.alloc(tables.nbytes)
+            ctx.upload(d, tables)
+            C, L, R, nx = parallel.sumcheck_mle_sharded_raw(ctx, d, n, 0, 0, ex2, batch)
+            ctx.free(d)
+            assert ex2.calls == nx and (nx == 5 if n == 20 else nx >= 1), (n, nx)   # 4 passes (5 + 3 + 5 + 1 rounds) + the gather
+            for b in range(batch):
+                want = cdense.sumcheck_mle_raw(tables[b], n)
+                assert np.array_equal(C[b], want[0]) and np.array_equal(L[b], want[1]) and np.array_equal(R[b], want[2]), (n, b)
     dist.destroy_process_group()
     print("OK")
 

@@ -33,4 +33,4 @@ def test_two_rank_gloo_sharded_sumchecks(tmp_path):
         assert [int(v) for v in o["allreduce"]] == [P - 3, 2 * 12345 + 1, 0]
         assert [[int(v) for v in row] for row in o["allgather"]] == [[7], [8]]
         assert o["or"] is True
-        assert o["layer_ok"] and o["layer_short_ok"] and o["mle_ok"] and o["gate_sharded_ok"]
+        assert o["layer_ok"] and o["layer_short_ok"] and o["mle_ok"] and o["gate_sharded_ok"] and o["mle_split_ok"]

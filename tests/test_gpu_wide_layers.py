@@ -148,6 +148,26 @@ def test_lane_group_passes_on_small_layers(scenario):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("nshards,device_exchange", [(3, True), (2, False)])
+def test_wide_layer_split_by_gates_over_logical_ranks(nshards, device_exchange):
+    """The gate-sharded form (two sum-over-ranks exchanges of 2 * 2^k field elements) on a wide layer: every rank's
+    lane-group passes over its own gates, exchange on the device or through the host hook."""
+    from gkr_amd import parallel
+    k_i, k = 17, 15
+    lay = _circom_like_layer(k_i, k, 99)
+    rng = np.random.default_rng(6)
+    z, W = synth.rand_fr(rng, k_i), synth.rand_fr(rng, 1 << k)
+    want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+    if device_exchange:
+        got = parallel.prove_sumcheck_opt_logical_gates_dev(0, lay, k, z, W, nshards)
+        assert len(got) == nshards and all(_same(g, want) for g in got)
+    else:
+        from gkr_amd.field import from_limbs
+        got = parallel.prove_sumcheck_opt_logical_gates(0, lay, k, from_limbs(z), from_limbs(W), nshards)
+        proof = [from_limbs(want[0][j])[3 - int(want[1][j]):] for j in range(2 * k)]
+        assert len(got) == nshards and all(g == (proof, from_limbs(want[2])) for g in got)
+
+
 def test_limits_are_reported(ctx):
     lay = Layer(2, [0, 1, 0, 1], [0, 1, 2, 3], [3, 2, 1, 0])
     with pytest.raises(GkrError) as e:
