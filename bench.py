@@ -18,6 +18,10 @@ configs[2]) and aggregated proofs/sec (configs[0] / configs[3]), one process per
     ranks by gates, two sum-over-ranks exchanges (RCCL all-reduce of limb-widened field elements) per sumcheck
     (gkr_sumcheck_layer_sharded); a step = one layer sumcheck; strong scaling.
 
+--mode mle-split: BASELINE's "within one proof, disjoint hypercube halves shard across the GPUs": ONE 2^n-point table
+    (--n 20, or 30) split over the ranks, one RCCL all-reduce per pass of up to five rounds + one gather per sumcheck
+    (gkr_sumcheck_mle_sharded_dev); a step = --split-batch sumchecks; strong scaling.
+
 field-ops: 5 (2^n - 1) per plain sumcheck, 25 (2^{2k} - 1) per layer sumcheck; algorithmic bytes 128 * 2^n
 (SURVEY.md section 8d).  The JSON line also carries
   roofline       the dominant kernel (k_mle_multifold_mfma, the fold pass) timed with HIP events on the library's
@@ -98,6 +102,15 @@ class World:
         t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def per_rank(self, value):
+        """[value of rank 0, value of rank 1, ...] on every rank (one all-reduce of a vector with one slot per rank)."""
+        if self.size == 1:
+            return [value]
+        t = self.torch.zeros(self.size, dtype=self.torch.float64, device=self.device)
+        t[self.rank] = float(value)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
 
     def close(self):
         if self.grouped:
@@ -306,6 +319,8 @@ def run_mle(args, world):
     value = ops_per_sumcheck * batch * args.steps * world.size / elapsed
     verified, verified_ok = ({"skipped": "--no-verify"}, True) if args.no_verify else verify_mle_outputs(ctx, tables, n, batch, outputs[0], world.rank)
     ranks_failed = world.max_over_ranks(0.0 if verified_ok else 1.0)
+    threads_per_rank = [int(x) for x in world.per_rank(transcript_threads())]
+    step_ms_per_rank = [round(x, 3) for x in world.per_rank(sum(each) / max(1, len(each)) * 1e3)]
 
     names = ["mle_multifold", "mle_multifold_late", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan",   # multi-round passes (default)
              "mle_fold_sum", "mle_sum_first", "mle_round_reduce", "mle_fold_sum_small", "mle_round_hash"]  # per-round paths
@@ -332,7 +347,8 @@ def run_mle(args, world):
             "tables_device_address": hex(tables.value),
             "step_ms_each": [round(x * 1e3, 3) for x in each],
             "host_threads": {"usable_cpus": usable_cpus(), "GKR_HOST_THREADS": os.environ.get("GKR_HOST_THREADS"),
-                             "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE"), "cgroup_throttling_in_timed_steps": dict(LAST_THROTTLE)},
+                             "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE"), "cgroup_throttling_in_timed_steps": dict(LAST_THROTTLE),
+                             "transcript_threads_per_rank": threads_per_rank, "mean_step_ms_per_rank": step_ms_per_rank},
             "roofline": {
                 "bound": "hbm", "kernel": "k_mle_multifold_mfma<5> (the 2^n -> 2^(n-5) fold pass)" if dom_name == "mle_multifold" else "k_" + dom_name,
                 "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS,
@@ -437,7 +453,7 @@ def run_mle(args, world):
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
-    layer24 = layer24_split = None
+    layer24 = layer24_split = mle_split_out = None
     split_hung = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
@@ -450,6 +466,14 @@ def run_mle(args, world):
             layer24_split, err, split_hung = guarded(split_leg, 180)
             if err:
                 layer24_split = {"error": err}
+            # and the metric's own path split the same way: one 2^n table over the ranks (gkr_sumcheck_mle_sharded_dev)
+            if not split_hung and (world.size & (world.size - 1)) == 0:
+                def mle_split():
+                    world.torch.cuda.set_device(world.local_rank)
+                    return mle_split_leg(world, args.n, 1, steps=10, warmup=3, ceilings=ceilings)
+                mle_split_out, err, split_hung = guarded(mle_split, 180)
+                if err:
+                    mle_split_out = {"error": err}
     if world.rank == 0:
         line.update(extras)
         if layer24:
@@ -458,6 +482,13 @@ def run_mle(args, world):
         if layer24_split:
             line["layer24_split"] = layer24_split
             verified_ok &= layer24_split.get("matches_golden_digest") is not False and "error" not in layer24_split
+        if mle_split_out:
+            line["mle_split"] = mle_split_out
+            verified_ok &= mle_split_out.get("matches_golden_digest") is not False and "error" not in mle_split_out
+        if world.size > 1:
+            line["collective"] = collective_info(world)
+            line["collective"]["note"] = ("the headline workload shards whole sumchecks over the ranks and needs no data-path collective; "
+                                          "layer24_split and mle_split carry the exchanges of the two paths that have one")
         if proofs:
             line["aggregated_proofs"] = proofs
         if world.size == 1 and not args.no_cpu_baseline:
@@ -625,11 +656,99 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
                          "hbm_bytes_per_gate_and_pass": 8, "note": "not memory-bound: per gate one 8-byte list entry is streamed from HBM, the eq and W "
                                           "operands are gathers from L2-resident tables"},
             "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
+            "collective": collective_info(world, exchange, exch, steps) if split else None,
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},
             "step_ms_each": [round(x * 1e3, 3) for x in each]}
     gates.close()
     ctx.close()
     return out
+
+
+# ------------------------------------------------------------------------------------------------ mode: mle-split
+
+def collective_info(world, exchange=None, exch_prof=None, steps=1):
+    """What the ranks' collective really was, for the line of an N > 1 run: the backend and world size torch.distributed
+    reports (not what --gpus said), and the exchanges of a step."""
+    info = {"backend": world.dist.get_backend() if world.grouped else None,
+            "world_size_seen": world.dist.get_world_size() if world.grouped else 1,
+            "transport": type(exchange).__name__ if exchange is not None else None}
+    if exch_prof and exch_prof["launches"]:
+        info["exchanges_per_step"] = exch_prof["launches"] / steps
+        info["us_per_exchange"] = exch_prof["total_ms"] * 1e3 / exch_prof["launches"]
+    return info
+
+
+def mle_split_leg(world, n, batch, steps, warmup, ceilings=None):
+    """ONE plain sumcheck (prove_sumcheck, sumcheck.rs:158-214) on a table of 2^n points split over the ranks
+    (gkr_sumcheck_mle_sharded_dev): rank p holds the entries whose index bits log2 P .. 1 are p, every pass's sub-block
+    sums cross the ranks in one all-reduce on the library's stream, the last entries are gathered and every rank ends
+    with the whole transcript.  `batch` such tables per step (default 1).  Strong scaling.  The transcript is compared
+    with the committed digest of the oracle's (tests/golden/config_hashes.json: n = 16, 20, 24, 27, 30)."""
+    from gkr_amd import Context, parallel, synth
+    P_ = world.size
+    lp = P_.bit_length() - 1
+    if (1 << lp) != P_:
+        return {"skipped": "the split needs a power-of-two number of ranks"} if world.rank == 0 else None
+    ctx = Context(world.local_rank)
+    count = 1 << (n - lp)
+    d = ctx.alloc(batch * count * 32)
+    seed0 = synth.SEED + (1 if n == 16 else 2)
+    for b in range(batch):
+        ctx.fill_shard(ctypes.c_void_p(d.value + b * count * 32), n, lp, world.rank, seed0 + 1000 * b)
+    ctx.synchronize()
+    limbs = parallel.exchange_limbs_mle(n, lp, batch)
+    exchange = parallel.TorchCollective().device_exchange(limbs) if world.grouped else parallel.NoExchange(ctx, limbs)
+    result = [None]
+
+    def step():
+        result[0] = parallel.sumcheck_mle_sharded_raw(ctx, d, n, lp, world.rank, exchange, batch)
+    ctx.profile(1)
+    elapsed, each = timed_steps(world, ctx, step, warmup, steps)
+    ctx.profile(False)
+    names = ["mle_multifold", "mle_sub_sums", "mle_sub_reduce", "mle_pass_small", "mle_fold_plan"]
+    prof = {k: ctx.profile_get(k) for k in names}
+    exch = ctx.profile_get("exchange")
+    C, L, R, nx = result[0]
+    digest = synth.transcript_digest(C[0], L[0], R[0])
+    want = synth.golden_digest("mle", "n=%d,seed=%d" % (n, seed0))
+    ok = (digest == want) if want is not None else None
+    bad_ranks = world.max_over_ranks(1.0 if ok is False else 0.0)
+    out = None
+    if world.rank == 0:
+        dom = prof["mle_multifold"] if prof["mle_multifold"]["launches"] else prof["mle_sub_sums"]
+        achieved = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else None
+        out = {
+            "metric": "BN254-Fr sumcheck field-ops/sec @ 2^%d vars, ONE table split over the ranks" % n,
+            "value": 5 * ((1 << n) - 1) * batch * steps / elapsed, "unit": "field-ops/s", "n_gpus": world.size, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
+            "config": {"workload": "plain MLE sumcheck, ONE table of 2^%d points split over %d rank(s) (%d table(s) per step): rank p "
+                                   "holds the entries whose index bits log2 P .. 1 are p (2^%d entries = %.1f MiB per table and rank)"
+                                   % (n, P_, batch, n - lp, count * 32 / 2**20),
+                       "exchanges": "one in-place int64 SUM all-reduce per pass of <= 5 rounds (batch x (2^J + 2) x 8 limbs) + one gather "
+                                    "of the 2^6 entries every shard has left; on the library's HIP stream"},
+            "collective": dict(collective_info(world, exchange, exch, steps), exchanges_per_sumcheck=nx, rounds_per_sumcheck=n),
+            "matches_golden_digest": ok, "all_ranks_match": bad_ranks == 0.0, "transcript_sha256": digest,
+            "roofline": {"bound": "hbm", "kernel": "k_mle_multifold_mfma (the shard's first fold pass)" if prof["mle_multifold"]["launches"] else "k_mle_sub_sums",
+                         "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s", "frac": achieved / PEAK_GBPS if achieved else None, "traffic": None,
+                         "copy_GBps_measured": ceilings["copy_GBps"] if ceilings else None,
+                         "note": "at 2^20 points a shard is a few MiB: the step is the latency of its passes, exchanges and hashes, not bandwidth"},
+            "kernel_ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]},
+            "host_threads": transcript_threads(),
+            "step_ms_each": [round(x * 1e3, 3) for x in each]}
+    ctx.free(d)
+    if hasattr(exchange, "close"):
+        exchange.close()
+    ctx.close()
+    return out
+
+
+def run_mle_split(args, world):
+    out = mle_split_leg(world, args.n, args.split_batch, args.steps, args.warmup)
+    if world.rank == 0:
+        emit(out)
+        if out.get("matches_golden_digest") is False or out.get("all_ranks_match") is False:
+            raise SystemExit("WRONG TRANSCRIPT")
 
 
 def run_layer_split(args, world):
@@ -745,8 +864,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["mle", "proofs", "layer-split"], default="mle")
-    ap.add_argument("--n", type=int, default=20, help="log2 of the table size")
+    ap.add_argument("--mode", choices=["mle", "proofs", "layer-split", "mle-split"], default="mle")
+    ap.add_argument("--split-batch", type=int, default=1, help="mle-split: tables per step, each split over all ranks")
+    ap.add_argument("--n", "--log2-points", dest="n", type=int, default=20, help="log2 of the table size (--log2-points under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--batch", type=int, default=1024, help="independent sumchecks per rank per step (32 GiB of tables)")
     ap.add_argument("--transcript", choices=["host", "device"], default="host",
                     help="where MiMC7 runs (host cores between launches, or one GPU lane per sumcheck)")
@@ -764,7 +884,7 @@ def main():
     args = ap.parse_args()
     world = World()
     try:
-        {"mle": run_mle, "proofs": run_proofs, "layer-split": run_layer_split}[args.mode](args, world)
+        {"mle": run_mle, "proofs": run_proofs, "layer-split": run_layer_split, "mle-split": run_mle_split}[args.mode](args, world)
     finally:
         world.close()
 

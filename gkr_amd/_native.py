@@ -25,17 +25,18 @@ GKR_TRANSCRIPT_HOST = 1
 
 # every symbol include/gkr_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "gkr_strerror", "gkr_version", "gkr_ctx_create", "gkr_ctx_destroy", "gkr_last_error",
+    "gkr_strerror", "gkr_version", "gkr_ctx_create", "gkr_ctx_create_multi", "gkr_ctx_device_count", "gkr_ctx_destroy", "gkr_last_error",
     "gkr_ctx_set_transcript", "gkr_ctx_set_host_threads", "gkr_host_help_while", "gkr_prove_many", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get", "gkr_ctx_profile_samples",
     "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
     "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_host_prod_pass", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_selftest_seg_item", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
-    "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_free", "gkr_exchange_limbs", "gkr_resident_layer_sumcheck_dev", "gkr_exchange_limbs_mle", "gkr_sumcheck_mle_sharded_dev", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
+    "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_free", "gkr_exchange_limbs", "gkr_resident_layer_sumcheck_dev", "gkr_exchange_limbs_mle", "gkr_sumcheck_mle_sharded_dev", "gkr_exchange_rccl_unique_id", "gkr_exchange_rccl_create", "gkr_exchange_rccl_dev",
+    "gkr_exchange_rccl_calls", "gkr_exchange_rccl_destroy", "gkr_exchange_rccl_error", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
     "gkr_circom_meta", "gkr_circom_input_json", "gkr_circom_verifier_source", "gkr_circom_inject",
     "gkr_r1cs_parse", "gkr_r1cs_build", "gkr_r1cs_info", "gkr_r1cs_export", "gkr_r1cs_serialize", "gkr_r1cs_free",
     "gkr_wtns_parse", "gkr_wtns_serialize", "gkr_r1cs_compile", "gkr_layered_count", "gkr_layered_circuit",
     "gkr_layered_input_layer", "gkr_layered_input_values", "gkr_layered_free",
     "gkr_device_alloc", "gkr_device_free", "gkr_device_upload", "gkr_device_download",
-    "gkr_device_fill_table", "gkr_device_synchronize", "gkr_ubench_ceilings", "gkr_ubench_host_hash",
+    "gkr_device_fill_table", "gkr_device_fill_shard", "gkr_device_synchronize", "gkr_ubench_ceilings", "gkr_ubench_host_hash",
     "gkr_layer_session_open", "gkr_layer_session_open_tables", "gkr_layer_session_dep", "gkr_layer_session_rounds",
     "gkr_layer_session_sums", "gkr_layer_session_bind", "gkr_layer_session_tail", "gkr_layer_session_close",
     "gkr_mle_session_open", "gkr_mle_session_sums", "gkr_mle_session_bind", "gkr_mle_session_value",

@@ -362,6 +362,7 @@ struct ProveCrew;
 
 struct gkr_ctx {
     int device = 0;
+    std::vector<int> devices;                  // gkr_ctx_create_multi: the devices gkr_prove_many's child contexts are dealt over (empty: `device` only)
     int host_threads = 0;                      // 0: from GKR_HOST_THREADS / the usable CPUs; else this many (caller included)
     std::vector<std::unique_ptr<PreparedCircuit>> circuits;   // most recently used last; bounded
     hipStream_t stream = nullptr;
@@ -2364,6 +2365,28 @@ int gkr_ctx_create(int device_id, gkr_ctx** out) {
     return GKR_OK;
 }
 
+// One host process driving several GPUs -- the reference is ONE process whose par_iter fans prover::prove out over the
+// (circuit, input) pairs of a step (aggregator.rs:350-355, 411-416): the context lives on device_ids[0], and
+// gkr_prove_many deals its items over child contexts created round-robin on ALL the listed devices (a device may be
+// listed more than once: that many child contexts on it per round).  Every other entry point runs on device_ids[0].
+int gkr_ctx_create_multi(const int* device_ids, int n_devices, gkr_ctx** out) {
+    if (!out) return GKR_ERR_INVALID;
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return GKR_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GKR_ERR_NO_DEVICE;
+    for (int i = 0; i < n_devices; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= count) return GKR_ERR_INVALID;
+    gkr_ctx* c = nullptr;
+    const int rc = gkr_ctx_create(device_ids[0], &c);
+    if (rc) return rc;
+    c->devices.assign(device_ids, device_ids + n_devices);
+    *out = c;
+    return GKR_OK;
+}
+
+int gkr_ctx_device_count(const gkr_ctx* ctx) { return ctx ? (ctx->devices.empty() ? 1 : (int)ctx->devices.size()) : 0; }
+
 void gkr_ctx_destroy(gkr_ctx* ctx) {
     if (!ctx) return;
     ctx->crew.reset();   // joins gkr_prove_many's threads and destroys their contexts
@@ -3747,6 +3770,9 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     }
     // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
     if (!max_concurrent && (size_t)want > n_items) want = (int)n_items;
+    // several devices: at least one member per device (as far as there are items), or a device would sit idle
+    if (!max_concurrent && !ctx->devices.empty() && want < (int)ctx->devices.size())
+        want = n_items < ctx->devices.size() ? (int)n_items : (int)ctx->devices.size();
     if (want > 64) want = 64;
     if (!ctx->crew) {
         ctx->crew = std::unique_ptr<ProveCrew, void (*)(ProveCrew*)>(new ProveCrew(), destroy_crew);
@@ -3756,7 +3782,9 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     ProveCrew* crew = ctx->crew.get();
     while ((int)crew->members.size() < want) {
         gkr_ctx* child = nullptr;
-        const int rc = gkr_ctx_create(ctx->device, &child);
+        // member m lives on device devices[m mod #devices] (member 0 = this context, on devices[0])
+        const int member_device = ctx->devices.empty() ? ctx->device : ctx->devices[crew->members.size() % ctx->devices.size()];
+        const int rc = gkr_ctx_create(member_device, &child);
         if (rc) return ctx->fail(rc, "child context of gkr_prove_many");
         child->crew_member = true;
         child->transcript = GKR_TRANSCRIPT_HOST;
@@ -4217,6 +4245,16 @@ int gkr_device_fill_table(gkr_ctx* ctx, void* d_table, size_t count, uint64_t se
     if (!ctx || !d_table || !count) return GKR_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     gkr::launch_fill_table(static_cast<Fr*>(d_table), count, seed, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return GKR_OK;
+}
+
+int gkr_device_fill_shard(gkr_ctx* ctx, void* d_shard, int n, int log2_shards, int shard, uint64_t seed) {
+    if (!ctx || !d_shard || log2_shards < 0 || log2_shards > 16 || n - log2_shards < 1 || n - log2_shards > GKR_MAX_MLE_N || shard < 0 ||
+        shard >= (1 << log2_shards))
+        return GKR_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gkr::launch_fill_shard(static_cast<Fr*>(d_shard), (size_t)1 << (n - log2_shards), (uint32_t)log2_shards, (uint32_t)shard, seed, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return GKR_OK;
 }

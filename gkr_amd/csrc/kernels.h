@@ -203,6 +203,7 @@ uint32_t layer_collapse_chunks(uint32_t k, uint32_t batch);
 void launch_layer_collapse(Fr* A, Fr* M, const Fr* eq, Fr* scratch, uint32_t k, LayerBatch lb, hipStream_t s);
 
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
+void launch_fill_shard(Fr* shard_table, size_t count, uint32_t lp, uint32_t shard, uint64_t seed, hipStream_t s);
 // sum over ranks without leaving the device: a, b (each `each` elements) + one flag element <-> (2 each + 1) x 8 int64 limbs
 void launch_exchange_widen(const Fr* a, const Fr* b, uint32_t each, const uint32_t* flag, uint32_t local_flag, long long* limbs, hipStream_t s);
 void launch_exchange_narrow(const long long* limbs, Fr* a, Fr* b, uint32_t each, uint32_t* flag_out, hipStream_t s);

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kernels.h"
 #include "dev_util.h"
 #include "gate_seg.h"
@@ -57,6 +59,23 @@ __global__ void k_fill_table(Fr* table, size_t count, uint64_t seed) {
             f.l[2 * j + 1] = (uint32_t)(w >> 32);
         }
         store_fr(table + i, f);
+    }
+}
+
+// the same stream of values, the entries one rank of gkr_sumcheck_mle_sharded_dev holds: local entry (h, x) of shard p of
+// 2^lp is entry h * 2P + 2p + x of the table
+__global__ void k_fill_shard(Fr* shard_table, size_t count, uint32_t lp, uint32_t shard, uint64_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t g = ((uint64_t)(i >> 1) << (lp + 1u)) | ((uint64_t)shard << 1) | (i & 1u);
+        Fr f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint64_t w = mix64(seed + (4 * g + (uint64_t)j + 1) * 0x9E3779B97F4A7C15ULL);
+            if (j == 3) w &= 0x1FFFFFFFFFFFFFFFULL;
+            f.l[2 * j] = (uint32_t)w;
+            f.l[2 * j + 1] = (uint32_t)(w >> 32);
+        }
+        store_fr(shard_table + i, f);
     }
 }
 
@@ -2372,6 +2391,9 @@ __global__ void __launch_bounds__(256) k_fold_small(Fr* __restrict__ W, uint32_t
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_table, dim3(blocks_for(count, 4096)), dim3(256), 0, s, table, count, seed);
 }
+void launch_fill_shard(Fr* shard_table, size_t count, uint32_t lp, uint32_t shard, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_shard, dim3(blocks_for(count, 4096)), dim3(256), 0, s, shard_table, count, lp, shard, seed);
+}
 
 // ---- what the box itself gives (bench.py quotes these beside its roofline fractions) -----------------
 // one 16-byte element per thread, no loop: the copy shape that measured fastest on this chip (tools/ubench_copy.hip)
@@ -2766,10 +2788,13 @@ template <bool ROWS, bool LDS_T>
 static void launch_seg_pass_t(const GateSegs& g, uint32_t k, const Fr* e_lo_mont, const Fr* T, Fr* X, Fr* Y, LayerBatch lb, hipStream_t s) {
     const uint32_t tlen = 1u << k;
     const size_t lds = LDS_T ? (size_t)tlen * sizeof(Fr) : 0;
-    static bool attr_set = false;   // (idempotent; a race sets it twice)
-    if (LDS_T && !attr_set) {
+    // the attribute is per device (a process may drive several: gkr_ctx_create_multi): one bit per device id, set once each
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (LDS_T && !((attr_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_pass<ROWS, LDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.fetch_or((uint64_t)1 << (dev & 63), std::memory_order_relaxed);
     }
     // resident blocks: one 1024-thread block per CU with the table in LDS; 256-thread blocks, four per CU, without
     const uint32_t blocks = LDS_T ? device_cus() : 4 * device_cus();

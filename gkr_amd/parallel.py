@@ -185,6 +185,69 @@ class StagedDeviceExchange(DeviceExchange):
         self.struct = N.ExchangeDev(self._fn, None, self._buf.data_ptr(), self._buf.numel())
 
 
+class RcclExchange:
+    """gkr_exchange_dev owned by the LIBRARY (csrc/exchange_rccl.cpp): RCCL loaded by the library itself, the all-reduce
+    queued by its own hook -- no torch in the data path, the form a non-Python host uses.  unique_id: the 128 bytes of
+    RcclExchange.unique_id() made on one rank and handed to the others (here: by torch.distributed's broadcast when there
+    is a process group, see from_torch_group); create() blocks until every rank has called it."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(RcclExchange.ID_BYTES)
+        rc = N.lib().gkr_exchange_rccl_unique_id(buf)
+        if rc:
+            raise GkrError(rc, RcclExchange._error())
+        return buf.raw
+
+    @staticmethod
+    def _error():
+        N.lib().gkr_exchange_rccl_error.restype = ctypes.c_char_p
+        return (N.lib().gkr_exchange_rccl_error() or b"").decode()
+
+    def __init__(self, device, unique_id, rank, world, limbs):
+        self._h = ctypes.c_void_p()
+        rc = N.lib().gkr_exchange_rccl_create(ctypes.c_int(device), ctypes.c_char_p(unique_id), ctypes.c_int(rank), ctypes.c_int(world),
+                                              ctypes.c_size_t(int(limbs)), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            raise GkrError(rc, RcclExchange._error())
+        N.lib().gkr_exchange_rccl_dev.restype = ctypes.POINTER(N.ExchangeDev)
+        N.lib().gkr_exchange_rccl_dev.argtypes = [ctypes.c_void_p]
+        N.lib().gkr_exchange_rccl_calls.restype = ctypes.c_uint64
+        N.lib().gkr_exchange_rccl_calls.argtypes = [ctypes.c_void_p]
+        N.lib().gkr_exchange_rccl_destroy.restype = None
+        N.lib().gkr_exchange_rccl_destroy.argtypes = [ctypes.c_void_p]
+        self.struct = N.lib().gkr_exchange_rccl_dev(self._h).contents
+        self.errors = []
+        self.backend = "rccl (library-owned communicator)"
+        self.world = world
+
+    @property
+    def calls(self):
+        return int(N.lib().gkr_exchange_rccl_calls(self._h)) if self._h else 0
+
+    @classmethod
+    def from_torch_group(cls, device, limbs):
+        """The id made on rank 0 of torch.distributed's default group and broadcast through it (torch only carries those
+        128 bytes; every all-reduce of the proving path then goes through the library's own communicator)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.zeros(cls.ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t = torch.tensor(list(cls.unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        return cls(device, bytes(t.cpu().tolist()), rank, world, limbs)
+
+    def close(self):
+        if self._h:
+            N.lib().gkr_exchange_rccl_destroy(self._h)
+            self._h = None
+
+
 class NoExchange:
     """gkr_exchange_dev for ONE rank (log2_shards = 0): a device buffer and a hook that has nothing to add."""
 
@@ -310,7 +373,7 @@ class ResidentGates:
         R = np.zeros((v, 4), dtype=np.uint64)
         zl = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
         wl = np.ascontiguousarray(w_limbs, dtype=np.uint64)
-        if isinstance(sum_limbs, DeviceExchange):
+        if hasattr(sum_limbs, "struct"):   # a gkr_exchange_dev: DeviceExchange (torch), RcclExchange (the library's own), ...
             rc = N.lib().gkr_resident_layer_sumcheck_dev(self._ctx._h, self._layer(k_next), _ptr(zl), _ptr(wl), ctypes.byref(sum_limbs.struct),
                                                          _ptr(C), _ptr(L), _ptr(R))
             if sum_limbs.errors:   # (taken off the list: a later call with the same exchange object starts clean)

@@ -153,9 +153,15 @@ def _terms_from_coeffs(coeffs, k):
 class Context:
     """One GPU context (one HIP stream).  Not thread-safe; use one per thread."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: the GPU of this context.  devices=[ids]: gkr_ctx_create_multi -- the context lives on ids[0] and
+        prove_many deals its items over child contexts on all of them (one host process, several GPUs)."""
         self._h = ctypes.c_void_p()
-        rc = N.lib().gkr_ctx_create(ctypes.c_int(device), ctypes.byref(self._h))
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            rc = N.lib().gkr_ctx_create_multi(ids, ctypes.c_int(len(devices)), ctypes.byref(self._h))
+        else:
+            rc = N.lib().gkr_ctx_create(ctypes.c_int(device), ctypes.byref(self._h))
         if rc:
             self._h = None
             raise GkrError(rc, "gkr_ctx_create(device=%d)" % device)
@@ -238,6 +244,11 @@ class Context:
 
     def fill_table(self, dptr, count, seed):
         self._check(N.lib().gkr_device_fill_table(self._h, dptr, ctypes.c_size_t(count), ctypes.c_uint64(seed)))
+
+    def fill_shard(self, dptr, n, log2_shards, shard, seed):
+        """Rank `shard`'s entries (gkr_sumcheck_mle_sharded_dev's layout) of the table fill_table(dptr, 2^n, seed) writes."""
+        self._check(N.lib().gkr_device_fill_shard(self._h, dptr, ctypes.c_int(n), ctypes.c_int(log2_shards), ctypes.c_int(shard),
+                                                  ctypes.c_uint64(seed)))
 
     def synchronize(self):
         self._check(N.lib().gkr_device_synchronize(self._h))

@@ -101,6 +101,14 @@ const char *gkr_version(void);
 
 /* ---- context ---------------------------------------------------------- */
 int  gkr_ctx_create(int device_id, gkr_ctx **out);
+/* ONE host process driving several GPUs, as the reference is one process whose par_iter fans prover::prove out over the
+ * (circuit, input) pairs of a step (aggregator.rs:350-355, 411-416): the context lives on device_ids[0]; gkr_prove_many
+ * deals its items, by estimated cost, over child contexts created round-robin on ALL the listed devices (each with its
+ * own thread, stream, workspaces and circuit cache; a device listed k times gets k child contexts per round -- which is
+ * also how the dealing is tested on a box with one GPU).  Every other entry point runs on device_ids[0].
+ * n_devices in [1, 64].  gkr_ctx_device_count: how many devices the context deals over (1 for gkr_ctx_create). */
+int  gkr_ctx_create_multi(const int *device_ids, int n_devices, gkr_ctx **out);
+int  gkr_ctx_device_count(const gkr_ctx *ctx);
 void gkr_ctx_destroy(gkr_ctx *ctx);
 const char *gkr_last_error(const gkr_ctx *ctx);
 int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
@@ -260,6 +268,26 @@ size_t gkr_exchange_limbs(int k_next);
 int  gkr_resident_layer_sumcheck_dev(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const gkr_fr *W,
                                      const gkr_exchange_dev *exchange, gkr_fr *out_coeffs, uint32_t *out_len,
                                      gkr_fr *out_r);
+/* ---- a sum over ranks the library owns: gkr_exchange_dev backed by RCCL ----------------------------------------------
+ * For hosts that are not Python (the reference's Rust binary): no callback of the host's own, no torch.  librccl is
+ * loaded on first use (dlopen), not linked.  One rank makes the 128-byte id (gkr_exchange_rccl_unique_id) and hands it
+ * to the others by whatever it has; every rank -- a process per GPU, or a thread per GPU of one process, the calls made
+ * concurrently -- then calls gkr_exchange_rccl_create(device, id, rank, nranks, capacity), which blocks until all ranks
+ * have arrived (ncclCommInitRank) and owns a device buffer of `capacity_limbs` int64.  gkr_exchange_rccl_dev() is the
+ * gkr_exchange_dev to pass to gkr_resident_layer_sumcheck_dev / gkr_sumcheck_mle_sharded_dev: its hook queues
+ * ncclAllReduce(buf, buf, count, ncclInt64, ncclSum, comm, stream) on the stream the library hands it.  Errors: a status,
+ * the text in gkr_exchange_rccl_error() (per thread).  What it stands for in the reference: the rayon reduce at
+ * sumcheck.rs:50-63, 97-124 (and :62 for prove_sumcheck), over xGMI instead of over cores. */
+#define GKR_RCCL_ID_BYTES 128
+typedef struct gkr_rccl_exchange gkr_rccl_exchange;
+int  gkr_exchange_rccl_unique_id(void *id_out /* GKR_RCCL_ID_BYTES */);
+int  gkr_exchange_rccl_create(int device_id, const void *unique_id, int rank, int nranks, size_t capacity_limbs,
+                              gkr_rccl_exchange **out);
+const gkr_exchange_dev *gkr_exchange_rccl_dev(const gkr_rccl_exchange *x);
+uint64_t gkr_exchange_rccl_calls(const gkr_rccl_exchange *x);   /* all-reduces queued so far */
+void gkr_exchange_rccl_destroy(gkr_rccl_exchange *x);
+const char *gkr_exchange_rccl_error(void);
+
 /* ---- one plain sumcheck split over GPUs: prove_sumcheck (sumcheck.rs:158-214), its reduce over the hypercube (the rayon
  * reduce of sumcheck.rs:62) as one RCCL all-reduce per PASS ------------------------------------------------------------
  * A table T of 2^n values is split over P = 2^log2_shards ranks; rank p holds the shard
@@ -496,6 +524,9 @@ int  gkr_device_download(gkr_ctx *ctx, void *h_dst, const void *d_src, size_t by
  * (definition: element i, limb j = mix64(seed + (4 i + j + 1) * 0x9E3779B97F4A7C15),
  * top limb masked to 61 bits; mix64 = splitmix64's finaliser) */
 int  gkr_device_fill_table(gkr_ctx *ctx, void *d_table, size_t count, uint64_t seed);
+/* the same stream of values, the 2^(n - log2_shards) entries rank `shard` of gkr_sumcheck_mle_sharded_dev holds of the
+ * 2^n-entry table gkr_device_fill_table would write (bench.py --mode mle-split; no table ever exists in one piece) */
+int  gkr_device_fill_shard(gkr_ctx *ctx, void *d_shard, int n, int log2_shards, int shard, uint64_t seed);
 int  gkr_device_synchronize(gkr_ctx *ctx);
 /* What this box itself gives, measured now (SURVEY section 8d asks bench.py to quote them beside the vendor
  * peaks): a plain device-to-device copy of `bytes` (>= 64 MiB; read + write counted) and a read-only stream, in

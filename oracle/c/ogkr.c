@@ -310,15 +310,30 @@ static void fold_table(u64 (*t)[4], size_t h, const u64 r_mont[4], int nt) {
     }
 }
 
+static int sumcheck_mle_on(u64 (*t)[4], int n, ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads);
+
 int ogkr_sumcheck_mle(const ogkr_fr *table, int n, ogkr_fr *out_coeffs, uint32_t *out_len,
                       ogkr_fr *out_r, int threads) {
     if (n < 2 || n > 40) return -1;
-    if (!cts_ready) init_constants();
-    int nt = set_threads(threads);
     size_t len = (size_t)1 << n;
     u64(*t)[4] = malloc(len * 32);
     if (!t) return -2;
     memcpy(t, table, len * 32);
+    int rc = sumcheck_mle_on(t, n, out_coeffs, out_len, out_r, threads);
+    free(t);
+    return rc;
+}
+
+/* the same on the caller's table, which is overwritten (a 2^30-entry table is 32 GiB: no room for a copy) */
+int ogkr_sumcheck_mle_inplace(ogkr_fr *table, int n, ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads) {
+    if (n < 2 || n > 40) return -1;
+    return sumcheck_mle_on((u64(*)[4])table, n, out_coeffs, out_len, out_r, threads);
+}
+
+static int sumcheck_mle_on(u64 (*t)[4], int n, ogkr_fr *out_coeffs, uint32_t *out_len, ogkr_fr *out_r, int threads) {
+    if (!cts_ready) init_constants();
+    int nt = set_threads(threads);
+    size_t len = (size_t)1 << n;
     int dep_last = 0;
 #pragma omp parallel for schedule(static) num_threads(nt) reduction(| : dep_last)
     for (size_t i = 0; i < len / 2; ++i)
@@ -354,7 +369,6 @@ int ogkr_sumcheck_mle(const ogkr_fr *table, int n, ogkr_fr *out_coeffs, uint32_t
         to_mont(out_r[j].l, rm);
         fold_table(t, h, rm, nt);
     }
-    free(t);
     return 0;
 }
 

@@ -51,6 +51,10 @@ void ogkr_fill_table(ogkr_fr *table, size_t count, uint64_t seed);
 int ogkr_sumcheck_mle(const ogkr_fr *table, int n, ogkr_fr *out_coeffs, uint32_t *out_len,
                       ogkr_fr *out_r, int threads);
 
+/* the same, overwriting the caller's table (no copy: for tables of tens of GiB) */
+int ogkr_sumcheck_mle_inplace(ogkr_fr *table, int n, ogkr_fr *out_coeffs, uint32_t *out_len,
+                              ogkr_fr *out_r, int threads);
+
 /* prove_sumcheck_opt for one layer: gates g = 0..2^k_i-1 of type gate_type[g]
  * (0 add, 1 mult) with operands left[g], right[g] in [0, 2^k_next); z has k_i
  * entries; W has 2^k_next evaluations.  out_coeffs: 2*k_next rows of 3 slots,

@@ -116,6 +116,18 @@ def sumcheck_mle_raw(table_limbs, n, threads=0):
     return C, L, R
 
 
+def sumcheck_mle_inplace_raw(table_limbs, n, threads=0):
+    """sumcheck_mle_raw on the caller's array, which is overwritten (no copy: 2^30 entries are 32 GiB)."""
+    assert table_limbs.flags["C_CONTIGUOUS"] and table_limbs.dtype == np.uint64 and table_limbs.shape == (1 << n, 4)
+    C = np.zeros((n, 2, 4), dtype=np.uint64)
+    L = np.zeros(n, dtype=np.uint32)
+    R = np.zeros((n, 4), dtype=np.uint64)
+    rc = lib().ogkr_sumcheck_mle_inplace(_p(table_limbs), ctypes.c_int(n), _p(C), _p(L), _p(R), ctypes.c_int(threads if threads > 0 else usable_threads()))
+    if rc:
+        raise ValueError("ogkr_sumcheck_mle_inplace rc=%d" % rc)
+    return C, L, R
+
+
 def sumcheck_mle(table, n, threads=0):
     C, L, R = sumcheck_mle_raw(to_limbs(table), n, threads)
     proof = [from_limbs(C[j])[2 - int(L[j]):] for j in range(n)]

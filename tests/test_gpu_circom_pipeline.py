@@ -140,6 +140,17 @@ def test_prove_many_matches_proofs_proven_one_by_one(ctx):
             for j in range(len(work)):
                 for a, b in zip(got[j], want[j]):
                     assert np.array_equal(a, b), (threads, j)
+        # one host process over several devices (gkr_ctx_create_multi; the one GPU listed four times: four logical devices,
+        # the items dealt over child contexts created round-robin on them) -- the same proofs
+        with Context(devices=[0, 0, 0, 0]) as multi:
+            assert N.lib().gkr_ctx_device_count(multi._h) == 4 and N.lib().gkr_ctx_device_count(many._h) == 1
+            for threads in (0, 3, 8):
+                got = multi.prove_many_raw(multi.prepare_many(work), threads)
+                for j in range(len(work)):
+                    for a, b in zip(got[j], want[j]):
+                        assert np.array_equal(a, b), ("multi", threads, j)
+        with pytest.raises(GkrError):
+            Context(devices=[0, 99])
         # an item whose witness does not satisfy the circuit: that item's status, the others still proven
         bad = many.prepare_many(work)
         bad["items"][0].require_zero_output = 1

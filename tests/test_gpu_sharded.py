@@ -132,6 +132,19 @@ def test_device_exchange_over_rccl_single_rank():
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_native_rccl_exchange_single_rank():
+    """The library's OWN collective (gkr_exchange_rccl_*: librccl loaded by the library, ncclAllReduce(ncclInt64, ncclSum)
+    queued by its own hook on its own stream): the gate-sharded layer sumcheck and the split plain sumcheck through it, in
+    a process that never imports torch."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_native_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_gate_sharded_bad_gate_fails_every_rank():
     """A bad gate on ONE rank: every rank must come back with an error (none may stay inside the collective)."""
     from gkr_amd import GkrError
