@@ -491,6 +491,7 @@ def run_mle(args, world):
                                           "layer24_split and mle_split carry the exchanges of the two paths that have one")
         if proofs:
             line["aggregated_proofs"] = proofs
+            verified_ok &= proofs.get("verified_ok", True)
         if world.size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_dense(n, args.cpu_seconds)
             line["cpu_ref_algo"] = cpu_ref_algo(args.ref_algo_seconds)
@@ -546,12 +547,44 @@ def aggregated_proofs(world, n_inputs):
         return world.max_over_ranks((time.perf_counter() - t) / reps), each
     ex = [synth.mimc7_demo_witness(a, b) for a, b in synth.EXAMPLE_INPUTS]
     dt3, each3 = measure(ex if world.rank == 0 else [], 5)     # configs[0] is one rank's work
+    def check(golden_rows, tag, sample=2):
+        """The proofs of the LAST measured step (the prepared list's output buffers) against the committed digests of
+        the CPU checker's proofs (tests/golden/proof_digests.json, made offline), every (input, sub-circuit) pair; and
+        gkr_amd.verify on `sample` inputs' proofs.  -> dict for the line."""
+        from gkr_amd import verify
+        from gkr_amd.prover import _decode_proofs
+        res = {"checked": "every proof of the last timed step: (sumcheck_proofs, sumcheck_r, q, z, r) digests; verifier on a sample"}
+        bad, total, verified = [], 0, 0
+        for j, (arrs, circuit) in enumerate(zip(step._prepared["outs"], step.circuits)):
+            proofs = _decode_proofs(arrs, circuit.get_k_list())
+            for i, pr in enumerate(proofs):
+                total += 1
+                dg = synth.proof_digest(pr.sumcheck_proofs, pr.sumcheck_r, pr.q, pr.z, pr.r)[:16]
+                if golden_rows is not None and dg != golden_rows[i][j]:
+                    bad.append((i, j))
+                if i < sample or i == len(proofs) - 1:
+                    verified += 1
+                    if not verify(pr, circuit):
+                        bad.append((i, j, "verifier"))
+        res.update({"proofs": total, "digests": "tests/golden/proof_digests.json[%s]" % tag if golden_rows is not None else None,
+                    "mismatches": bad[:8], "verifier_accepts": verified, "ok": not bad})
+        return res
+    golden = synth.proof_digests() if not os.environ.get("GKR_BENCH_NO_VERIFY") else None
+    ver0 = check(golden["config0"]["digests"] if golden else None, "config0", sample=3) if world.rank == 0 and not os.environ.get("GKR_BENCH_NO_VERIFY") else None
     mine = parallel.shard_units(n_inputs, world.rank, world.size)
-    dt, each = measure([synth.mimc7_demo_witness(2 + i, 3 + (i % 5)) for i in mine], 5)
+    dt, each = measure([synth.mimc7_demo_witness(a, b) for a, b in [synth.demo_proof_inputs(n_inputs)[i] for i in mine]], 5)
+    ver3 = None
+    if len(mine) and not os.environ.get("GKR_BENCH_NO_VERIFY"):
+        rows = [golden["config3"]["digests"][i] for i in mine] if golden and golden["config3"]["inputs"] == n_inputs else None
+        ver3 = check(rows, "config3")
+    bad_ranks = world.max_over_ranks(1.0 if (ver3 and not ver3["ok"]) or (ver0 and not ver0["ok"]) else 0.0)
     out["config0_three_inputs"] = {"inputs": 3, "proofs": 3 * subs, "ms": dt3 * 1e3, "proofs_per_sec": 3 * subs / dt3, "ms_each": each3}
     out["config3"] = {"inputs": n_inputs, "inputs_per_rank": [len(parallel.shard_units(n_inputs, r, world.size)) for r in range(world.size)],
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt,
                       "ms_each_rank0": each}
+    out["config0_three_inputs"]["verified"] = ver0
+    out["config3"]["verified"] = dict(ver3 or {}, all_ranks_ok=bad_ranks == 0.0)
+    out["verified_ok"] = bad_ranks == 0.0 and (ver0 is None or ver0["ok"]) and (ver3 is None or ver3["ok"])
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
     hashed = sum(int(arrs[1].sum()) for arrs in step._prepared["outs"])   # lengths of all round vectors of the last step
     out["config3"]["roofline"] = transcript_floor(hashed, 3, threads, dt * 1e3)

@@ -67,6 +67,40 @@ def proof_batch_witnesses(n_proofs, input_k=PROOF_BATCH_KS[-1], first=0):
     return np.stack([rand_fr(np.random.default_rng(1000 + first + i), 1 << input_k) for i in range(n_proofs)])
 
 
+def proof_digest(sumcheck_proofs, sumcheck_r, q, z, r):
+    """sha256 over one proof's (sumcheck_proofs, sumcheck_r, q, z, r) as nested lists of integers (the reference's
+    Proof fields, gkr.rs:7-19, trimmed vectors): brackets mark the nesting, every integer is 32 little-endian bytes.
+    Both the library's decoded proofs and the CPU checker's produce these lists."""
+    h = hashlib.sha256()
+
+    def put(x):
+        if isinstance(x, (list, tuple)):
+            h.update(b"[")
+            for y in x:
+                put(y)
+            h.update(b"]")
+        else:
+            h.update(int(x).to_bytes(32, "little"))
+    put([sumcheck_proofs, sumcheck_r, q, z, r])
+    return h.hexdigest()
+
+
+def demo_proof_inputs(n_inputs):
+    """The (in1, in2) pairs bench.py proves for configs[3] (input i of `n_inputs`)."""
+    return [(2 + i, 3 + (i % 5)) for i in range(n_inputs)]
+
+
+def proof_digests():
+    """tests/golden/proof_digests.json (make_config_hashes.py --proofs): per input and sub-circuit the digest of the CPU
+    checker's proof of the demo circuit, for configs[0]'s three example inputs and configs[3]'s 64; or None."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "proof_digests.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
 def transcript_digest(*arrays):
     """sha256 over the raw output arrays of a sumcheck (coefficients | lengths | challenges)."""
     h = hashlib.sha256()

@@ -68,7 +68,36 @@ def bench_batch_digests(ranks=8, batch=1024, n16_tables=4096):
     return out
 
 
+def _demo_digests(pair):
+    from oracle import convert as oconv
+    a, b = pair
+    r = _demo_digests.r1cs
+    return [synth.proof_digest(p["sumcheck_proofs"], p["sumcheck_r"], p["q"], p["z"], p["r"])[:16]
+            for p in (cdense.prove(sub["layers"], sub["input_values"]) for sub in oconv.convert_r1cs_wtns_gkr(r, synth.mimc7_demo_witness(a, b)))]
+
+
+def proof_digests(n_inputs=64):
+    """The CPU checker's proofs (oracle/convert.py + the dense C prover, both pinned by the reference's fixtures / the
+    hand-derived circuits) of the demo circuit's 12 sub-circuits: configs[0]'s three example inputs and the 64 inputs of
+    configs[3], one 16-hex-digit digest per (input, sub-circuit)."""
+    from oracle import convert as oconv
+    _demo_digests.r1cs = oconv.read_r1cs(synth.mimc7_demo_r1cs().serialize())
+    # (serially: ~10 s; a process pool forked after the C checker's OpenMP runtime has started hangs)
+    ex = [_demo_digests(p) for p in synth.EXAMPLE_INPUTS]
+    many = [_demo_digests(p) for p in synth.demo_proof_inputs(n_inputs)]
+    return {"what": "sha256[:16] of gkr_amd.synth.proof_digest over (sumcheck_proofs, sumcheck_r, q, z, r) per (input, sub-circuit)",
+            "config0": {"inputs": [list(p) for p in synth.EXAMPLE_INPUTS], "digests": ex},
+            "config3": {"inputs": n_inputs, "digests": many}}
+
+
 def main():
+    if "--proofs" in sys.argv:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "proof_digests.json")
+        with open(path, "w") as f:
+            json.dump(proof_digests(), f, indent=0, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        return
     out = {"what": "sha256(coeffs | lens | challenges) of the C oracle's transcript; inputs: gkr_amd.synth", "layer": {}, "mle": {}}
     if "--bench-batch" in sys.argv:   # ~6 min on 8 cores: kept in its own file, regenerated only when asked
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_batch_hashes.json")
