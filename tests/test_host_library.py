@@ -439,3 +439,63 @@ def test_line_restriction_by_binding_equals_the_monomial_expansion(k):
         want = dense.line_restriction(b, c, w, k)
         got = from_limbs(out)
         assert got[k + 1 - ln.value:] == want and all(v == 0 for v in got[:k + 1 - ln.value])
+
+
+# ---- the limits and the knobs: one table each, checked against the code -------------------------------------------------
+
+def _header_limits():
+    import re
+    text = open(os.path.join(REPO, "include", "gkr_amd.h")).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(GKR_MAX_[A-Z_]+)\s+(\d+)", text)}
+
+
+def test_limits_table_matches_the_code():
+    """include/gkr_amd.h's limits are the ones the entry points enforce (no device needed: gkr_proof_sizes validates the
+    circuit description the way gkr_prove does)."""
+    import ctypes
+    import numpy as np
+    lim = _header_limits()
+    assert set(lim) == {"GKR_MAX_K_NEXT", "GKR_MAX_K_I", "GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT", "GKR_MAX_MLE_N", "GKR_MAX_BATCH"}
+    assert lim["GKR_MAX_K_NEXT"] >= 20, "the reference's compiler emits layers far beyond 2^14 values (convert.rs:10-11, 171-186)"
+    lib = N.lib()
+
+    def sizes_rc(ks):
+        karr = np.asarray(ks, dtype=np.uint32)
+        L = len(ks) - 1
+        dummy = (ctypes.c_void_p * L)(*([1] * L))     # never dereferenced by gkr_proof_sizes
+        desc = N.CircuitDesc(L, karr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), dummy, dummy, dummy)
+        out = N.ProofSizes()
+        return lib.gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(out)), out
+    rc, out = sizes_rc([3, lim["GKR_MAX_K_NEXT"], 5])
+    assert rc == 0 and out.rounds == 2 * (lim["GKR_MAX_K_NEXT"] + 5) and out.input_coeffs == 32
+    assert sizes_rc([3, lim["GKR_MAX_K_NEXT"] + 1, 5])[0] == N.GKR_ERR_INVALID
+    assert sizes_rc([lim["GKR_MAX_K_I"], 4])[0] == 0
+    assert sizes_rc([lim["GKR_MAX_K_I"] + 1, 4])[0] == N.GKR_ERR_INVALID
+    assert sizes_rc([3, 0])[0] == N.GKR_ERR_DEGENERATE
+    lib.gkr_exchange_limbs.restype = ctypes.c_size_t
+    assert lib.gkr_exchange_limbs(ctypes.c_int(lim["GKR_MAX_K_NEXT"])) == ((2 << lim["GKR_MAX_K_NEXT"]) + 1) * 8
+    assert lib.gkr_exchange_limbs(ctypes.c_int(lim["GKR_MAX_K_NEXT"] + 1)) == 0
+    lib.gkr_exchange_limbs_mle.restype = ctypes.c_size_t
+    assert lib.gkr_exchange_limbs_mle(ctypes.c_int(lim["GKR_MAX_MLE_N"] + 3), ctypes.c_int(3), ctypes.c_int(1)) > 0
+    assert lib.gkr_exchange_limbs_mle(ctypes.c_int(lim["GKR_MAX_MLE_N"] + 4), ctypes.c_int(3), ctypes.c_int(1)) == 0
+    # the limits are spelled in the sources by name, not as literals scattered over the file
+    capi = open(os.path.join(REPO, "gkr_amd", "csrc", "gkr_capi.hip")).read()
+    for name in lim:
+        assert name in capi or name == "GKR_MAX_BATCH", name
+
+
+def test_every_environment_knob_is_documented():
+    """INTEGRATION.md section 4 is the table of the library's environment knobs: every getenv("GKR_...") of the sources
+    appears there, and nothing is listed that the sources no longer read."""
+    import glob
+    import re
+    code = set()
+    for path in glob.glob(os.path.join(REPO, "gkr_amd", "csrc", "*")):
+        if path.endswith((".hip", ".h", ".cpp")):
+            code |= set(re.findall(r'getenv\("(GKR_[A-Z0-9_]+)"\)', open(path).read()))
+    doc_text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    section = doc_text[doc_text.index("## 4. Environment knobs"):]
+    documented = set(re.findall(r"`(GKR_[A-Z0-9_]+)[`=]", section))
+    assert code - documented == set(), "undocumented knobs: %s" % sorted(code - documented)
+    stale = {k for k in documented - code if not k.startswith(("GKR_TRANSCRIPT", "GKR_BENCH", "GKR_TEST", "GKR_ERR", "GKR_MAX"))}
+    assert stale == set(), "documented but no longer read: %s" % sorted(stale)
