@@ -1985,7 +1985,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         const uint32_t max_blocks = gkr::prod_pass_max_blocks((uint32_t)k);
         HIP_TRY(ctx, ctx->pinned_host("layer.prec", sizeof(gkr::ProdPassRec) * batch, reinterpret_cast<void**>(&prec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.pw", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_pw)));
-        WS(ctx, "layer.ppart", Fr, (size_t)batch * max_blocks * gkr::kProdRecValues, d_ppart);
+        WS(ctx, "layer.ppart", Fr, (size_t)batch * gkr::prod_pass_scratch_values((uint32_t)k), d_ppart);
+        (void)max_blocks;
         WS(ctx, "layer.X", Fr, wlen * batch, Xc);
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
         gkr::SpinPool::Session session(pool, nullptr);

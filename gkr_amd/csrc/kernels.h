@@ -64,6 +64,9 @@ inline uint32_t prod_pass_max_blocks(uint32_t k) {
     for (uint32_t l = 0; l < k; ++l) m = prod_pass_blocks(1u << l) > m ? prod_pass_blocks(1u << l) : m;
     return m;
 }
+// Fr values of pass scratch per proof for tables of 2^k entries (the blocks' partials, and behind them the first-level
+// totals of passes with more than 1024 blocks)
+inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_max_blocks(k) + 64u) * kProdRecValues; }
 // One pass on the tables W (Montgomery), X, Y (canonical) of 2^m_in entries per proof (stride wstride): bind the jp
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
 // the cross sums for the next J rounds -> the pinned records (seq = ticket, system-scope release); partials: scratch of

@@ -584,6 +584,23 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     }
 }
 
+// many blocks (a wide layer's first passes): first level of the totals over a grid -- block r of kProdReduceBlocks totals
+// every kProdReduceBlocks-th partial (four threads per value), k_prod_publish then totals the kProdReduceBlocks results.
+// grid = (kProdReduceBlocks, batch), block = 288
+constexpr uint32_t kProdReduceBlocks = 64;
+__global__ void __launch_bounds__(320) k_prod_reduce(const Fr* __restrict__ partials, uint32_t blocks, Fr* __restrict__ out) {
+    __shared__ Fr s_q[4][kProdRecValues];
+    const uint32_t tid = threadIdx.x, q = tid / (uint32_t)kProdRecValues, val = tid % (uint32_t)kProdRecValues;
+    const Fr* p = partials + (size_t)blockIdx.y * blocks * kProdRecValues + val;
+    Fr v = fr_zero();
+    for (uint32_t k = blockIdx.x + q * kProdReduceBlocks; k < blocks; k += 4u * kProdReduceBlocks) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
+    s_q[q][val] = v;
+    __syncthreads();
+    if (tid < (uint32_t)kProdRecValues)
+        store_fr(out + ((size_t)blockIdx.y * kProdReduceBlocks + blockIdx.x) * kProdRecValues + tid,
+                 fr_add(fr_add(s_q[0][tid], s_q[1][tid]), fr_add(s_q[2][tid], s_q[3][tid])));
+}
+
 // grid = (batch), block = Q * 72 (Q = 4, or 14 for the many blocks of a wide layer): totals of the blocks' partials -> the
 // pinned record.  Q threads per value, each a Q-th of the blocks (the kernel sits between two hashes of the round path: 32
 // dependent additions took 12 us)
@@ -690,6 +707,55 @@ __device__ __forceinline__ void eq_table_part(const Fr* __restrict__ points, uin
             store_fr(out + ((size_t)proof << nvars) + g, p);
         }
     }
+}
+
+// The same table for MANY variables (eq(u, .) of a wide layer: 2^20 entries x 20 factors were 237 us): a block owns 4096
+// consecutive entries, i.e. one value of the leading nvars - 12 index bits.  Its product over those bits once (four lanes,
+// strided factors, as above), the sixteen products over the next four bits, the 256 over the last eight from two
+// sixteen-entry tables -- then TWO products per entry: (hi * mid[..]) * lo[..].  Same field elements as eq_table_part.
+// nvars >= 12.  grid = (2^(nvars - 12), batch), block = 256
+__global__ void __launch_bounds__(256) k_eq_table_split(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
+                                                        Fr* __restrict__ out, uint32_t montgomery) {
+    __shared__ Fr s_f[2][32];
+    __shared__ Fr s_a[16], s_b[16], s_hm[16], s_lo[256];
+    __shared__ Fr s_hi;
+    const uint32_t proof = blockIdx.y, tid = threadIdx.x, nh = nvars - 12u, hi_idx = blockIdx.x;
+    const Fr* pt = points + (size_t)proof * stride + first;
+    if (tid < nvars) {
+        const Fr x = load_fr(pt + tid);
+        Fr one = fr_zero();
+        one.l[0] = 1u;
+        s_f[1][tid] = to_mont(x);
+        s_f[0][tid] = to_mont(fr_sub(one, x));
+    }
+    __syncthreads();
+    if (tid < 4u) {   // the leading bits' product: lane q takes factors q, q + 4, ...; then the four partial products together
+        Fr p = fr_mont_one();
+        for (uint32_t i = tid; i < nh; i += 4u) p = mont_mul(p, s_f[(hi_idx >> (nh - 1u - i)) & 1u][i]);
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {
+            Fr o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.l[j] = __shfl_xor(p.l[j], step, 64);
+            p = mont_mul(p, o);
+        }
+        if (tid == 0) s_hi = montgomery ? p : from_mont(p);   // canonical here makes every entry canonical without a product per entry
+    } else if (tid >= 64u && tid < 64u + 48u) {   // three sixteen-entry tables over four variables each: mid, lo-a, lo-b
+        const uint32_t which = (tid - 64u) >> 4, e = (tid - 64u) & 15u, v0 = nh + 4u * which;
+        Fr p = s_f[(e >> 3) & 1u][v0];
+        p = mont_mul(p, s_f[(e >> 2) & 1u][v0 + 1u]);
+        p = mont_mul(p, s_f[(e >> 1) & 1u][v0 + 2u]);
+        p = mont_mul(p, s_f[e & 1u][v0 + 3u]);
+        (which == 0 ? s_hm : (which == 1 ? s_a : s_b))[e] = p;
+    }
+    __syncthreads();
+    s_lo[tid] = mont_mul(s_a[tid >> 4], s_b[tid & 15u]);
+    if (tid < 16u) s_hm[tid] = mont_mul(s_hi, s_hm[tid]);
+    __syncthreads();
+    Fr* dst = out + ((size_t)proof << nvars) + ((size_t)hi_idx << 12);
+    const Fr lo = s_lo[tid];
+#pragma unroll 4
+    for (uint32_t m = 0; m < 16u; ++m) store_fr(dst + (m << 8) + tid, mont_mul(s_hm[m], lo));
 }
 
 __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
@@ -2478,7 +2544,14 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
         hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
     else
         hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
-    if (blocks > 1) hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((blocks > 256 ? 14 : 4) * kProdRecValues), 0, s, partials, blocks, rec, ticket);
+    if (blocks > 1024) {
+        // (the second level's input sits behind the partials: launch_prod_pass's callers size the scratch with prod_pass_scratch_values)
+        Fr* level2 = partials + (size_t)batch * blocks * kProdRecValues;
+        hipLaunchKernelGGL(k_prod_reduce, dim3(kProdReduceBlocks, batch), dim3(4 * kProdRecValues), 0, s, partials, blocks, level2);
+        hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(4 * kProdRecValues), 0, s, level2, kProdReduceBlocks, rec, ticket);
+    } else if (blocks > 1) {
+        hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((blocks > 256 ? 14 : 4) * kProdRecValues), 0, s, partials, blocks, rec, ticket);
+    }
 }
 
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
@@ -2537,6 +2610,10 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) 
 
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
                      hipStream_t s) {
+    if (nvars >= 14) {   // many variables: a few products per block, two per entry (k_eq_table_split)
+        hipLaunchKernelGGL(k_eq_table_split, dim3(1u << (nvars - 12u), batch), dim3(256), 0, s, points, stride, first, nvars, out, montgomery ? 1u : 0u);
+        return;
+    }
     hipLaunchKernelGGL(k_eq_table, dim3(blocks_for((size_t)4 << nvars, 4096), batch), dim3(256), 0, s, points, stride, first, nvars, out,
                        montgomery ? 1u : 0u);
 }
