@@ -3770,7 +3770,13 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         want = share >= 6 ? share - 2 : (share >= 3 ? share - 1 : share);   // two (one, none) left to the runtime's own threads
     }
     // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
-    if (!max_concurrent && (size_t)want > n_items) want = (int)n_items;
+    {
+        // (members beyond what the items -- cut in two where they are large, below -- can occupy have nothing to prove)
+        size_t can_use = n_items;
+        if (getenv("GKR_PROVE_MANY_PIECES"))
+            for (size_t i = 0; i < n_items; ++i) can_use += items[i].batch >= 32 ? (size_t)items[i].batch / 32 : 0;
+        if (!max_concurrent && (size_t)want > can_use) want = (int)can_use;
+    }
     // several devices: at least one member per device (as far as there are items), or a device would sit idle
     if (!max_concurrent && !ctx->devices.empty() && want < (int)ctx->devices.size())
         want = n_items < ctx->devices.size() ? (int)n_items : (int)ctx->devices.size();
@@ -3794,14 +3800,55 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         const int index = (int)crew->members.size() - 1;
         crew->members.back()->th = std::thread(crew_thread, crew, index);
     }
+    // GKR_PROVE_MANY_PIECES = n (opt-in): the costliest items with >= 32 witnesses are cut in two until there are n items --
+    // the halves are independent proving chains like any other item.  Meant for the deep sub-circuits of an R1CS, which run
+    // alone for the last third of a step; measured on MI355X (64 inputs x 12 sub-circuits, 14 threads, ms per step, two
+    // runs each): no cut 9.0 / 9.2, 14 items 8.4 / 10.1, 16: 9.2 / 10.1, 19 (all seven deep ones cut): 11.1 / 12.2,
+    // 24: 12.1 / 12.8 (profiles/r04/e_prove_many_item_split_ab.txt) -- every extra chain adds its launches and hand-offs
+    // (~750 launches per step already) and the step gets SLOWER; the default is no cut.
+    auto item_cost = [](const gkr_prove_item& it) {
+        double rounds = 0;
+        const gkr_circuit_desc* c = it.circuit;
+        if (c && c->k && c->depth <= 4096)
+            for (uint32_t l = 1; l <= c->depth; ++l) rounds += 2.0 * c->k[l];
+        return rounds * (50.0 + 2.0 * (it.batch > 0 ? it.batch : 1));
+    };
+    static const int pieces_env = [] { const char* e = getenv("GKR_PROVE_MANY_PIECES"); return e ? atoi(e) : -1; }();
+    std::vector<gkr_prove_item> work(items, items + n_items);
+    std::vector<int> origin(n_items);
+    for (size_t i = 0; i < n_items; ++i) origin[i] = (int)i;
+    const size_t aim = pieces_env > 0 ? (size_t)pieces_env : 0;
+    while (work.size() < aim) {
+        int best = -1;
+        double best_cost = 0;
+        for (size_t i = 0; i < work.size(); ++i) {
+            const gkr_prove_item& it = work[i];
+            if (it.batch < 32 || !it.circuit || !it.circuit->k || !it.input_values || !it.outs) continue;
+            const double c = item_cost(it);
+            if (c > best_cost) {
+                best_cost = c;
+                best = (int)i;
+            }
+        }
+        if (best < 0) break;
+        gkr_prove_item a = work[best], b = work[best];
+        const int half = ((a.batch / 2 + 15) / 16) * 16;   // whole sixteen-lane hash calls in the first half
+        a.batch = half;
+        b.batch = work[best].batch - half;
+        b.input_values = a.input_values + ((size_t)half << a.circuit->k[a.circuit->depth]);
+        b.outs = a.outs + half;
+        work[best] = a;
+        work.push_back(b);
+        origin.push_back(origin[best]);
+    }
+    gkr_prove_item* const caller_items = items;
+    const size_t caller_n = n_items;
+    items = work.data();
+    n_items = work.size();
     // deal the items out by estimated cost, longest first, each to the member with the least so far (deterministic)
     std::vector<std::pair<double, int>> cost(n_items);
     for (size_t i = 0; i < n_items; ++i) {
-        double rounds = 0;
-        const gkr_circuit_desc* c = items[i].circuit;
-        if (c && c->k && c->depth <= 4096)
-            for (uint32_t l = 1; l <= c->depth; ++l) rounds += 2.0 * c->k[l];
-        cost[i] = {rounds * (50.0 + 2.0 * (items[i].batch > 0 ? items[i].batch : 1)), (int)i};
+        cost[i] = {item_cost(items[i]), (int)i};
         items[i].status = GKR_OK;
     }
     std::stable_sort(cost.begin(), cost.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
@@ -3834,13 +3881,18 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     }
     ctx->crew_member = false;
     ctx->transcript = saved_transcript;
+    for (size_t i = 0; i < caller_n; ++i) caller_items[i].status = GKR_OK;
+    int first_bad = GKR_OK;
     for (int m = 0; m < want; ++m)
         for (int idx : crew->members[m]->items)
             if (items[idx].status != GKR_OK) {
-                if (m) ctx->err = crew->members[m]->ctx->err;
-                return items[idx].status;
+                if (caller_items[origin[idx]].status == GKR_OK) caller_items[origin[idx]].status = items[idx].status;
+                if (first_bad == GKR_OK) {
+                    if (m) ctx->err = crew->members[m]->ctx->err;
+                    first_bad = items[idx].status;
+                }
             }
-    return GKR_OK;
+    return first_bad;
 }
 
 // ---- step-wise sessions: one sumcheck split across GPUs ------------------------
