@@ -45,6 +45,22 @@ def main():
         if not (np.array_equal(C[0], want[0]) and np.array_equal(L[0], want[1]) and np.array_equal(R[0], want[2])):
             print("MISMATCH against the oracle")
             return 1
+    # the table bench.py --mode mle-split splits over the ranks (seed SEED + 2): its transcript against the committed digest
+    # of the CPU checker's (tests/golden/config_hashes.json; n = 30 made with the in-place C prover, 32 GiB of host memory)
+    from gkr_amd import synth
+    want = synth.golden_digest("mle", "n=%d,seed=%d" % (n, synth.SEED + 2))
+    if want is not None:
+        with Context(0) as ctx:
+            d = ctx.alloc(count * 32)
+            try:
+                ctx.fill_table(d, count, synth.SEED + 2)
+                C, L, R = ctx.sumcheck_mle_batch_device(d, n, 1)
+            finally:
+                ctx.free(d)
+        if synth.transcript_digest(C[0], L[0], R[0]) != want:
+            print("MISMATCH against the committed digest of the oracle's transcript")
+            return 1
+        print("digest of the oracle's 2^%d transcript: equal" % n)
     print("OK")
     return 0
 
