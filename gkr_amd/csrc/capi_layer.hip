@@ -1,0 +1,1448 @@
+// The GKR layer sumcheck (prove_sumcheck_opt, rust/src/gkr/sumcheck.rs:36-156): predicate tables, the linear-time form over gate
+// lists with product passes, the gate-sharded form, resident layers, the dense step-wise sessions.  C ABI: include/gkr_amd.h.
+#include "capi_internal.h"
+
+namespace gkr_host {
+
+void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16],
+                                  uint64_t (*c2)[16][4], uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4],
+                                  uint64_t* weights, size_t w_row_words) {
+    using namespace gkr::h64;
+    const F* cts = host_mimc_constants64();
+    const F one_m = to_mont(F{{1, 0, 0, 0}});
+    for (int k = 0; k < count; ++k) {
+        F M[64], SY[8], rm[gkr::kProdMaxJ];
+        const F* rec = reinterpret_cast<const F*>(recs + (size_t)k * rec_row_words);
+        const int n = 1 << J;
+        for (int a = 0; a < n; ++a) {
+            for (int b = 0; b < n; ++b) M[a * 8 + b] = rec[a * 8 + b];
+            SY[a] = rec[64 + a];
+        }
+        for (int t = 0; t < J; ++t) {
+            const int half = 1 << (J - t - 1);
+            F p00 = M[0], p01 = M[half], p10 = M[half * 8], p11 = M[half * 8 + half], s0 = SY[0], s1 = SY[half];
+            for (int x = 1; x < half; ++x) {
+                p00 = add(p00, M[x * 8 + x]);
+                p01 = add(p01, M[x * 8 + half + x]);
+                p10 = add(p10, M[(half + x) * 8 + x]);
+                p11 = add(p11, M[(half + x) * 8 + half + x]);
+                s0 = add(s0, SY[x]);
+                s1 = add(s1, SY[half + x]);
+            }
+            const F vc0 = add(p00, s0), g1 = add(p11, s1);
+            const F vc2 = sub(add(p11, p00), add(p10, p01));
+            const F vlin = sub(sub(g1, vc0), vc2);
+            const uint32_t ln = vec_len[t][k];
+            const F vec[3] = {vc2, vlin, vc0};
+            const F rc = host_multi_hash(vec + (3 - ln), (int)ln, cts);
+            memcpy(c2[t][k], &vc2, 32);
+            memcpy(lin[t][k], &vlin, 32);
+            memcpy(c0[t][k], &vc0, 32);
+            memcpy(r[t][k], &rc, 32);
+            rm[t] = to_mont(rc);
+            for (int ra = 0; ra < half; ++ra)
+                for (int cb = 0; cb < 2 * half; ++cb) M[ra * 8 + cb] = add(M[ra * 8 + cb], mont_mul(sub(M[(half + ra) * 8 + cb], M[ra * 8 + cb]), rm[t]));
+            for (int ra = 0; ra < half; ++ra)
+                for (int cb = 0; cb < half; ++cb) M[ra * 8 + cb] = add(M[ra * 8 + cb], mont_mul(sub(M[ra * 8 + half + cb], M[ra * 8 + cb]), rm[t]));
+            for (int ra = 0; ra < half; ++ra) SY[ra] = add(SY[ra], mont_mul(sub(SY[half + ra], SY[ra]), rm[t]));
+        }
+        if (!weights) continue;
+        F tmp[8];
+        tmp[0] = one_m;
+        int cur = 1;
+        for (int t = 0; t < J; ++t) {
+            const F nr = sub(one_m, rm[t]);
+            for (int b = cur; b-- > 0;) {
+                tmp[2 * b + 1] = mont_mul(tmp[b], rm[t]);
+                tmp[2 * b] = mont_mul(tmp[b], nr);
+            }
+            cur <<= 1;
+        }
+        memcpy(weights + (size_t)k * w_row_words, tmp, sizeof(F) << J);
+    }
+}
+
+// Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
+// 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
+// eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
+// variables at once.  Length rules as in run_mle_batch.
+// ------------------------------------------------------------- predicate tables
+// builds canonical A, M (2^{2k} each) in device memory from device gate arrays
+
+// shard (log_p, p) keeps the gates whose right operand has low bits p; tables then have 2^{2k - log_p} entries.
+// batch > 1: `batch` proofs of one circuit -- same gates (the cell lists are built once), z is batch x k_i,
+// d_A / d_M hold batch tables of N entries each.
+// E[g] = eq(z, g) = E_hi[g >> kl] * E_lo[g & mask]: two small tables per proof, built on the device from the points
+// the host left in pinned memory (k_eq_table), E_lo in Montgomery form so that the product of the two is canonical.
+static int upload_eq_tables(gkr_ctx* ctx, int k_i, const gkr_fr* z, int batch, Fr** e_hi_out, Fr** e_lo_out, int kl = -1) {
+    if (kl < 0) kl = k_i / 2;
+    const int kh = k_i - kl;
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
+    WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
+    // the points go to pinned memory, the tables are built on the device from there (k_eq_table): no transfer call
+    gkr_fr* hz = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz)));
+    memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
+    gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, 0u, (uint32_t)kh, e_hi, false, (uint32_t)batch, ctx->stream);
+    gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, (uint32_t)kl, e_lo, true, (uint32_t)batch, ctx->stream);
+    *e_hi_out = e_hi;
+    *e_lo_out = e_lo;
+    return GKR_OK;
+}
+
+int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                     const gkr_fr* z, Fr* d_A, Fr* d_M, uint32_t log_p = 0, uint32_t shard = 0, int batch = 1) {
+    const size_t N = (size_t)1 << (2 * k - log_p);
+    hipStream_t s = ctx->stream;
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    uint32_t* bad = nullptr;
+    const int kl = k_i / 2;
+    WS(ctx, "pred.bad", uint32_t, 1, bad);
+    {
+        const int rc_eq = upload_eq_tables(ctx, k_i, z, batch, &e_hi, &e_lo);
+        if (rc_eq) return rc_eq;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+    static const bool use_atomics = getenv("GKR_PREDICATE_ATOMICS") != nullptr;
+    if (!use_atomics || batch > 1) {
+        // counting sort by cell, then one modular sum per cell (per proof)
+        uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *bsums = nullptr, *list = nullptr;
+        WS(ctx, "pred.counts", uint32_t, 2 * N, counts);
+        WS(ctx, "pred.offsets", uint32_t, 2 * N, offsets);
+        WS(ctx, "pred.cursor", uint32_t, 2 * N, cursor);
+        WS(ctx, "pred.bsums", uint32_t, (2 * N + 2047) / 2048 + 1, bsums);
+        WS(ctx, "pred.list", uint32_t, (size_t)1 << k_i, list);
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 2 * N * sizeof(uint32_t), s));
+        Timed t(ctx, "predicate_sorted", (double)((size_t)1 << k_i) * (2 * 9.0 + 8.0) + (double)N * 2.0 * (3 * 4.0 + 32.0) * batch);
+        gkr::launch_predicate_sorted(k_i, k, d_gt, d_l, d_r, e_hi, e_lo, (uint32_t)kl, log_p, shard, N, counts, offsets, cursor,
+                                     bsums, list, bad, d_A, d_M, (uint32_t)batch, s);
+    } else {
+        // widened-atomic scatter (kept for comparison): 8 u64 limb atomics per gate into 64-byte cells
+        unsigned long long *wideA = nullptr, *wideM = nullptr;
+        WS(ctx, "pred.wideA", unsigned long long, N * 8, wideA);
+        WS(ctx, "pred.wideM", unsigned long long, N * 8, wideM);
+        HIP_TRY(ctx, hipMemsetAsync(wideA, 0, N * 64, s));
+        HIP_TRY(ctx, hipMemsetAsync(wideM, 0, N * 64, s));
+        {
+            Timed t(ctx, "predicate_scatter", (double)((size_t)1 << k_i) * (9.0 + 64.0));
+            gkr::launch_predicate_scatter(k_i, k, d_gt, d_l, d_r, e_hi, e_lo, (uint32_t)kl, wideA, wideM, bad, log_p, shard, s);
+        }
+        {
+            Timed t(ctx, "predicate_normalise", (double)N * 2.0 * (64.0 + 32.0));
+            gkr::launch_predicate_normalise(wideA, d_A, N, s);
+            gkr::launch_predicate_normalise(wideM, d_M, N, s);
+        }
+    }
+    uint32_t hbad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // also keeps the host tables alive until their upload is done
+    if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+    return GKR_OK;
+}
+
+// ------------------------------------------------------------- layer sumcheck
+// `batch` layer sumchecks that share their gates (the same layer of `batch` proofs of one circuit), or
+// one (batch = 1).  z: batch x k_i challenges (host); d_W: batch tables of 2^k canonical values;
+// outputs: per proof 2k rows (out_coeffs 3 slots per row), laid out [proof][round] with the given strides.
+// One rank's share of a layer split across GPUs by GATES (gkr_sumcheck_layer_sharded): the device gate arrays hold
+// gates gate_base .. gate_base + gate_count - 1, and the two tables that are sums over gates -- (U, V) before the
+// b-rounds, the row (a_u, m_u) before the c-rounds -- are completed by the caller's sum-over-ranks hook.
+int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                         const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                         const LayerShardArgs* shard, GateLists* cached);
+
+// Gate lists that this call built (cached->ready false on entry) count as ready only if the whole call succeeded: a bad
+// gate, a HIP error or a timeout after the sort was queued must not leave half-validated lists marked usable.
+int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                    const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                    const LayerShardArgs* shard, GateLists* cached) {
+    const bool was_ready = cached && cached->ready;
+    int rc = GKR_OK;
+    if (ctx->transcript != GKR_TRANSCRIPT_HOST && batch > 1 && !shard) {
+        // The device transcript hashes on one lane per sumcheck and its round kernels take one proof: the proofs of a
+        // batch go through one after the other (complete and host-free, not fast: ~1 ms per round and proof).
+        const size_t wlen = (size_t)1 << k;
+        for (int b = 0; b < batch && rc == GKR_OK; ++b)
+            rc = run_layer_batch_impl(ctx, 1, k_i, k, d_gt, d_l, d_r, z + (size_t)b * k_i, d_W + (size_t)b * wlen, out_coeffs + b, out_len + b,
+                                      out_r + b, nullptr, cached);
+    } else {
+        rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached);
+    }
+    if (rc && cached && !was_ready) cached->ready = false;
+    return rc;
+}
+
+int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
+                         const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
+                         const LayerShardArgs* shard, GateLists* cached) {
+    const size_t N = (size_t)1 << (2 * k);
+    const size_t wlen = (size_t)1 << k;
+    const uint32_t v = 2 * k;
+    const double t_entry_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
+    if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
+    if (shard && (!host_tx || batch != 1)) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript and one proof");
+    if (k > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "layer wider than the library's limits (gkr_amd.h: GKR_MAX_K_NEXT, GKR_MAX_K_I)");
+    if (!host_tx && k > kMaxDenseK)
+        return ctx->fail(GKR_ERR_INVALID, "the device transcript works on dense 2^(2 k_next)-entry predicate tables: k_next <= 14 (GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT)");
+    const gkr::GateSpan span{shard ? shard->gate_base : 0, shard ? shard->gate_count : (uint64_t)1 << k_i};
+    hipStream_t s = ctx->stream;
+    Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr, *d_coeffs = nullptr, *d_r_out = nullptr;
+    gkr::FixedMul* d_rtab = nullptr;
+    uint32_t *d_len = nullptr, *dep = nullptr;
+    gkr::LayerPartial* partials = nullptr;
+    // Three forms of the b-phase (all the same transcript):
+    //   gate lists (default with the host transcript; the only form for k > 13): no 2^{2k}-entry tables at all -- U, V and the
+    //     c-phase row are summed straight from the gates grouped by left / right operand (kernels.hip, k_gate_*);
+    //   dense predicate tables, U, V and the row from two passes over them (layers with more than 2^{2k-2} gates;
+    //     GKR_LAYER_DENSE_TABLES forces it, GKR_LAYER_GATE_LISTS forces the gate lists);
+    //   GKR_LAYER_DENSE_B (and the device transcript): k passes over the dense tables.
+    static const bool dense_b = getenv("GKR_LAYER_DENSE_B") != nullptr;
+    static const bool dense_tables = getenv("GKR_LAYER_DENSE_TABLES") != nullptr;
+    const bool lin_b = host_tx && !dense_b && k >= 1;
+    // gate lists pay when the layer is sparse in its 2^{2k} cells (every circom layer is); for a layer with a gate in
+    // (nearly) every cell the dense tables' counting sort is the cheaper grouping (k_i = 24, k = 12: 8.9 ms against 9.1)
+    static const bool gate_lists_always = getenv("GKR_LAYER_GATE_LISTS") != nullptr;
+    // Small layers (every layer of a circom-sized circuit) can run their whole sumcheck as ONE resident kernel, tables
+    // in LDS, rounds handed over through pinned memory (kernels.hip, k_layer_persistent): GKR_LAYER_PERSISTENT=1.
+    // Opt-in: measured on MI355X it saves the launch per round but a round stays at 70 - 80 us, because what
+    // dominates is the host's 24 - 30 us hash call and ~20 us of PCIe latency per hand-off in either form (64 inputs
+    // x 12 sub-circuits: 63 instead of 75 ms from one context, 19.6 instead of 22 ms from six) -- not enough to make a
+    // kernel that waits on the host the default.
+    static const bool want_persistent = getenv("GKR_LAYER_PERSISTENT") != nullptr;
+    const bool persistent = lin_b && !shard && !dense_tables && want_persistent && !gate_lists_always && k <= (int)gkr::kPersistentMaxK &&
+                            k_i <= k + 4;
+    // gate lists also for dense layers when the block-private sort applies (k <= 12, >= 2^16 gates: 2^24 gates sort in
+    // ~0.5 ms, against 2.7 ms for the dense tables' cell sort)
+    const bool lds_sort = gkr::gate_lists_lds_blocks(span.count, (uint32_t)k) != 0;
+    const bool sparse = shard || persistent || (lin_b && (k > 13 || (!dense_tables && (gate_lists_always || lds_sort || k_i + 2 <= 2 * k))));
+    // Wide layers (2^13 buckets and more per half, each with a few gates): the gate passes run with a group of lanes per
+    // bucket and the rare long buckets in units (kernels_wide.hip) -- a block per bucket would be 2^20 blocks for a gate apiece.
+    // GKR_GATE_GROUPS_MIN_K moves the switch (tests run the form on small layers too).
+    static const int wide_min_k = [] { const char* e = getenv("GKR_GATE_GROUPS_MIN_K"); return e ? atoi(e) : (int)gkr::kWideMinK; }();
+    const bool wide = sparse && !persistent && k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
+    const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
+    WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
+    WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
+    WS(ctx, "layer.Wb", Fr, wlen * batch, Wb);
+    WS(ctx, "layer.Wc", Fr, wlen * batch, Wc);
+    WS(ctx, "layer.coeffs", Fr, (size_t)v * 3, d_coeffs);
+    WS(ctx, "layer.r", Fr, v, d_r_out);
+    WS(ctx, "layer.rtab", gkr::FixedMul, v, d_rtab);
+    WS(ctx, "layer.len", uint32_t, v, d_len);
+    WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
+    WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
+    Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
+    gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
+    Fr *e_hi = nullptr, *e_lo = nullptr;
+    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_heavy = nullptr;
+    Fr* heavy_partials = nullptr;
+    // where eq(z, g) is split into E_hi, E_lo: in the middle, or -- large layers, whose gate passes run over segments
+    // of the sorted lists (gate_seg.h) -- where the segments are cut
+    const uint32_t kl = gkr::gate_seg_shift(span, (uint32_t)k_i, (uint32_t)k);
+    gkr::GateSegs local_segs;
+    gkr::GateSegs* segs = cached ? &cached->segs : &local_segs;
+    Fr* seg_partials = nullptr;
+    if (lin_b) {
+        WS(ctx, "layer.U", Fr, wlen * batch, U);
+        WS(ctx, "layer.V", Fr, wlen * batch, V);
+        WS(ctx, "layer.eq", Fr, wlen * batch, d_eq);
+        if (!sparse)
+            WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
+        HIP_TRY(ctx, ctx->pinned_host("layer.u", sizeof(gkr_fr) * (size_t)k * batch, reinterpret_cast<void**>(&h_u)));
+    }
+    int rc = GKR_OK;
+    uint32_t* bad = nullptr;
+    uint32_t* h_dep = nullptr;   // pinned: which variables W depends on, per proof; the device leaves it there before round 0
+    if (host_tx) HIP_TRY(ctx, ctx->pinned_host("layer.hdep", sizeof(uint32_t) * 32 * batch, reinterpret_cast<void**>(&h_dep)));
+    bool lists_fresh = true;   // the gate lists are built (and the gates validated) in this call
+    if (sparse) {
+        uint32_t *g_counts = nullptr, *g_bsums = nullptr;
+        const size_t nb2 = (size_t)2 << k;
+        WS(ctx, "pred.bad", uint32_t, 1, bad);
+        {
+            // the eq tables of z (built on the device from the points in pinned memory), the Montgomery copies of W and the
+            // dependence flags: one launch (k_layer_prologue)
+            const int kh = k_i - (int)kl;
+            WS(ctx, "pred.ehi", Fr, (size_t)batch << kh, e_hi);
+            WS(ctx, "pred.elo", Fr, (size_t)batch << kl, e_lo);
+            gkr_fr* hz = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz)));
+            memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
+            // (the dependence flags of a table beyond 2^13 values are found over a grid, not by the prologue's one block)
+            const bool dep_wide = k > 13;
+            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, persistent ? nullptr : Wb,
+                                       persistent ? nullptr : Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s);
+            if (dep_wide) {
+                uint32_t* dep_bits = nullptr;
+                WS(ctx, "layer.depbits", uint32_t, (size_t)batch, dep_bits);
+                gkr::launch_depends_wide(d_W, (uint32_t)k, dep_bits, dep, h_dep, (uint32_t)batch, s);
+            }
+        }
+        if (wide) WS(ctx, "gates.heavypart", Fr, gkr::gate_heavy_partial_elems(span.count, (uint32_t)k) * batch, heavy_partials);
+        if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)
+        if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
+        if (cached && cached->ready) {
+            lists_fresh = false;
+            g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
+            g_cursor = cached->cursor;
+            g_list = cached->list;
+            g_heavy = cached->heavy;
+            if (wide && !g_heavy) return ctx->fail(GKR_ERR_INVALID, "cached gate lists were built without the wide layer's work lists");
+        } else {
+            WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
+            WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
+            if (cached) {
+                if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
+                if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
+                if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
+                if (wide && !cached->heavy)
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->heavy), gkr::gate_heavy_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
+                g_offsets = cached->offsets;
+                g_cursor = cached->cursor;
+                g_list = cached->list;
+                g_heavy = cached->heavy;
+            } else {
+                WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
+                WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
+                WS(ctx, "gates.list", uint32_t, 2 * gkr::gate_list_words(span.count), g_list);
+                if (wide) WS(ctx, "gates.heavy", uint32_t, gkr::gate_heavy_words(span.count, (uint32_t)k), g_heavy);
+            }
+            HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
+            uint32_t *lds_scratch = nullptr, *seg_scratch = nullptr;
+            if (const size_t words = gkr::gate_lists_lds_scratch_words(span.count, (uint32_t)k)) WS(ctx, "gates.lds", uint32_t, words, lds_scratch);
+            if (const size_t words = gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k)) {
+                if (cached) {
+                    if (!cached->segs.words) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->segs.words), words * sizeof(uint32_t)));
+                } else {
+                    WS(ctx, "gates.segs", uint32_t, words, local_segs.words);
+                }
+                WS(ctx, "gates.segscratch", uint32_t, gkr::gate_segs_scratch_words(span, (uint32_t)k_i, (uint32_t)k), seg_scratch);
+            }
+            Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
+            gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch,
+                                   segs, seg_scratch, s);
+            if (wide) gkr::launch_gate_heavy_lists(span, (uint32_t)k, g_offsets, g_cursor, g_heavy, s);
+            if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
+        }
+    } else {
+        rc = build_predicates(ctx, k_i, k, d_gt, d_l, d_r, z, A, M, 0, 0, batch);
+        if (rc) return rc;
+    }
+    gkr::LayerBatch lb{(uint32_t)batch, gkr::kMaxLayerBlocks, tlen, wlen};
+    if (!sparse) {   // (the gate-list form did all of this in its prologue launch above)
+        HIP_TRY(ctx, hipMemsetAsync(dep, 0, sizeof(uint32_t) * 32 * batch, s));
+        gkr::launch_to_mont(d_W, Wb, (uint32_t)(wlen * batch), s);
+        gkr::launch_to_mont(d_W, Wc, (uint32_t)(wlen * batch), s);
+        gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
+    }
+    if (persistent) {
+        // U, V, the rounds and the row are all inside the one kernel launched below
+    } else if (sparse) {
+        Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
+        if (wide)
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s);
+        else
+            gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
+    } else if (lin_b) {
+        Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
+        gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
+    }
+
+    // The two tables d_a, d_b (`each` elements) := their sums over all ranks.  One more element travels along: "some rank
+    // failed" (a bad gate seen on the device, or `local_fail`: this rank's own error status), so that every rank enters
+    // every collective and all of them leave with an error together instead of one leaving the others inside it.
+    // Device exchange: widen -> the caller's all-reduce on this stream -> narrow, no host copy and no synchronisation;
+    // the summed flag lands in pinned memory and is looked at when the next record has landed (xflag_check).
+    uint32_t* h_xflag = nullptr;
+    if (shard && shard->dev) {
+        HIP_TRY(ctx, ctx->pinned_host("layer.xflag", 64, reinterpret_cast<void**>(&h_xflag)));
+        *h_xflag = 0;
+        if (shard->dev->capacity < gkr_exchange_limbs(k) || !shard->dev->d_limbs || !shard->dev->fn)
+            return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs(k_next) int64");
+    }
+    auto sum_over_ranks = [&](Fr* d_a, Fr* d_b, size_t each, const uint32_t* d_flag, int local_fail) -> int {
+        if (shard->dev) {
+            Timed t(ctx, "exchange", 0.0);
+            long long* limbs = reinterpret_cast<long long*>(shard->dev->d_limbs);
+            gkr::launch_exchange_widen(d_a, d_b, (uint32_t)each, d_flag, local_fail ? 1u : 0u, limbs, s);
+            const int arc = shard->dev->fn(shard->dev->user, (2 * each + 1) * 8, static_cast<void*>(s));
+            gkr::launch_exchange_narrow(limbs, d_a, d_b, (uint32_t)each, h_xflag, s);
+            if (arc) return ctx->fail(GKR_ERR_INVALID, "the device sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+            HIP_TRY(ctx, hipGetLastError());
+            return local_fail;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        gkr_fr* buf = nullptr;   // pinned, kept by the context: no pageable staging vector per exchange
+        HIP_TRY(ctx, ctx->pinned_host("layer.xbuf", sizeof(gkr_fr) * (2 * each + 1), reinterpret_cast<void**>(&buf)));
+        uint32_t hflag = local_fail ? 1u : 0u;
+        gkr::launch_copy_words(d_a, buf, each * 8, s);
+        gkr::launch_copy_words(d_b, buf + each, each * 8, s);
+        // (no early return between here and the hook: the peers are on their way into the collective)
+        if (d_flag && !local_fail && hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) hflag = 1u;
+        const hipError_t se = hipStreamSynchronize(s);
+        if (se != hipSuccess) hflag = 1u;   // still enter the collective: the peers are on their way into it
+        buf[2 * each] = gkr_fr{{(uint64_t)(hflag != 0), 0, 0, 0}};
+        const int arc = shard->allreduce(shard->user, buf, 2 * each + 1);
+        if (se != hipSuccess) return ctx->hip_fail(se, "hipStreamSynchronize before the sum over ranks");
+        if (arc) return ctx->fail(GKR_ERR_INVALID, "the sum-over-ranks hook failed (status " + std::to_string(arc) + ")");
+        if (!all_canonical(buf, 2 * each + 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "the sum-over-ranks hook returned a value >= r");
+        const bool some_failed = (buf[2 * each].l[0] | buf[2 * each].l[1] | buf[2 * each].l[2] | buf[2 * each].l[3]) != 0;
+        gkr::launch_copy_words(buf, d_a, each * 8, s);
+        gkr::launch_copy_words(buf + each, d_b, each * 8, s);   // (the next exchange waits for the stream before it rewrites buf)
+        if (ctx->profile == 1)
+            ctx->add_host_sample("exchange", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (local_fail) return local_fail;
+        if (some_failed) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range, or another failure, on some rank");
+        return GKR_OK;
+    };
+    // device exchange: has the flag that travelled with the exchanges come back set?  Valid once a kernel queued after
+    // the narrow step has published something the host waited for.
+    auto xflag_check = [&]() -> int {
+        if (h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE))
+            return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range, or another failure, on some rank");
+        return GKR_OK;
+    };
+    if (shard) {
+        rc = sum_over_ranks(U, V, wlen, lists_fresh ? bad : nullptr, GKR_OK);
+        if (rc) return rc;
+    }
+
+    gkr::LayerHostRec* rec = nullptr;
+    gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
+    const gkr::h64::F* cts64 = host_mimc_constants64();
+    const bool ifma = host_ifma_ready();
+    gkr::SpinPool* pool = nullptr;
+    if (host_tx) {
+        HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
+        // h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record
+        // (the gate-list form's prologue launch wrote it)
+        if (!sparse) gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
+        // (gate-sharded with the device exchange: the flag travels with the first exchange and is looked at after the
+        // first round's record, on every rank alike -- a rank that left here would leave its peers inside a collective)
+        if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
+            uint32_t hbad = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+        }
+        if (batch >= 16) pool = ctx->host_pool();
+    }
+    if (persistent) {
+        static const bool dbg_s = getenv("GKR_DEBUG_TIMING") != nullptr;
+        if (dbg_s)
+            fprintf(stderr, "[gkr timing] resident layer set-up (eq upload, gate lists, dep readback): %.0f us\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_entry_us);
+        gkr::LayerChallenge* chal = nullptr;
+        uint32_t* abort_flag = nullptr;
+        HIP_TRY(ctx, ctx->pinned_host("layer.chal", sizeof(gkr::LayerChallenge) * batch, reinterpret_cast<void**>(&chal)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.abort", 64, reinterpret_cast<void**>(&abort_flag)));
+        __atomic_store_n(abort_flag, 0u, __ATOMIC_RELEASE);
+        const uint32_t base = ctx->ticket + 1;
+        ctx->ticket += v;
+        static const bool dbg_p = getenv("GKR_DEBUG_TIMING") != nullptr;
+        const auto tp0 = std::chrono::steady_clock::now();
+        {
+            Timed t(ctx, "layer_persistent", 0.0);
+            gkr::launch_layer_persistent(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, d_r, e_hi, e_lo, kl, d_W,
+                                         rec, chal, abort_flag, base, lb, s);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        struct AbortGuard {   // whatever path leaves this scope early, the resident kernel is told to stop waiting
+            uint32_t* flag;
+            bool armed = true;
+            ~AbortGuard() {
+                if (armed) __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);
+            }
+        } guard{abort_flag};
+        std::atomic<int> slice_rc{GKR_OK};
+        // a slice of proofs, each advanced independently: whichever records have landed are answered (hashed up to
+        // sixteen at a time), so a proof never waits for another one's block to become resident
+        static const bool dbg_r = getenv("GKR_DEBUG_TIMING") != nullptr;
+        auto run_slice = [&](int first, int count) {
+            std::vector<uint32_t> round(count, 0);
+            int done = 0;
+            double us_gather = 0, us_hash = 0, us_write = 0, us_wait = 0;
+            long calls = 0, lanes = 0;
+            auto t_mark = std::chrono::steady_clock::now();
+            auto lap_us = [&](double& bucket) {
+                const auto t = std::chrono::steady_clock::now();
+                bucket += std::chrono::duration<double, std::micro>(t - t_mark).count();
+                t_mark = t;
+            };
+            auto last_progress = std::chrono::steady_clock::now();
+            uint32_t idle = 0;
+            while (done < count && slice_rc.load(std::memory_order_relaxed) == GKR_OK) {
+                int idx[kHashChunkMax], nr = 0;
+                auto scan = [&] {
+                    nr = 0;
+                    for (int i = 0; i < count && nr < kHashChunkMax; ++i)
+                        if (round[i] < v && __atomic_load_n(&rec[first + i].seq, __ATOMIC_ACQUIRE) == base + round[i]) idx[nr++] = i;
+                };
+                scan();
+                if (nr > 0 && dbg_r) lap_us(us_wait);
+                // A hash call costs the same for one lane as for sixteen (one serial chain of ~1100 products either
+                // way: 24 - 30 us), so answering a few records now and the rest in a second call doubles every proof's
+                // round time -- and the two cohorts then stay out of phase for the rest of the layer.  So a record waits
+                // for the slice's other unfinished proofs, up to about two hash calls' time (blocks that are not resident
+                // yet must not hold the others up for ever).
+                if (nr > 0 && nr < (count - done < kHashChunkMax ? count - done : kHashChunkMax)) {
+                    const int want = count - done < kHashChunkMax ? count - done : kHashChunkMax;
+                    const auto t_gather = std::chrono::steady_clock::now();
+                    while (nr < want && std::chrono::steady_clock::now() - t_gather < std::chrono::microseconds(50)) {
+                        GKR_CPU_RELAX();
+                        scan();
+                    }
+                }
+                if (nr == 0) {
+                    GKR_CPU_RELAX();
+                    // No HIP call in here: another context's thread may sit inside the runtime waiting for work that is
+                    // queued BEHIND this context's resident kernel (streams share hardware queues), and a runtime lock
+                    // taken by this loop would then wait for a kernel that waits for this loop.  Only the clock.
+                    if ((++idle & 0x3FFF) == 0 && std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(30))
+                        slice_rc.store(-2);   // no record for 30 s
+                    continue;
+                }
+                idle = 0;
+                last_progress = std::chrono::steady_clock::now();
+                if (dbg_r) {
+                    lap_us(us_gather);
+                    ++calls;
+                    lanes += nr;
+                }
+                gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
+                uint32_t ln[kHashChunkMax] = {};
+                for (int j = 0; j < nr; ++j) {
+                    const int b = first + idx[j];
+                    gkr::h64::F g1;
+                    memcpy(&c0[j], &rec[b].c0, 32);
+                    memcpy(&g1, &rec[b].g1, 32);
+                    memcpy(&c2[j], &rec[b].c2, 32);
+                    lin[j] = gkr::h64::sub(gkr::h64::sub(g1, c0[j]), c2[j]);
+                    ln[j] = 2u + (h_dep[(size_t)b * 32 + round[idx[j]] % k] ? 1u : 0u);
+                }
+                if (ifma && nr >= 3) {
+                    uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
+                    memset(vec, 0, sizeof vec);
+                    for (int j = 0; j < nr; ++j) {
+                        memcpy(vec[j][0], &c2[j], 32);
+                        memcpy(vec[j][1], &lin[j], 32);
+                        memcpy(vec[j][2], &c0[j], 32);
+                    }
+                    ifma_hash_chunk(vec, ln, nr, out);
+                    for (int j = 0; j < nr; ++j) memcpy(&r[j], out[j], 32);
+                } else {
+                    for (int j = 0; j < nr; ++j) {
+                        gkr::h64::F vec[3] = {c2[j], lin[j], c0[j]};
+                        r[j] = host_multi_hash(vec + (3 - ln[j]), (int)ln[j], cts64);
+                    }
+                }
+                if (dbg_r) lap_us(us_hash);
+                for (int j = 0; j < nr; ++j) {
+                    const int i = idx[j], b = first + i;
+                    const uint32_t rd = round[i];
+                    const gkr::h64::F rm = gkr::h64::to_mont(r[j]);
+                    memcpy(&chal[b].r_mont, &rm, 32);
+                    __atomic_store_n(&chal[b].seq, base + rd, __ATOMIC_RELEASE);   // the device folds while the host writes out
+                    gkr_fr* oc = out_coeffs[b] + (size_t)rd * 3;
+                    memset(&oc[0], 0, 32);
+                    if (ln[j] == 3) memcpy(&oc[0], &c2[j], 32);
+                    memcpy(&oc[1], &lin[j], 32);
+                    memcpy(&oc[2], &c0[j], 32);
+                    out_len[b][rd] = ln[j];
+                    memcpy(&out_r[b][rd], &r[j], 32);
+                    if (++round[i] == v) ++done;
+                }
+                if (dbg_r) lap_us(us_write);
+            }
+            if (dbg_r)
+                fprintf(stderr, "[gkr timing] slice of %d proofs: %ld hash calls, %.1f lanes each; per call: waiting %.1f us, gathering %.1f, hashing %.1f, writing %.1f\n",
+                        count, calls, calls ? (double)lanes / calls : 0.0, calls ? us_wait / calls : 0.0, calls ? us_gather / calls : 0.0,
+                        calls ? us_hash / calls : 0.0, calls ? us_write / calls : 0.0);
+        };
+        if (pool) {
+            const int want = (batch + 15) / 16, most = pool->workers() + 1;
+            const int slices = want < most ? want : most;
+            std::atomic<int> next{0};
+            const std::function<bool()> work = [&]() -> bool {
+                const int sidx = next.fetch_add(1, std::memory_order_relaxed);
+                if (sidx >= slices) return false;
+                const int f = (int)((long long)batch * sidx / slices), e = (int)((long long)batch * (sidx + 1) / slices);
+                run_slice(f, e - f);
+                return true;
+            };
+            gkr::SpinPool::Session session(pool, nullptr);
+            pool->run_now(&work);
+        } else {
+            run_slice(0, batch);
+        }
+        if (const int src = slice_rc.load()) {
+            __atomic_store_n(abort_flag, 1u, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(s);
+            (void)src;
+            return ctx->fail(GKR_ERR_HIP, "timed out waiting for the resident layer kernel to publish a round");
+        }
+        guard.armed = false;
+        const auto tp1 = std::chrono::steady_clock::now();
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->drain_events();
+        if (dbg_p) {
+            const auto tp2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[gkr timing] resident layer k_i=%d k=%d batch=%d: launch + %u rounds %.0f us, final sync %.0f us\n", k_i, k, batch, v,
+                    std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(tp2 - tp1).count());
+        }
+        return GKR_OK;
+    }
+    // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
+    // (get_univariate_coeff, poly.rs:388-420), hashed together (eight-lane IFMA where available)
+    auto hash_chunk = [&](int first, int count, uint32_t round, gkr::FixedMul* slot) {
+        gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
+        uint32_t ln[kHashChunkMax] = {};
+        for (int i = 0; i < count; ++i) {
+            const int b = first + i;
+            gkr::h64::F g1;
+            memcpy(&c0[i], &rec[b].c0, 32);
+            memcpy(&g1, &rec[b].g1, 32);
+            memcpy(&c2[i], &rec[b].c2, 32);
+            lin[i] = gkr::h64::sub(gkr::h64::sub(g1, c0[i]), c2[i]);
+            ln[i] = 2u + (h_dep[(size_t)b * 32 + round % k] ? 1u : 0u);
+        }
+        if (ifma && count >= 3) {
+            uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
+            memset(vec, 0, sizeof vec);
+            for (int i = 0; i < count; ++i) {
+                memcpy(vec[i][0], &c2[i], 32);
+                memcpy(vec[i][1], &lin[i], 32);
+                memcpy(vec[i][2], &c0[i], 32);
+            }
+            ifma_hash_chunk(vec, ln, count, out);
+            for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
+        } else {
+            for (int i = 0; i < count; ++i) {
+                gkr::h64::F vec[3] = {c2[i], lin[i], c0[i]};
+                r[i] = host_multi_hash(vec + (3 - ln[i]), (int)ln[i], cts64);
+            }
+        }
+        for (int i = 0; i < count; ++i) {
+            const int b = first + i;
+            gkr_fr* oc = out_coeffs[b] + (size_t)round * 3;
+            memset(&oc[0], 0, 32);
+            if (ln[i] == 3) memcpy(&oc[0], &c2[i], 32);
+            memcpy(&oc[1], &lin[i], 32);
+            memcpy(&oc[2], &c0[i], 32);
+            out_len[b][round] = ln[i];
+            memcpy(&out_r[b][round], &r[i], 32);
+            gkr::h64::make_fixed_mul(r[i], slot[b].w);
+        }
+    };
+    // Product passes (kernels.hip): both phases as sumchecks of W X + Y over three small tables, up to three rounds per
+    // device round trip.  The default for the linear-time form over gate lists; GKR_LAYER_PER_ROUND=1: one round per trip.
+    static const bool per_round = getenv("GKR_LAYER_PER_ROUND") != nullptr;
+    if (lin_b && sparse && (k > 13 || !per_round)) {   // (the per-round kernels' c-phase keeps a row in one block: k <= 13)
+        gkr::ProdPassRec* prec = nullptr;
+        Fr *h_pw = nullptr, *d_ppart = nullptr, *Xc = nullptr, *Yc = nullptr;
+        const uint32_t max_blocks = gkr::prod_pass_max_blocks((uint32_t)k);
+        HIP_TRY(ctx, ctx->pinned_host("layer.prec", sizeof(gkr::ProdPassRec) * batch, reinterpret_cast<void**>(&prec)));
+        HIP_TRY(ctx, ctx->pinned_host("layer.pw", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_pw)));
+        WS(ctx, "layer.ppart", Fr, (size_t)batch * gkr::prod_pass_scratch_values((uint32_t)k), d_ppart);
+        (void)max_blocks;
+        WS(ctx, "layer.X", Fr, wlen * batch, Xc);
+        WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
+        gkr::SpinPool::Session session(pool, nullptr);
+        uint32_t round0 = 0, jp = 0;
+        bool second_exchange_done = false;
+        for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
+            Fr *Tw = Wb, *Tx = U, *Ty = V;
+            if (phase == 1) {
+                // all of b is bound: the rows of a, m at u = (r_1 .. r_k), then the c-phase's tables X = a_u + W(u) m_u,
+                // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
+                for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
+                gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
+                bool c_tables_done = false;   // (one rank holds all gates and the rows come from segments: the row pass writes X, Y too)
+                {
+                    Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
+                    const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
+                    if (wide)
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
+                                                   heavy_partials, s);
+                    else
+                        c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
+                                                              segs, seg_partials, s, shard ? nullptr : &fuse);
+                }
+                if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
+                    second_exchange_done = true;
+                    rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
+                    if (rc) break;
+                }
+                if (!c_tables_done) gkr::launch_prod_c_setup(Wb, jp, h_pw, A, M, Xc, Yc, (uint32_t)k, (uint32_t)wlen, (uint32_t)batch, s);
+                Tw = Wc;
+                Tx = Xc;
+                Ty = Yc;
+                jp = 0;
+            }
+            uint32_t m = (uint32_t)k;   // log2 of the tables' length before the pending fold
+            for (uint32_t rem = (uint32_t)k; rem > 0 && rc == GKR_OK;) {
+                const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
+                const uint32_t ticket = ++ctx->ticket;
+                {
+                    Timed t(ctx, "layer_prod_pass", 0.0);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s);
+                }
+                if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+                    rc = ctx->hip_fail(le, "launch of a layer pass");
+                    break;
+                }
+                m -= jp;
+                rc = wait_records(ctx, prec, batch, ticket);
+                if (!rc) rc = xflag_check();
+                if (rc) break;
+                const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
+                std::atomic<int> next{0};
+                const std::function<bool()> work = [&]() -> bool {
+                    const int first = next.fetch_add(chunk, std::memory_order_relaxed);
+                    if (first >= batch) return false;
+                    const int cnt = batch - first < chunk ? batch - first : chunk;
+                    uint64_t c2[gkr::kProdMaxJ][16][4], lin[gkr::kProdMaxJ][16][4], c0[gkr::kProdMaxJ][16][4], rr[gkr::kProdMaxJ][16][4];
+                    uint32_t vl[gkr::kProdMaxJ][16];
+                    for (uint32_t t = 0; t < J; ++t)
+                        for (int i = 0; i < cnt; ++i) vl[t][i] = 2u + (h_dep[(size_t)(first + i) * 32 + (round0 + t) % k] ? 1u : 0u);
+                    (ifma && cnt >= 3 ? gkr::gkr_ifma_prod_pass : host_prod_pass_scalar)(
+                        reinterpret_cast<const uint64_t*>(prec + first), sizeof(gkr::ProdPassRec) / 8, cnt, (int)J, vl, c2, lin, c0, rr,
+                        reinterpret_cast<uint64_t*>(h_pw + (size_t)first * 8), 32);
+                    for (int i = 0; i < cnt; ++i) {
+                        const int b = first + i;
+                        for (uint32_t t = 0; t < J; ++t) {
+                            const uint32_t round = round0 + t;
+                            gkr_fr* oc = out_coeffs[b] + (size_t)round * 3;
+                            memset(&oc[0], 0, 32);
+                            if (vl[t][i] == 3) memcpy(&oc[0], c2[t][i], 32);
+                            memcpy(&oc[1], lin[t][i], 32);
+                            memcpy(&oc[2], c0[t][i], 32);
+                            out_len[b][round] = vl[t][i];
+                            memcpy(&out_r[b][round], rr[t][i], 32);
+                        }
+                    }
+                    return true;
+                };
+                run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
+                jp = J;
+                round0 += J;
+                rem -= J;
+            }
+        }
+        session.close();
+        // a rank that failed between the exchanges still enters the second one (flag set): its peers are waiting in it.
+        // (Not when the failure is the travelling flag itself: then every rank is leaving at this very point.)
+        if (rc && shard && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
+            (void)sum_over_ranks(A, M, wlen, nullptr, rc);
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        rc = xflag_check();
+        if (rc) return rc;
+        ctx->drain_events();
+        return GKR_OK;
+    }
+    // The fold with r_j is deferred into the pass that computes round j+1's sums (b-phase: the
+    // fused kernel; c-phase: a separate fold of the single remaining row).
+    const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
+    static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
+    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    double t_launch = 0, t_wait = 0, t_hash = 0, worst_lap = 0;
+    int worst_round = -1, worst_kind = 0, cur_round = 0;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now_us();
+    auto lap = [&](double& bucket) {
+        const double t = now_us();
+        bucket += t - t_mark;
+        if (t - t_mark > worst_lap) {
+            worst_lap = t - t_mark;
+            worst_round = cur_round;
+            worst_kind = &bucket == &t_launch ? 0 : (&bucket == &t_wait ? 1 : 2);
+        }
+        t_mark = t;
+    };
+    gkr::SpinPool::Session session(pool, nullptr);   // closed on every path out of the round loop
+    bool second_exchange_done = false;
+    for (uint32_t round = 0; round < v; ++round) {
+        cur_round = (int)round;
+        const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
+        const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
+        const uint32_t hb = phase == 0 ? (h >> k) : 0u;
+        uint32_t nblk = 0;
+        bool published = false;   // the round's kernel wrote the host record itself
+        if (lin_b && round == (uint32_t)k) {
+            // all of b is bound: collapse the rows of A, M at u = (r_1 .. r_k) into the single row the c-phase works on
+            for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
+            gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
+            if (sparse) {
+                {
+                    Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
+                    if (wide)
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
+                                                   heavy_partials, s);
+                    else
+                        gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
+                                              A, M, lb, segs, seg_partials, s);
+                }
+                if (shard) {
+                    second_exchange_done = true;
+                    rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
+                    if (rc) break;
+                }
+            } else {
+                Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
+                gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
+            }
+            pending = nullptr;   // U, V are done with; the row is already taken at u
+        }
+        if (phase == 0 && lin_b) {
+            const uint32_t ticket = ++ctx->ticket;
+            {
+                Timed t(ctx, "layer_uv_round", 0.0);
+                gkr::launch_uv_round(pending != nullptr, Wb, U, V, 1u << (k - 1 - (int)round), pending, rec, ticket, lb, s);
+            }
+            pending = nullptr;
+            published = true;
+            lap(t_launch);
+            rc = wait_records(ctx, rec, batch, ticket);
+            if (!rc) rc = xflag_check();
+            lap(t_wait);
+            if (rc) break;
+        } else if (phase == 1 && lin_b && k <= 13) {
+            // the single remaining row: one small block per proof folds it and publishes the round's sums
+            const uint32_t ticket = ++ctx->ticket;
+            {
+                Timed t(ctx, "layer_c_round", 0.0);
+                gkr::launch_c_round(pending != nullptr, A, M, Wc, Wb, h, pending, rec, ticket, lb, s);
+            }
+            pending = nullptr;
+            published = true;
+            lap(t_launch);
+            rc = wait_records(ctx, rec, batch, ticket);
+            lap(t_wait);
+            if (rc) break;
+        } else if (phase == 0 && !no_fused) {
+            Timed t(ctx, "layer_round_fused", (pending ? (double)h * 2.0 * 6.0 : (double)h * 2.0 * 2.0) * 32.0 * batch);
+            nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, lb, s);
+            pending = nullptr;
+        } else {
+            if (pending) {
+                Timed t(ctx, "layer_fold", (double)h * 2.0 * 6.0 * 32.0 * batch);
+                gkr::launch_layer_fold(A, M, 2 * h, pending, lb, s);
+                pending = nullptr;
+            }
+            nblk = gkr::layer_blocks(h);
+            if (nblk * (uint32_t)batch > 4096u) nblk = 4096u / batch ? 4096u / batch : 1u;
+            Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0 * batch);
+            gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, lb, s);
+        }
+        if (host_tx) {
+            if (!published) {
+                const uint32_t ticket = ++ctx->ticket;
+                {
+                    Timed t(ctx, "layer_round_reduce", 0.0);
+                    gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, lb, s);
+                }
+                lap(t_launch);
+                rc = wait_records(ctx, rec, batch, ticket);
+                lap(t_wait);
+                if (rc) break;
+            }
+            // two sets of pinned tables used alternately: the deferred fold of round j reads set j % 2
+            // while the host already writes round j+1's
+            gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
+            const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
+            {
+                std::atomic<int> next{0};
+                const std::function<bool()> work = [&]() -> bool {
+                    const int first = next.fetch_add(chunk, std::memory_order_relaxed);
+                    if (first >= batch) return false;
+                    hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
+                    return true;
+                };
+                run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round));
+            }
+            lap(t_hash);
+            // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc); the linear-time
+            // round kernels fold W themselves with the pending challenge, except for the last b round, whose
+            // fold leaves the scalar W(u) the c-phase multiplies with
+            const bool fused_w = lin_b && (phase == 0 ? round + 1 < (uint32_t)k : k <= 13);
+            if (!fused_w) gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
+            pending = slot;
+        } else {
+            Timed t(ctx, "layer_round_hash", 0.0);
+            gkr::launch_layer_round_hash(partials, nblk, round, k, dep, ctx->d_cts, d_coeffs, d_len, d_r_out, d_rtab, Wb,
+                                         Wc, s);
+            pending = d_rtab + round;
+        }
+    }
+    session.close();
+    if (rc && shard && lin_b && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
+        (void)sum_over_ranks(A, M, wlen, nullptr, rc);   // the peers are waiting in the second exchange
+    if (dbg)
+        fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us; longest single step %.0f us (%s, round %d)\n",
+                k, batch, v, t_launch, t_wait, t_hash, worst_lap, worst_kind == 0 ? "launch" : (worst_kind == 1 ? "wait" : "hash"), worst_round);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (!host_tx) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_coeffs[0], d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_len[0], d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(out_r[0], d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (const int xr = xflag_check()) return xr;
+    ctx->drain_events();
+    return GKR_OK;
+}
+
+int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z,
+              const Fr* d_W, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    return run_layer_batch(ctx, 1, k_i, k, d_gt, d_l, d_r, z, d_W, &out_coeffs, &out_len, &out_r);
+}
+
+// evaluation table -> monomial coefficients, variable 1 = most significant bit
+
+}  // namespace gkr_host
+
+// =========================================================================== C ABI
+
+extern "C" {
+
+// ---- layer sumcheck / predicates / layer eval -------------------------------------
+
+static int upload_gates(gkr_ctx* ctx, size_t gates, const uint8_t* gt, const uint32_t* l, const uint32_t* r,
+                        DevBuf<uint8_t>& dgt, DevBuf<uint32_t>& dl, DevBuf<uint32_t>& dr) {
+    HIP_TRY(ctx, dgt.alloc(gates));
+    HIP_TRY(ctx, dl.alloc(gates));
+    HIP_TRY(ctx, dr.alloc(gates));
+    HIP_TRY(ctx, hipMemcpyAsync(dgt.p, gt, gates, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dl.p, l, gates * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dr.p, r, gates * 4, hipMemcpyHostToDevice, ctx->stream));
+    return GKR_OK;
+}
+
+static int check_layer_args(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gt, const uint32_t* l, const uint32_t* r,
+                            const gkr_fr* z) {
+    if (!gt || !l || !r || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT], k_i in [0, GKR_MAX_K_I]");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    // every gate is validated on the device by the scatter kernel; small layers are also checked here
+    // so that the error names the cause
+    const size_t gates = (size_t)1 << k_i;
+    for (size_t g = 0; g < gates && gates <= ((size_t)1 << 16); ++g) {
+        if (gt[g] > 1) return ctx->fail(GKR_ERR_INVALID, "gate_type must be 0 (add) or 1 (mult)");
+        if ((l[g] >> k_next) || (r[g] >> k_next)) return ctx->fail(GKR_ERR_INVALID, "gate operand index out of range");
+    }
+    return GKR_OK;
+}
+
+int gkr_sumcheck_layer(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_type, const uint32_t* left,
+                       const uint32_t* right, const gkr_fr* z, const gkr_fr* W, gkr_fr* out_coeffs, uint32_t* out_len,
+                       gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!W || !out_coeffs || !out_len || !out_r) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
+    if (rc) return rc;
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dW;
+    rc = upload_gates(ctx, (size_t)1 << k_i, gate_type, left, right, dgt, dl, dr);
+    if (rc) return rc;
+    HIP_TRY(ctx, dW.alloc((size_t)1 << k_next));
+    HIP_TRY(ctx, hipMemcpyAsync(dW.p, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
+    return run_layer(ctx, k_i, k_next, dgt.p, dl.p, dr.p, z, dW.p, out_coeffs, out_len, out_r);
+}
+
+int gkr_sumcheck_layer_sharded(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
+                               const uint8_t* gate_type, const uint32_t* left, const uint32_t* right, const gkr_fr* z,
+                               const gkr_fr* W, gkr_allreduce_fn allreduce, void* user, gkr_fr* out_coeffs, uint32_t* out_len,
+                               gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!W || !out_coeffs || !out_len || !out_r || !allreduce || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (gate_count && (!gate_type || !left || !right)) return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > kMaxLayerK) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT]");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    // gates are validated on the device (k_gate_count); a bad one fails every rank through the first exchange
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dW;
+    const size_t n_alloc = gate_count ? (size_t)gate_count : 1;
+    HIP_TRY(ctx, dgt.alloc(n_alloc));
+    HIP_TRY(ctx, dl.alloc(n_alloc));
+    HIP_TRY(ctx, dr.alloc(n_alloc));
+    if (gate_count) {
+        HIP_TRY(ctx, hipMemcpyAsync(dgt.p, gate_type, gate_count, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dl.p, left, gate_count * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dr.p, right, gate_count * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, dW.alloc((size_t)1 << k_next));
+    HIP_TRY(ctx, hipMemcpyAsync(dW.p, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
+    LayerShardArgs sh;
+    sh.gate_base = gate_first;
+    sh.gate_count = gate_count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    return run_layer_batch(ctx, 1, k_i, k_next, dgt.p, dl.p, dr.p, z, dW.p, &out_coeffs, &out_len, &out_r, &sh);
+}
+
+int gkr_sumcheck_layer_device(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count, const void* d_gate_type,
+                              const void* d_left, const void* d_right, const gkr_fr* z, const gkr_fr* W, gkr_allreduce_fn allreduce,
+                              void* user, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!W || !out_coeffs || !out_len || !out_r || (k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    if (!d_gate_type || !d_left || !d_right) return ctx->fail(GKR_ERR_INVALID, "null device gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > (allreduce ? 13 : 14)) return ctx->fail(GKR_ERR_INVALID, "k_next out of range");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    if (!allreduce && (gate_first != 0 || gate_count != ((uint64_t)1 << k_i)))
+        return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the arrays must hold the whole layer");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k_next, reinterpret_cast<void**>(&dW)));
+    HIP_TRY(ctx, hipMemcpyAsync(dW, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t* gt = static_cast<const uint8_t*>(d_gate_type);
+    const uint32_t* dl = static_cast<const uint32_t*>(d_left);
+    const uint32_t* dr = static_cast<const uint32_t*>(d_right);
+    if (!allreduce) return run_layer(ctx, k_i, k_next, gt, dl, dr, z, dW, out_coeffs, out_len, out_r);
+    LayerShardArgs sh;
+    sh.gate_base = gate_first;
+    sh.gate_count = gate_count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    return run_layer_batch(ctx, 1, k_i, k_next, gt, dl, dr, z, dW, &out_coeffs, &out_len, &out_r, &sh);
+}
+
+struct gkr_resident_layer {
+    int k_i = 0, k = 0;
+    uint64_t first = 0, count = 0;
+    uint8_t* gt = nullptr;
+    uint32_t *l = nullptr, *r = nullptr;
+    GateLists lists;
+};
+
+void gkr_resident_layer_free(gkr_ctx* ctx, gkr_resident_layer* layer) {
+    if (!layer) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (layer->gt) (void)hipFree(layer->gt);
+    if (layer->l) (void)hipFree(layer->l);
+    if (layer->r) (void)hipFree(layer->r);
+    layer->lists.release();
+    delete layer;
+}
+
+int gkr_resident_layer_create(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count, const uint8_t* gate_type,
+                              const uint32_t* left, const uint32_t* right, gkr_resident_layer** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!out) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    if ((!gate_type || !left || !right) && gate_count) return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    if (k_i < 0 || k_i > 28) return ctx->fail(GKR_ERR_INVALID, "k_i must be in [0, 28]");
+    if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
+    if (k_next < 0 || k_next > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT], k_i in [0, GKR_MAX_K_I]");
+    if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<gkr_resident_layer, void (*)(gkr_resident_layer*)> L(new gkr_resident_layer(), [](gkr_resident_layer* p) {
+        gkr_resident_layer_free(nullptr, p);
+    });
+    L->k_i = k_i;
+    L->k = k_next;
+    L->first = gate_first;
+    L->count = gate_count;
+    const size_t n = gate_count ? (size_t)gate_count : 1;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->gt), n));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->l), n * 4));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&L->r), n * 4));
+    if (gate_count) {
+        HIP_TRY(ctx, hipMemcpy(L->gt, gate_type, gate_count, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(L->l, left, gate_count * 4, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(L->r, right, gate_count * 4, hipMemcpyHostToDevice));
+    }
+    *out = L.release();
+    return GKR_OK;
+}
+
+int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const gkr_fr* W, gkr_allreduce_fn allreduce,
+                                void* user, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    const int k_i = layer->k_i, k = layer->k;
+    if (!allreduce && (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)))
+        return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the layer must be whole");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
+    gkr_fr* hW = nullptr;   // through pinned memory and a copy kernel (no transfer call on the path, see k_copy_words)
+    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
+    memcpy(hW, W, sizeof(gkr_fr) << k);
+    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    LayerShardArgs sh;
+    sh.gate_base = layer->first;
+    sh.gate_count = layer->count;
+    sh.allreduce = allreduce;
+    sh.user = user;
+    const int rc = run_layer_batch(ctx, 1, k_i, k, layer->gt, layer->l, layer->r, z, dW, &out_coeffs, &out_len, &out_r, allreduce ? &sh : nullptr,
+                                   &layer->lists);
+    if (rc) {   // a failed first use may have left half-built lists behind
+        layer->lists.ready = false;
+    }
+    return rc;
+}
+
+size_t gkr_exchange_limbs(int k_next) {
+    if (k_next < 0 || k_next > kMaxLayerK) return 0;
+    return (((size_t)2 << k_next) + 1) * 8;
+}
+
+int gkr_resident_layer_sumcheck_dev(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const gkr_fr* W, const gkr_exchange_dev* exchange,
+                                    gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z) || !exchange) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    const int k_i = layer->k_i, k = layer->k;
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
+    gkr_fr* hW = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
+    memcpy(hW, W, sizeof(gkr_fr) << k);
+    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    LayerShardArgs sh;
+    sh.gate_base = layer->first;
+    sh.gate_count = layer->count;
+    sh.dev = exchange;
+    const int rc = run_layer_batch(ctx, 1, k_i, k, layer->gt, layer->l, layer->r, z, dW, &out_coeffs, &out_len, &out_r, &sh, &layer->lists);
+    if (rc) layer->lists.ready = false;
+    return rc;
+}
+
+int gkr_fr_widen(const gkr_fr* values, size_t count, int64_t* limbs) {
+    if ((!values || !limbs) && count) return GKR_ERR_INVALID;
+    for (size_t i = 0; i < count; ++i)
+        for (int j = 0; j < 4; ++j) {
+            limbs[8 * i + 2 * j] = (int64_t)(values[i].l[j] & 0xffffffffull);
+            limbs[8 * i + 2 * j + 1] = (int64_t)(values[i].l[j] >> 32);
+        }
+    return GKR_OK;
+}
+
+int gkr_fr_narrow(const int64_t* limbs, size_t count, gkr_fr* values) {
+    if ((!values || !limbs) && count) return GKR_ERR_INVALID;
+    for (size_t i = 0; i < count; ++i) {
+        gkr::Acc<10> a = gkr::acc_zero<10>();
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; ++j) {
+            if (limbs[8 * i + j] < 0) return GKR_ERR_INVALID;
+            const uint64_t w = (uint64_t)limbs[8 * i + j];
+            const uint64_t lo = (w & 0xffffffffull) + (carry & 0xffffffffull);
+            a.l[j] = (uint32_t)lo;
+            carry = (w >> 32) + (carry >> 32) + (lo >> 32);
+        }
+        a.l[8] = (uint32_t)carry;
+        a.l[9] = (uint32_t)(carry >> 32);
+        values[i] = to_abi(gkr::acc_reduce(a));
+    }
+    return GKR_OK;
+}
+
+int gkr_predicate_tables(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_type, const uint32_t* left,
+                         const uint32_t* right, const gkr_fr* z, gkr_fr* out_A, gkr_fr* out_M) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!out_A || !out_M) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)1 << (2 * k_next);
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> A, M;
+    rc = upload_gates(ctx, (size_t)1 << k_i, gate_type, left, right, dgt, dl, dr);
+    if (rc) return rc;
+    HIP_TRY(ctx, A.alloc(N));
+    HIP_TRY(ctx, M.alloc(N));
+    rc = build_predicates(ctx, k_i, k_next, dgt.p, dl.p, dr.p, z, A.p, M.p);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_A, A.p, N * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_M, M.p, N * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->drain_events();
+    return GKR_OK;
+}
+
+int gkr_layer_eval(gkr_ctx* ctx, size_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
+                   const gkr_fr* prev, size_t n_prev, gkr_fr* out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!gate_type || !left || !right || !prev || !out || !gates || !n_prev || gates > ((size_t)1 << 30))
+        return ctx->fail(GKR_ERR_INVALID, "null pointer or empty layer");
+    for (size_t g = 0; g < gates; ++g)
+        if (gate_type[g] > 1 || left[g] >= n_prev || right[g] >= n_prev)
+            return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+    if (!all_canonical(prev, n_prev)) return ctx->fail(GKR_ERR_NON_CANONICAL, "prev entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dprev, dout;
+    int rc = upload_gates(ctx, gates, gate_type, left, right, dgt, dl, dr);
+    if (rc) return rc;
+    HIP_TRY(ctx, dprev.alloc(n_prev));
+    HIP_TRY(ctx, dout.alloc(gates));
+    HIP_TRY(ctx, hipMemcpyAsync(dprev.p, prev, n_prev * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    gkr::launch_layer_eval((uint32_t)gates, dgt.p, dl.p, dr.p, dprev.p, dout.p, 1, 0, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, gates * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GKR_OK;
+}
+
+// ---- step-wise sessions: one sumcheck split across GPUs ------------------------
+//
+// The hypercube is partitioned by its TRAILING log2(P) variables: rank p owns the entries whose
+// low index bits are p.  Rounds bind the LEADING variable, so both members of every pair live on
+// the same rank for the first v - log2(P) rounds; each round every rank produces partial sums, one
+// tiny all-reduce (<= 96 bytes of field elements) gives every rank the round polynomial, every
+// rank derives the same challenge and folds its shard.  The library does the table work per rank;
+// the collective and the transcript sit in the caller (gkr_amd/parallel.py: torch.distributed over
+// RCCL, or gloo in the CPU tests).  P = 1 is the whole sumcheck with an external transcript.
+
+struct gkr_layer_session {
+    int k = 0, kc = 0;          // W has 2^k entries; this shard's column index has kc = k - log2(P) bits
+    uint32_t round = 0, rounds = 0;
+    size_t cells = 0;           // current entries per table half pair (A, M each)
+    Fr *A = nullptr, *M = nullptr, *Wb = nullptr, *Wc = nullptr;
+    gkr::LayerPartial* partials = nullptr;
+    uint32_t* d_dep = nullptr;
+    uint32_t dep[32] = {0};
+    gkr::LayerHostRec* rec = nullptr;
+    gkr::FixedMul* rtab = nullptr;   // pinned
+};
+
+
+static void free_layer_session(gkr_layer_session* s) {
+    if (!s) return;
+    if (s->A) (void)hipFree(s->A);
+    if (s->M) (void)hipFree(s->M);
+    if (s->Wb) (void)hipFree(s->Wb);
+    if (s->Wc) (void)hipFree(s->Wc);
+    if (s->partials) (void)hipFree(s->partials);
+    if (s->d_dep) (void)hipFree(s->d_dep);
+    if (s->rec) (void)hipHostFree(s->rec);
+    if (s->rtab) (void)hipHostFree(s->rtab);
+    delete s;
+}
+
+static int alloc_layer_session(gkr_ctx* ctx, gkr_layer_session* S, size_t cells, size_t wb, size_t wc) {
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->A), cells * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->M), cells * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->Wb), wb * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->Wc), wc * sizeof(Fr)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->partials), gkr::kMaxLayerBlocks * sizeof(gkr::LayerPartial)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&S->d_dep), 32 * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&S->rec), sizeof(gkr::LayerHostRec), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&S->rtab), sizeof(gkr::FixedMul), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(S->rec, 0, sizeof(gkr::LayerHostRec));
+    return GKR_OK;
+}
+
+int gkr_layer_session_open(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_type, const uint32_t* left,
+                           const uint32_t* right, const gkr_fr* z, const gkr_fr* W, uint32_t nshards, uint32_t shard,
+                           gkr_layer_session** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!out || !W) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
+    if (rc) return rc;
+    uint32_t log_p = 0;
+    while ((1u << log_p) < nshards) ++log_p;
+    if (nshards == 0 || (1u << log_p) != nshards || (int)log_p > k_next || shard >= nshards)
+        return ctx->fail(GKR_ERR_INVALID, "shard count must be a power of two <= 2^k_next and shard < count");
+    if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr_layer_session* S = new gkr_layer_session();
+    S->k = k_next;
+    S->kc = k_next - (int)log_p;
+    S->rounds = (uint32_t)(2 * k_next) - log_p;
+    S->cells = (size_t)1 << (2 * k_next - log_p);
+    DevBuf<uint8_t> dgt;
+    DevBuf<uint32_t> dl, dr;
+    DevBuf<Fr> dW;
+    rc = alloc_layer_session(ctx, S, S->cells, (size_t)1 << k_next, (size_t)1 << S->kc);
+    if (!rc) rc = upload_gates(ctx, (size_t)1 << k_i, gate_type, left, right, dgt, dl, dr);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    hipError_t e = dW.alloc((size_t)1 << k_next);
+    if (e == hipSuccess) e = hipMemcpyAsync(dW.p, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "upload W");
+    }
+    rc = build_predicates(ctx, k_i, k_next, dgt.p, dl.p, dr.p, z, S->A, S->M, log_p, shard);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    (void)hipMemsetAsync(S->d_dep, 0, 32 * sizeof(uint32_t), s);
+    gkr::launch_to_mont(dW.p, S->Wb, 1u << k_next, s);
+    gkr::launch_to_mont_strided(dW.p, S->Wc, 1u << S->kc, nshards, shard, s);
+    gkr::launch_depends(dW.p, k_next, S->d_dep, 1, s);
+    e = hipMemcpyAsync(S->dep, S->d_dep, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "layer session setup");
+    }
+    *out = S;
+    return GKR_OK;
+}
+
+// the redundant tail after the all-gather: explicit tables of 2^kc entries (A, M, Wc) and the scalar W(b*)
+int gkr_layer_session_open_tables(gkr_ctx* ctx, int kc, const gkr_fr* A, const gkr_fr* M, const gkr_fr* wb,
+                                  const gkr_fr* Wc, gkr_layer_session** out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!A || !M || !wb || !Wc || !out || kc < 1 || kc > 14) return ctx->fail(GKR_ERR_INVALID, "bad tail tables");
+    const size_t n = (size_t)1 << kc;
+    if (!all_canonical(A, n) || !all_canonical(M, n) || !all_canonical(Wc, n) || !all_canonical(wb, 1))
+        return ctx->fail(GKR_ERR_NON_CANONICAL, "tail table entry >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr_layer_session* S = new gkr_layer_session();
+    S->k = kc;           // only c-variables remain: phase 1 from the first round
+    S->kc = kc;
+    S->round = (uint32_t)kc;   // counts as if k = kc b-rounds were already done
+    S->rounds = (uint32_t)(2 * kc);
+    S->cells = n;
+    int rc = alloc_layer_session(ctx, S, n, 1, n);
+    if (rc) {
+        free_layer_session(S);
+        return rc;
+    }
+    // W copies are kept in Montgomery form
+    std::vector<Fr> wcm(n);
+    for (size_t i = 0; i < n; ++i) wcm[i] = gkr::to_mont(to_dev(Wc[i]));
+    Fr wbm = gkr::to_mont(to_dev(*wb));
+    hipError_t e = hipMemcpyAsync(S->A, A, n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->M, M, n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->Wc, wcm.data(), n * sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->Wb, &wbm, sizeof(Fr), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        free_layer_session(S);
+        return ctx->hip_fail(e, "tail session upload");
+    }
+    *out = S;
+    return GKR_OK;
+}
+
+int gkr_layer_session_dep(gkr_ctx* ctx, const gkr_layer_session* S, uint32_t* out_dep, uint32_t count) {
+    if (!ctx || !S || !out_dep || count > 32) return GKR_ERR_INVALID;
+    for (uint32_t i = 0; i < count; ++i) out_dep[i] = S->dep[i];
+    return GKR_OK;
+}
+
+int gkr_layer_session_rounds(const gkr_layer_session* S, uint32_t* done, uint32_t* total) {
+    if (!S) return GKR_ERR_INVALID;
+    if (done) *done = S->round;
+    if (total) *total = S->rounds;
+    return GKR_OK;
+}
+
+// partial sums of the current round over this shard: out = {c0, g(1), c2}, canonical
+int gkr_layer_session_sums(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t h = (uint32_t)(S->cells / 2);
+    const uint32_t phase = S->round < (uint32_t)S->k ? 0u : 1u;
+    const uint32_t hb = phase == 0 ? (h >> S->kc) : 0u;
+    const uint32_t nblk = gkr::layer_blocks(h);
+    gkr::launch_layer_round(S->A, S->M, h, (uint32_t)S->kc, phase, hb, S->Wb, S->Wc, nblk, S->partials, gkr::single_layer(), s);
+    const uint32_t ticket = ++ctx->ticket;
+    gkr::launch_layer_round_reduce(S->partials, nblk, S->rec, ticket, gkr::single_layer(), s);
+    HIP_TRY(ctx, hipGetLastError());
+    int rc = wait_records(ctx, S->rec, 1, ticket);
+    if (rc) return rc;
+    memcpy(&out[0], &S->rec->c0, 32);
+    memcpy(&out[1], &S->rec->g1, 32);
+    memcpy(&out[2], &S->rec->c2, 32);
+    return GKR_OK;
+}
+
+// bind the current variable to r
+int gkr_layer_session_bind(gkr_ctx* ctx, gkr_layer_session* S, const gkr_fr* r) {
+    if (!ctx || !S || !r) return GKR_ERR_INVALID;
+    if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
+    if (!all_canonical(r, 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "r >= modulus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gkr::h64::F r64;
+    memcpy(&r64, r, 32);
+    gkr::h64::make_fixed_mul(r64, S->rtab->w);
+    const uint32_t h = (uint32_t)(S->cells / 2);
+    const bool bphase = S->round < (uint32_t)S->k;
+    // the W copy bound in this round: b-rounds fold Wb (2^k entries at the start), c-rounds fold Wc
+    const uint32_t idx = bphase ? S->round : S->round - (uint32_t)S->k;
+    const uint32_t hw = bphase ? (1u << (S->k - 1 - idx)) : (1u << (S->kc - 1 - idx));
+    gkr::launch_fold_small(bphase ? S->Wb : S->Wc, hw, S->rtab, gkr::single_layer(), s);
+    gkr::launch_layer_fold(S->A, S->M, h, S->rtab, gkr::single_layer(), s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // rtab is reused by the next bind
+    S->cells = h;
+    S->round += 1;
+    return GKR_OK;
+}
+
+// when every local round is done: out = {A, M, Wc (canonical), W(b*) (canonical)} of this shard
+int gkr_layer_session_tail(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
+    if (!ctx || !S || !out) return GKR_ERR_INVALID;
+    if (S->round != S->rounds || S->cells != 1) return ctx->fail(GKR_ERR_INVALID, "session still has rounds to run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Fr a, m, wc, wb;
+    HIP_TRY(ctx, hipMemcpyAsync(&a, S->A, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&m, S->M, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&wc, S->Wc, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&wb, S->Wb, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    out[0] = to_abi(a);
+    out[1] = to_abi(m);
+    out[2] = to_abi(gkr::from_mont(wc));
+    out[3] = to_abi(gkr::from_mont(wb));
+    return GKR_OK;
+}
+
+void gkr_layer_session_close(gkr_ctx* ctx, gkr_layer_session* S) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    free_layer_session(S);
+}
+
+
+}  // extern "C"

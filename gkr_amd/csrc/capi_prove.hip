@@ -1,0 +1,612 @@
+// Whole proofs (prover::prove, rust/src/gkr/prover.rs:6-96; its par_iter, aggregator.rs:350-355): gkr_prove / _batch / _many, the
+// line restriction's host twin, the Moebius transform, circuit checks.  C ABI: include/gkr_amd.h.
+#include "capi_internal.h"
+
+namespace gkr_host {
+
+void mobius_msb(std::vector<gkr::h64::F>& c, int k) {
+    const size_t n = (size_t)1 << k;
+    for (int b = 0; b < k; ++b) {
+        const size_t bit = (size_t)1 << (k - 1 - b);
+        for (size_t i = 0; i < n; ++i)
+            if (i & bit) c[i] = gkr::h64::sub(c[i], c[i ^ bit]);
+    }
+}
+
+// reduce_multiple_polynomial (poly.rs:469-500): q(t) = W(b + t (c - b)).
+// vals: the evaluation table of W (canonical); coeffs: its monomial coefficients (only their support is used).
+// out: k+1 slots right-aligned, highest first; *out_len = 1 + the largest total degree of a non-zero monomial of W
+// (:484-497).  The reference expands every monomial along the line (2^k products of up to k linear factors); the
+// same polynomial comes out of binding the variables one after the other on the evaluation table with the linear
+// polynomial l_j(t) = b_j + t (c_j - b_j) in place of a challenge:
+//     P'[i](t) = P[i](t) + l_j(t) (P[i + h](t) - P[i](t)),
+// entries being coefficient vectors in t whose degree grows by one per variable -- about 4 * 2^k products instead
+// of ~k^2 * 2^(k-1), and the coefficients above the largest monomial degree come out as the zeros they are.
+void line_restriction(const std::vector<gkr::h64::F>& vals, const std::vector<gkr::h64::F>& coeffs, int k, const gkr_fr* b,
+                      const gkr_fr* c, gkr_fr* out, uint32_t* out_len) {
+    using gkr::h64::F;
+    const F zero = {{0, 0, 0, 0}};
+    int maxdeg = 0;
+    const size_t n = (size_t)1 << k;
+    for (size_t mono = 0; mono < n; ++mono)
+        if (!gkr::h64::is_zero(coeffs[mono])) {
+            const int deg = __builtin_popcountll((unsigned long long)mono);
+            if (deg > maxdeg) maxdeg = deg;
+        }
+    // table of polynomials, stride k + 1 coefficients (lowest degree first); canonical values, Montgomery multipliers
+    const size_t stride = (size_t)k + 1;
+    std::vector<F> tab(n * stride, zero);
+    for (size_t i = 0; i < n; ++i) tab[i * stride] = vals[i];
+    size_t h = n >> 1;
+    for (int j = 0; j < k; ++j, h >>= 1) {
+        F bj, cj;
+        memcpy(&bj, &b[j], 32);
+        memcpy(&cj, &c[j], 32);
+        const F grad = gkr::h64::to_mont(gkr::h64::sub(cj, bj)), cst = gkr::h64::to_mont(bj);
+        for (size_t i = 0; i < h; ++i) {
+            F* lo = &tab[i * stride];
+            const F* hi = &tab[(i + h) * stride];
+            F carry = zero;   // grad * d[m - 1]
+            for (int m = 0; m <= j + 1; ++m) {
+                const F d = m <= j ? gkr::h64::sub(hi[m], lo[m]) : zero;
+                const F v = gkr::h64::add(gkr::h64::add(m <= j ? lo[m] : zero, gkr::h64::mont_mul(d, cst)), carry);
+                carry = gkr::h64::mont_mul(d, grad);
+                lo[m] = v;
+            }
+        }
+    }
+    *out_len = (uint32_t)(maxdeg + 1);
+    for (int d = 0; d <= k; ++d) memcpy(&out[k - d], &tab[d], 32);
+}
+
+int check_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c) {
+    if (!c || !c->k || c->depth < 1 || !c->gate_type || !c->left || !c->right)
+        return ctx ? ctx->fail(GKR_ERR_INVALID, "null circuit description") : GKR_ERR_INVALID;
+    if (c->k[0] > (uint32_t)kMaxLayerKi) return ctx ? ctx->fail(GKR_ERR_INVALID, "output layer wider than 2^GKR_MAX_K_I") : GKR_ERR_INVALID;
+    for (uint32_t i = 1; i <= c->depth; ++i) {
+        if (c->k[i] == 0) return ctx ? ctx->fail(GKR_ERR_DEGENERATE, "k[i+1] == 0: v = 0 (sumcheck.rs:49)") : GKR_ERR_DEGENERATE;
+        if (c->k[i] > (uint32_t)kMaxLayerK)
+            return ctx ? ctx->fail(GKR_ERR_INVALID, "layer of more than 2^GKR_MAX_K_NEXT values (gkr_amd.h, limits)") : GKR_ERR_INVALID;
+        if (ctx && ctx->transcript != GKR_TRANSCRIPT_HOST && c->k[i] > (uint32_t)kMaxDenseK)
+            return ctx->fail(GKR_ERR_INVALID, "the device transcript needs k[i+1] <= GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT (dense predicate tables)");
+    }
+    return GKR_OK;
+}
+
+}  // namespace gkr_host
+
+// =========================================================================== C ABI
+
+extern "C" {
+
+// ---- full proof ---------------------------------------------------------------------
+
+int gkr_proof_sizes(const gkr_circuit_desc* c, gkr_proof_sizes_t* out) {
+    if (!out) return GKR_ERR_INVALID;
+    int rc = check_circuit(nullptr, c);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    for (uint32_t i = 0; i < c->depth; ++i) {
+        out->rounds += 2 * (size_t)c->k[i + 1];
+        out->q_slots += (size_t)c->k[i + 1] + 1;
+    }
+    for (uint32_t i = 0; i <= c->depth; ++i) out->z_values += c->k[i];
+    out->d_coeffs = (size_t)1 << c->k[0];
+    out->input_coeffs = (size_t)1 << c->k[c->depth];
+    return GKR_OK;
+}
+
+// `batch` proofs of ONE circuit (different witnesses) advanced together: every layer's sumcheck runs as
+// one batched sumcheck (run_layer_batch), so a round costs one set of launches and one host round trip
+// for all proofs.  This is the multi-proof form of the reference's rayon par_iter over independent
+// (circuit, input) pairs (aggregator.rs:350-355) for the case where the circuits coincide
+// (BASELINE configs[3]: 64 inputs of one circom circuit).
+static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch,
+                            int require_zero_output, gkr_proof_buf* outs) {
+    using gkr::h64::F;
+    const auto t_entry = std::chrono::steady_clock::now();
+    int rc = check_circuit(ctx, c);
+    if (rc) return rc;
+    if (!input_values || !outs || batch < 1 || batch > 4096) return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of [1, 4096]");
+    for (int b = 0; b < batch; ++b) {
+        const gkr_proof_buf* out = &outs[b];
+        if (!out->sumcheck_coeffs || !out->sumcheck_len || !out->sumcheck_r || !out->q || !out->q_len || !out->z || !out->r ||
+            !out->d_coeffs || !out->input_coeffs)
+            return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
+    }
+    const uint32_t L = c->depth;
+    for (uint32_t i = 0; i < L; ++i)
+        if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    const size_t n_in = (size_t)1 << c->k[L];
+    if (!all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    // the circuit on the device: from the context's cache when this circuit was proven before (two independent
+    // 64-bit hashes over the k list and the gate arrays decide), else validated, uploaded and remembered
+    uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x9E3779B97F4A7C15ULL;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* q = static_cast<const unsigned char*>(p);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, q + i, 8);
+            h1 = (h1 ^ w) * 0x100000001b3ULL;
+            h2 = (h2 + w) * 0xBF58476D1CE4E5B9ULL;
+            h2 ^= h2 >> 29;
+        }
+        for (; i < n; ++i) {
+            h1 = (h1 ^ q[i]) * 0x100000001b3ULL;
+            h2 = (h2 + q[i]) * 0x94D049BB133111EBULL;
+        }
+    };
+    mix(&L, sizeof L);
+    mix(c->k, (L + 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < L; ++i) {
+        const size_t gates = (size_t)1 << c->k[i];
+        mix(c->gate_type[i], gates);
+        mix(c->left[i], gates * 4);
+        mix(c->right[i], gates * 4);
+    }
+    PreparedCircuit* pc = nullptr;
+    for (size_t i = 0; i < ctx->circuits.size(); ++i)
+        if (ctx->circuits[i]->h1 == h1 && ctx->circuits[i]->h2 == h2 && ctx->circuits[i]->k.size() == L + 1 &&
+            memcmp(ctx->circuits[i]->k.data(), c->k, (L + 1) * sizeof(uint32_t)) == 0) {
+            std::unique_ptr<PreparedCircuit> hit = std::move(ctx->circuits[i]);
+            ctx->circuits.erase(ctx->circuits.begin() + i);
+            ctx->circuits.push_back(std::move(hit));   // most recently used last
+            pc = ctx->circuits.back().get();
+            break;
+        }
+    static const bool no_cache = getenv("GKR_NO_CIRCUIT_CACHE") != nullptr;
+    std::unique_ptr<PreparedCircuit> fresh;
+    struct DropFresh {   // an uncached or failed circuit's device arrays do not outlive the call
+        gkr_ctx* ctx;
+        std::unique_ptr<PreparedCircuit>& p;
+        ~DropFresh() {
+            if (p) {
+                (void)hipStreamSynchronize(ctx->stream);
+                p->release();
+            }
+        }
+    } drop_fresh{ctx, fresh};
+    if (!pc) {
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t gates = (size_t)1 << c->k[i];
+            for (size_t g = 0; g < gates; ++g)
+                if (c->gate_type[i][g] > 1 || (c->left[i][g] >> c->k[i + 1]) || (c->right[i][g] >> c->k[i + 1]))
+                    return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+        }
+        fresh.reset(new PreparedCircuit());
+        fresh->h1 = h1;
+        fresh->h2 = h2;
+        fresh->k.assign(c->k, c->k + L + 1);
+        fresh->lists.resize(L);
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t gates = (size_t)1 << c->k[i];
+            uint8_t* dg = nullptr;
+            uint32_t *dl_ = nullptr, *dr_ = nullptr;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dg), gates));
+            fresh->gt.push_back(dg);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dl_), gates * 4));
+            fresh->l.push_back(dl_);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dr_), gates * 4));
+            fresh->r.push_back(dr_);
+            HIP_TRY(ctx, hipMemcpyAsync(dg, c->gate_type[i], gates, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(dl_, c->left[i], gates * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(dr_, c->right[i], gates * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(s));   // the caller's gate arrays may go away after the call
+        pc = fresh.get();
+    }
+
+    // forward-evaluate every layer of every proof on the device (calculate_input, convert.rs:787-831)
+    std::vector<Fr*> dW(L + 1, nullptr);
+    for (uint32_t i = 0; i <= L; ++i) {
+        const std::string slot = "prove.W" + std::to_string(i);
+        HIP_TRY(ctx, ctx->workspace(slot.c_str(), ((size_t)batch << c->k[i]) * sizeof(Fr), reinterpret_cast<void**>(&dW[i])));
+    }
+    // Small transfers go through pinned buffers and a copy kernel, not through the runtime's transfer calls (see
+    // k_copy_words); large ones (a 2^20-value input layer) keep the copy engine's bandwidth.
+    constexpr size_t kKernelCopyLimit = (size_t)4 << 20;
+    const size_t in_bytes = n_in * batch * sizeof(Fr);
+    if (in_bytes <= kKernelCopyLimit) {
+        gkr_fr* h_in = nullptr;
+        HIP_TRY(ctx, ctx->pinned_host("prove.in", in_bytes, reinterpret_cast<void**>(&h_in)));
+        memcpy(h_in, input_values, in_bytes);
+        gkr::launch_copy_words(h_in, dW[L], in_bytes / 4, s);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, in_bytes, hipMemcpyHostToDevice, s));
+    }
+    for (int i = (int)L - 1; i >= 0; --i)
+        gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s);
+    HIP_TRY(ctx, hipGetLastError());
+    // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
+    const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
+    std::vector<F> hW_big[2];
+    // d and input_func are the monomial forms of W_0 and W_L (get_multi_ext, poly.rs:502-536): tables beyond 2^12 values are
+    // transformed on the device (k launches over a grid) and land in the proof buffers directly; small ones on the host
+    constexpr uint32_t kDeviceMobiusMinK = 13;
+    bool coeffs_done[2] = {false, false};
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t i = e ? L : 0;
+        if (c->k[i] < kDeviceMobiusMinK) continue;
+        const size_t n = (size_t)1 << c->k[i];
+        Fr* mono = nullptr;
+        HIP_TRY(ctx, ctx->workspace(e ? "prove.monoL" : "prove.mono0", n * batch * sizeof(Fr), reinterpret_cast<void**>(&mono)));
+        HIP_TRY(ctx, hipMemcpyAsync(mono, dW[i], n * batch * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+        gkr::launch_mobius(mono, c->k[i], n, (uint32_t)batch, s);
+        for (int b = 0; b < batch; ++b)
+            HIP_TRY(ctx, hipMemcpyAsync(e ? outs[b].input_coeffs : outs[b].d_coeffs, mono + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        coeffs_done[e] = true;
+    }
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t i = e ? L : 0;
+        const size_t bytes = ((size_t)batch << c->k[i]) * sizeof(Fr);
+        if (coeffs_done[e] && e == 1) continue;   // (W_0 is still read below: output 0 must be zero)
+        if (bytes <= kKernelCopyLimit) {
+            F* dst = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host(e ? "prove.hWL" : "prove.hW0", bytes, reinterpret_cast<void**>(&dst)));
+            gkr::launch_copy_words(dW[i], dst, bytes / 4, s);
+            hW[e] = dst;
+        } else {
+            hW_big[e].resize((size_t)batch << c->k[i]);
+            HIP_TRY(ctx, hipMemcpyAsync(hW_big[e].data(), dW[i], bytes, hipMemcpyDeviceToHost, s));
+            hW[e] = hW_big[e].data();
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const auto tpb0 = std::chrono::steady_clock::now();
+    if (dbg_pb) t_account = ThreadTimeAccount();
+    if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
+    for (int b = 0; b < batch; ++b) {
+        if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
+            return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
+        // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
+        std::vector<F> co;
+        if (!coeffs_done[0]) {
+            co.assign(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
+            mobius_msb(co, c->k[0]);
+            memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
+        }
+        if (!coeffs_done[1]) {
+            co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
+            mobius_msb(co, c->k[L]);
+            memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
+        }
+        // z[0] = 0 (prover.rs:16-21)
+        for (uint32_t j = 0; j < c->k[0]; ++j) memset(&outs[b].z[j], 0, sizeof(gkr_fr));
+    }
+    std::vector<gkr_fr> z_cur((size_t)batch * (c->k[0] ? c->k[0] : 1));
+    memset(z_cur.data(), 0, z_cur.size() * sizeof(gkr_fr));
+    std::vector<gkr_fr*> scp(batch), srp(batch);
+    std::vector<uint32_t*> slp(batch);
+    size_t row_off = 0, q_off = 0, z_off = 0;
+    gkr::SpinPool* pool = batch >= 16 ? ctx->host_pool() : nullptr;
+    // q_i (W_{i+1} on the line b* -> c*, prover.rs:70) is output only -- nothing later in the proof depends on it -- so
+    // it is computed on the side stream while the next layers' sumchecks run, and read back once at the end
+    uint32_t kmax = 0;
+    size_t q_total = 0;
+    for (uint32_t i = 1; i <= L; ++i) {
+        kmax = c->k[i] > kmax ? c->k[i] : kmax;
+        q_total += (size_t)c->k[i] + 1;
+    }
+    gkr_fr* h_lines = nullptr;   // pinned: per layer and proof b*_1..b*_k, c*_1..c*_k; the kernel reads it in place
+    Fr *d_q = nullptr, *d_lr = nullptr;
+    uint32_t* d_qlen = nullptr;
+    HIP_TRY(ctx, ctx->pinned_host("prove.lines", (size_t)L * batch * 2 * kmax * sizeof(gkr_fr), reinterpret_cast<void**>(&h_lines)));
+    // (the kernel stores q and its length straight into pinned host memory: read after the side stream's last kernel)
+    HIP_TRY(ctx, ctx->pinned_host("prove.q", q_total * batch * sizeof(Fr), reinterpret_cast<void**>(&d_q)));
+    HIP_TRY(ctx, ctx->pinned_host("prove.qlen", (size_t)L * batch * sizeof(uint32_t), reinterpret_cast<void**>(&d_qlen)));
+    WS(ctx, "prove.lr", Fr, (size_t)batch * 3 * ((size_t)1 << kmax), d_lr);
+    uint32_t* d_lrdeg = nullptr;
+    WS(ctx, "prove.lrdeg", uint32_t, (size_t)batch, d_lrdeg);
+    HIP_TRY(ctx, ctx->aux_stream(0));
+    for (uint32_t i = 0; i < L; ++i) {
+        const int k_i = c->k[i], k = c->k[i + 1];
+        for (int b = 0; b < batch; ++b) {
+            scp[b] = outs[b].sumcheck_coeffs + row_off * 3;
+            slp[b] = outs[b].sumcheck_len + row_off;
+            srp[b] = outs[b].sumcheck_r + row_off;
+        }
+        const auto tl0 = std::chrono::steady_clock::now();
+        ctx->rounds_ahead = 0;
+        for (uint32_t later = i + 1; later < L; ++later) ctx->rounds_ahead += 2 * (int)c->k[later + 1];
+        rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
+                             srp.data(), nullptr, &pc->lists[i]);
+        ctx->rounds_ahead = 0;
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->aux);   // earlier layers' line restrictions still write the pinned q buffers the next call reuses
+            return rc;
+        }
+        const auto tl1 = std::chrono::steady_clock::now();
+        std::vector<gkr_fr> z_next((size_t)batch * k);
+        {
+            gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
+            for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
+            Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
+            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, d_q + q_off * batch,
+                                         d_qlen + (size_t)i * batch, (uint32_t)batch, ctx->aux);
+        }
+        auto finish = [&](int b) {
+            const gkr_fr* sr = srp[b];
+            const gkr_fr* b_star = sr;
+            const gkr_fr* c_star = sr + k;
+            // r* = multi_hash(last round vector) (prover.rs:74-78) -- the same hash, vector and key as the
+            // sumcheck's last challenge, so it is that challenge
+            const gkr_fr r_star = sr[2 * k - 1];
+            outs[b].r[i] = r_star;
+            // z_{i+1} = b* + r* (c* - b*) (l_function, poly.rs:538-551)
+            F rs;
+            memcpy(&rs, &r_star, 32);
+            rs = gkr::h64::to_mont(rs);
+            gkr_fr* zn = outs[b].z + z_off + k_i;
+            for (int j = 0; j < k; ++j) {
+                F bj, cj;
+                memcpy(&bj, &b_star[j], 32);
+                memcpy(&cj, &c_star[j], 32);
+                const F v = gkr::h64::add(bj, gkr::h64::mont_mul(gkr::h64::sub(cj, bj), rs));
+                memcpy(&zn[j], &v, 32);
+                memcpy(&z_next[(size_t)b * k + j], &v, 32);
+            }
+        };
+        {
+            std::atomic<int> next{0};
+            const std::function<bool()> work = [&]() -> bool {
+                const int b = next.fetch_add(1, std::memory_order_relaxed);
+                if (b >= batch) return false;
+                finish(b);
+                return true;
+            };
+            gkr::SpinPool::Session session(pool, nullptr);
+            run_pieces(pool, &work, batch > 1);
+        }
+        if (dbg_pb)
+            fprintf(stderr, "[gkr timing] prove layer %u: sumcheck %.0f us, q / z on the host %.0f us (since entry of the hand-off: %.0f us)\n", i,
+                    std::chrono::duration<double, std::micro>(tl1 - tl0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl1).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tpb0).count());
+        z_cur.swap(z_next);
+        row_off += (size_t)2 * k;
+        q_off += (size_t)k + 1;
+        z_off += (size_t)k_i;
+    }
+    {
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+        const F* hq = reinterpret_cast<const F*>(d_q);
+        const uint32_t* hqlen = d_qlen;
+        size_t off = 0;
+        for (uint32_t i = 0; i < L; ++i) {
+            const size_t kq = (size_t)c->k[i + 1] + 1;
+            for (int b = 0; b < batch; ++b) {
+                memcpy(outs[b].q + off, &hq[off * batch + (size_t)b * kq], kq * sizeof(F));
+                outs[b].q_len[i] = hqlen[(size_t)i * batch + b];
+            }
+            off += kq;
+        }
+    }
+    if (dbg_pb) {
+        const auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gkr timing] prove batch=%d depth=%u: %.0f us before the layers (circuit lookup, forward evaluation, readback), "
+                        "%.0f us layers + q readback, since entry %.0f us\n", batch, L, us(t_entry, tpb0), us(tpb0, t_end), us(t_entry, t_end));
+        fprintf(stderr, "[gkr timing] this thread: own hashing pieces (incl. waiting for helpers) %.0f us, others' pieces %.0f us, spinning with nothing to take %.0f us, "
+                        "the rest (launches, set-up, copies) %.0f us\n", t_account.own_pieces_us, t_account.helped_us, t_account.spin_us,
+                us(t_entry, t_end) - t_account.own_pieces_us - t_account.helped_us - t_account.spin_us);
+    }
+    if (fresh && !no_cache) {
+        constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
+        if (ctx->circuits.size() >= kMaxCachedCircuits) {
+            ctx->circuits.front()->release();
+            ctx->circuits.erase(ctx->circuits.begin());
+        }
+        ctx->circuits.push_back(std::move(fresh));
+    }
+    return GKR_OK;
+}
+
+int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int require_zero_output,
+              gkr_proof_buf* out) {
+    if (!ctx) return GKR_ERR_INVALID;
+    return prove_batch_impl(ctx, c, input_values, 1, require_zero_output, out);
+}
+
+int gkr_prove_batch(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch, int require_zero_output,
+                    gkr_proof_buf* outs) {
+    if (!ctx) return GKR_ERR_INVALID;
+    return prove_batch_impl(ctx, c, input_values, batch, require_zero_output, outs);
+}
+
+// ---- gkr_prove_many: the items of one aggregation step proven side by side ----------------------------------------
+static void crew_prove_items(ProveCrew* crew, ProveCrew::Member* m) {
+    for (int idx : m->items) {
+        gkr_prove_item& it = crew->items[idx];
+        if (!it.circuit || !it.input_values || !it.outs) {
+            it.status = m->ctx->fail(GKR_ERR_INVALID, "null pointer in a prove item");
+            continue;
+        }
+        it.status = prove_batch_impl(m->ctx, it.circuit, it.input_values, it.batch, it.require_zero_output, it.outs);
+    }
+    __atomic_fetch_sub(&crew->busy, 1, __ATOMIC_ACQ_REL);
+    (void)gkr_host_help_while(&crew->busy);   // out of items: pieces of the others' host work until all are done
+}
+
+static void crew_thread(ProveCrew* crew, int index) {
+    ProveCrew::Member* m = crew->members[index].get();
+    (void)hipSetDevice(m->ctx->device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> g(crew->mu);
+            crew->cv_start.wait(g, [&] { return crew->stop || crew->generation != seen; });
+            if (crew->stop) return;
+            seen = crew->generation;
+            if (index >= crew->active) continue;   // not needed in this call
+        }
+        crew_prove_items(crew, m);
+        {
+            std::lock_guard<std::mutex> g(crew->mu);
+            ++crew->finished;
+        }
+        crew->cv_done.notify_one();
+    }
+}
+
+static void destroy_crew(ProveCrew* crew) {
+    if (!crew) return;
+    {
+        std::lock_guard<std::mutex> g(crew->mu);
+        crew->stop = true;
+    }
+    crew->cv_start.notify_all();
+    for (size_t i = 1; i < crew->members.size(); ++i) {
+        if (crew->members[i]->th.joinable()) crew->members[i]->th.join();
+        gkr_ctx_destroy(crew->members[i]->ctx);
+    }
+    delete crew;
+}
+
+int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_concurrent) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if ((!items && n_items) || max_concurrent < 0 || n_items > (size_t)1 << 20) return ctx->fail(GKR_ERR_INVALID, "null item list or negative thread count");
+    if (n_items == 0) return GKR_OK;
+    if (ctx->crew_member) return ctx->fail(GKR_ERR_INVALID, "gkr_prove_many from inside a crew");
+    int want = max_concurrent;
+    if (!want) {
+        int share = usable_cpus();
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) {   // ranks of one node share its CPUs
+            const int ranks = atoi(e);
+            if (ranks > 1) share = share / ranks > 1 ? share / ranks : 1;
+        }
+        want = share >= 6 ? share - 2 : (share >= 3 ? share - 1 : share);   // two (one, none) left to the runtime's own threads
+    }
+    // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
+    {
+        // (members beyond what the items -- cut in two where they are large, below -- can occupy have nothing to prove)
+        size_t can_use = n_items;
+        if (getenv("GKR_PROVE_MANY_PIECES"))
+            for (size_t i = 0; i < n_items; ++i) can_use += items[i].batch >= 32 ? (size_t)items[i].batch / 32 : 0;
+        if (!max_concurrent && (size_t)want > can_use) want = (int)can_use;
+    }
+    // several devices: at least one member per device (as far as there are items), or a device would sit idle
+    if (!max_concurrent && !ctx->devices.empty() && want < (int)ctx->devices.size())
+        want = n_items < ctx->devices.size() ? (int)n_items : (int)ctx->devices.size();
+    if (want > 64) want = 64;
+    if (!ctx->crew) {
+        ctx->crew = std::unique_ptr<ProveCrew, void (*)(ProveCrew*)>(new ProveCrew(), destroy_crew);
+        ctx->crew->members.emplace_back(new ProveCrew::Member());
+        ctx->crew->members[0]->ctx = ctx;
+    }
+    ProveCrew* crew = ctx->crew.get();
+    while ((int)crew->members.size() < want) {
+        gkr_ctx* child = nullptr;
+        // member m lives on device devices[m mod #devices] (member 0 = this context, on devices[0])
+        const int member_device = ctx->devices.empty() ? ctx->device : ctx->devices[crew->members.size() % ctx->devices.size()];
+        const int rc = gkr_ctx_create(member_device, &child);
+        if (rc) return ctx->fail(rc, "child context of gkr_prove_many");
+        child->crew_member = true;
+        child->transcript = GKR_TRANSCRIPT_HOST;
+        crew->members.emplace_back(new ProveCrew::Member());
+        crew->members.back()->ctx = child;
+        const int index = (int)crew->members.size() - 1;
+        crew->members.back()->th = std::thread(crew_thread, crew, index);
+    }
+    // GKR_PROVE_MANY_PIECES = n (opt-in): the costliest items with >= 32 witnesses are cut in two until there are n items --
+    // the halves are independent proving chains like any other item.  Meant for the deep sub-circuits of an R1CS, which run
+    // alone for the last third of a step; measured on MI355X (64 inputs x 12 sub-circuits, 14 threads, ms per step, two
+    // runs each): no cut 9.0 / 9.2, 14 items 8.4 / 10.1, 16: 9.2 / 10.1, 19 (all seven deep ones cut): 11.1 / 12.2,
+    // 24: 12.1 / 12.8 (profiles/r04/e_prove_many_item_split_ab.txt) -- every extra chain adds its launches and hand-offs
+    // (~750 launches per step already) and the step gets SLOWER; the default is no cut.
+    auto item_cost = [](const gkr_prove_item& it) {
+        double rounds = 0;
+        const gkr_circuit_desc* c = it.circuit;
+        if (c && c->k && c->depth <= 4096)
+            for (uint32_t l = 1; l <= c->depth; ++l) rounds += 2.0 * c->k[l];
+        return rounds * (50.0 + 2.0 * (it.batch > 0 ? it.batch : 1));
+    };
+    static const int pieces_env = [] { const char* e = getenv("GKR_PROVE_MANY_PIECES"); return e ? atoi(e) : -1; }();
+    std::vector<gkr_prove_item> work(items, items + n_items);
+    std::vector<int> origin(n_items);
+    for (size_t i = 0; i < n_items; ++i) origin[i] = (int)i;
+    const size_t aim = pieces_env > 0 ? (size_t)pieces_env : 0;
+    while (work.size() < aim) {
+        int best = -1;
+        double best_cost = 0;
+        for (size_t i = 0; i < work.size(); ++i) {
+            const gkr_prove_item& it = work[i];
+            if (it.batch < 32 || !it.circuit || !it.circuit->k || !it.input_values || !it.outs) continue;
+            const double c = item_cost(it);
+            if (c > best_cost) {
+                best_cost = c;
+                best = (int)i;
+            }
+        }
+        if (best < 0) break;
+        gkr_prove_item a = work[best], b = work[best];
+        const int half = ((a.batch / 2 + 15) / 16) * 16;   // whole sixteen-lane hash calls in the first half
+        a.batch = half;
+        b.batch = work[best].batch - half;
+        b.input_values = a.input_values + ((size_t)half << a.circuit->k[a.circuit->depth]);
+        b.outs = a.outs + half;
+        work[best] = a;
+        work.push_back(b);
+        origin.push_back(origin[best]);
+    }
+    gkr_prove_item* const caller_items = items;
+    const size_t caller_n = n_items;
+    items = work.data();
+    n_items = work.size();
+    // deal the items out by estimated cost, longest first, each to the member with the least so far (deterministic)
+    std::vector<std::pair<double, int>> cost(n_items);
+    for (size_t i = 0; i < n_items; ++i) {
+        cost[i] = {item_cost(items[i]), (int)i};
+        items[i].status = GKR_OK;
+    }
+    std::stable_sort(cost.begin(), cost.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    std::vector<double> load(want, 0.0);
+    for (int m = 0; m < want; ++m) crew->members[m]->items.clear();
+    for (const auto& ci : cost) {
+        int best = 0;
+        for (int m = 1; m < want; ++m)
+            if (load[m] < load[best]) best = m;
+        load[best] += ci.first;
+        crew->members[best]->items.push_back(ci.second);
+    }
+    const int saved_transcript = ctx->transcript;
+    ctx->transcript = GKR_TRANSCRIPT_HOST;
+    ctx->crew_member = true;   // the parent proves its share like the others: one thread, no workers of its own
+    {
+        std::lock_guard<std::mutex> g(crew->mu);
+        crew->items = items;
+        crew->active = want;
+        crew->finished = 0;
+        __atomic_store_n(&crew->busy, want, __ATOMIC_RELEASE);
+        ++crew->generation;
+    }
+    crew->cv_start.notify_all();
+    crew_prove_items(crew, crew->members[0].get());
+    {
+        std::unique_lock<std::mutex> g(crew->mu);
+        crew->cv_done.wait(g, [&] { return crew->finished == want - 1; });
+        crew->items = nullptr;
+    }
+    ctx->crew_member = false;
+    ctx->transcript = saved_transcript;
+    for (size_t i = 0; i < caller_n; ++i) caller_items[i].status = GKR_OK;
+    int first_bad = GKR_OK;
+    for (int m = 0; m < want; ++m)
+        for (int idx : crew->members[m]->items)
+            if (items[idx].status != GKR_OK) {
+                if (caller_items[origin[idx]].status == GKR_OK) caller_items[origin[idx]].status = items[idx].status;
+                if (first_bad == GKR_OK) {
+                    if (m) ctx->err = crew->members[m]->ctx->err;
+                    first_bad = items[idx].status;
+                }
+            }
+    return first_bad;
+}
+
+
+}  // extern "C"

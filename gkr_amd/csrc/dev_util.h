@@ -57,6 +57,20 @@ __device__ __forceinline__ void store_fr(Fr* p, const Fr& f) {
     q[1] = make_uint4(f.l[4], f.l[5], f.l[6], f.l[7]);
 }
 
+// device-side build of the round's fixed-multiplier table (device transcript only):
+// R_i = r * 2^(32 i) * 2^64 mod p, canonical
+__device__ __forceinline__ void store_fixed_mul(FixedMul* out, const Fr& r_canonical) {
+    Fr two32 = fr_zero(), two64 = fr_zero();
+    two32.l[1] = 1;
+    two64.l[2] = 1;
+    Fr cur = mont_mul(to_mont(r_canonical), two64);
+    const Fr two32_m = to_mont(two32);
+    for (int i = 0; i < 8; ++i) {
+        for (int c = 0; c < 8; ++c) out->w[i][c] = cur.l[c];
+        cur = mont_mul(cur, two32_m);
+    }
+}
+
 static inline uint32_t blocks_for(uint64_t items, uint32_t cap) {
     uint64_t b = (items + 255) / 256;
     if (b < 1) b = 1;

@@ -479,7 +479,8 @@ def test_limits_table_matches_the_code():
     assert lib.gkr_exchange_limbs_mle(ctypes.c_int(lim["GKR_MAX_MLE_N"] + 3), ctypes.c_int(3), ctypes.c_int(1)) > 0
     assert lib.gkr_exchange_limbs_mle(ctypes.c_int(lim["GKR_MAX_MLE_N"] + 4), ctypes.c_int(3), ctypes.c_int(1)) == 0
     # the limits are spelled in the sources by name, not as literals scattered over the file
-    capi = open(os.path.join(REPO, "gkr_amd", "csrc", "gkr_capi.hip")).read()
+    import glob
+    capi = "".join(open(f).read() for f in glob.glob(os.path.join(REPO, "gkr_amd", "csrc", "*capi*")) if f.endswith((".hip", ".h")))
     for name in lim:
         assert name in capi or name == "GKR_MAX_BATCH", name
 
