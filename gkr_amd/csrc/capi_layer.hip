@@ -183,6 +183,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
     if (shard && (!host_tx || batch != 1)) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript and one proof");
+    // (argument checks come before anything is queued: a rank that returns here has not left its peers inside a collective
+    // -- the same arguments fail on every rank)
+    if (shard && shard->dev && (shard->dev->capacity < gkr_exchange_limbs(k) || !shard->dev->d_limbs || !shard->dev->fn))
+        return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs(k_next) int64");
     if (k > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "layer wider than the library's limits (gkr_amd.h: GKR_MAX_K_NEXT, GKR_MAX_K_I)");
     if (!host_tx && k > kMaxDenseK)
         return ctx->fail(GKR_ERR_INVALID, "the device transcript works on dense 2^(2 k_next)-entry predicate tables: k_next <= 14 (GKR_MAX_K_NEXT_DEVICE_TRANSCRIPT)");
@@ -359,8 +363,6 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     if (shard && shard->dev) {
         HIP_TRY(ctx, ctx->pinned_host("layer.xflag", 64, reinterpret_cast<void**>(&h_xflag)));
         *h_xflag = 0;
-        if (shard->dev->capacity < gkr_exchange_limbs(k) || !shard->dev->d_limbs || !shard->dev->fn)
-            return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs(k_next) int64");
     }
     auto sum_over_ranks = [&](Fr* d_a, Fr* d_b, size_t each, const uint32_t* d_flag, int local_fail) -> int {
         if (shard->dev) {

@@ -2030,7 +2030,12 @@ static void launch_seg_pass_t(const GateSegs& g, uint32_t k, const Fr* e_lo_mont
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (LDS_T && !((attr_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_pass<ROWS, LDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // (a device whose blocks cannot take the table -- not gfx950 -- refuses here: the gather form runs instead)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_pass<ROWS, LDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            launch_seg_pass_t<ROWS, false>(g, k, e_lo_mont, T, X, Y, lb, s);
+            return;
+        }
         attr_set.fetch_or((uint64_t)1 << (dev & 63), std::memory_order_relaxed);
     }
     // resident blocks: one 1024-thread block per CU with the table in LDS; 256-thread blocks, four per CU, without

@@ -254,9 +254,11 @@ void gkr_resident_layer_free(gkr_ctx *ctx, gkr_resident_layer *layer);
  * must enqueue an in-place integer SUM all-reduce of d_limbs[0 .. count) ON THAT STREAM (ncclAllReduce(buf, buf, count,
  * ncclInt64, ncclSum, comm, stream); torch.distributed.all_reduce under torch.cuda.ExternalStream(stream)), and
  * reduces the sums mod r on the device.  No host copy, no stream synchronisation: the host next touches the stream
- * when the first round's record lands.  fn is called on every rank the same number of times even when a rank has
- * failed locally (the flag element carries "some rank failed", and all ranks then return an error together); fn
- * itself must not fail on one rank only. */
+ * when the first round's record lands.  Once a call has passed its argument checks and workspace allocations (which come
+ * first and fail alike on every rank given the same arguments), fn is called on every rank the same number of times even
+ * when a rank fails locally (the flag element carries "some rank failed", and all ranks then return an error together); fn
+ * itself must not fail on one rank only.  (A rank whose device runs out of memory while its peers' do not returns before
+ * the first exchange: give every rank the same budget.) */
 typedef int (*gkr_allreduce_dev_fn)(void *user, size_t count, void *hip_stream);
 typedef struct {
     gkr_allreduce_dev_fn fn;
