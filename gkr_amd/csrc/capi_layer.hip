@@ -655,6 +655,25 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
         bool second_exchange_done = false;
+        // GKR_LAUNCH_AHEAD=1 (opt-in, <= 8 proofs): the NEXT pass of a phase is queued before this pass's record is waited for and
+        // starts by polling pinned memory for the weights the host is about to write, so that its launch and dispatch gap
+        // overlap the hashing (VERDICT r03 item 7's proposal).  Built and measured on MI355X: NO gain -- the 2^24-gate layer
+        // 1.033 ms per sumcheck either way, the three-input proving step 3.51 against 3.56 ms (profiles/r04/f_launch_ahead_ab.txt):
+        // a waiting block's wake-up (a PCIe read of the flag, then of the weights) costs what the launch it saves does.
+        static const bool want_ahead = getenv("GKR_LAUNCH_AHEAD") != nullptr;
+        const bool ahead = want_ahead && batch <= 8;
+        uint32_t* h_wseq = nullptr;   // pinned: [0] the ticket whose weights are written, [1] "the host gave up"
+        HIP_TRY(ctx, ctx->pinned_host("layer.wseq", 64, reinterpret_cast<void**>(&h_wseq)));
+        __atomic_store_n(h_wseq + 1, 0u, __ATOMIC_RELEASE);
+        struct GiveUp {   // whatever path leaves this scope with a pass still waiting for its weights: it is told to stop waiting
+            uint32_t* flag;
+            bool armed = false;
+            ~GiveUp() {
+                if (armed) __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);
+            }
+        } give_up{h_wseq + 1};
+        bool launched_ahead = false;
+        uint32_t ahead_ticket = 0;
         for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
             Fr *Tw = Wb, *Tx = U, *Ty = V;
             if (phase == 1) {
@@ -687,16 +706,29 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             uint32_t m = (uint32_t)k;   // log2 of the tables' length before the pending fold
             for (uint32_t rem = (uint32_t)k; rem > 0 && rc == GKR_OK;) {
                 const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
-                const uint32_t ticket = ++ctx->ticket;
-                {
+                uint32_t ticket;
+                if (launched_ahead) {   // queued during the previous pass's hashing
+                    ticket = ahead_ticket;
+                    launched_ahead = false;
+                    give_up.armed = false;
+                } else {
+                    ticket = ++ctx->ticket;
                     Timed t(ctx, "layer_prod_pass", 0.0);
                     gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s);
+                }
+                m -= jp;
+                if (ahead && rem > J) {   // the phase's next pass, behind this one: it waits for this pass's weights
+                    const uint32_t Jn = rem - J < (uint32_t)gkr::kProdMaxJ ? rem - J : (uint32_t)gkr::kProdMaxJ;
+                    ahead_ticket = ++ctx->ticket;
+                    give_up.armed = true;
+                    Timed t(ctx, "layer_prod_pass_ahead", 0.0);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, J, h_pw, Jn, d_ppart, (uint32_t)wlen, prec, ahead_ticket, (uint32_t)batch, s, h_wseq, ticket);
+                    launched_ahead = true;
                 }
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) {
                     rc = ctx->hip_fail(le, "launch of a layer pass");
                     break;
                 }
-                m -= jp;
                 rc = wait_records(ctx, prec, batch, ticket);
                 if (!rc) rc = xflag_check();
                 if (rc) break;
@@ -729,12 +761,14 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     return true;
                 };
                 run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
+                if (launched_ahead) __atomic_store_n(h_wseq, ticket, __ATOMIC_RELEASE);   // the weights are written: the waiting pass goes
                 jp = J;
                 round0 += J;
                 rem -= J;
             }
         }
         session.close();
+        if (give_up.armed) __atomic_store_n(h_wseq + 1, 1u, __ATOMIC_RELEASE);   // (an error left a pass waiting for weights: it stops before the stream is waited for)
         // a rank that failed between the exchanges still enters the second one (flag set): its peers are waiting in it.
         // (Not when the failure is the travelling flag itself: then every rank is leaving at this very point.)
         if (rc && shard && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))

@@ -71,8 +71,11 @@ inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_m
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
 // the cross sums for the next J rounds -> the pinned records (seq = ticket, system-scope release); partials: scratch of
 // batch x prod_pass_blocks(2^(m_in - jp - 1)) x 72 values for passes that span several blocks per proof.
+// wait_seq (pinned host words, may be null): the pass is launched AHEAD of its weights and starts once wait_seq[0] == wait_ticket
+// (the host has written the weights) or wait_seq[1] != 0 (the host gave up).
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s);
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq = nullptr,
+                      uint32_t wait_ticket = 0);
 // start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
 // the 2^k entries of the rows A, M (gate_rows), per proof
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,

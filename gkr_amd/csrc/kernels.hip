@@ -510,8 +510,19 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
 template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
                                                     const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
-                                                    ProdPassRec* __restrict__ rec, uint32_t ticket) {
+                                                    ProdPassRec* __restrict__ rec, uint32_t ticket, const uint32_t* __restrict__ wait_seq,
+                                                    uint32_t wait_ticket) {
     __shared__ Fr s_w[8];
+    // Launched AHEAD of its weights (a lone proof's round path: the launch and its ~6 us dispatch gap overlap the host's
+    // hashing of the previous pass): the block waits until the host has released them -- wait_seq[0] = the previous pass's
+    // ticket (pinned host memory, written after the weights), or wait_seq[1] != 0: the host gave up (every error path sets it).
+    if (wait_seq) {
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(wait_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != wait_ticket &&
+                   !__hip_atomic_load(wait_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+    }
     __shared__ Fr s_t[3][8][TILE];               // folded tile: table, sub-block, i
     __shared__ Fr s_red[4][kProdRecValues];
     const uint32_t tid = threadIdx.x, proof = blockIdx.y;
@@ -1698,12 +1709,14 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
 }
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s) {
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq, uint32_t wait_ticket) {
     const uint32_t S = 1u << (m_in - jp - J), blocks = prod_pass_blocks(S);
     if (prod_pass_tile(S) == kProdTileWide)
-        hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
+        hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
+                           wait_seq, wait_ticket);
     else
-        hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket);
+        hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
+                           wait_seq, wait_ticket);
     if (blocks > 1024) {
         // (the second level's input sits behind the partials: launch_prod_pass's callers size the scratch with prod_pass_scratch_values)
         Fr* level2 = partials + (size_t)batch * blocks * kProdRecValues;
