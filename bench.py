@@ -453,10 +453,12 @@ def run_mle(args, world):
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
-    layer24 = layer24_split = mle_split_out = None
+    layer24 = layer24_split = mle_split_out = wide20 = None
     split_hung = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
+        # a WIDE layer, the shape of a compiled R1CS's big layers (2^20 gates over 2^20 values; round 3 rejected it)
+        wide20 = layer_leg(world, 20, 20, steps=5, warmup=2, split=False, ceilings=ceilings) if args.layer_k_i >= 20 else None
         if world.size > 1:
             # configs[4] as BASELINE words it: the layer's gates split over the ranks, two RCCL all-reduces per sumcheck
             # (device exchange).  Under a watchdog: a rank stuck in a collective must not cost the whole line.
@@ -479,6 +481,9 @@ def run_mle(args, world):
         if layer24:
             line["layer24"] = layer24
             verified_ok &= layer24["matches_golden_digest"] is not False
+        if wide20:
+            line["wide20"] = wide20
+            verified_ok &= wide20["matches_golden_digest"] is not False
         if layer24_split:
             line["layer24_split"] = layer24_split
             verified_ok &= layer24_split.get("matches_golden_digest") is not False and "error" not in layer24_split
@@ -678,12 +683,14 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
         products = 2.0 * cnt
         rate = products / (gate_ms * 1e-3) if gate_ms else None
         peak = own["modmul_per_sec"] if own else None
+        wide = k >= 13   # lane-group passes: the operand table (2^k x 32 B) no longer sits in LDS / L2 -- a gather per gate
         out = {
             "metric": "BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" % k_i, "value": 25 * (N - 1) * steps / elapsed,
             "unit": "field-ops/s", "n_gpus": world.size if split else 1, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: one GKR layer, k_i = %d, k = %d%s" % (
+            "config": {"workload": "%s: one GKR layer, k_i = %d, k = %d%s" % (
+                           "BASELINE configs[4]" if (k_i, k) == (24, 12) else "a WIDE layer (beyond round 3's 2^14 cap; the shape of a compiled R1CS's big layers)",
                            k_i, k, ", gates split over the ranks, two sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" if split else
                            ", the whole layer on one GPU"),
                        "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z and W per sumcheck)"},
@@ -699,6 +706,10 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
                                           "Montgomery products measured in this process (gkr_ubench_ceilings, 16 waves per SIMD)",
                          "hbm_bytes_per_gate_and_pass": 8, "note": "not memory-bound: per gate one 8-byte list entry is streamed from HBM, the eq and W "
                                           "operands are gathers from L2-resident tables"},
+            "gather": ({"bound": "the random 32-byte gather of W[right] / eq(u, left) per gate and pass from a 2^%d-entry table (%.0f MiB: beyond L2), "
+                                 "plus the 8-byte list entry" % (k, (32 << k) / 2**20),
+                        "gathers_per_sec": rate, "GBps_of_40_B_per_gate": rate * 40 / 1e9 if rate else None,
+                        "frac_of_hbm_peak": rate * 40 / 1e9 / PEAK_GBPS if rate else None} if wide else None),
             "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
             "collective": collective_info(world, exchange, exch, steps) if split else None,
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},

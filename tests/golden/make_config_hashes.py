@@ -110,6 +110,12 @@ def main():
         lay, z, W = synth.config5_layer(k_i, k)
         C, L, R = cdense.sumcheck_layer_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
         out["layer"]["k_i=%d,k=%d" % (k_i, k)] = digest(C, L, R)
+    # a WIDE layer (2^20 gates over a next layer of 2^20 values: the shape of a compiled R1CS's big layers), by the linear-time
+    # C prover -- the dense form cannot follow
+    for k_i, k in ((20, 20),):
+        lay, z, W = synth.config5_layer(k_i, k)
+        C, L, R = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+        out["layer"]["k_i=%d,k=%d" % (k_i, k)] = digest(C, L, R)
     for n, seed in ((16, synth.SEED + 1), (20, synth.SEED + 2)):
         C, L, R = cdense.sumcheck_mle_raw(cdense.fill_table(1 << n, seed), n)
         out["mle"]["n=%d,seed=%d" % (n, seed)] = digest(C, L, R)

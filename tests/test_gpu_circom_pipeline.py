@@ -164,6 +164,19 @@ def test_prove_many_matches_proofs_proven_one_by_one(ctx):
     step.close()
 
 
+@pytest.mark.parametrize("pieces", ["0", "14", "19"])
+def test_prove_many_with_items_cut_in_two(pieces):
+    """GKR_PROVE_MANY_PIECES: gkr_prove_many cuts its costliest items (>= 32 witnesses) in two until there are that many --
+    the halves write into the caller's proof buffers at their offsets.  40 inputs x 12 sub-circuits, every proof against
+    the committed digests of the CPU checker's proofs (tests/prove_many_pieces_worker.py)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "prove_many_pieces_worker.py")], env=dict(os.environ, GKR_PROVE_MANY_PIECES=pieces),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_cli_prove_demo_on_the_gpu(tmp_path):
     """`gkr-aggregator prove -c t.circom -i input1.json input2.json input3.json` (bin.rs:17-22) with the real prover:
     the artefacts of the first step and the inputs of the second (tests/test_cli.py checks their content on the CPU

@@ -135,6 +135,17 @@ def test_prove_batch_of_three_through_wide_layers(ctx):
     assert all(np.array_equal(a[:2], b) for a, b in zip(arrs, arrs2))
 
 
+@pytest.mark.parametrize("k_i,k", [(20, 15), (20, 20), (22, 16)])
+def test_wide_layer_batch_of_three(ctx, k_i, k):
+    """Three witnesses through a circuit whose first layer is (k_i, k): gkr_prove_batch advances the three proofs together
+    (every lane-group pass, heavy-bucket unit, product pass and exchange-free hand-off with its batch index)."""
+    ks = [k_i, k, 8]
+    layers = _random_circuit(ks, 500 + k_i + k)
+    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(len(layers))], ks[-1])
+    wit = np.stack([synth.rand_fr(np.random.default_rng(830 + b), 1 << ks[-1]) for b in range(3)])
+    _check_proofs(ctx.prove_batch_raw(circuit, wit, all_arrays=True), layers, ks, wit)
+
+
 @pytest.mark.parametrize("scenario", ["small", "heavy-batch", "per-round"])
 def test_lane_group_passes_on_small_layers(scenario):
     """tests/wide_scenarios_worker.py (a child: GKR_GATE_GROUPS_MIN_K is read once per process): the lane-group form of the
