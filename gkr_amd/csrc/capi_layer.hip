@@ -1121,6 +1121,35 @@ int gkr_resident_layer_create(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_f
     return GKR_OK;
 }
 
+// A layer's W from host memory into the context's workspace, validated (every entry < r, sumcheck.rs:16,21 unwrap()s): small
+// tables through pinned memory and a copy kernel (no transfer call on a small proof's path, see k_copy_words), tables of 2^16
+// entries and more by the copy engine with the check on the device -- the host loop and the staging copy of a 2^20-entry W
+// took longer than the layer's gate passes.
+static int upload_W(gkr_ctx* ctx, const gkr_fr* W, int k, Fr** out) {
+    const size_t n = (size_t)1 << k;
+    Fr* dW = nullptr;
+    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
+    if (k < 16) {
+        if (!all_canonical(W, n)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+        gkr_fr* hW = nullptr;
+        HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
+        memcpy(hW, W, sizeof(gkr_fr) << k);
+        gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    } else {
+        uint32_t* d_flag = nullptr;
+        WS(ctx, "layer.Wflag", uint32_t, 1, d_flag);
+        uint32_t hflag = 0;
+        HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dW, W, sizeof(Fr) << k, hipMemcpyHostToDevice, ctx->stream));
+        gkr::launch_check_canonical(dW, n, d_flag, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(&hflag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (hflag) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    }
+    *out = dW;
+    return GKR_OK;
+}
+
 int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const gkr_fr* W, gkr_allreduce_fn allreduce,
                                 void* user, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r) {
     if (!ctx) return GKR_ERR_INVALID;
@@ -1129,14 +1158,9 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
     if (!allreduce && (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)))
         return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the layer must be whole");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
-    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Fr* dW = nullptr;
-    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
-    gkr_fr* hW = nullptr;   // through pinned memory and a copy kernel (no transfer call on the path, see k_copy_words)
-    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
-    memcpy(hW, W, sizeof(gkr_fr) << k);
-    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    if (const int urc = upload_W(ctx, W, k, &dW)) return urc;
     LayerShardArgs sh;
     sh.gate_base = layer->first;
     sh.gate_count = layer->count;
@@ -1161,14 +1185,9 @@ int gkr_resident_layer_sumcheck_dev(gkr_ctx* ctx, gkr_resident_layer* layer, con
     if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z) || !exchange) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     const int k_i = layer->k_i, k = layer->k;
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
-    if (!all_canonical(W, (size_t)1 << k)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Fr* dW = nullptr;
-    HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k, reinterpret_cast<void**>(&dW)));
-    gkr_fr* hW = nullptr;
-    HIP_TRY(ctx, ctx->pinned_host("layer.hWin", sizeof(gkr_fr) << k, reinterpret_cast<void**>(&hW)));
-    memcpy(hW, W, sizeof(gkr_fr) << k);
-    gkr::launch_copy_words(hW, dW, ((size_t)8) << k, ctx->stream);
+    if (const int urc = upload_W(ctx, W, k, &dW)) return urc;
     LayerShardArgs sh;
     sh.gate_base = layer->first;
     sh.gate_count = layer->count;

@@ -247,8 +247,8 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
 // ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------
 // The gate passes with a group of 2^lg lanes per bucket; buckets longer than gate_heavy_threshold() gates are cut into
 // units of kHeavyUnit gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
-constexpr uint32_t kHeavyPerLane = 32;    // a lane of a group walks at most this many gates
-constexpr uint32_t kHeavyUnit = 256;      // gates per unit of a heavy bucket (one wave, four gates per lane)
+constexpr uint32_t kHeavyPerLane = 64;    // a lane of a group walks at most this many gates (about eight on average)
+constexpr uint32_t kHeavyUnit = 1024;     // gates per unit of a heavy bucket (one wave, sixteen gates per lane)
 constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the lane-group passes
 uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k);
 uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k);
@@ -261,6 +261,8 @@ void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
                            uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s);
+// *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)
+void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s);
 // dependence flags over a grid: bits = batch zeroed-by-the-launcher words of scratch; dep / host_dep as launch_layer_prologue
 void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
 // in-place Moebius transform (evaluations -> monomial coefficients, MSB-first) of `batch` tables of 2^k, `stride` apart

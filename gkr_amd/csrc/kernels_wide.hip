@@ -6,10 +6,10 @@
 // The linear-time form of kernels.hip has no inherent width limit: U, V, the c-phase row and W are 2^k-entry tables in
 // HBM.  What changes with the width is the SHAPE of the work:
 //   * 2^k buckets of the gate lists with only a few gates each (a circom layer has about as many gates as the next
-//     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here a GROUP of L = 4..64
-//     lanes sums a bucket (k_gate_group), and the few buckets far longer than the rest -- the constant wires every
-//     relay gate reads (convert.rs:307-342) -- are cut into units of 256 gates summed a wave per unit (k_gate_heavy,
-//     k_heavy_combine), so that no lane ever walks more than 32 gates;
+//     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here a GROUP of L = 1..64
+//     lanes sums a bucket, about eight gates per lane (k_gate_group), and the few buckets far longer than the rest -- the constant wires every
+//     relay gate reads (convert.rs:307-342) -- are cut into units of 1024 gates summed a wave per unit (k_gate_heavy,
+//     k_heavy_combine), so that no lane ever walks more than 64 gates;
 //   * tables the one-block helpers cannot walk: the dependence flags (k_depends_wide), the Moebius transform
 //     (k_mobius_pass) and the set-up of the line restriction (k_line_copy, k_line_maxdeg) run over a grid.
 // Same field elements as every other form: bit-exact (tests/test_gpu_wide_layers.py).
@@ -25,14 +25,20 @@ namespace gkr {
 // gate passes: a group of lanes per bucket, heavy buckets in units
 // ---------------------------------------------------------------------------
 
-// lanes of a wave that sum one bucket: four times the mean bucket length, within [4, 64]
+// Lanes of a wave that sum one bucket: about EIGHT gates per lane.  A lane's fixed cost -- two reductions of its unreduced
+// sums, the group's shuffles, two more reductions -- is ~1000 instructions whether it walked one gate or sixteen; measured on
+// MI355X, ms per gate pass (profiles/r04/h_gate_group_lanes_sweep.txt): 2^24 gates over 2^18 buckets (64 per bucket) 1.74 with
+// a whole wave per bucket, 0.52 with four lanes; 2^20 over 2^15 (32 per bucket) 0.216 with 32 lanes, 0.065 with four; 2^20
+// over 2^20 (one per bucket) 0.40 with four lanes, 0.17 with one.
 uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k) {
-    const uint64_t mean4 = (gates >> k) * 4;
-    uint32_t lg = 2;
-    while (lg < 6 && ((uint64_t)1 << lg) < mean4) ++lg;
+    static const int forced = [] { const char* e = getenv("GKR_GATE_GROUP_LANES_LOG2"); return e ? atoi(e) : -1; }();   // (measurement knob)
+    if (forced >= 0 && forced <= 6) return (uint32_t)forced;
+    const uint64_t mean = gates >> k;
+    uint32_t lg = 0;
+    while (lg < 6 && ((uint64_t)8 << lg) < mean) ++lg;
     return lg;
 }
-uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k) { return kHeavyPerLane << gate_group_lanes_log2(gates, k); }
+uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k) { return kHeavyPerLane << gate_group_lanes_log2(gates, k); }   // (at least 64: a lane group's first lane)
 // capacities of one half (left-operand buckets / right-operand buckets)
 static inline size_t heavy_cap_buckets(uint64_t gates, uint32_t k) { return (size_t)(gates / gate_heavy_threshold(gates, k)) + 1; }
 static inline size_t heavy_cap_units(uint64_t gates, uint32_t k) { return (size_t)(gates / kHeavyUnit) + heavy_cap_buckets(gates, k); }
@@ -233,6 +239,17 @@ void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
                            uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s) {
     launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s);
+}
+
+// every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries
+// cost more than the layer's gate passes)  *flag |= 1 on an entry >= r.  grid = blocks, block = 256
+__global__ void __launch_bounds__(256) k_check_canonical(const Fr* __restrict__ t, size_t n, uint32_t* __restrict__ flag) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad |= !fr_is_canonical(load_fr(t + i));
+    if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flag, 1u);
+}
+void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s) {
+    hipLaunchKernelGGL(k_check_canonical, dim3(blocks_for(n, 2048)), dim3(256), 0, s, t, n, flag);
 }
 
 // ---------------------------------------------------------------------------

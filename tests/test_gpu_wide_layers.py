@@ -179,6 +179,26 @@ def test_wide_layer_split_by_gates_over_logical_ranks(nshards, device_exchange):
         assert len(got) == nshards and all(g == (proof, from_limbs(want[2])) for g in got)
 
 
+def test_wide_W_is_validated_on_the_device(ctx):
+    """A W of 2^16 entries and more is copied by the copy engine and checked for entries >= r where it lands (the reference
+    unwrap()s from_repr, sumcheck.rs:16,21): GKR_ERR_NON_CANONICAL, and the context keeps working."""
+    from gkr_amd import parallel
+    from gkr_amd import _native as N
+    k_i, k = 12, 16
+    lay, z, W = synth.config5_layer(k_i, k, seed=3)
+    gates = parallel.ResidentGates(ctx, k_i, 0, *lay.arrays())
+    try:
+        bad = W.copy()
+        bad[12345] = np.array([0xffffffffffffffff] * 4, dtype=np.uint64)
+        with pytest.raises(GkrError) as e:
+            gates.sumcheck_raw(k, z, bad)
+        assert e.value.status == N.GKR_ERR_NON_CANONICAL
+        want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+        assert _same(gates.sumcheck_raw(k, z, W), want)
+    finally:
+        gates.close()
+
+
 def test_limits_are_reported(ctx):
     lay = Layer(2, [0, 1, 0, 1], [0, 1, 2, 3], [3, 2, 1, 0])
     with pytest.raises(GkrError) as e:
