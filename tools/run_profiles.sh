@@ -25,6 +25,14 @@ python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer
 GKR_BENCH_FORCE_GROUP=1 python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split_rccl_one_rank.json 2>/dev/null
 python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
 LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --no-verify --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
+python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20.json 2>/dev/null
+GKR_BENCH_FORCE_GROUP=1 python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20_rccl_one_rank.json 2>/dev/null
+python bench.py --mode mle-split --log2-points 30 --steps 5 > $OUT/bench_mode_mle_split_n30.json 2>/dev/null
+# the default line with two ranks (two processes over gloo sharing the one GPU): every N > 1 field of the line
+GKR_BENCH_BACKEND=gloo GKR_BENCH_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 2 --steps 4 --warmup 2 --batch 256 > $OUT/bench_default_2ranks_gloo_one_gpu.json 2> $OUT/bench_default_2ranks_gloo_one_gpu.err
+python tools/bench_wide.py 20,15 22,16 24,18 20,20 22,22 > $OUT/bench_wide_layers.txt 2>&1
+bash tools/stats_wide.sh 20,20 24,18 > /dev/null 2>&1; cp gpurun_out/wide_stats_20_20.csv $OUT/kernel_stats_wide_layer_k_i20_k20.csv; cp gpurun_out/wide_stats_24_18.csv $OUT/kernel_stats_wide_layer_k_i24_k18.csv
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
 bash tools/trace_layer_timeline.sh > $OUT/layer24_kernel_timeline.txt 2>&1
 bash tools/trace_mle_latency_timeline.sh > $OUT/mle_batch1_kernel_timeline.txt 2>&1
