@@ -500,3 +500,26 @@ def test_every_environment_knob_is_documented():
     assert code - documented == set(), "undocumented knobs: %s" % sorted(code - documented)
     stale = {k for k in documented - code if not k.startswith(("GKR_TRANSCRIPT", "GKR_BENCH", "GKR_TEST", "GKR_ERR", "GKR_MAX"))}
     assert stale == set(), "documented but no longer read: %s" % sorted(stale)
+
+
+def test_rccl_exchange_without_a_device_is_an_error_not_a_crash():
+    """gkr_exchange_rccl_* (the library-owned collective): librccl is loaded on first use; on a box without a GPU every entry
+    point comes back with a status and a text, never a crash and never a fallback."""
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = N.lib()
+    lib.gkr_exchange_rccl_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    rc = lib.gkr_exchange_rccl_create(ctypes.c_int(0), ctypes.create_string_buffer(128), ctypes.c_int(0), ctypes.c_int(1), ctypes.c_size_t(64), ctypes.byref(h))
+    assert rc == N.GKR_ERR_NO_DEVICE and not h.value and lib.gkr_exchange_rccl_error()
+    assert lib.gkr_exchange_rccl_create(ctypes.c_int(0), None, ctypes.c_int(0), ctypes.c_int(1), ctypes.c_size_t(64), ctypes.byref(h)) == N.GKR_ERR_INVALID
+    assert lib.gkr_exchange_rccl_create(ctypes.c_int(0), ctypes.create_string_buffer(128), ctypes.c_int(2), ctypes.c_int(2), ctypes.c_size_t(64), ctypes.byref(h)) == N.GKR_ERR_INVALID
+    lib.gkr_exchange_rccl_dev.restype = ctypes.c_void_p
+    assert lib.gkr_exchange_rccl_dev(None) is None
+    lib.gkr_exchange_rccl_destroy.restype = None
+    lib.gkr_exchange_rccl_destroy(None)
+    ctx = ctypes.c_void_p()
+    assert lib.gkr_ctx_create_multi((ctypes.c_int * 2)(0, 1), ctypes.c_int(2), ctypes.byref(ctx)) == N.GKR_ERR_NO_DEVICE
+    assert lib.gkr_ctx_create_multi(None, ctypes.c_int(2), ctypes.byref(ctx)) == N.GKR_ERR_INVALID
