@@ -29,7 +29,7 @@ def _same(got, want):
     return all(np.array_equal(a, b) for a, b in zip(got, want))
 
 
-@pytest.mark.parametrize("k_i,k", [(20, 15), (22, 16), (24, 18), (20, 20), (14, 14), (10, 17), (21, 13)])
+@pytest.mark.parametrize("k_i,k", [(20, 15), (22, 16), (24, 18), (20, 20), (14, 14), (10, 17), (21, 13), (0, 14), (5, 19), (26, 14), (23, 23)])
 def test_wide_layer_sumcheck_matches_oracle(ctx, k_i, k):
     lay, z, W = synth.config5_layer(k_i, k, seed=synth.SEED + 100 * k_i + k)
     want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
