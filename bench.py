@@ -453,12 +453,13 @@ def run_mle(args, world):
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
-    layer24 = layer24_split = mle_split_out = wide20 = None
+    layer24 = layer24_split = mle_split_out = wide20 = wide_prove = None
     split_hung = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
         # a WIDE layer, the shape of a compiled R1CS's big layers (2^20 gates over 2^20 values; round 3 rejected it)
         wide20 = layer_leg(world, 20, 20, steps=5, warmup=2, split=False, ceilings=ceilings) if args.layer_k_i >= 20 else None
+        wide_prove = wide_prove_leg(world) if args.layer_k_i >= 20 else None
         if world.size > 1:
             # configs[4] as BASELINE words it: the layer's gates split over the ranks, two RCCL all-reduces per sumcheck
             # (device exchange).  Under a watchdog: a rank stuck in a collective must not cost the whole line.
@@ -484,6 +485,9 @@ def run_mle(args, world):
         if wide20:
             line["wide20"] = wide20
             verified_ok &= wide20["matches_golden_digest"] is not False
+        if wide_prove:
+            line["wide_prove"] = wide_prove
+            verified_ok &= wide_prove["matches_golden_digest"] is not False
         if layer24_split:
             line["layer24_split"] = layer24_split
             verified_ok &= layer24_split.get("matches_golden_digest") is not False and "error" not in layer24_split
@@ -717,6 +721,33 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
     gates.close()
     ctx.close()
     return out
+
+
+def wide_prove_leg(world, ks=(18, 20, 20), reps=5):
+    """A whole proof (prover::prove, prover.rs:6-96) of a circuit with WIDE layers -- 2^18 gates over 2^20 values over a 2^20-value
+    input layer (gkr_amd.synth.wide_circuit) -- on every rank alike; the proof's arrays against the committed digest of the CPU
+    checker's proof (tests/golden/config_hashes.json["prove"]).  Round 3 rejected this circuit (k[i+1] > 14)."""
+    from gkr_amd import Context, synth
+    circuit, _, wit = synth.wide_circuit(ks)
+    with Context(world.local_rank) as ctx:
+        t = time.perf_counter()
+        arrs = ctx.prove_batch_raw(circuit, wit, all_arrays=True)     # uploads and sorts the circuit
+        first = time.perf_counter() - t
+        each = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            ctx.prove_batch_raw(circuit, wit, out=arrs)              # circuit in the context's cache, proof buffers reused
+            each.append((time.perf_counter() - t) * 1e3)
+    digest = synth.proof_arrays_digest(list(ks), *[a[0] for a in arrs[:7]])
+    want = synth.golden_digest("prove", "k=" + ",".join(map(str, ks)))
+    dt = world.max_over_ranks(statistics.median(each) / 1e3)
+    if world.rank != 0:
+        return None
+    return {"workload": "gkr_prove of a circuit with k = %s (gates per layer 2^%d, 2^%d; input layer 2^%d values), one witness" % (list(ks), ks[0], ks[1], ks[-1]),
+            "ms_per_proof": dt * 1e3, "ms_each": [round(x, 3) for x in each], "first_call_ms": first * 1e3,
+            "first_call": "gate arrays uploaded, gate lists sorted, workspaces and proof buffers allocated",
+            "matches_golden_digest": None if want is None else digest == want, "proof_sha256": digest,
+            "outputs_bytes": int(sum(a.nbytes for a in arrs))}
 
 
 # ------------------------------------------------------------------------------------------------ mode: mle-split

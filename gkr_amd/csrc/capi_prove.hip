@@ -118,7 +118,12 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     for (uint32_t i = 0; i < L; ++i)
         if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
     const size_t n_in = (size_t)1 << c->k[L];
-    if (!all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+    static const bool dbg_pre = getenv("GKR_DEBUG_TIMING") != nullptr;
+    auto us_since_entry = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(); };
+    // (a large input layer is validated where it lands, on the device: the host loop over 2^20 values took 1.6 ms of a 12 ms proof)
+    const bool check_on_device = n_in * (size_t)batch >= ((size_t)1 << 16);
+    if (!check_on_device && !all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+    const double us_canon = us_since_entry();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
@@ -128,6 +133,26 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* q = static_cast<const unsigned char*>(p);
         size_t i = 0;
+        if (n >= 4096) {
+            // long arrays (the gate lists of a wide layer: megabytes per call): four independent multiply chains over
+            // 32-byte blocks, folded into the two running hashes at the end -- the single chain below is latency-bound
+            // (1.8 ms for 12 MB of gate arrays per proof)
+            uint64_t a[4] = {h1, h1 ^ 0x9E3779B97F4A7C15ULL, h1 + 0x632BE59BD9B4E019ULL, ~h1}, b[4] = {h2, ~h2, h2 ^ 0xD6E8FEB86659FD93ULL, h2 + 1};
+            for (; i + 32 <= n; i += 32) {
+                uint64_t w[4];
+                memcpy(w, q + i, 32);
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = (a[t] ^ w[t]) * 0x100000001b3ULL;
+                    b[t] = (b[t] + w[t]) * 0xBF58476D1CE4E5B9ULL;
+                    b[t] ^= b[t] >> 29;
+                }
+            }
+            for (int t = 0; t < 4; ++t) {
+                h1 = (h1 ^ a[t]) * 0x100000001b3ULL;
+                h2 = (h2 + b[t]) * 0xBF58476D1CE4E5B9ULL;
+                h2 ^= h2 >> 29;
+            }
+        }
         for (; i + 8 <= n; i += 8) {
             uint64_t w;
             memcpy(&w, q + i, 8);
@@ -148,6 +173,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         mix(c->left[i], gates * 4);
         mix(c->right[i], gates * 4);
     }
+    const double us_hash = us_since_entry();
     PreparedCircuit* pc = nullptr;
     for (size_t i = 0; i < ctx->circuits.size(); ++i)
         if (ctx->circuits[i]->h1 == h1 && ctx->circuits[i]->h2 == h2 && ctx->circuits[i]->k.size() == L + 1 &&
@@ -218,16 +244,26 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     } else {
         HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, in_bytes, hipMemcpyHostToDevice, s));
     }
+    uint32_t* d_in_flag = nullptr;
+    uint32_t h_in_flag = 0;
+    if (check_on_device) {
+        WS(ctx, "prove.inflag", uint32_t, 1, d_in_flag);
+        HIP_TRY(ctx, hipMemsetAsync(d_in_flag, 0, 4, s));
+        gkr::launch_check_canonical(dW[L], n_in * (size_t)batch, d_in_flag, s);
+        HIP_TRY(ctx, hipMemcpyAsync(&h_in_flag, d_in_flag, 4, hipMemcpyDeviceToHost, s));
+    }
     for (int i = (int)L - 1; i >= 0; --i)
         gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s);
     HIP_TRY(ctx, hipGetLastError());
     // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
     const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
+    const F* hW0_first = nullptr;           // or only output 0 of every proof
     std::vector<F> hW_big[2];
     // d and input_func are the monomial forms of W_0 and W_L (get_multi_ext, poly.rs:502-536): tables beyond 2^12 values are
     // transformed on the device (k launches over a grid) and land in the proof buffers directly; small ones on the host
     constexpr uint32_t kDeviceMobiusMinK = 13;
     bool coeffs_done[2] = {false, false};
+    const Fr* coeff_src[2] = {nullptr, nullptr};
     for (int e = 0; e < 2; ++e) {
         const uint32_t i = e ? L : 0;
         if (c->k[i] < kDeviceMobiusMinK) continue;
@@ -236,14 +272,60 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         HIP_TRY(ctx, ctx->workspace(e ? "prove.monoL" : "prove.mono0", n * batch * sizeof(Fr), reinterpret_cast<void**>(&mono)));
         HIP_TRY(ctx, hipMemcpyAsync(mono, dW[i], n * batch * sizeof(Fr), hipMemcpyDeviceToDevice, s));
         gkr::launch_mobius(mono, c->k[i], n, (uint32_t)batch, s);
-        for (int b = 0; b < batch; ++b)
-            HIP_TRY(ctx, hipMemcpyAsync(e ? outs[b].input_coeffs : outs[b].d_coeffs, mono + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToHost, s));
+        coeff_src[e] = mono;
         coeffs_done[e] = true;
+    }
+    // Their way to the caller's (pageable) buffers -- tens of MiB at the staged-copy rate, 2.5 ms for a 2^20-value input
+    // layer -- runs on a helper thread beside the layers' sumchecks: the coefficients are outputs only, nothing waits for
+    // them but the end of the call.  The thread waits for the transforms through an event, then copies synchronously.
+    struct CoeffCopier {
+        std::thread th;
+        hipError_t err = hipSuccess;
+        hipStream_t side = nullptr;
+        // every path out of the call: the copies are all queued (join) and have landed (the side stream is waited for) before
+        // the caller sees its buffers again
+        void finish() {
+            if (th.joinable()) {
+                th.join();
+                if (side) (void)hipStreamSynchronize(side);
+            }
+        }
+        ~CoeffCopier() { finish(); }
+    } copier;
+    if (coeffs_done[0] || coeffs_done[1]) {
+        HIP_TRY(ctx, ctx->aux_stream(1));
+        hipEvent_t ready = ctx->aux_events[0];
+        HIP_TRY(ctx, hipEventRecord(ready, s));
+        const int device = ctx->device;
+        const uint32_t k0 = c->k[0], kL = c->k[L];
+        // (on the context's side stream, which the line restrictions use later in the call: stream order keeps them apart; a
+        // synchronous hipMemcpy on the null stream held every other thread's HIP calls up for its whole duration -- 23 ms)
+        hipStream_t side = ctx->aux;
+        copier.side = side;
+        copier.th = std::thread([=, &copier]() {
+            hipError_t e = hipSetDevice(device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ready, 0);
+            for (int which = 0; which < 2 && e == hipSuccess; ++which) {
+                if (!coeff_src[which]) continue;
+                const size_t n = (size_t)1 << (which ? kL : k0);
+                for (int b = 0; b < batch && e == hipSuccess; ++b)
+                    e = hipMemcpyAsync(which ? outs[b].input_coeffs : outs[b].d_coeffs, coeff_src[which] + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToHost, side);
+            }
+            copier.err = e;
+        });
     }
     for (int e = 0; e < 2; ++e) {
         const uint32_t i = e ? L : 0;
         const size_t bytes = ((size_t)batch << c->k[i]) * sizeof(Fr);
-        if (coeffs_done[e] && e == 1) continue;   // (W_0 is still read below: output 0 must be zero)
+        if (coeffs_done[e] && e == 1) continue;
+        if (coeffs_done[e] && batch <= 64) {
+            // (of a W_0 whose coefficients come from the device only output 0 of every proof is looked at: "must be zero")
+            F* dst = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host("prove.hW0first", sizeof(F) * (size_t)batch, reinterpret_cast<void**>(&dst)));
+            for (int b = 0; b < batch; ++b) gkr::launch_copy_words(dW[0] + ((size_t)b << c->k[0]), dst + b, 8, s);
+            hW0_first = dst;
+            continue;
+        }
         if (bytes <= kKernelCopyLimit) {
             F* dst = nullptr;
             HIP_TRY(ctx, ctx->pinned_host(e ? "prove.hWL" : "prove.hW0", bytes, reinterpret_cast<void**>(&dst)));
@@ -260,8 +342,12 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     const auto tpb0 = std::chrono::steady_clock::now();
     if (dbg_pb) t_account = ThreadTimeAccount();
     if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
+    if (dbg_pre)
+        fprintf(stderr, "[gkr timing] prove, before the layers: input check %.0f us, circuit hash %.0f us, upload + evaluation + Moebius + readback %.0f us\n", us_canon,
+                us_hash - us_canon, us_since_entry() - us_hash);
+    if (h_in_flag) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     for (int b = 0; b < batch; ++b) {
-        if (require_zero_output && !gkr::h64::is_zero(hW[0][(size_t)b << c->k[0]]))
+        if (require_zero_output && !gkr::h64::is_zero(hW0_first ? hW0_first[b] : hW[0][(size_t)b << c->k[0]]))
             return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
         // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
         std::vector<F> co;
@@ -374,6 +460,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     }
     {
         HIP_TRY(ctx, hipGetLastError());
+        copier.finish();   // (all coefficient copies are queued on the side stream before it is waited for)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
         const F* hq = reinterpret_cast<const F*>(d_q);
         const uint32_t* hqlen = d_qlen;
@@ -396,6 +483,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
                         "the rest (launches, set-up, copies) %.0f us\n", t_account.own_pieces_us, t_account.helped_us, t_account.spin_us,
                 us(t_entry, t_end) - t_account.own_pieces_us - t_account.helped_us - t_account.spin_us);
     }
+    copier.finish();
+    if (copier.err != hipSuccess) return ctx->hip_fail(copier.err, "copy of the d / input_func coefficients to the proof buffers");
     if (fresh && !no_cache) {
         constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
         if (ctx->circuits.size() >= kMaxCachedCircuits) {

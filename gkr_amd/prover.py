@@ -418,7 +418,7 @@ class Context:
         outs = self.prove_many_raw(prepared, max_concurrent)
         return [_decode_proofs(arrs, circuit.get_k_list()) for arrs, (circuit, _) in zip(outs, work)]
 
-    def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs, all_arrays=False):
+    def prove_batch_raw(self, circuit: GKRCircuit, inputs_limbs, all_arrays=False, out=None):
         """gkr_prove_batch without decoding the outputs into Python ints (bench.py's proofs/sec leg; circuits with wide
         layers, whose d / input_func tables have 2^18 and more entries).
         inputs_limbs: (B, 2^input_k, 4) uint64.  Returns the challenge arrays (B, rounds, 4), or with all_arrays the nine
@@ -435,14 +435,17 @@ class Context:
         sizes = N.ProofSizes()
         self._check(N.lib().gkr_proof_sizes(ctypes.byref(desc), ctypes.byref(sizes)))
         inp = np.ascontiguousarray(inputs_limbs, dtype=np.uint64)
-        arrs = [np.zeros((B, sizes.rounds, 3, 4), dtype=np.uint64), np.zeros((B, sizes.rounds), dtype=np.uint32),
-                np.zeros((B, sizes.rounds, 4), dtype=np.uint64), np.zeros((B, sizes.q_slots, 4), dtype=np.uint64),
-                np.zeros((B, L), dtype=np.uint32), np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64),
-                np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
-                np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
+        # (out: the nine arrays of an earlier call with the same shapes, reused -- a proof with a 2^20-value input layer
+        # carries 40 MiB of coefficients, and fresh pages for them cost more than the proof)
+        arrs = out if out is not None else [
+            np.zeros((B, sizes.rounds, 3, 4), dtype=np.uint64), np.zeros((B, sizes.rounds), dtype=np.uint32),
+            np.zeros((B, sizes.rounds, 4), dtype=np.uint64), np.zeros((B, sizes.q_slots, 4), dtype=np.uint64),
+            np.zeros((B, L), dtype=np.uint32), np.zeros((B, max(sizes.z_values, 1), 4), dtype=np.uint64),
+            np.zeros((B, L, 4), dtype=np.uint64), np.zeros((B, sizes.d_coeffs, 4), dtype=np.uint64),
+            np.zeros((B, sizes.input_coeffs, 4), dtype=np.uint64)]
         bufs = _proof_bufs(arrs, B)
         self._check(N.lib().gkr_prove_batch(self._h, ctypes.byref(desc), _ptr(inp), ctypes.c_int(B), ctypes.c_int(0), bufs))
-        return arrs if all_arrays else arrs[2]
+        return arrs if (all_arrays or out is not None) else arrs[2]
 
 
 _default_ctx = None

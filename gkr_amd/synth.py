@@ -31,6 +31,39 @@ def config5_layer(k_i=24, k=12, seed=SEED + 5):
     return lay, z, W
 
 
+def wide_circuit(ks=(18, 20, 20), seed=SEED + 7):
+    """A circuit with WIDE layers (2^k[i] random gates over 2^k[i+1] values) and one witness: what bench.py's wide_prove leg
+    and tools/bench_wide_prove.py prove.  -> (GKRCircuit, [(gate_type, left, right)], witness limbs (1, 2^k[-1], 4))."""
+    rng = np.random.default_rng(seed)
+    ks = list(ks)
+    raw = []
+    for i in range(len(ks) - 1):
+        g, m = 1 << ks[i], 1 << ks[i + 1]
+        raw.append((rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, m, g, dtype=np.uint32), rng.integers(0, m, g, dtype=np.uint32)))
+    circuit = GKRCircuit([Layer(ks[i], *raw[i]) for i in range(len(raw))], ks[-1])
+    return circuit, raw, rand_fr(rng, 1 << ks[-1])[None]
+
+
+def proof_arrays_digest(ks, sc, sl, sr, q, ql, z, rr):
+    """sha256 over one proof's raw arrays (round coefficients | lengths | challenges | q | q lengths | z | r) in the C ABI's
+    layout -- the product's gkr_prove_batch outputs for proof 0, or the same arrays assembled from the CPU checker's
+    prove_raw (proof_arrays_from_oracle)."""
+    return transcript_digest(sc, sl, sr, q, ql, z, rr)
+
+
+def proof_arrays_from_oracle(ref, ks):
+    """cdense.prove_raw's dict -> the seven arrays in gkr_proof_buf layout (one proof)."""
+    L = len(ks) - 1
+    sc = np.concatenate(ref["C"])
+    sl = np.concatenate(ref["L"]).astype(np.uint32)
+    sr = np.concatenate(ref["R"])
+    q = np.concatenate(ref["q"])
+    ql = np.asarray(ref["q_len"], dtype=np.uint32)
+    z = np.concatenate([x.reshape(-1, 4) for x in ref["z"]]) if sum(ks) else np.zeros((1, 4), dtype=np.uint64)
+    rr = np.asarray(ref["r"], dtype=np.uint64).reshape(L, 4)
+    return sc, sl, sr, q, ql, z, rr
+
+
 def bench_table_seed(rank, b):
     """Seed of table b of rank `rank` in bench.py's default workload (1024 x 2^20 points per rank); rank 0's table 0 is
     the table of tests/golden/config_hashes.json["mle"]["n=20,seed=12648432"]."""

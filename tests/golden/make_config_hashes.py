@@ -116,6 +116,12 @@ def main():
         lay, z, W = synth.config5_layer(k_i, k)
         C, L, R = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
         out["layer"]["k_i=%d,k=%d" % (k_i, k)] = digest(C, L, R)
+    # a whole proof through wide layers (gkr_amd.synth.wide_circuit): the limb-only CPU prover on the linear-time layer form
+    out["prove"] = {}
+    for ks in ((18, 20, 20),):
+        circuit, raw, wit = synth.wide_circuit(ks)
+        ref = cdense.prove_raw(raw, wit[0])
+        out["prove"]["k=" + ",".join(map(str, ks))] = synth.proof_arrays_digest(list(ks), *synth.proof_arrays_from_oracle(ref, list(ks)))
     for n, seed in ((16, synth.SEED + 1), (20, synth.SEED + 2)):
         C, L, R = cdense.sumcheck_mle_raw(cdense.fill_table(1 << n, seed), n)
         out["mle"]["n=%d,seed=%d" % (n, seed)] = digest(C, L, R)
