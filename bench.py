@@ -783,7 +783,11 @@ def mle_split_leg(world, n, batch, steps, warmup, ceilings=None):
         ctx.fill_shard(ctypes.c_void_p(d.value + b * count * 32), n, lp, world.rank, seed0 + 1000 * b)
     ctx.synchronize()
     limbs = parallel.exchange_limbs_mle(n, lp, batch)
-    exchange = parallel.TorchCollective().device_exchange(limbs) if world.grouped else parallel.NoExchange(ctx, limbs)
+    if world.grouped and os.environ.get("GKR_BENCH_NATIVE_RCCL") == "1":
+        # the collective the LIBRARY owns (csrc/exchange_rccl.cpp): torch only hands the 128-byte id round
+        exchange = parallel.RcclExchange.from_torch_group(world.local_rank, limbs)
+    else:
+        exchange = parallel.TorchCollective().device_exchange(limbs) if world.grouped else parallel.NoExchange(ctx, limbs)
     result = [None]
 
     def step():
