@@ -146,6 +146,29 @@ def test_wide_layer_batch_of_three(ctx, k_i, k):
     _check_proofs(ctx.prove_batch_raw(circuit, wit, all_arrays=True), layers, ks, wit)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_circuits_across_the_width_thresholds(ctx, seed):
+    """Random circuits whose layer widths straddle every switch of the path -- k = 12 / 13 (block-per-bucket vs lane-group gate
+    passes, one-block vs grid Moebius and line set-up), 13 / 14 (dependence flags in the prologue vs over a grid, the eq table's
+    split form), 2^16 values (host vs device validation and upload), narrow layers between wide ones, a one-gate output layer,
+    batches of 1 .. 3 -- every array of every proof against the CPU checker's."""
+    rng = np.random.default_rng(9000 + seed)
+    depth = int(rng.integers(2, 5))
+    ks = [int(rng.integers(0, 15))] + [int(rng.integers(11, 17)) if rng.random() < 0.7 else int(rng.integers(1, 8)) for _ in range(depth)]
+    layers = _random_circuit(ks, 9100 + seed)
+    if seed % 3 == 0:          # a constant wire every second gate reads, as relay gates do
+        gt, l, r = (a.copy() for a in layers[-1])
+        r[::2] = 1
+        gt[::2] = 0
+        layers[-1] = (gt, l, r)
+    circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(len(layers))], ks[-1])
+    batch = 1 + seed % 3
+    wit = np.stack([synth.rand_fr(np.random.default_rng(9200 + 10 * seed + b), 1 << ks[-1]) for b in range(batch)])
+    if seed == 4:              # an input layer that does not depend on its last variables: short round vectors, short q
+        wit = np.repeat(wit[:, ::4], 4, axis=1)
+    _check_proofs(ctx.prove_batch_raw(circuit, np.ascontiguousarray(wit), all_arrays=True), layers, ks, np.ascontiguousarray(wit))
+
+
 @pytest.mark.parametrize("scenario", ["small", "heavy-batch", "per-round"])
 def test_lane_group_passes_on_small_layers(scenario):
     """tests/wide_scenarios_worker.py (a child: GKR_GATE_GROUPS_MIN_K is read once per process): the lane-group form of the
