@@ -595,6 +595,41 @@ def aggregated_proofs(world, n_inputs):
     out["config3"]["verified"] = dict(ver3 or {}, all_ranks_ok=bad_ranks == 0.0)
     out["verified_ok"] = bad_ranks == 0.0 and (ver0 is None or ver0["ok"]) and (ver3 is None or ver3["ok"])
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
+    # The same pipeline on an R1CS of the size the reference is FOR (aggregating real circuits): 262 144 constraints -> 16
+    # layered circuits with layers of 2^14 .. 2^16 values (round 3's boundary rejected them), one input, every rank alike;
+    # every proof's arrays against the CPU checker's END-TO-END digests (its own restatement of convert.rs compiled the R1CS).
+    if os.environ.get("GKR_BENCH_LARGE_R1CS", "1") != "0":
+        gold = synth.large_r1cs_digests()
+        nrounds = gold["nrounds"] if gold else 65536
+        pair = tuple(gold["input"]) if gold else (2, 3)
+        t0 = time.perf_counter()
+        big = ProvingStep(synth.mimc7_demo_r1cs(nrounds=nrounds))
+        big_compile_ms = (time.perf_counter() - t0) * 1e3
+        big_inputs = big.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(pair[0], pair[1], nrounds=nrounds))]))
+        for _ in range(2):
+            big.prove_raw_many(ctx, big_inputs, threads)
+        world.barrier(ctx)
+        each_big = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            big.prove_raw_many(ctx, big_inputs, threads)
+            each_big.append((time.perf_counter() - t1) * 1e3)
+        world.barrier(ctx)
+        dt_big = world.max_over_ranks(statistics.median(each_big) / 1e3)
+        ks_big = [c.get_k_list() for c in big.circuits]
+        bad_big = None
+        if gold and not os.environ.get("GKR_BENCH_NO_VERIFY"):
+            bad_big = [j for j, (arrs, ks) in enumerate(zip(big._prepared["outs"], ks_big))
+                       if j >= len(gold["digests"]) or ks != gold["k"][j] or synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) != gold["digests"][j]]
+        big_bad_ranks = world.max_over_ranks(1.0 if bad_big else 0.0)
+        out["large_r1cs"] = {"constraints": 4 * nrounds, "sub_circuits": len(big.circuits), "k_lists": ks_big, "inputs": 1,
+                             "compile_ms": big_compile_ms, "ms": dt_big * 1e3, "ms_each": [round(x, 3) for x in each_big],
+                             "proofs_per_sec": len(big.circuits) / dt_big, "constraints_per_sec": 4 * nrounds / dt_big,
+                             "verified": None if bad_big is None else {"digests": "tests/golden/large_r1cs_digests.json (compile and proofs by the CPU checker)",
+                                                                        "proofs": len(big.circuits), "mismatches": bad_big, "ok": not bad_big, "all_ranks_ok": big_bad_ranks == 0.0}}
+        if bad_big or big_bad_ranks:
+            out["verified_ok"] = False
+        big.close()
     hashed = sum(int(arrs[1].sum()) for arrs in step._prepared["outs"])   # lengths of all round vectors of the last step
     out["config3"]["roofline"] = transcript_floor(hashed, 3, threads, dt * 1e3)
     ctx.close()

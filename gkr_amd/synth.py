@@ -134,6 +134,17 @@ def proof_digests():
         return None
 
 
+def large_r1cs_digests():
+    """tests/golden/large_r1cs_digests.json (make_config_hashes.py --large-r1cs): the CPU checker's compile and proofs of the
+    262 144-constraint R1CS bench.py's large_r1cs leg proves, per sub-circuit; or None."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "large_r1cs_digests.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def transcript_digest(*arrays):
     """sha256 over the raw output arrays of a sumcheck (coefficients | lengths | challenges)."""
     h = hashlib.sha256()
@@ -184,7 +195,8 @@ def mimc7_demo_constraints(nrounds=91, style="plain"):
             c = [((P - co) % P, w) for co, w in c]
         cons.append((a, b, c))
     for i in range(nrounds):
-        t = [(1, 2)] if i == 0 else ([(cts[i], 0), (1, prev_t7)] if cts[i] else [(1, prev_t7)])
+        ci = cts[i % len(cts)]    # (more than 91 rounds: the constants repeat -- a long chain for R1CS of any size, not MiMC7 any more)
+        t = [(1, 2)] if i == 0 else ([(ci, 0), (1, prev_t7)] if ci else [(1, prev_t7)])
         t2, t4, t6 = wire, wire + 1, wire + 2
         wire += 3
         emit(list(t), list(t), [(1, t2)])
@@ -212,7 +224,7 @@ def mimc7_demo_witness(in1, in2, nrounds=91):
     w = [1, 0, in1 % P, in2 % P]
     t7 = None
     for i in range(nrounds):
-        t = in1 % P if i == 0 else (t7 + cts[i]) % P
+        t = in1 % P if i == 0 else (t7 + cts[i % len(cts)]) % P
         t2 = t * t % P
         t4 = t2 * t2 % P
         t6 = t4 * t2 % P

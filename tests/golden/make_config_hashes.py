@@ -90,7 +90,35 @@ def proof_digests(n_inputs=64):
             "config3": {"inputs": n_inputs, "digests": many}}
 
 
+def large_r1cs_digests(nrounds=65536, pair=(2, 3)):
+    """A 262 144-constraint R1CS (gkr_amd.synth.mimc7_demo_r1cs with 65 536 rounds: the demo's constraint shapes, the
+    constants repeating) through the CPU checker END TO END: oracle/convert.py's restatement of convert.rs compiles it into
+    its layered circuits (layers of 2^14 .. 2^16 values), the linear-time C prover proves each for one witness; per sub-circuit
+    the k list and the digest of the proof's arrays (gkr_amd.synth.proof_arrays_digest)."""
+    import time
+    from oracle import convert as oconv
+    t = time.time()
+    r = oconv.read_r1cs(synth.mimc7_demo_r1cs(nrounds=nrounds).serialize())
+    subs = oconv.convert_r1cs_wtns_gkr(r, synth.mimc7_demo_witness(pair[0], pair[1], nrounds=nrounds))
+    print("oracle compile: %.0f s, %d sub-circuits" % (time.time() - t, len(subs)), flush=True)
+    out = {"what": "sha256 of gkr_amd.synth.proof_arrays_digest per sub-circuit; compile and proofs by the CPU checker",
+           "nrounds": nrounds, "constraints": 4 * nrounds, "input": list(pair), "k": [], "digests": []}
+    for sub in subs:
+        layers = [(np.asarray(a, dtype=np.uint8), np.asarray(b, dtype=np.uint32), np.asarray(c, dtype=np.uint32)) for a, b, c in sub["layers"]]
+        ref = cdense.prove_raw(layers, cdense.to_limbs(sub["input_values"]))
+        out["k"].append(list(sub["k"]))
+        out["digests"].append(synth.proof_arrays_digest(list(sub["k"]), *synth.proof_arrays_from_oracle(ref, list(sub["k"]))))
+    return out
+
+
 def main():
+    if "--large-r1cs" in sys.argv:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "large_r1cs_digests.json")
+        with open(path, "w") as f:
+            json.dump(large_r1cs_digests(), f, indent=0, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        return
     if "--proofs" in sys.argv:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "proof_digests.json")
         with open(path, "w") as f:

@@ -197,3 +197,32 @@ def test_cli_prove_demo_on_the_gpu(tmp_path):
     assert [os.path.basename(w) for w in written] == ["input1_output.json", "aggregated.json", "aggregated.circom"]
     agg = json.load(open(tmp_path / "aggregated.json"))
     assert agg["in1"] == "3" and len(agg) == 2 + 7 * 12
+
+
+def test_large_r1cs_end_to_end_through_wide_layers():
+    """The reference's use case at size: an R1CS of 262 144 constraints (the demo's constraint shapes, 65 536 rounds) -> the
+    product's compiler -> 16 layered circuits with layers of 2^14 .. 2^16 values -> gkr_prove_many, output 0 of every
+    sub-circuit required to be zero (convert.rs:838) -> every proof's arrays against the CPU checker's linear-time prover on
+    the same circuits, and -- when the committed file is there -- against the checker's END-TO-END digests, its own
+    restatement of convert.rs having compiled the R1CS (tests/golden/large_r1cs_digests.json, made offline)."""
+    import numpy as np
+    from gkr_amd.aggregate import ProvingStep
+    from gkr_amd.field import as_limbs
+    nrounds, pair = 65536, (2, 3)
+    step = ProvingStep(synth.mimc7_demo_r1cs(nrounds=nrounds))
+    ks_all = [c.get_k_list() for c in step.circuits]
+    assert max(max(ks) for ks in ks_all) >= 15
+    inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(pair[0], pair[1], nrounds=nrounds))]))
+    gold = synth.large_r1cs_digests()
+    with Context(0) as ctx:
+        prepared = ctx.prepare_many(list(zip(step.circuits, inputs)), require_zero_output=True)
+        outs = ctx.prove_many_raw(prepared, 0)
+        for j, (circuit, arrs) in enumerate(zip(step.circuits, outs)):
+            ks = ks_all[j]
+            if j % 5 == 0:      # (the checker's prover on four of the sixteen: ~2 s each)
+                ref = cdense.prove_raw([lay.arrays() for lay in circuit.layer], inputs[j][0])
+                want = synth.proof_arrays_from_oracle(ref, ks)
+                assert all(np.array_equal(np.asarray(a[0]).reshape(w.shape), w) for a, w in zip(arrs[:7], want)), j
+            if gold is not None:
+                assert ks == gold["k"][j] and synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) == gold["digests"][j], j
+    step.close()
