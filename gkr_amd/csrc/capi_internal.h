@@ -329,6 +329,8 @@ using namespace gkr_host;
 struct GateLists {
     uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
     uint32_t* heavy = nullptr;   // wide layers: the work lists of the buckets too long for a lane group (kernels_wide.hip)
+    uint32_t heavy_hdr[4] = {0, 0, 0, 0};   // ... and their header as read back when they were built (heavy_known)
+    bool heavy_known = false;
     gkr::GateSegs segs;   // the lists' segments (large layers; segs.words is one more device allocation)
     bool ready = false;
     void release() {
@@ -338,6 +340,7 @@ struct GateLists {
         if (heavy) (void)hipFree(heavy);
         if (segs.words) (void)hipFree(segs.words);
         offsets = cursor = list = heavy = nullptr;
+        heavy_known = false;
         segs = gkr::GateSegs();
         ready = false;
     }
@@ -362,6 +365,53 @@ struct PreparedCircuit {
 
 struct ProveCrew;
 
+// One helper thread per context, started on first use and kept: work that must not hold the proving thread up (the staged
+// copies of a wide proof's coefficient tables to the caller's pageable buffers).  One task at a time: run() hands it over,
+// wait() returns when it is done.  (A thread per call would do, but costs its start-up on every proof and churns the
+// per-thread state of whatever tool is attached to the process.)
+struct AsyncWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool busy = false, stop = false;
+    void loop() {
+        std::unique_lock<std::mutex> g(mu);
+        for (;;) {
+            cv.wait(g, [this] { return stop || (busy && task); });
+            if (stop) return;
+            std::function<void()> t = std::move(task);
+            task = nullptr;
+            g.unlock();
+            t();
+            g.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void run(std::function<void()> fn) {
+        std::unique_lock<std::mutex> g(mu);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        cv.wait(g, [this] { return !busy; });
+        task = std::move(fn);
+        busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [this] { return !busy; });
+    }
+    ~AsyncWorker() {
+        {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [this] { return !busy; });
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct gkr_ctx {
     int device = 0;
     std::vector<int> devices;                  // gkr_ctx_create_multi: the devices gkr_prove_many's child contexts are dealt over (empty: `device` only)
@@ -382,6 +432,7 @@ struct gkr_ctx {
     uint32_t ticket = 0;                       // unique per hand-off, never reused within a context
     std::unique_ptr<gkr::SpinPool> pool;       // host transcript workers (lazy)
     std::unique_ptr<gkr::SpinPool> solo_pool;  // the empty pool a context uses while it is one of a crew (gkr_prove_many)
+    std::unique_ptr<AsyncWorker> copier;       // helper thread for a wide proof's coefficient copies (lazy)
     bool crew_member = false;                  // one thread of several proving side by side: no workers of its own
     int rounds_ahead = 0;                      // sumcheck rounds left in the proof being proven AFTER the current layer (help priority)
     std::unique_ptr<ProveCrew, void (*)(ProveCrew*)> crew{nullptr, nullptr};   // gkr_prove_many's threads and child contexts (lazy)

@@ -346,7 +346,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     } else if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
-            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s);
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s,
+                                     cached && cached->heavy_known && !lists_fresh ? cached->heavy_hdr : nullptr);
         else
             gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
     } else if (lin_b) {
@@ -427,8 +428,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
             uint32_t hbad = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+            if (wide && cached) HIP_TRY(ctx, hipMemcpyAsync(cached->heavy_hdr, g_heavy, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+            if (wide && cached) cached->heavy_known = true;
         }
         if (batch >= 16) pool = ctx->host_pool();
     }
@@ -687,7 +690,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
                     if (wide)
                         gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
-                                                   heavy_partials, s);
+                                                   heavy_partials, s, cached && cached->heavy_known ? cached->heavy_hdr : nullptr);
                     else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
                                                               segs, seg_partials, s, shard ? nullptr : &fuse);
@@ -825,7 +828,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     if (wide)
                         gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
-                                                   heavy_partials, s);
+                                                   heavy_partials, s, cached && cached->heavy_known ? cached->heavy_hdr : nullptr);
                     else
                         gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
                                               A, M, lb, segs, seg_partials, s);

@@ -279,15 +279,17 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     // layer -- runs on a helper thread beside the layers' sumchecks: the coefficients are outputs only, nothing waits for
     // them but the end of the call.  The thread waits for the transforms through an event, then copies synchronously.
     struct CoeffCopier {
-        std::thread th;
+        AsyncWorker* worker = nullptr;
+        bool started = false;
         hipError_t err = hipSuccess;
         hipStream_t side = nullptr;
-        // every path out of the call: the copies are all queued (join) and have landed (the side stream is waited for) before
-        // the caller sees its buffers again
+        // every path out of the call: the copies are all queued (the helper is done) and have landed (the side stream is
+        // waited for) before the caller sees its buffers again
         void finish() {
-            if (th.joinable()) {
-                th.join();
+            if (started) {
+                worker->wait();
                 if (side) (void)hipStreamSynchronize(side);
+                started = false;
             }
         }
         ~CoeffCopier() { finish(); }
@@ -301,8 +303,12 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         // (on the context's side stream, which the line restrictions use later in the call: stream order keeps them apart; a
         // synchronous hipMemcpy on the null stream held every other thread's HIP calls up for its whole duration -- 23 ms)
         hipStream_t side = ctx->aux;
+        if (!ctx->copier) ctx->copier.reset(new AsyncWorker());
+        copier.worker = ctx->copier.get();
         copier.side = side;
-        copier.th = std::thread([=, &copier]() {
+        copier.started = true;
+        CoeffCopier* cp = &copier;
+        ctx->copier->run([=]() {
             hipError_t e = hipSetDevice(device);
             if (e == hipSuccess) e = hipStreamWaitEvent(side, ready, 0);
             for (int which = 0; which < 2 && e == hipSuccess; ++which) {
@@ -311,7 +317,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
                 for (int b = 0; b < batch && e == hipSuccess; ++b)
                     e = hipMemcpyAsync(which ? outs[b].input_coeffs : outs[b].d_coeffs, coeff_src[which] + (size_t)b * n, n * sizeof(Fr), hipMemcpyDeviceToHost, side);
             }
-            copier.err = e;
+            cp->err = e;
         });
     }
     for (int e = 0; e < 2; ++e) {

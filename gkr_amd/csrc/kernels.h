@@ -257,17 +257,18 @@ size_t gate_heavy_partial_elems(uint64_t gates, uint32_t k);    // Fr elements o
 void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, uint32_t* heavy_words, hipStream_t s);
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                          const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s);
+                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr);
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s);
+                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr);
+// host_hdr (may be null): the first four words of heavy_words as the host read them back ([2 * half] = heavy buckets of the half)
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)
 void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s);
 // dependence flags over a grid: bits = batch zeroed-by-the-launcher words of scratch; dep / host_dep as launch_layer_prologue
 void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
 // in-place Moebius transform (evaluations -> monomial coefficients, MSB-first) of `batch` tables of 2^k, `stride` apart
 void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStream_t s);
-void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t* out_len, uint32_t batch, hipStream_t s);
+void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t batch, hipStream_t s);
 
 // ---- one plain sumcheck split over ranks (kernels_wide.hip): the per-pass exchange of the sub-block sums and the final gather
 // rec: the pass's records in DEVICE memory; limbs: batch x (2^J + 2) x 8 int64 (sums | dep | fail per table)

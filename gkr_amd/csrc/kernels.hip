@@ -936,6 +936,42 @@ __global__ void __launch_bounds__(256) k_line_step(uint32_t k, uint32_t j, const
     }
 }
 
+// The last steps of a wide layer's line restriction in ONE launch (from variable j0 on the table has 2^(k - j0) <= 64 entries):
+// one block per proof binds the remaining variables one after the other (the same arithmetic as k_line_step, a barrier
+// between the steps), then writes q -- highest degree first -- and its length (1 + the largest degree of a non-zero monomial
+// of W, found by the set-up kernels).  grid = (batch), block = 256
+__global__ void __launch_bounds__(256) k_line_tail(uint32_t k, uint32_t j0, const Fr* __restrict__ bc, Fr* __restrict__ scratch,
+                                                   Fr* __restrict__ out, const uint32_t* __restrict__ maxdeg, uint32_t* __restrict__ out_len) {
+    const uint32_t n = 1u << k;
+    const Fr* line = bc + (size_t)blockIdx.x * 2u * k;
+    Fr* base = scratch + (size_t)blockIdx.x * 3u * n;
+    for (uint32_t j = j0; j < k; ++j) {
+        const uint32_t h = n >> (j + 1u);
+        const Fr* src = base + ((j & 1u) ? n : 0u);
+        Fr* dst = base + ((j & 1u) ? 0u : n);
+        const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
+        const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+        const uint32_t in_len = j + 1u, out_len_j = j + 2u;
+        for (uint32_t item = threadIdx.x; item < h * out_len_j; item += blockDim.x) {
+            const uint32_t i = item / out_len_j, m = item - i * out_len_j;
+            const Fr* lo = src + (size_t)i * in_len;
+            const Fr* hi = src + (size_t)(i + h) * in_len;
+            Fr v = fr_zero();
+            if (m < in_len) {
+                const Fr l = load_fr(lo + m);
+                v = fr_add(l, mont_mul(fr_sub(load_fr(hi + m), l), cst));
+            }
+            if (m > 0) v = fr_add(v, mont_mul(fr_sub(load_fr(hi + m - 1), load_fr(lo + m - 1)), grad));
+            store_fr(dst + (size_t)i * out_len_j + m, v);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const Fr* fin = base + ((k & 1u) ? n : 0u);
+    for (uint32_t d = threadIdx.x; d <= k; d += blockDim.x) store_fr(out + (size_t)blockIdx.x * (k + 1u) + (k - d), load_fr(fin + d));
+    if (threadIdx.x == 0) out_len[blockIdx.x] = maxdeg[blockIdx.x] + 1u;   // (out_len may be pinned host memory: a plain store)
+}
+
 __global__ void k_line_out(uint32_t k, const Fr* __restrict__ scratch, Fr* __restrict__ out) {
     const uint32_t n = 1u << k;
     const Fr* fin = scratch + (size_t)blockIdx.x * 3u * n + ((k & 1u) ? n : 0u);
@@ -1808,10 +1844,20 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
     }
     // (the set-up -- copy, Moebius transform, largest monomial degree -- in one block per proof up to 2^12 values, over a
     // grid beyond: kernels_wide.hip)
-    if (k <= 12)
-        hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
-    else
-        launch_line_setup_wide(W, k, scratch, deg_scratch, out_len, batch, s);
+    if (k > 12) {
+        // wide layers: the set-up over a grid (kernels_wide.hip), one launch per variable while the table is large, the last
+        // six variables, q and its length in one block per proof -- 4 + (k - 6) + 1 launches instead of 2 k + 6 (the proving
+        // thread issues them between two layers' sumchecks)
+        launch_line_setup_wide(W, k, scratch, deg_scratch, batch, s);
+        const uint32_t j0 = k - 6u;
+        for (uint32_t j = 0; j < j0; ++j) {
+            const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
+            hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bc, scratch);
+        }
+        hipLaunchKernelGGL(k_line_tail, dim3(batch), dim3(256), 0, s, k, j0, bc, scratch, out, deg_scratch, out_len);
+        return;
+    }
+    hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
         hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bc, scratch);

@@ -215,13 +215,16 @@ void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets,
 template <bool ROWS>
 static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                                 const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
-                                uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s) {
+                                uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
     const uint32_t lg = gate_group_lanes_log2(span.count, k), threshold = gate_heavy_threshold(span.count, k);
     const uint32_t* meta = list + gate_list_words(span.count);
     const uint64_t threads = (uint64_t)1 << (k + lg);
     hipLaunchKernelGGL((k_gate_group<ROWS>), dim3((unsigned)((threads + 255) / 256), lb.batch), dim3(256), 0, s, offsets, cursor, list, meta, e_hi,
                        e_lo_mont, kl, k_i - kl, T, out0, out1, k, (uint32_t)lb.wstride, (uint32_t)span.base, lg, threshold);
     const uint32_t half = ROWS ? 1u : 0u;
+    // (the work lists' header as the host read it back when the lists were built: a half without a heavy bucket -- most
+    // layers -- skips two launches per pass)
+    if (host_hdr && host_hdr[2u * half] == 0u) return;
     const HeavyView hv = heavy_view(heavy_words, span.count, k, half);
     const size_t pstride = gate_heavy_partial_elems(span.count, k);
     hipLaunchKernelGGL((k_gate_heavy<ROWS>), dim3(512, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.units, offsets, cursor, list, meta, e_hi, e_lo_mont,
@@ -232,13 +235,13 @@ static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const u
 
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                          const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s) {
-    launch_gate_group_t<false>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, W, U, V, lb, heavy_words, heavy_partials, s);
+                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
+    launch_gate_group_t<false>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, W, U, V, lb, heavy_words, heavy_partials, s, host_hdr);
 }
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s) {
-    launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s);
+                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
+    launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s, host_hdr);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries
@@ -300,10 +303,34 @@ __global__ void __launch_bounds__(256) k_mobius_pass(Fr* __restrict__ t, uint32_
         store_fr(p + i, fr_sub(load_fr(p + i), load_fr(p + (i ^ bit))));
     }
 }
+// Up to ten variables per launch (the transform over different variables commutes): a block takes the 2^m entries that
+// differ only in index bits s .. s + m - 1 into LDS, runs the m butterfly stages there and writes them back -- a table of
+// 2^20 entries in two launches instead of twenty (a proof's line restrictions and coefficient tables issued 35 launches per
+// layer from the proving thread, as many as the layer's sumcheck).  grid = (2^(k - m), batch), block = 256
+constexpr uint32_t kMobiusBitsPerLaunch = 10;
+__global__ void __launch_bounds__(256) k_mobius_lds(Fr* __restrict__ t, uint32_t k, uint32_t s, uint32_t m, size_t stride) {
+    __shared__ Fr sh[1u << kMobiusBitsPerLaunch];
+    Fr* p = t + (size_t)blockIdx.y * stride;
+    const uint32_t n = 1u << m, lo_mask = (1u << s) - 1u;
+    const uint32_t lo = blockIdx.x & lo_mask, hi = blockIdx.x >> s;
+    const size_t base = ((size_t)hi << (s + m)) | lo;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) sh[e] = load_fr(p + base + ((size_t)e << s));
+    __syncthreads();
+    for (uint32_t bit = 1u; bit < n; bit <<= 1) {
+        for (uint32_t j = threadIdx.x; j < (n >> 1); j += blockDim.x) {
+            const uint32_t l = j & (bit - 1u), i = ((j & ~(bit - 1u)) << 1) | bit | l;
+            sh[i] = fr_sub(sh[i], sh[i ^ bit]);
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) store_fr(p + base + ((size_t)e << s), sh[e]);
+}
 void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStream_t s) {
     if (k == 0) return;
-    for (uint32_t bit = 1u << (k - 1u); bit; bit >>= 1)
-        hipLaunchKernelGGL(k_mobius_pass, dim3(blocks_for((uint64_t)1 << (k - 1u), 2048), batch), dim3(256), 0, s, tables, k, bit, stride);
+    for (uint32_t b = 0; b < k; b += kMobiusBitsPerLaunch) {
+        const uint32_t m = k - b < kMobiusBitsPerLaunch ? k - b : kMobiusBitsPerLaunch;
+        hipLaunchKernelGGL(k_mobius_lds, dim3(1u << (k - m), batch), dim3(256), 0, s, tables, k, b, m, stride);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -311,8 +338,9 @@ void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStr
 // proof -- the table (first 2^k), its ping-pong half, and W's monomial coefficients, of which only the support counts:
 // q's length = 1 + the largest total degree of a non-zero monomial (reduce_multiple_polynomial, poly.rs:484-497).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_line_copy(const Fr* __restrict__ W, uint32_t k, Fr* __restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_line_copy(const Fr* __restrict__ W, uint32_t k, Fr* __restrict__ scratch, uint32_t* __restrict__ maxdeg) {
     const uint32_t n = 1u << k;
+    if (blockIdx.x == 0 && threadIdx.x == 0) maxdeg[blockIdx.y] = 0u;   // (k_line_maxdeg, two launches later, raises it)
     const Fr* w = W + ((size_t)blockIdx.y << k);
     Fr* base = scratch + (size_t)blockIdx.y * 3u * n;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -334,16 +362,12 @@ __global__ void __launch_bounds__(256) k_line_maxdeg(uint32_t k, const Fr* __res
     __syncthreads();
     if (threadIdx.x == 0 && s_deg) atomicMax(maxdeg + blockIdx.y, s_deg);
 }
-__global__ void k_line_len_out(const uint32_t* __restrict__ maxdeg, uint32_t* __restrict__ out_len) {
-    out_len[blockIdx.x] = maxdeg[blockIdx.x] + 1u;   // (out_len may be pinned host memory: a plain store, no atomic)
-}
-void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t* out_len, uint32_t batch, hipStream_t s) {
+// (the length itself, maxdeg + 1, is written with q by k_line_tail)
+void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t batch, hipStream_t s) {
     const size_t n = (size_t)1 << k;
-    (void)hipMemsetAsync(maxdeg_scratch, 0, sizeof(uint32_t) * batch, s);
-    hipLaunchKernelGGL(k_line_copy, dim3(blocks_for(n, 2048), batch), dim3(256), 0, s, W, k, scratch);
+    hipLaunchKernelGGL(k_line_copy, dim3(blocks_for(n, 2048), batch), dim3(256), 0, s, W, k, scratch, maxdeg_scratch);
     launch_mobius(scratch + 2 * n, k, 3 * n, batch, s);
     hipLaunchKernelGGL(k_line_maxdeg, dim3(blocks_for(n, 1024), batch), dim3(256), 0, s, k, scratch, maxdeg_scratch);
-    hipLaunchKernelGGL(k_line_len_out, dim3(batch), dim3(1), 0, s, maxdeg_scratch, out_len);
 }
 
 // ---------------------------------------------------------------------------
