@@ -655,6 +655,16 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         (void)max_blocks;
         WS(ctx, "layer.X", Fr, wlen * batch, Xc);
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
+        // (passes of a few blocks per proof publish from their last block: one arrival counter per proof, zero between passes)
+        static const bool no_fused_publish = getenv("GKR_NO_FUSED_PUBLISH") != nullptr;
+        uint32_t* d_arrivals = nullptr;
+        if (!no_fused_publish) {
+            WS(ctx, "layer.arrivals", uint32_t, (size_t)(batch < 4096 ? 4096 : batch), d_arrivals);   // (one size for every batch: zeroed once)
+            if (ctx->arrivals_zeroed != d_arrivals) {
+                HIP_TRY(ctx, hipMemsetAsync(d_arrivals, 0, sizeof(uint32_t) * (size_t)(batch < 4096 ? 4096 : batch), s));
+                ctx->arrivals_zeroed = d_arrivals;
+            }
+        }
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
         bool second_exchange_done = false;
@@ -721,7 +731,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 } else {
                     ticket = ++ctx->ticket;
                     Timed t(ctx, "layer_prod_pass", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, nullptr, 0, d_arrivals);
                 }
                 m -= jp;
                 if (ahead && rem > J) {   // the phase's next pass, behind this one: it waits for this pass's weights
@@ -729,7 +739,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     ahead_ticket = ++ctx->ticket;
                     give_up.armed = true;
                     Timed t(ctx, "layer_prod_pass_ahead", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, J, h_pw, Jn, d_ppart, (uint32_t)wlen, prec, ahead_ticket, (uint32_t)batch, s, h_wseq, ticket);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, J, h_pw, Jn, d_ppart, (uint32_t)wlen, prec, ahead_ticket, (uint32_t)batch, s, h_wseq, ticket, d_arrivals);
                     launched_ahead = true;
                 }
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) {
@@ -782,6 +792,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             (void)sum_over_ranks(A, M, wlen, nullptr, rc);
         if (rc) {
             (void)hipStreamSynchronize(s);
+            ctx->arrivals_zeroed = nullptr;   // (a pass that was given up may have left its counters half way)
             return rc;
         }
         HIP_TRY(ctx, hipGetLastError());

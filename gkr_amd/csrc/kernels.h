@@ -73,9 +73,12 @@ inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_m
 // batch x prod_pass_blocks(2^(m_in - jp - 1)) x 72 values for passes that span several blocks per proof.
 // wait_seq (pinned host words, may be null): the pass is launched AHEAD of its weights and starts once wait_seq[0] == wait_ticket
 // (the host has written the weights) or wait_seq[1] != 0 (the host gave up).
+// arrivals (may be null): `batch` zeroed words; passes of 2 .. kProdFuseBlocks blocks per proof then publish from their last
+// block instead of a second launch (the words are zero again when the kernel ends).
+constexpr uint32_t kProdFuseBlocks = 64;
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq = nullptr,
-                      uint32_t wait_ticket = 0);
+                      uint32_t wait_ticket = 0, uint32_t* arrivals = nullptr);
 // start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
 // the 2^k entries of the rows A, M (gate_rows), per proof
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
@@ -246,9 +249,11 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
 
 // ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------
 // The gate passes with a group of 2^lg lanes per bucket; buckets longer than gate_heavy_threshold() gates are cut into
-// units of kHeavyUnit gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
+// units of gate_heavy_unit() gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
 constexpr uint32_t kHeavyPerLane = 64;    // a lane of a group walks at most this many gates (about eight on average)
-constexpr uint32_t kHeavyUnit = 1024;     // gates per unit of a heavy bucket (one wave, sixteen gates per lane)
+// gates per unit of a heavy bucket (one wave each): sixteen gates per lane where there is plenty of work, four where a layer
+// is small and its one or two heavy buckets -- the constant wires -- are a latency chain on every proof's path
+inline uint32_t gate_heavy_unit(uint64_t gates) { return gates < ((uint64_t)1 << 20) ? 256u : 1024u; }
 constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the lane-group passes
 uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k);
 uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k);

@@ -511,8 +511,9 @@ template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
                                                     const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
                                                     ProdPassRec* __restrict__ rec, uint32_t ticket, const uint32_t* __restrict__ wait_seq,
-                                                    uint32_t wait_ticket) {
+                                                    uint32_t wait_ticket, uint32_t* __restrict__ arrivals) {
     __shared__ Fr s_w[8];
+    __shared__ uint32_t s_last;
     // Launched AHEAD of its weights (a lone proof's round path: the launch and its ~6 us dispatch gap overlap the host's
     // hashing of the previous pass): the block waits until the host has released them -- wait_seq[0] = the previous pass's
     // ticket (pinned host memory, written after the weights), or wait_seq[1] != 0: the host gave up (every error path sets it).
@@ -578,6 +579,32 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
     if (alone) {
         __syncthreads();   // every record store is issued and waited for before the release below
         if (tid == 0) __hip_atomic_store(&rec[proof].seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (arrivals) {
+        // A few blocks per proof (<= kProdFuseBlocks): the LAST block to arrive totals the partials and publishes -- no second
+        // launch (a publish kernel cost its ~10 us plus the ~6 us to the next dependent launch on every such pass of every
+        // layer).  The partials cross the XCDs' L2s: release (write-back) before the arrival counter, acquire (invalidate)
+        // after it; the streaming passes of the plain sumcheck do NOT do this (there the fences cost 15 % of the bandwidth).
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(arrivals + proof, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const uint32_t q = tid / (uint32_t)kProdRecValues, val = tid % (uint32_t)kProdRecValues;   // three threads per value
+            if (q < 3u) {
+                const Fr* pp = partials + (size_t)proof * gridDim.x * kProdRecValues + val;
+                Fr v = fr_zero();
+                for (uint32_t b = q; b < gridDim.x; b += 3u) v = fr_add(v, load_fr(pp + (size_t)b * kProdRecValues));
+                s_red[q][val] = v;
+            }
+            __syncthreads();
+            if (tid < (uint32_t)kProdRecValues) store_fr(&rec[proof].v[tid], fr_add(fr_add(s_red[0][tid], s_red[1][tid]), s_red[2][tid]));
+            __syncthreads();   // every record store is issued and waited for before the release below
+            if (tid == 0) {
+                arrivals[proof] = 0u;   // (the next pass's blocks start after this kernel)
+                __hip_atomic_store(&rec[proof].seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -1745,14 +1772,17 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
 }
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq, uint32_t wait_ticket) {
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq, uint32_t wait_ticket,
+                      uint32_t* arrivals) {
     const uint32_t S = 1u << (m_in - jp - J), blocks = prod_pass_blocks(S);
+    uint32_t* fused = (arrivals && blocks > 1 && blocks <= kProdFuseBlocks) ? arrivals : nullptr;   // the last block publishes
     if (prod_pass_tile(S) == kProdTileWide)
         hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           wait_seq, wait_ticket);
+                           wait_seq, wait_ticket, fused);
     else
         hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           wait_seq, wait_ticket);
+                           wait_seq, wait_ticket, fused);
+    if (fused) return;
     if (blocks > 1024) {
         // (the second level's input sits behind the partials: launch_prod_pass's callers size the scratch with prod_pass_scratch_values)
         Fr* level2 = partials + (size_t)batch * blocks * kProdRecValues;

@@ -8,7 +8,7 @@
 //   * 2^k buckets of the gate lists with only a few gates each (a circom layer has about as many gates as the next
 //     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here a GROUP of L = 1..64
 //     lanes sums a bucket, about eight gates per lane (k_gate_group), and the few buckets far longer than the rest -- the constant wires every
-//     relay gate reads (convert.rs:307-342) -- are cut into units of 1024 gates summed a wave per unit (k_gate_heavy,
+//     relay gate reads (convert.rs:307-342) -- are cut into units of 256 / 1024 gates summed a wave per unit (k_gate_heavy,
 //     k_heavy_combine), so that no lane ever walks more than 64 gates;
 //   * tables the one-block helpers cannot walk: the dependence flags (k_depends_wide), the Moebius transform
 //     (k_mobius_pass) and the set-up of the line restriction (k_line_copy, k_line_maxdeg) run over a grid.
@@ -41,7 +41,7 @@ uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k) {
 uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k) { return kHeavyPerLane << gate_group_lanes_log2(gates, k); }   // (at least 64: a lane group's first lane)
 // capacities of one half (left-operand buckets / right-operand buckets)
 static inline size_t heavy_cap_buckets(uint64_t gates, uint32_t k) { return (size_t)(gates / gate_heavy_threshold(gates, k)) + 1; }
-static inline size_t heavy_cap_units(uint64_t gates, uint32_t k) { return (size_t)(gates / kHeavyUnit) + heavy_cap_buckets(gates, k); }
+static inline size_t heavy_cap_units(uint64_t gates, uint32_t k) { return (size_t)(gates / gate_heavy_unit(gates)) + heavy_cap_buckets(gates, k); }
 size_t gate_heavy_words(uint64_t gates, uint32_t k) {
     // header (8 words) | per half: heavy buckets {bucket, first unit, units} (3 words each) | units {bucket, chunk} (2 words each)
     return 8 + 2 * (3 * heavy_cap_buckets(gates, k) + 2 * heavy_cap_units(gates, k));
@@ -61,13 +61,13 @@ static inline HeavyView heavy_view(uint32_t* words, uint64_t gates, uint32_t k, 
 
 // one thread per bucket of both halves: buckets longer than `threshold` go to the half's work lists
 __global__ void __launch_bounds__(256) k_heavy_list(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
-                                                    uint32_t threshold, uint32_t* __restrict__ hdr, uint32_t* __restrict__ bucketsL,
+                                                    uint32_t threshold, uint32_t unit, uint32_t* __restrict__ hdr, uint32_t* __restrict__ bucketsL,
                                                     uint32_t* __restrict__ unitsL, uint32_t* __restrict__ bucketsR, uint32_t* __restrict__ unitsR) {
     const uint32_t b2 = blockIdx.x * blockDim.x + threadIdx.x;
     if (b2 >= 2u * nb) return;
     const uint32_t len = cursor[b2] - offsets[b2];
     if (len <= threshold) return;
-    const uint32_t half = b2 >= nb ? 1u : 0u, nunits = (len + kHeavyUnit - 1u) / kHeavyUnit;
+    const uint32_t half = b2 >= nb ? 1u : 0u, nunits = (len + unit - 1u) / unit;
     const uint32_t slot = atomicAdd(hdr + 2u * half, 1u), first = atomicAdd(hdr + 2u * half + 1u, nunits);
     uint32_t* hb = (half ? bucketsR : bucketsL) + 3u * (size_t)slot;
     hb[0] = b2;
@@ -146,14 +146,14 @@ __global__ void __launch_bounds__(256) k_gate_group(const uint32_t* __restrict__
     }
 }
 
-// a wave per unit (256 gates of a heavy bucket, four per lane); grid = (blocks, batch), any number of blocks
+// a wave per unit (gate_heavy_unit() gates of a heavy bucket); grid = (blocks, batch), any number of blocks
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_gate_heavy(const uint32_t* __restrict__ hdr, uint32_t half, const uint32_t* __restrict__ units,
                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
                                                     const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                     const Fr* __restrict__ T, Fr* __restrict__ partials, size_t pstride, uint32_t wstride,
-                                                    uint32_t gate_base) {
+                                                    uint32_t gate_base, uint32_t unit) {
     const uint32_t nunits = hdr[2u * half + 1u];
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t lmask = (1u << kl) - 1u;
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(256) k_gate_heavy(const uint32_t* __restrict__
     partials += (size_t)blockIdx.y * pstride;
     for (uint32_t u = wave; u < nunits; u += nwaves) {
         const uint32_t bucket = units[2u * u], chunk = units[2u * u + 1u];
-        const uint32_t begin = offsets[bucket] + chunk * kHeavyUnit, stop = cursor[bucket];
-        const uint32_t end = begin + kHeavyUnit < stop ? begin + kHeavyUnit : stop;
+        const uint32_t begin = offsets[bucket] + chunk * unit, stop = cursor[bucket];
+        const uint32_t end = begin + unit < stop ? begin + unit : stop;
         Lazy17 P = lazy_zero(), Q = lazy_zero();
         Acc<9> S = acc_zero<9>();
         for (uint32_t i = begin + lane; i < end; i += 64u) gate_term<ROWS>(P, Q, S, list[i] + gate_base, meta[i], e_hi, e_lo_mont, kl, lmask, T);
@@ -208,7 +208,8 @@ void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets,
     const uint32_t nb = 1u << k;
     (void)hipMemsetAsync(heavy_words, 0, 8 * sizeof(uint32_t), s);
     const HeavyView L = heavy_view(heavy_words, span.count, k, 0), R = heavy_view(heavy_words, span.count, k, 1);
-    hipLaunchKernelGGL(k_heavy_list, dim3((2u * nb + 255u) / 256u), dim3(256), 0, s, offsets, cursor, nb, gate_heavy_threshold(span.count, k), heavy_words,
+    hipLaunchKernelGGL(k_heavy_list, dim3((2u * nb + 255u) / 256u), dim3(256), 0, s, offsets, cursor, nb, gate_heavy_threshold(span.count, k),
+                       gate_heavy_unit(span.count), heavy_words,
                        L.buckets, L.units, R.buckets, R.units);
 }
 
@@ -228,7 +229,7 @@ static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const u
     const HeavyView hv = heavy_view(heavy_words, span.count, k, half);
     const size_t pstride = gate_heavy_partial_elems(span.count, k);
     hipLaunchKernelGGL((k_gate_heavy<ROWS>), dim3(512, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.units, offsets, cursor, list, meta, e_hi, e_lo_mont,
-                       kl, k_i - kl, T, heavy_partials, pstride, (uint32_t)lb.wstride, (uint32_t)span.base);
+                       kl, k_i - kl, T, heavy_partials, pstride, (uint32_t)lb.wstride, (uint32_t)span.base, gate_heavy_unit(span.count));
     hipLaunchKernelGGL(k_heavy_combine, dim3(64, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.buckets, 1u << k, heavy_partials, pstride, out0, out1,
                        (uint32_t)lb.wstride);
 }

@@ -288,7 +288,7 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
                                  {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
                                  {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_LAYER_PER_ROUND": "1"},
                                  {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_LINE_STEPWISE": "1"},
-                                 {"GKR_LAUNCH_AHEAD": "1"}],
+                                 {"GKR_LAUNCH_AHEAD": "1"}, {"GKR_NO_FUSED_PUBLISH": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
     """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from
