@@ -47,11 +47,11 @@ def wide_circuit(ks=(18, 20, 20), seed=SEED + 7):
 def proof_arrays_digest(ks, sc, sl, sr, q, ql, z, rr):
     """sha256 over one proof's raw arrays (round coefficients | lengths | challenges | q | q lengths | z | r) in the C ABI's
     layout -- the product's gkr_prove_batch outputs for proof 0, or the same arrays assembled from the CPU checker's
-    prove_raw (proof_arrays_from_oracle)."""
+    prove_raw (proof_arrays_from_checker)."""
     return transcript_digest(sc, sl, sr, q, ql, z, rr)
 
 
-def proof_arrays_from_oracle(ref, ks):
+def proof_arrays_from_checker(ref, ks):
     """cdense.prove_raw's dict -> the seven arrays in gkr_proof_buf layout (one proof)."""
     L = len(ks) - 1
     sc = np.concatenate(ref["C"])

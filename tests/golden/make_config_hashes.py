@@ -107,7 +107,7 @@ def large_r1cs_digests(nrounds=65536, pair=(2, 3)):
         layers = [(np.asarray(a, dtype=np.uint8), np.asarray(b, dtype=np.uint32), np.asarray(c, dtype=np.uint32)) for a, b, c in sub["layers"]]
         ref = cdense.prove_raw(layers, cdense.to_limbs(sub["input_values"]))
         out["k"].append(list(sub["k"]))
-        out["digests"].append(synth.proof_arrays_digest(list(sub["k"]), *synth.proof_arrays_from_oracle(ref, list(sub["k"]))))
+        out["digests"].append(synth.proof_arrays_digest(list(sub["k"]), *synth.proof_arrays_from_checker(ref, list(sub["k"]))))
     return out
 
 
@@ -149,7 +149,7 @@ def main():
     for ks in ((18, 20, 20),):
         circuit, raw, wit = synth.wide_circuit(ks)
         ref = cdense.prove_raw(raw, wit[0])
-        out["prove"]["k=" + ",".join(map(str, ks))] = synth.proof_arrays_digest(list(ks), *synth.proof_arrays_from_oracle(ref, list(ks)))
+        out["prove"]["k=" + ",".join(map(str, ks))] = synth.proof_arrays_digest(list(ks), *synth.proof_arrays_from_checker(ref, list(ks)))
     for n, seed in ((16, synth.SEED + 1), (20, synth.SEED + 2)):
         C, L, R = cdense.sumcheck_mle_raw(cdense.fill_table(1 << n, seed), n)
         out["mle"]["n=%d,seed=%d" % (n, seed)] = digest(C, L, R)

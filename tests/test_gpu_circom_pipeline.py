@@ -221,7 +221,7 @@ def test_large_r1cs_end_to_end_through_wide_layers():
             ks = ks_all[j]
             if j % 5 == 0:      # (the checker's prover on four of the sixteen: ~2 s each)
                 ref = cdense.prove_raw([lay.arrays() for lay in circuit.layer], inputs[j][0])
-                want = synth.proof_arrays_from_oracle(ref, ks)
+                want = synth.proof_arrays_from_checker(ref, ks)
                 assert all(np.array_equal(np.asarray(a[0]).reshape(w.shape), w) for a, w in zip(arrs[:7], want)), j
             if gold is not None:
                 assert ks == gold["k"][j] and synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) == gold["digests"][j], j
