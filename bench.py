@@ -606,11 +606,11 @@ def aggregated_proofs(world, n_inputs):
         big = ProvingStep(synth.mimc7_demo_r1cs(nrounds=nrounds))
         big_compile_ms = (time.perf_counter() - t0) * 1e3
         big_inputs = big.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(pair[0], pair[1], nrounds=nrounds))]))
-        for _ in range(2):
+        for _ in range(3):
             big.prove_raw_many(ctx, big_inputs, threads)
         world.barrier(ctx)
         each_big = []
-        for _ in range(3):
+        for _ in range(9):
             t1 = time.perf_counter()
             big.prove_raw_many(ctx, big_inputs, threads)
             each_big.append((time.perf_counter() - t1) * 1e3)
