@@ -92,6 +92,29 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     WS(ctx, "mlep.plans", unsigned char, (size_t)batch * gkr::mle_fold_plan_bytes(), plans);
     HIP_TRY(ctx, ctx->pinned_host("mlep.rec", sizeof(gkr::MleHostRecSub) * batch, reinterpret_cast<void**>(&rec)));
     HIP_TRY(ctx, ctx->pinned_host("mlep.w", sizeof(Fr) * gkr::kMleMaxSub * batch, reinterpret_cast<void**>(&h_w)));
+    // Latency-bound passes (a few sumchecks of moderate size: at most kFusedPublishBytes read per launch) publish from their
+    // last block instead of through k_mle_sub_reduce: one launch and one dependent-launch gap less per pass on the round
+    // path of a lone sumcheck.  Streaming passes keep the second launch (see mle_publish_from_last_block).
+    static const bool no_fused = getenv("GKR_NO_FUSED_REDUCE") != nullptr;
+    constexpr double kFusedPublishBytes = 64.0 * 1024 * 1024;
+    uint32_t* d_arrivals = nullptr;
+    if (!no_fused && (double)len * 32.0 <= kFusedPublishBytes) {
+        constexpr size_t kCounters = 4096;   // (one size: zeroed once per allocation, every pass leaves them zero)
+        WS(ctx, "mlep.arrivals", uint32_t, kCounters, d_arrivals);
+        if (ctx->mle_arrivals_zeroed != d_arrivals) {
+            HIP_TRY(ctx, hipMemsetAsync(d_arrivals, 0, sizeof(uint32_t) * kCounters, s));
+            ctx->mle_arrivals_zeroed = d_arrivals;
+        }
+    }
+    constexpr uint32_t kFusedPublishBlocks = 256;   // blocks per launch: each pays one L2 write-back (~30 ns, one after the other)
+    auto fused_publish = [&](int b0, int nb, uint32_t nblk, double bytes_read, uint32_t ticket, int jout, gkr::MlePublish& pub) {
+        if (!d_arrivals || b0 + nb > 4096 || bytes_read > kFusedPublishBytes || (uint64_t)nblk * nb > kFusedPublishBlocks || nblk > 128u) return false;
+        pub.rec = rec + b0;
+        pub.arrivals = d_arrivals + b0;
+        pub.ticket = ticket;
+        pub.jout = (uint32_t)jout;
+        return true;
+    };
     const bool ifma = host_ifma_ready();
     const bool scalar_book = getenv("GKR_HOST_PASS_SCALAR") != nullptr;   // A/B switch: host_pass_scalar even where the CPU has IFMA
     std::vector<uint32_t> dep_last(batch, 0);
@@ -201,10 +224,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         }
         const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)len, (uint32_t)G.j, nb);
         gkr::MleSubPartial* part = partials + (size_t)b0 * gkr::kMaxBlocksPerTable;
+        gkr::MlePublish pub;
+        const bool fused = fused_publish(b0, nb, nblk, (double)nb * len * 32.0, G.ticket, G.j, pub);
         {
-            Timed t(ctx, "mle_sub_sums", (double)nb * len * 32.0);
-            gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, s);
+            Timed t(ctx, "mle_sub_sums", (double)nb * len * 32.0, nullptr, fused);
+            gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, s, fused ? &pub : nullptr);
         }
+        if (fused) return;
         Timed t(ctx, "mle_sub_reduce", 0.0, nullptr, true);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
     };
@@ -252,13 +278,16 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                 (void)hipStreamWaitEvent(s, ctx->aux_events[G.index], 0);
             }
         }
+        gkr::MlePublish pub;
+        const bool fused = fused_publish(b0, nb, nblk, (double)nb * (double)src_len * 32.0, G.ticket, G.j, pub);
         {
             // late passes run beside other groups' streaming passes: their elapsed time is not their own cost, so they
             // are booked under their own name and stay out of the streaming fold pass's bandwidth figure
-            Timed t(ctx, st == s ? "mle_multifold" : "mle_multifold_late", bytes, st);
+            Timed t(ctx, st == s ? "mle_multifold" : "mle_multifold_late", bytes, st, fused);
             gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub,
-                                      plan, part, st);
+                                      plan, part, st, fused ? &pub : nullptr);
         }
+        if (fused) return;
         Timed t(ctx, "mle_sub_reduce", 0.0, st, true);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st);
     };
@@ -387,6 +416,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     if (rc) {
         (void)hipStreamSynchronize(s);
         if (late != s) (void)hipStreamSynchronize(late);
+        ctx->mle_arrivals_zeroed = nullptr;   // (a pass that was given up may have left its counters half way)
         return rc;
     }
     dbg_d = dbg_us();

@@ -103,19 +103,27 @@ struct MleHostRecSub {   // pinned hand-off record: up to 32 sub-block sums, seq
     uint32_t pad[14];
 };
 static_assert(sizeof(MleHostRecSub) == 1088, "hand-off record layout");
+// a pass that publishes its own sums (latency-bound passes: the last block to arrive totals the partials; arrivals == nullptr:
+// launch_mle_sub_reduce does it)
+struct MlePublish {
+    MleHostRecSub* rec = nullptr;   // the first sumcheck of the launch
+    uint32_t* arrivals = nullptr;   // one zeroed counter per sumcheck of the launch; left zero
+    uint32_t ticket = 0, jout = 0;
+};
 constexpr uint32_t kSmallPassEntries = 512;   // passes whose output has <= this many entries run as one block per sumcheck
 uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch);
 uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch);
 bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk);
 // Every pass: per-block partial sums, then a reduce kernel that writes the pinned host record.
 void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk, MleSubPartial* partials,
-                         hipStream_t s);
+                         hipStream_t s, const MlePublish* publish = nullptr);
 void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRecSub* host_rec,
                            uint32_t ticket, hipStream_t s);
 size_t mle_fold_plan_bytes();
 void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batch, hipStream_t s);
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s);
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s,
+                          const MlePublish* publish = nullptr);
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
                                 uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,

@@ -235,11 +235,84 @@ __device__ __forceinline__ Fr multifold_entry(const Fr* __restrict__ s, uint32_t
     }
 }
 
+// The nblk partials of ONE sumcheck (2^jout sub-blocks of bps = nblk / 2^jout consecutive partials) -> the canonical
+// sub-block sums in the host record.  Every partial is loaded by its own thread at once (nblk > blockDim: r consecutive
+// ones per thread) and the sub-blocks are totalled by shuffles over min(bps / r, 64) lanes -- one round of loads and
+// log2 steps on a lone sumcheck's round path, where a wave walking its sub-blocks one after the other paid a load
+// latency per sub-block (11 us for 32 sub-blocks).  Called by all threads of a block of <= 1024.
+__device__ __forceinline__ void mle_total_and_publish(const MleSubPartial* __restrict__ p, uint32_t nblk, uint32_t jout,
+                                                      MleHostRecSub* __restrict__ r, uint32_t ticket) {
+    __shared__ uint32_t s_pdep;
+    __shared__ Acc<10> s_tot[kMleMaxSub], s_wave[16];
+    const uint32_t T = blockDim.x, t = threadIdx.x, lane = t & 63u;
+    const uint32_t nsub = 1u << jout, per = nblk > T ? nblk / T : 1u, eff = nblk / per, bps = (nblk >> jout) / per;
+    if (t == 0) s_pdep = 0;
+    __syncthreads();
+    Acc<10> tot = acc_zero<10>();
+    uint32_t dep = 0;
+    if (t < eff) {
+        for (uint32_t i = 0; i < per; ++i) {
+            acc_add_acc(tot, p[(size_t)t * per + i].sum);
+            dep |= p[(size_t)t * per + i].dep;
+        }
+    }
+    if (__any(dep) && lane == 0) atomicOr(&s_pdep, 1u);
+    const uint32_t seg = bps < 64u ? bps : 64u;
+    for (uint32_t off = seg >> 1; off >= 1u; off >>= 1) {
+        Acc<10> o;
+#pragma unroll
+        for (int l = 0; l < 10; ++l) o.l[l] = __shfl_down(tot.l[l], off, 64);
+        acc_add_acc(tot, o);
+    }
+    if (bps <= 64u) {
+        if (t < eff && (t & (seg - 1u)) == 0) s_tot[t / seg] = tot;
+        __syncthreads();
+    } else {
+        // a sub-block spans bps / 64 waves (<= 16 wave totals in all)
+        if (t < eff && lane == 0) s_wave[t >> 6] = tot;
+        __syncthreads();
+        if (t < nsub) {
+            Acc<10> a = acc_zero<10>();
+            for (uint32_t w = 0; w < (bps >> 6); ++w) acc_add_acc(a, s_wave[t * (bps >> 6) + w]);
+            s_tot[t] = a;
+        }
+    }
+    if (t < nsub) r->sums[t] = acc_reduce(s_tot[t]);
+    __syncthreads();   // every record store is issued and waited for before the release below
+    if (t == 0) {
+        r->dep = s_pdep;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// A latency-bound pass publishes from its LAST block (pub.arrivals != nullptr): every block leaves its partial, the
+// last one to arrive at the sumcheck's counter totals them -- k_mle_sub_reduce's arithmetic on this block's waves -- and
+// writes the host record: no second launch on the round path of a lone sumcheck (k_mle_sub_reduce there: 6 - 11 us
+// plus the ~6 us to a dependent launch, on three passes of a 2^20-point sumcheck).  The partials cross the XCDs' L2s:
+// release before the counter, acquire after it.  Streaming passes and passes of many blocks do NOT take this path: the
+// fences cost the fold pass 15 % of its bandwidth (measured in round 2), three times what the launch saves.
+__device__ __forceinline__ void mle_publish_from_last_block(const MleSubPartial* __restrict__ partials, const MlePublish& pub) {
+    __shared__ uint32_t s_last;
+    const uint32_t b = blockIdx.y, nblk = gridDim.x;
+    if (threadIdx.x == 0) {
+        // (thread 0 wrote the block's partial: ITS release is the one that counts.  A release is a write-back of the XCD's
+        // L2 and costs ~30 ns, one after the other across the grid: 4096 of them -- every wave of a 1024-block pass --
+        // turned an 11 us pass into a 149 us one, which is why only passes of few blocks come here at all)
+        __threadfence();
+        s_last = atomicAdd(pub.arrivals + b, 1u) == nblk - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) pub.arrivals[b] = 0u;   // (the next pass's blocks start after this kernel)
+    mle_total_and_publish(partials + (size_t)b * nblk, nblk, pub.jout, pub.rec + b, pub.ticket);
+}
+
 // pass 0: sub-block sums of the input tables.  grid = (nblk, batch), nblk = 2^J * blocks-per-sub-block,
 // every block a contiguous chunk of len / nblk entries.  dep: does the table depend on x_n
 // (entry 2m vs 2m+1; the neighbour is read through the cache the partner lane just filled).
 __global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tables, size_t table_stride, uint32_t len,
-                                                      MleSubPartial* __restrict__ partials) {
+                                                      MleSubPartial* __restrict__ partials, MlePublish pub) {
     __shared__ Acc<9> smem[4];
     __shared__ uint32_t s_dep;
     const Fr* t = tables + (size_t)blockIdx.y * table_stride;
@@ -266,6 +339,7 @@ __global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tab
         p->sum = acc[0];
         p->dep = s_dep;
     }
+    if (pub.arrivals) mle_publish_from_last_block(partials, pub);
 }
 
 // one pass: bind JIN variables with the weights w[0 .. 2^JIN) (Montgomery, wave-uniform), write the
@@ -273,7 +347,7 @@ __global__ void __launch_bounds__(256) k_mle_sub_sums(const Fr* __restrict__ tab
 template <int JIN>
 __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                        size_t dst_stride, uint32_t S, const Fr* __restrict__ weights,
-                                                       MleSubPartial* __restrict__ partials) {
+                                                       MleSubPartial* __restrict__ partials, MlePublish pub) {
     __shared__ Acc<9> smem[4];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
     Fr* d = dst + (size_t)blockIdx.y * dst_stride;
@@ -292,13 +366,14 @@ __global__ void __launch_bounds__(256) k_mle_multifold(const Fr* __restrict__ sr
         p->sum = acc[0];
         p->dep = 0;
     }
+    if (pub.arrivals) mle_publish_from_last_block(partials, pub);
 }
 
 // the same pass with the products on the matrix cores (mfma_fold.h): k_mle_fold_plan turns each sumcheck's
 // weights into its digit matrix (grid = batch), k_mle_multifold_mfma streams the tables through it
 // (chunk = S / nblk a multiple of 64)
 template <int JIN>
-__global__ void __launch_bounds__(256) k_mle_fold_plan(const Fr* __restrict__ weights, MfmaFoldPlan* __restrict__ plans) {
+__global__ void __launch_bounds__(1024) k_mle_fold_plan(const Fr* __restrict__ weights, MfmaFoldPlan* __restrict__ plans) {
     __shared__ __attribute__((aligned(16))) unsigned char digits[32 * 32 * (1 << JIN)];
     mfma_plan_block<JIN>(weights + (size_t)blockIdx.x * kMleMaxSub, plans + blockIdx.x, digits);
 }
@@ -306,7 +381,7 @@ __global__ void __launch_bounds__(256) k_mle_fold_plan(const Fr* __restrict__ we
 template <int JIN>
 __global__ void __launch_bounds__(256) k_mle_multifold_mfma(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                             size_t dst_stride, uint32_t S, const MfmaFoldPlan* __restrict__ plans,
-                                                            MleSubPartial* __restrict__ partials) {
+                                                            MleSubPartial* __restrict__ partials, MlePublish pub) {
     __shared__ Acc<9> smem[4];
     __shared__ __attribute__((aligned(16))) unsigned char digits[JIN > 2 ? 32 * 32 * (1 << JIN) : 16];
     const Fr* s = src + (size_t)blockIdx.y * src_stride;
@@ -321,92 +396,134 @@ __global__ void __launch_bounds__(256) k_mle_multifold_mfma(const Fr* __restrict
         p->sum = acc[0];
         p->dep = 0;
     }
+    if (pub.arrivals) mle_publish_from_last_block(partials, pub);
 }
 
-// partials of a pass -> 2^jout canonical sub-block sums per table -> pinned host record.  (Fusing this into the
-// passes -- the last block to arrive at a per-sumcheck counter reduces -- was measured: the write-through partial
-// stores and the counter round trip cost the fold pass 15 % of its bandwidth, three times what the launch saves.)  The eight waves total the
-// sub-blocks (wave w: sub-blocks w, w + 8, ...), then one thread per sub-block reduces its total mod p.
+// partials of a pass -> 2^jout canonical sub-block sums per table -> pinned host record (mle_total_and_publish).  Streaming
+// passes and passes of many blocks publish through this second launch; fusing it into them (the last block to arrive
+// reduces: mle_publish_from_last_block) costs a streaming pass 15 % of its bandwidth, three times what the launch saves.
 // grid = (batch), block = 512
 __global__ void __launch_bounds__(512) k_mle_sub_reduce(const MleSubPartial* __restrict__ partials, uint32_t nblk,
                                                         uint32_t jout, MleHostRecSub* __restrict__ host_rec, uint32_t ticket) {
-    __shared__ uint32_t s_dep;
-    __shared__ Acc<10> s_tot[kMleMaxSub];
-    const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nsub = 1u << jout, bps = nblk >> jout;
-    if (threadIdx.x == 0) s_dep = 0;
-    __syncthreads();
-    MleHostRecSub* r = host_rec + b;
-    for (uint32_t sb = wave; sb < nsub; sb += 8u) {
-        const MleSubPartial* p = partials + (size_t)b * nblk + (size_t)sb * bps;
-        Acc<10> tot = acc_zero<10>();
-        uint32_t dep = 0;
-        for (uint32_t i = lane; i < bps; i += 64) {
-            acc_add_acc(tot, p[i].sum);
-            dep |= p[i].dep;
-        }
-        tot = wave_sum(tot);
-        if (__any(dep) && lane == 0) atomicOr(&s_dep, 1u);
-        if (lane == 0) s_tot[sb] = tot;
-    }
-    __syncthreads();
-    if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_tot[threadIdx.x]);
-    __syncthreads();   // every record store is issued and waited for before the release below
-    if (threadIdx.x == 0) {
-        r->dep = s_dep;
-        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    mle_total_and_publish(partials + (size_t)blockIdx.x * nblk, nblk, jout, host_rec + blockIdx.x, ticket);
 }
 
-// small tables: one block per sumcheck does the whole pass (multifold, sub-block sums, publish)
-template <int JIN>
-__global__ void __launch_bounds__(256) k_mle_multifold_small(const Fr* __restrict__ src, size_t src_stride,
-                                                             Fr* __restrict__ dst, size_t dst_stride, uint32_t S,
-                                                             uint32_t jout, const Fr* __restrict__ weights,
-                                                             MleHostRecSub* __restrict__ host_rec, uint32_t ticket) {
+// small tables: one block per sumcheck does the whole pass (multifold, sub-block sums, publish).  JIN == 0: no fold,
+// only the sub-block sums of the table as it stands (tiny first pass).  grid = (batch), block = 256
+__global__ void __launch_bounds__(256) k_mle_sums_small(const Fr* __restrict__ src, size_t src_stride, uint32_t S, uint32_t jout,
+                                                        MleHostRecSub* __restrict__ host_rec, uint32_t ticket) {
     const uint32_t b = blockIdx.x;
-    const Fr* s = src + (size_t)b * src_stride;
-    Fr* d = dst + (size_t)b * dst_stride;
-    const Fr* w = weights + (size_t)b * kMleMaxSub;
-    // JIN == 0: no fold, only the sub-block sums of the table as it stands (tiny first pass)
-    if (JIN > 0) {
-        for (uint32_t i = threadIdx.x; i < S; i += blockDim.x) {
-            store_fr(d + i, multifold_entry<(JIN > 0 ? JIN : 1)>(s, S, i, w));
-        }
-        __threadfence_block();
-        __syncthreads();   // the folded table is complete and visible to the block
-    }
-    const Fr* tbl = JIN > 0 ? d : s;
+    const Fr* tbl = src + (size_t)b * src_stride;
     const uint32_t sub = S >> jout, nsub = 1u << jout;
     MleHostRecSub* r = host_rec + b;
     uint32_t dep = 0;
     // 256 / nsub threads per sub-block (nsub <= 32): partial sums, totals through LDS, then one thread per
     // sub-block reduces its total mod p
-    {
-        __shared__ Acc<9> s_part[256];
-        const uint32_t tps = 256u >> jout, sb = threadIdx.x / tps, rr = threadIdx.x % tps;
-        Acc<9> acc = acc_zero<9>();
-        for (uint32_t i = rr; i < sub; i += tps) {
-            const Fr x = load_fr(tbl + (size_t)sb * sub + i);
-            acc_add_fr(acc, x);
-            if (JIN == 0) dep |= fr_eq(x, load_fr(tbl + (((size_t)sb * sub + i) ^ 1u))) ? 0u : 1u;
-        }
-        s_part[threadIdx.x] = acc;
-        __syncthreads();
-        // tree over the tps partials of each sub-block (tps is a power of two)
-        for (uint32_t step = tps >> 1; step >= 1u; step >>= 1) {
-            if (rr < step) {
-                Acc<9> mine = s_part[threadIdx.x];
-                acc_add_acc(mine, s_part[threadIdx.x + step]);
-                s_part[threadIdx.x] = mine;
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_part[threadIdx.x * tps]);
+    __shared__ Acc<9> s_part[256];
+    const uint32_t tps = 256u >> jout, sb = threadIdx.x / tps, rr = threadIdx.x % tps;
+    Acc<9> acc = acc_zero<9>();
+    for (uint32_t i = rr; i < sub; i += tps) {
+        const Fr x = load_fr(tbl + (size_t)sb * sub + i);
+        acc_add_fr(acc, x);
+        dep |= fr_eq(x, load_fr(tbl + (((size_t)sb * sub + i) ^ 1u))) ? 0u : 1u;
     }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    // tree over the tps partials of each sub-block (tps is a power of two)
+    for (uint32_t step = tps >> 1; step >= 1u; step >>= 1) {
+        if (rr < step) {
+            Acc<9> mine = s_part[threadIdx.x];
+            acc_add_acc(mine, s_part[threadIdx.x + step]);
+            s_part[threadIdx.x] = mine;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_part[threadIdx.x * tps]);
     dep = __syncthreads_or(dep);
     if (threadIdx.x == 0) {
         r->dep = dep ? 1u : 0u;
+        __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The fold passes of small tables: S <= 512 outputs, each a sum of 2^jin products.  These are the latency-bound tail of
+// every sumcheck (2^12 -> 2^7 -> 2^2 at n = 20), so the (output, term) pairs are spread over ALL 1024 threads of the
+// block -- thread (i, q) sums the terms b = q * per .. q * per + per - 1 of output i, per = max(1, S 2^jin / 1024) --
+// instead of one thread per output walking its 32 products (128 and then 4 busy threads of 256: 31 and 29 us per pass
+// for a lone sumcheck; the pass's weights, which sit in pinned host memory, are fetched once per block, not once per
+// product).  The partial sums are reduced where they are (any order of exact sums gives the same canonical element),
+// totalled per output, and the outputs' sub-block sums are taken from LDS.  grid = (batch), block = 1024
+__global__ void __launch_bounds__(1024) k_mle_multifold_small(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
+                                                              size_t dst_stride, uint32_t S, uint32_t jin, uint32_t jout,
+                                                              const Fr* __restrict__ weights, MleHostRecSub* __restrict__ host_rec,
+                                                              uint32_t ticket) {
+    __shared__ Fr s_w[kMleMaxSub];
+    __shared__ Fr s_y[1024];       // partial sums [q][i], then (the first S) the outputs
+    __shared__ Acc<9> s_part[kMleMaxSub];
+    const uint32_t b = blockIdx.x;
+    const Fr* s = src + (size_t)b * src_stride;
+    Fr* d = dst + (size_t)b * dst_stride;
+    const uint32_t nterm = 1u << jin;
+    if (threadIdx.x < nterm * 8u)
+        s_w[threadIdx.x >> 3].l[threadIdx.x & 7u] = reinterpret_cast<const uint32_t*>(weights + (size_t)b * kMleMaxSub)[threadIdx.x];
+    __syncthreads();
+    const uint32_t items = S << jin, per = items > 1024u ? items >> 10 : 1u, groups = nterm / per;
+    const uint32_t i = threadIdx.x & (S - 1u), q = threadIdx.x / S;   // S is a power of two
+    if (q < groups) {
+        Lazy17 acc = lazy_zero();
+        for (uint32_t t = 0; t < per; ++t) {
+            const uint32_t term = q * per + t;
+            lazy_mac_v(acc, load_fr(s + (size_t)term * S + i), s_w[term]);
+        }
+        s_y[q * S + i] = lazy_reduce(acc);
+    }
+    __syncthreads();
+    Fr y;
+    if (threadIdx.x < S) {
+        Acc<9> tot = acc_zero<9>();
+        for (uint32_t g = 0; g < groups; ++g) acc_add_fr(tot, s_y[g * S + threadIdx.x]);
+        y = acc_reduce(tot);
+        store_fr(d + threadIdx.x, y);
+    }
+    __syncthreads();   // every partial has been read
+    if (threadIdx.x < S) s_y[threadIdx.x] = y;
+    __syncthreads();
+    // sub-block sums of the outputs: min(sub, 1024 / nsub) threads per sub-block, totals through LDS
+    const uint32_t nsub = 1u << jout, sub = S >> jout;
+    uint32_t tps = 1024u >> jout;
+    if (tps > sub) tps = sub;
+    const uint32_t sb = threadIdx.x / tps, rr = threadIdx.x % tps;
+    MleHostRecSub* r = host_rec + b;
+    const bool mine = sb < nsub;
+    Acc<9> acc = acc_zero<9>();
+    if (mine)
+        for (uint32_t k = rr; k < sub; k += tps) acc_add_fr(acc, s_y[sb * sub + k]);
+    // tree over the tps partials of a sub-block: within a wave by shuffles, across waves (tps > 64) through LDS
+    const uint32_t within = tps < 64u ? tps : 64u;
+    for (uint32_t off = within >> 1; off >= 1u; off >>= 1) {
+        Acc<9> o;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) o.l[l] = __shfl_down(acc.l[l], off, 64);
+        acc_add_acc(acc, o);
+    }
+    if (tps > 64u) {
+        // nsub * (tps / 64) <= 16 wave totals
+        __shared__ Acc<9> s_wave[16];
+        if (mine && (threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x < nsub) {
+            Acc<9> tot = acc_zero<9>();
+            for (uint32_t w = 0; w < (tps >> 6); ++w) acc_add_acc(tot, s_wave[threadIdx.x * (tps >> 6) + w]);
+            s_part[threadIdx.x] = tot;
+        }
+    } else if (mine && rr == 0) {
+        s_part[sb] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < nsub) r->sums[threadIdx.x] = acc_reduce(s_part[threadIdx.x]);
+    __syncthreads();   // every record store is issued and waited for before the release below
+    if (threadIdx.x == 0) {
+        r->dep = 0u;
         __hip_atomic_store(&r->seq, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -2199,8 +2316,8 @@ uint32_t mle_pass_blocks(uint32_t items, uint32_t jout, uint32_t batch) {
 }
 
 void launch_mle_sub_sums(const Fr* tables, size_t stride, uint32_t len, uint32_t batch, uint32_t nblk, MleSubPartial* partials,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(k_mle_sub_sums, dim3(nblk, batch), dim3(256), 0, s, tables, stride, len, partials);
+                         hipStream_t s, const MlePublish* publish) {
+    hipLaunchKernelGGL(k_mle_sub_sums, dim3(nblk, batch), dim3(256), 0, s, tables, stride, len, partials, publish ? *publish : MlePublish{});
 }
 
 void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_t jout, uint32_t batch, MleHostRecSub* host_rec,
@@ -2217,45 +2334,48 @@ bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk) {
 size_t mle_fold_plan_bytes() { return sizeof(MfmaFoldPlan); }
 
 // the plans of `batch` sumchecks (batch * mle_fold_plan_bytes() of device memory) from their weights; only needed
-// when mle_multifold_uses_mfma says so
+// when mle_multifold_uses_mfma says so.  One thread per row of the digit matrix (32 * 2^jin rows: the kernel sits on a lone
+// sumcheck's round path, where four rows per thread cost 14 us instead of 7)
 void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batch, hipStream_t s) {
     MfmaFoldPlan* pl = static_cast<MfmaFoldPlan*>(plans);
     if (jin == 1)
-        hipLaunchKernelGGL(k_mle_fold_plan<1>, dim3(batch), dim3(256), 0, s, weights, pl);
+        hipLaunchKernelGGL(k_mle_fold_plan<1>, dim3(batch), dim3(64), 0, s, weights, pl);
     else if (jin == 2)
-        hipLaunchKernelGGL(k_mle_fold_plan<2>, dim3(batch), dim3(256), 0, s, weights, pl);
+        hipLaunchKernelGGL(k_mle_fold_plan<2>, dim3(batch), dim3(128), 0, s, weights, pl);
     else if (jin == 3)
         hipLaunchKernelGGL(k_mle_fold_plan<3>, dim3(batch), dim3(256), 0, s, weights, pl);
     else if (jin == 4)
-        hipLaunchKernelGGL(k_mle_fold_plan<4>, dim3(batch), dim3(256), 0, s, weights, pl);
+        hipLaunchKernelGGL(k_mle_fold_plan<4>, dim3(batch), dim3(512), 0, s, weights, pl);
     else
-        hipLaunchKernelGGL(k_mle_fold_plan<5>, dim3(batch), dim3(256), 0, s, weights, pl);
+        hipLaunchKernelGGL(k_mle_fold_plan<5>, dim3(batch), dim3(1024), 0, s, weights, pl);
 }
 
 // plans: what launch_mle_fold_plan built for this pass (matrix-core form), unused otherwise
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
-                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s) {
+                          uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s,
+                          const MlePublish* publish) {
     dim3 grid(nblk, batch);
+    const MlePublish pub = publish ? *publish : MlePublish{};
     if (mle_multifold_uses_mfma(S, nblk)) {
         const MfmaFoldPlan* pl = static_cast<const MfmaFoldPlan*>(plans);
         if (jin == 1)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials, pub);
         else if (jin == 2)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials, pub);
         else if (jin == 3)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials, pub);
         else if (jin == 4)
-            hipLaunchKernelGGL(k_mle_multifold_mfma<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials, pub);
         else
-            hipLaunchKernelGGL(k_mle_multifold_mfma<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials);
+            hipLaunchKernelGGL(k_mle_multifold_mfma<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, pl, partials, pub);
         return;
     }
     if (jin == 1)
-        hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+        hipLaunchKernelGGL(k_mle_multifold<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials, pub);
     else if (jin == 2)
-        hipLaunchKernelGGL(k_mle_multifold<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+        hipLaunchKernelGGL(k_mle_multifold<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials, pub);
     else
-        hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials);
+        hipLaunchKernelGGL(k_mle_multifold<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, weights, partials, pub);
 }
 
 // blocks per table for a multifold pass of S output entries split into 2^jout sub-blocks: a power of two >= 2^jout.
@@ -2286,17 +2406,10 @@ void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* d
                                 uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s) {
     dim3 grid(batch);
     if (jin == 0)
-        hipLaunchKernelGGL(k_mle_multifold_small<0>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
-    else if (jin == 1)
-        hipLaunchKernelGGL(k_mle_multifold_small<1>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
-    else if (jin == 2)
-        hipLaunchKernelGGL(k_mle_multifold_small<2>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
-    else if (jin == 3)
-        hipLaunchKernelGGL(k_mle_multifold_small<3>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
-    else if (jin == 4)
-        hipLaunchKernelGGL(k_mle_multifold_small<4>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+        hipLaunchKernelGGL(k_mle_sums_small, grid, dim3(256), 0, s, src, src_stride, S, jout, host_rec, ticket);
     else
-        hipLaunchKernelGGL(k_mle_multifold_small<5>, grid, dim3(256), 0, s, src, src_stride, dst, dst_stride, S, jout, weights, host_rec, ticket);
+        hipLaunchKernelGGL(k_mle_multifold_small, grid, dim3(1024), 0, s, src, src_stride, dst, dst_stride, S, (uint32_t)jin, jout, weights,
+                           host_rec, ticket);
 }
 
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,

@@ -118,7 +118,8 @@ def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
 @pytest.mark.parametrize("env", [{"GKR_NO_MFMA_FOLD": "1"}, {"GKR_ROUNDS_PER_PASS": "1"}, {"GKR_ROUNDS_PER_PASS": "3"},
                                  {"GKR_ROUNDS_PER_PASS": "4"}, {"GKR_HASH_CHUNK": "16", "GKR_HOST_THREADS": "2"},
                                  {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_HOST_PASS_SCALAR": "1"}, {"GKR_PLAN_MAIN": "1", "GKR_FOLD_BLOCKS": "8192"},
-                                 {"GKR_PASS_QUEUE_DEPTH": "1", "GKR_GROUP_SIZE": "3"}, {"GKR_PASS_QUEUE_DEPTH": "16", "GKR_GROUP_SIZE": "2"}],
+                                 {"GKR_PASS_QUEUE_DEPTH": "1", "GKR_GROUP_SIZE": "3"}, {"GKR_PASS_QUEUE_DEPTH": "16", "GKR_GROUP_SIZE": "2"},
+                                 {"GKR_NO_FUSED_REDUCE": "1"}, {"GKR_NO_FUSED_REDUCE": "1", "GKR_NO_MFMA_FOLD": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_fold_pass_variants_match_oracle(env):
     """Every schedule of the host-transcript sumcheck gives the same transcript: the v_mad_u64_u32 fold instead
