@@ -212,6 +212,17 @@ __device__ inline __attribute__((always_inline)) void mac96_first(uint64_t& acc,
         : "v"(x), "v"(y));
     ex = e;
 }
+// the start of a column: {hi, lo} = {k1, k0} + a -- what the previous column carried on (its high word and its carry
+// count) plus the accumulator's limb.  Two full-rate adds; written as a 64-bit sum the compiler assembles both operands
+// in register pairs first (two moves) and adds them with v_lshl_add_u64 (half rate): four issue slots per column.
+__device__ inline __attribute__((always_inline)) uint64_t column_start(uint32_t k0, uint32_t k1, uint32_t a) {
+    uint32_t lo, hi;
+    asm("v_add_co_u32_e32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
+        : "=&v"(lo), "=v"(hi)
+        : "v"(k0), "v"(a), "v"(k1)
+        : "vcc");
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 // y wave-uniform (an SGPR or a constant the compiler puts in one)
 __device__ inline __attribute__((always_inline)) void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y_uniform) {
     uint64_t carry;
@@ -317,6 +328,7 @@ GKR_HD void mac96_first(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) {
     ex = (s < acc) ? 1u : 0u;
     acc = s;
 }
+GKR_HD uint64_t column_start(uint32_t k0, uint32_t k1, uint32_t a) { return ((uint64_t)k0 | ((uint64_t)k1 << 32)) + a; }
 GKR_HD void mac96_s(uint64_t& acc, uint32_t& ex, uint32_t x, uint32_t y) { mac96(acc, ex, x, y); }
 GKR_HD void mac96x2_s(uint64_t& accA, uint32_t& exA, uint32_t xA, uint32_t yA, uint64_t& accB, uint32_t& exB, uint32_t xB,
                       uint32_t yB) {
@@ -591,17 +603,19 @@ GKR_HD Lazy17 lazy_zero() {
 }
 
 GKR_HD void lazy_mac_s(Lazy17& acc, const Fr& a, const Fr& b_uniform) {
-    uint64_t col = 0;
+    uint64_t col = acc.l[0];
     uint32_t ex = 0;
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
-        col += acc.l[c];   // col < 2^35 after the shift: cannot overflow
+        if (c) {
+            col = column_start((uint32_t)(col >> 32), ex, acc.l[c]);   // < 2^35 + 2^32: cannot overflow
+            ex = 0;
+        }
 #pragma unroll
         for (int i = (c > 7 ? c - 7 : 0); i <= (c < 7 ? c : 7); ++i) mac96_s(col, ex, a.l[i], b_uniform.l[c - i]);
         acc.l[c] = (uint32_t)col;
-        col = (col >> 32) | ((uint64_t)ex << 32);
-        ex = 0;
     }
+    col = (col >> 32) | ((uint64_t)ex << 32);
     col += acc.l[15];
     acc.l[15] = (uint32_t)col;
     col >>= 32;
@@ -611,18 +625,18 @@ GKR_HD void lazy_mac_s(Lazy17& acc, const Fr& a, const Fr& b_uniform) {
 
 // the same with a per-lane multiplier (both operands in vector registers)
 GKR_HD void lazy_mac_v(Lazy17& acc, const Fr& a, const Fr& b) {
-    uint64_t col = 0;
+    uint64_t col = acc.l[0];
     uint32_t ex = 0;
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
-        col += acc.l[c];   // col < 2^35 after the shift: cannot overflow
+        if (c) col = column_start((uint32_t)(col >> 32), ex, acc.l[c]);   // < 2^35 + 2^32: cannot overflow
         const int i0 = c > 7 ? c - 7 : 0, i1 = c < 7 ? c : 7;
         mac96_first(col, ex, a.l[i0], b.l[c - i0]);
 #pragma unroll
         for (int i = i0 + 1; i <= i1; ++i) mac96(col, ex, a.l[i], b.l[c - i]);
         acc.l[c] = (uint32_t)col;
-        col = (col >> 32) | ((uint64_t)ex << 32);
     }
+    col = (col >> 32) | ((uint64_t)ex << 32);
     col += acc.l[15];
     acc.l[15] = (uint32_t)col;
     col >>= 32;
@@ -633,11 +647,11 @@ GKR_HD void lazy_mac_v(Lazy17& acc, const Fr& a, const Fr& b) {
 // One product, added to ONE of two accumulators chosen per lane -- without a branch: a wave whose lanes pick different
 // accumulators would otherwise run the 64 multiply-adds twice (once per side of the branch).  Three selects per column.
 GKR_HD void lazy_mac_sel(Lazy17& A, Lazy17& B, bool toA, const Fr& a, const Fr& b) {
-    uint64_t col = 0;
+    uint64_t col = toA ? A.l[0] : B.l[0];
     uint32_t ex = 0;
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
-        col += toA ? A.l[c] : B.l[c];
+        if (c) col = column_start((uint32_t)(col >> 32), ex, toA ? A.l[c] : B.l[c]);
         const int i0 = c > 7 ? c - 7 : 0, i1 = c < 7 ? c : 7;
         mac96_first(col, ex, a.l[i0], b.l[c - i0]);
 #pragma unroll
@@ -645,8 +659,8 @@ GKR_HD void lazy_mac_sel(Lazy17& A, Lazy17& B, bool toA, const Fr& a, const Fr& 
         const uint32_t lo = (uint32_t)col;
         A.l[c] = toA ? lo : A.l[c];
         B.l[c] = toA ? B.l[c] : lo;
-        col = (col >> 32) | ((uint64_t)ex << 32);
     }
+    col = (col >> 32) | ((uint64_t)ex << 32);
 #pragma unroll
     for (int c = 15; c < 17; ++c) {
         col += toA ? A.l[c] : B.l[c];
