@@ -153,6 +153,22 @@ def test_mle_every_pass_schedule_matches_oracle(ctx, n, batch):
         assert np.array_equal(C[b], c2) and np.array_equal(L[b], l2) and np.array_equal(R[b], r2), (n, b)
 
 
+@pytest.mark.parametrize("n", [14, 16, 20])
+def test_lone_sumcheck_publishing_from_its_last_block_is_repeatable(ctx, n):
+    """A lone sumcheck's fold passes publish from the last block to arrive (arrival counters, release / acquire across the
+    XCDs' L2s, counters left zero for the next pass): the oracle's transcript, and the same bytes 500 times over."""
+    count = 1 << n
+    d = ctx.alloc(count * 32)
+    try:
+        ctx.fill_table(d, count, 4242 + n)
+        want = cdense.sumcheck_mle_raw(cdense.fill_table(count, 4242 + n), n)
+        for rep in range(500):
+            C, L, R = ctx.sumcheck_mle_batch_device(d, n, 1)
+            assert np.array_equal(C[0], want[0]) and np.array_equal(L[0], want[1]) and np.array_equal(R[0], want[2]), (n, rep)
+    finally:
+        ctx.free(d)
+
+
 def test_mle_batch_is_independent_sumchecks(ctx):
     n, batch = 12, 5
     count = 1 << n
