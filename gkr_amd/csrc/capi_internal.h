@@ -420,6 +420,7 @@ struct gkr_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
     hipStream_t late = nullptr;                // separate stream for a group's small late passes (lazy), see late_stream()
+    hipStream_t chain = nullptr;               // the device-hashed sumchecks' chain of kernels (lazy), see chain_stream()
     std::vector<hipEvent_t> aux_events;        // one per group of a batch: "the side kernel of this group is done"
     Fr* d_cts = nullptr;
     int transcript = GKR_TRANSCRIPT_HOST;
@@ -507,6 +508,18 @@ struct gkr_ctx {
             if (rc != hipSuccess) return rc;
         }
         *out = late;
+        return hipSuccess;
+    }
+    // The sumchecks hashed on the device run as ONE chain on this stream (kernels_transcript.hip): with the main, side and
+    // late streams that makes four -- ROCm's default number of hardware queues; a fifth stream would share a queue with
+    // one of them, and its kernels would queue behind that stream's.
+    hipError_t chain_stream(hipStream_t* out) {
+        if (!chain) {
+            // (normal priority: at high priority the step got slower, 18.0 against 16.2 ms -- profiles/r04/p_*)
+            hipError_t rc = hipStreamCreateWithFlags(&chain, hipStreamNonBlocking);
+            if (rc != hipSuccess) return rc;
+        }
+        *out = chain;
         return hipSuccess;
     }
     hipError_t aux_stream(int events) {

@@ -142,22 +142,41 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // last group's late passes); measured on MI355X, 1024 x 2^20, interleaved repeats on one box, ms per step with
     // 14 / 3 / 2 host threads: 4 groups, all pass 0s queued first 12.3-12.9 / 15.0-16.3 / 18.5-19.0; 8 groups, pass 0
     // queue depth 2 (below) 12.0-12.5 / 13.5-14.0 / 16.5-17.8; 6, 10 and 12 groups in between.
-    const double batch_bytes = (double)batch * (double)len * 32.0;
+    // Sumchecks hashed ON THE DEVICE (kernels_transcript.hip): the first n_dev of the batch run as one chain of kernels on
+    // a stream of their own -- pass, the pass's rounds with MiMC7 on eight lanes per element, fold, ... -- without the host;
+    // the host hashes the rest as always.  A device-hashed pass takes 0.33 ms per round whatever the number of sumchecks
+    // (the chain of 2 x 91 x 4 dependent products), so this is for steps that are bound by the host's hashing: a rank with
+    // two or three host threads, tables so small that the GPU is mostly idle.  GKR_DEVICE_HASH_PERCENT = share of the batch
+    // (0 = none; unset: the rule below).
+    static const int dev_percent_env = [] {
+        const char* e = getenv("GKR_DEVICE_HASH_PERCENT");
+        return e ? (atoi(e) < 0 ? 0 : (atoi(e) > 90 ? 90 : atoi(e))) : -1;
+    }();
+    int dev_percent = dev_percent_env >= 0 ? dev_percent_env : 0;
+    int n_dev = 0;
+    if (dev_percent > 0 && !tail && batch >= 64 && j_first >= 1) {
+        n_dev = (int)((long long)batch * dev_percent / 100) & ~7;
+        if (batch - n_dev < 16) n_dev = (batch - 16) & ~7;
+        if (n_dev < 8) n_dev = 0;
+    }
+    const int host_b0 = n_dev, host_batch = batch - n_dev;
+    const double batch_bytes = (double)host_batch * (double)len * 32.0;
     int want_groups = (int)(batch_bytes / (4.0 * 1024 * 1024 * 1024));
     want_groups = want_groups < 4 ? 4 : (want_groups > 8 ? (batch_bytes > 96.0 * 1024 * 1024 * 1024 ? 16 : 8) : want_groups);
     // Small tables (BASELINE configs[1]: 4096 x 2^16) are bound by the host's hashing, not by the stream: sixteen groups
     // with pass 0 of four of them queued ahead keep the hashing threads fed from start to end (MI355X, 14 threads, ms per
     // 4096 x 2^16: 4 groups 8.1 - 8.2, 8 groups 8.1, 16 groups 7.2, 16 groups / depth 4 7.0 - 7.2, 32 groups / depth 8 7.1;
     // profiles/r03/f_n16_groups*.jsonl)
-    const bool small_tables = n <= 17 && batch >= 256;
+    const bool small_tables = n <= 17 && host_batch >= 256;
     if (small_tables) want_groups = 16;
     // A rank with two or three host threads (eight ranks on a 16-core host) is bound by its hashing: smaller groups shorten
     // the stretch before the first hashes and after the last fold (1024 x 2^20, two threads: 16.3 - 16.7 ms with eight
     // groups, 16.0 with sixteen; profiles/r03/w_two_host_threads_group_size.jsonl)
-    if (hash_threads <= 3 && batch >= 256 && want_groups < 16) want_groups = 16;
-    int group_size = batch >= 128 ? (batch + want_groups - 1) / want_groups : (batch >= 16 ? (batch + 1) / 2 : batch);
+    if (hash_threads <= 3 && host_batch >= 256 && want_groups < 16) want_groups = 16;
+    int group_size = host_batch >= 128 ? (host_batch + want_groups - 1) / want_groups : (host_batch >= 16 ? (host_batch + 1) / 2 : host_batch);
+    if (n_dev && hash_threads <= 3 && host_batch >= 256) group_size = 64;   // (whole sixteen-lane chunks for both threads, as without a device share)
     if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
-    int groups = (batch + group_size - 1) / group_size;
+    int groups = (host_batch + group_size - 1) / group_size;
     if (groups > kMaxGroups) groups = kMaxGroups;
     struct Group {
         int b0 = 0, nb = 0;
@@ -170,6 +189,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         std::atomic<int> done{0};
         int pass = 0;
         int index = 0;
+        hipStream_t chain = nullptr;   // a device-hashed group: the stream its whole chain runs on
     };
     // Shares of the batch per group, in per cent (GKR_GROUP_SPLIT="40,30,20,10"): the groups finish in order, and the
     // LAST one's latency-bound late passes (four host round trips with nothing left to overlap them) are the exposed
@@ -191,7 +211,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         }
         return v;
     }();
-    if (!split.empty() && batch >= 16 * (int)split.size()) groups = (int)split.size();
+    if (!split.empty() && host_batch >= 16 * (int)split.size()) groups = (int)split.size();
     std::vector<Group> grp(groups);
     HIP_TRY(ctx, ctx->aux_stream(groups));
     {
@@ -201,11 +221,11 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             int end;
             if (!split.empty() && groups == (int)split.size()) {
                 acc += split[g];
-                end = g + 1 == groups ? batch : (int)((long long)batch * acc / 100);
+                end = g + 1 == groups ? host_batch : (int)((long long)host_batch * acc / 100);
             } else {
-                end = (int)((long long)batch * (g + 1) / groups);
+                end = (int)((long long)host_batch * (g + 1) / groups);
             }
-            grp[g].b0 = start;
+            grp[g].b0 = host_b0 + start;
             grp[g].nb = end - start;
             start = end;
             grp[g].m = n;
@@ -217,22 +237,23 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         const int b0 = G.b0, nb = G.nb;
         G.ticket = ++ctx->ticket;
         if (len <= gkr::kSmallPassEntries) {
-            Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0, nullptr, true);
+            Timed t(ctx, "mle_pass_small", (double)nb * len * 32.0, G.chain, true);
             gkr::launch_mle_multifold_small(0, d_tables + (size_t)b0 * len, len, nullptr, 0, (uint32_t)len, (uint32_t)G.j, nb,
-                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, s);
+                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, G.chain ? G.chain : s);
             return;
         }
         const uint32_t nblk = gkr::mle_pass_blocks((uint32_t)len, (uint32_t)G.j, nb);
         gkr::MleSubPartial* part = partials + (size_t)b0 * gkr::kMaxBlocksPerTable;
         gkr::MlePublish pub;
         const bool fused = fused_publish(b0, nb, nblk, (double)nb * len * 32.0, G.ticket, G.j, pub);
+        hipStream_t st0 = G.chain ? G.chain : s;
         {
-            Timed t(ctx, "mle_sub_sums", (double)nb * len * 32.0, nullptr, fused);
-            gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, s, fused ? &pub : nullptr);
+            Timed t(ctx, G.chain ? "mle_sub_sums_dev" : "mle_sub_sums", (double)nb * len * 32.0, st0, fused);
+            gkr::launch_mle_sub_sums(d_tables + (size_t)b0 * len, len, (uint32_t)len, nb, nblk, part, st0, fused ? &pub : nullptr);
         }
         if (fused) return;
-        Timed t(ctx, "mle_sub_reduce", 0.0, nullptr, true);
-        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, s);
+        Timed t(ctx, "mle_sub_reduce", 0.0, st0, true);
+        gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st0);
     };
     // a fold pass: bind the jin variables just hashed, produce the sums of the next jout rounds
     static const bool no_late = getenv("GKR_NO_LATE_STREAM") != nullptr;
@@ -246,7 +267,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         const size_t src_stride = from_input ? len : work_len;
         Fr* dst = work + (size_t)b0 * work_len;
         // small source tables: a latency-bound late pass, not to be queued behind other groups' streaming passes
-        hipStream_t st = (!from_input && src_len <= ((size_t)1 << 16)) ? late : s;
+        hipStream_t st = G.chain ? G.chain : ((!from_input && src_len <= ((size_t)1 << 16)) ? late : s);
         G.m -= jin;
         G.round0 += jin;
         G.j = rounds_for(G.m);
@@ -283,7 +304,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         {
             // late passes run beside other groups' streaming passes: their elapsed time is not their own cost, so they
             // are booked under their own name and stay out of the streaming fold pass's bandwidth figure
-            Timed t(ctx, st == s ? "mle_multifold" : "mle_multifold_late", bytes, st, fused);
+            Timed t(ctx, G.chain ? "mle_multifold_dev" : (st == s ? "mle_multifold" : "mle_multifold_late"), bytes, st, fused);
             gkr::launch_mle_multifold(jin, src, src_stride, dst, work_len, (uint32_t)S, nb, nblk, h_w + (size_t)b0 * gkr::kMleMaxSub,
                                       plan, part, st, fused ? &pub : nullptr);
         }
@@ -367,6 +388,39 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     }();
     const int depth = depth_env ? depth_env : (small_tables ? 4 : 2);
     int next_first = 0;   // groups [next_first, groups): pass 0 still to launch
+    if (next_first < groups) launch_first(grp[next_first++]);   // (the host's first sums before the device chain's first pass)
+    // the device-hashed sumchecks [0, n_dev): their whole chain is queued here, on its own stream
+    Group dev;
+    hipStream_t chain = nullptr;
+    gkr_fr* stage_c = nullptr;
+    gkr_fr* stage_r = nullptr;
+    uint32_t* stage_len = nullptr;
+    if (n_dev) {
+        HIP_TRY(ctx, ctx->chain_stream(&chain));
+        uint32_t* dep_dev = nullptr;
+        WS(ctx, "mlep.dev_dep", uint32_t, (size_t)n_dev, dep_dev);
+        HIP_TRY(ctx, ctx->pinned_host("mlep.stage_c", sizeof(gkr_fr) * 2 * (size_t)n_dev * n, reinterpret_cast<void**>(&stage_c)));
+        HIP_TRY(ctx, ctx->pinned_host("mlep.stage_r", sizeof(gkr_fr) * (size_t)n_dev * n, reinterpret_cast<void**>(&stage_r)));
+        HIP_TRY(ctx, ctx->pinned_host("mlep.stage_len", sizeof(uint32_t) * (size_t)n_dev * n, reinterpret_cast<void**>(&stage_len)));
+        dev.b0 = 0;
+        dev.nb = n_dev;
+        dev.m = n;
+        dev.j = j_first;
+        dev.index = groups;
+        dev.chain = chain;
+        launch_first(dev);
+        for (bool first = true;; first = false) {
+            const int J = dev.j;
+            const bool final_pass = dev.round0 + J == n;
+            {
+                Timed t(ctx, "mle_pass_hash_dev", 0.0, chain);
+                gkr::launch_mle_pass_hash_lanes(rec, (uint32_t)n_dev, (uint32_t)J, (uint32_t)dev.round0, (uint32_t)n, final_pass, first, ctx->d_cts, dep_dev,
+                                                dev.m - J > 0 ? h_w : nullptr, reinterpret_cast<Fr*>(stage_c), stage_len, reinterpret_cast<Fr*>(stage_r), chain);
+            }
+            if (dev.m - J <= 0) break;
+            launch_fold(dev, J);
+        }
+    }
     while (next_first < groups && next_first < depth) launch_first(grp[next_first++]);
     dbg_b = dbg_us();
     int active = groups;
@@ -416,6 +470,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     if (rc) {
         (void)hipStreamSynchronize(s);
         if (late != s) (void)hipStreamSynchronize(late);
+        if (chain) (void)hipStreamSynchronize(chain);
         ctx->mle_arrivals_zeroed = nullptr;   // (a pass that was given up may have left its counters half way)
         return rc;
     }
@@ -423,6 +478,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (late != s) HIP_TRY(ctx, hipStreamSynchronize(late));
+    if (n_dev) {
+        HIP_TRY(ctx, hipStreamSynchronize(chain));
+        // (tail == nullptr here: n_out = n, r_off = 0 -- the staging arrays have the caller's layout)
+        memcpy(out_coeffs, stage_c, sizeof(gkr_fr) * 2 * (size_t)n_dev * n);
+        memcpy(out_r, stage_r, sizeof(gkr_fr) * (size_t)n_dev * n);
+        memcpy(out_len, stage_len, sizeof(uint32_t) * (size_t)n_dev * n);
+    }
     dbg_e = dbg_us();
     if (ctx->pending.size() > 8192) ctx->drain_events();   // otherwise when the profile is read
     if (dbg)

@@ -89,6 +89,7 @@ void gkr_ctx_destroy(gkr_ctx* ctx) {
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->late) (void)hipStreamDestroy(ctx->late);
+    if (ctx->chain) (void)hipStreamDestroy(ctx->chain);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

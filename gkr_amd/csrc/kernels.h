@@ -124,6 +124,10 @@ void launch_mle_fold_plan(int jin, const Fr* weights, void* plans, uint32_t batc
 void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t batch,
                           uint32_t nblk, const Fr* weights, const void* plans, MleSubPartial* partials, hipStream_t s,
                           const MlePublish* publish = nullptr);
+// the host's share of a pass ON THE DEVICE (kernels_transcript.hip): J rounds of `count` sumchecks from their records
+void launch_mle_pass_hash_lanes(const MleHostRecSub* rec, uint32_t count, uint32_t J, uint32_t round0, uint32_t n_out, bool final_pass,
+                                bool first_pass, const Fr* cts, uint32_t* dep_last, Fr* weights, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
+                                hipStream_t s);
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
                                 uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,

@@ -119,17 +119,24 @@ def test_mle_extreme_byte_patterns_match_oracle(ctx, n):
                                  {"GKR_ROUNDS_PER_PASS": "4"}, {"GKR_HASH_CHUNK": "16", "GKR_HOST_THREADS": "2"},
                                  {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_HOST_PASS_SCALAR": "1"}, {"GKR_PLAN_MAIN": "1", "GKR_FOLD_BLOCKS": "8192"},
                                  {"GKR_PASS_QUEUE_DEPTH": "1", "GKR_GROUP_SIZE": "3"}, {"GKR_PASS_QUEUE_DEPTH": "16", "GKR_GROUP_SIZE": "2"},
-                                 {"GKR_NO_FUSED_REDUCE": "1"}, {"GKR_NO_FUSED_REDUCE": "1", "GKR_NO_MFMA_FOLD": "1"}],
+                                 {"GKR_NO_FUSED_REDUCE": "1"}, {"GKR_NO_FUSED_REDUCE": "1", "GKR_NO_MFMA_FOLD": "1"},
+                                 {"GKR_DEVICE_HASH_PERCENT": "50"}, {"GKR_DEVICE_HASH_PERCENT": "90", "GKR_ROUNDS_PER_PASS": "3"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_fold_pass_variants_match_oracle(env):
     """Every schedule of the host-transcript sumcheck gives the same transcript: the v_mad_u64_u32 fold instead
     of the matrix-core one, 1 / 3 / 4 rounds per pass instead of 5, sixteen-lane and scalar host hashing, other
-    block counts, many small groups with pass 0 queued one at a time or all at once.  The knobs are read once per process, hence the child interpreter."""
+    block counts, many small groups with pass 0 queued one at a time or all at once, part of the batch hashed ON THE DEVICE
+    (MiMC7 on eight lanes per element, the whole chain of passes without the host).  The knobs are read once per process,
+    hence the child interpreter."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sizes = ((14, 20), (17, 3), (18, 2)) if "GKR_ROUNDS_PER_PASS" in env or "GKR_NO_MFMA_FOLD" in env else ((14, 20), (17, 3))
+    if "GKR_DEVICE_HASH_PERCENT" in env:
+        # a share of the batch hashed on the device (kernels_transcript.hip; batches of >= 64): one-block passes only,
+        # every kind of pass, a ragged last wave of eight-lane groups, the long first pass
+        sizes = ((6, 100), (10, 72), (14, 99), (17, 64), (20, 64))
     for n, batch in sizes:
         out = subprocess.run([sys.executable, os.path.join(here, "fold_variants_worker.py"), str(n), str(batch)],
                              env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
