@@ -182,6 +182,14 @@ def test_lane_group_passes_on_small_layers(scenario):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_line_restriction_of_wide_layers_in_whole_proofs():
+    """q (and its length) of layers of 2^13 .. 2^15 values -- the line restriction's launches over a grid, an even and an odd
+    number of them, then its one-block tail -- in whole proofs against the C checker."""
+    out = subprocess.run([sys.executable, os.path.join(HERE, "wide_scenarios_worker.py"), "prove-wide"], env=dict(os.environ),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("nshards,device_exchange", [(3, True), (2, False)])
 def test_wide_layer_split_by_gates_over_logical_ranks(nshards, device_exchange):
     """The gate-sharded form (two sum-over-ranks exchanges of 2 * 2^k field elements) on a wide layer: every rank's

@@ -54,7 +54,33 @@ def heavy_batch():
     return bool(ok)
 
 
+def prove_wide():
+    # whole proofs through layers of 2^13 .. 2^15 values (an even and an odd number of variables bound by the line
+    # restriction's launches over the grid): sumchecks, q and its length, r against the C checker
+    ok = True
+    for seed, ks in enumerate(([12, 13, 14], [13, 15, 15])):
+        rng = np.random.default_rng(5150 + seed)
+        layers = []
+        for i in range(2):
+            g, m = 1 << ks[i], 1 << ks[i + 1]
+            layers.append((rng.integers(0, 2, g, dtype=np.uint8), rng.integers(0, m, g, dtype=np.uint32), rng.integers(0, m, g, dtype=np.uint32)))
+        circuit = GKRCircuit([Layer(ks[i], *layers[i]) for i in range(2)], ks[-1])
+        wit = np.stack([synth.rand_fr(np.random.default_rng(77 + seed), 1 << ks[-1])])
+        with Context(0) as ctx:
+            sc, sl, sr, q, ql, z, rr, dco, ico = ctx.prove_batch_raw(circuit, wit, all_arrays=True)
+        ref = cdense.prove_raw(layers, wit[0])
+        ro = qo = 0
+        for i in range(2):
+            k = ks[i + 1]
+            ok &= np.array_equal(sc[0, ro:ro + 2 * k], ref["C"][i]) and np.array_equal(sr[0, ro:ro + 2 * k], ref["R"][i])
+            ok &= int(ql[0, i]) == ref["q_len"][i] and np.array_equal(q[0, qo:qo + k + 1], ref["q"][i])
+            ro += 2 * k
+            qo += k + 1
+        ok &= np.array_equal(rr[0], ref["r"])
+    return bool(ok)
+
+
 if __name__ == "__main__":
-    ok = {"small": small, "heavy-batch": heavy_batch, "per-round": small}[sys.argv[1]]()
+    ok = {"small": small, "heavy-batch": heavy_batch, "per-round": small, "prove-wide": prove_wide}[sys.argv[1]]()
     print("OK" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
