@@ -701,9 +701,13 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
         // launch (a publish kernel cost its ~10 us plus the ~6 us to the next dependent launch on every such pass of every
         // layer).  The partials cross the XCDs' L2s: release (write-back) before the arrival counter, acquire (invalidate)
         // after it; the streaming passes of the plain sumcheck do NOT do this (there the fences cost 15 % of the bandwidth).
-        __threadfence();
+        // (ONE release per block, by one thread, after the barrier that orders the other threads' partial stores before it: a
+        // release is a write-back of the XCD's L2, ~30 ns each and one after the other across the grid -- mle_publish_from_last_block)
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(arrivals + proof, 1u) == gridDim.x - 1u ? 1u : 0u;
+        if (tid == 0) {
+            __threadfence();
+            s_last = atomicAdd(arrivals + proof, 1u) == gridDim.x - 1u ? 1u : 0u;
+        }
         __syncthreads();
         if (s_last) {
             __threadfence();
