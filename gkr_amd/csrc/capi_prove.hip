@@ -394,6 +394,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     WS(ctx, "prove.lr", Fr, (size_t)batch * 3 * ((size_t)1 << kmax), d_lr);
     uint32_t* d_lrdeg = nullptr;
     WS(ctx, "prove.lrdeg", uint32_t, (size_t)batch, d_lrdeg);
+    Fr* d_lrbc = nullptr;   // per layer: the next layer's restriction may start before this one's last step has read them
+    WS(ctx, "prove.lrbc", Fr, (size_t)L * batch * 2 * kmax, d_lrbc);
     HIP_TRY(ctx, ctx->aux_stream(0));
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = c->k[i], k = c->k[i + 1];
@@ -418,7 +420,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
             for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
             Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
-            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, d_q + q_off * batch,
+            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, d_lrbc + (size_t)i * batch * 2 * kmax, d_q + q_off * batch,
                                          d_qlen + (size_t)i * batch, (uint32_t)batch, ctx->aux);
         }
         auto finish = [&](int b) {

@@ -256,7 +256,8 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
                            uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
 // q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, deg_scratch batch
 // words (device), out batch x (k + 1) highest degree first, out_len batch
-void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* out, uint32_t* out_len,
+// bcm: batch * 2k elements of device scratch (the line's coefficients in Montgomery form; unused for k <= 9)
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,
                              uint32_t batch, hipStream_t s);
 
 // ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------

@@ -1031,6 +1031,19 @@ __global__ void __launch_bounds__(256) k_line_restriction(const Fr* __restrict__
     if (tid == 0) out_len[blockIdx.x] = s_maxdeg + 1u;
 }
 
+// The line's coefficients for the step kernels below, once per restriction: l_j(t) = b_j + t (c_j - b_j) as (cst_j,
+// grad_j) in Montgomery form, in device memory.  Every step used to fetch b_j, c_j from pinned host memory and convert
+// them itself: a PCIe round trip and two products at the head of each of its k launches -- 4.5 of a step's 11 us, and these
+// launches are a seventh of a many-circuit proving step's kernel time.  grid = (batch), block = 64
+__global__ void __launch_bounds__(64) k_line_coeffs(uint32_t k, const Fr* __restrict__ bc, Fr* __restrict__ bcm) {
+    const uint32_t j = threadIdx.x;
+    if (j >= k) return;
+    const Fr* line = bc + (size_t)blockIdx.x * 2u * k;
+    const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
+    store_fr(bcm + (size_t)blockIdx.x * 2u * k + j, to_mont(bj));
+    store_fr(bcm + (size_t)blockIdx.x * 2u * k + k + j, to_mont(fr_sub(cj, bj)));
+}
+
 // The same for wide layers (k > 9), where one block per proof would run the 2^k (k + 1) products of a step on 256
 // threads: the Moebius part and the set-up in one block (subtractions only), then one launch per variable over
 // (blocks, batch), then the read-out.  Same buffers, same results.
@@ -1067,8 +1080,7 @@ __global__ void __launch_bounds__(256) k_line_step(uint32_t k, uint32_t j, const
     Fr* base = scratch + (size_t)blockIdx.y * 3u * n;
     const Fr* src = base + ((j & 1u) ? n : 0u);
     Fr* dst = base + ((j & 1u) ? 0u : n);
-    const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
-    const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+    const Fr cst = load_fr(line + j), grad = load_fr(line + k + j);   // (k_line_coeffs: Montgomery form, device memory)
     const uint32_t in_len = j + 1u, out_len_j = j + 2u;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < h * out_len_j; item += gridDim.x * blockDim.x) {
         const uint32_t i = item / out_len_j, m = item - i * out_len_j;
@@ -1097,8 +1109,7 @@ __global__ void __launch_bounds__(256) k_line_tail(uint32_t k, uint32_t j0, cons
         const uint32_t h = n >> (j + 1u);
         const Fr* src = base + ((j & 1u) ? n : 0u);
         Fr* dst = base + ((j & 1u) ? 0u : n);
-        const Fr bj = load_fr(line + j), cj = load_fr(line + k + j);
-        const Fr cst = to_mont(bj), grad = to_mont(fr_sub(cj, bj));
+        const Fr cst = load_fr(line + j), grad = load_fr(line + k + j);
         const uint32_t in_len = j + 1u, out_len_j = j + 2u;
         for (uint32_t item = threadIdx.x; item < h * out_len_j; item += blockDim.x) {
             const uint32_t i = item / out_len_j, m = item - i * out_len_j;
@@ -1986,7 +1997,7 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
                        Wc, k, dep, host_dep, nb_hi, nb_lo, nb_mont);
 }
 
-void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* out, uint32_t* out_len,
+void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,
                              uint32_t batch, hipStream_t s) {
     static const bool stepwise = getenv("GKR_LINE_STEPWISE") != nullptr;   // (test hook: the wide-layer form at every width)
     if (k <= 9 && !stepwise) {
@@ -1999,19 +2010,21 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
         // wide layers: the set-up over a grid (kernels_wide.hip), one launch per variable while the table is large, the last
         // six variables, q and its length in one block per proof -- 4 + (k - 6) + 1 launches instead of 2 k + 6 (the proving
         // thread issues them between two layers' sumchecks)
+        hipLaunchKernelGGL(k_line_coeffs, dim3(batch), dim3(64), 0, s, k, bc, bcm);
         launch_line_setup_wide(W, k, scratch, deg_scratch, batch, s);
         const uint32_t j0 = k - 6u;
         for (uint32_t j = 0; j < j0; ++j) {
             const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
-            hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bc, scratch);
+            hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bcm, scratch);
         }
-        hipLaunchKernelGGL(k_line_tail, dim3(batch), dim3(256), 0, s, k, j0, bc, scratch, out, deg_scratch, out_len);
+        hipLaunchKernelGGL(k_line_tail, dim3(batch), dim3(256), 0, s, k, j0, bcm, scratch, out, deg_scratch, out_len);
         return;
     }
+    hipLaunchKernelGGL(k_line_coeffs, dim3(batch), dim3(64), 0, s, k, bc, bcm);
     hipLaunchKernelGGL(k_line_init, dim3(batch), dim3(256), 0, s, W, k, scratch, out_len);
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
-        hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bc, scratch);
+        hipLaunchKernelGGL(k_line_step, dim3(blocks_for(items, 4096), batch), dim3(256), 0, s, k, j, bcm, scratch);
     }
     hipLaunchKernelGGL(k_line_out, dim3(batch), dim3(64), 0, s, k, scratch, out);
 }
