@@ -858,8 +858,10 @@ __device__ __forceinline__ void eq_table_part(const Fr* __restrict__ points, uin
 // consecutive entries, i.e. one value of the leading nvars - 12 index bits.  Its product over those bits once (four lanes,
 // strided factors, as above), the sixteen products over the next four bits, the 256 over the last eight from two
 // sixteen-entry tables -- then TWO products per entry: (hi * mid[..]) * lo[..].  Same field elements as eq_table_part.
-// nvars >= 12.  grid = (2^(nvars - 12), batch), block = 256
-__global__ void __launch_bounds__(256) k_eq_table_split(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
+// nvars >= 12.  grid = (2^(nvars - 12), batch), block = 1024 (four entries = eight products per thread; with 256 threads a
+// thread's sixteen entries were a chain of 32 products -- 40 us for the eight blocks of a 2^15-entry table, on a device that
+// fourteen proving threads keep short of queues, not of lanes)
+__global__ void __launch_bounds__(1024) k_eq_table_split(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
                                                         Fr* __restrict__ out, uint32_t montgomery) {
     __shared__ Fr s_f[2][32];
     __shared__ Fr s_a[16], s_b[16], s_hm[16], s_lo[256];
@@ -894,13 +896,14 @@ __global__ void __launch_bounds__(256) k_eq_table_split(const Fr* __restrict__ p
         (which == 0 ? s_hm : (which == 1 ? s_a : s_b))[e] = p;
     }
     __syncthreads();
-    s_lo[tid] = mont_mul(s_a[tid >> 4], s_b[tid & 15u]);
-    if (tid < 16u) s_hm[tid] = mont_mul(s_hi, s_hm[tid]);
+    if (tid < 256u) s_lo[tid] = mont_mul(s_a[tid >> 4], s_b[tid & 15u]);
+    else if (tid < 256u + 16u) s_hm[tid - 256u] = mont_mul(s_hi, s_hm[tid - 256u]);
     __syncthreads();
     Fr* dst = out + ((size_t)proof << nvars) + ((size_t)hi_idx << 12);
-    const Fr lo = s_lo[tid];
-#pragma unroll 4
-    for (uint32_t m = 0; m < 16u; ++m) store_fr(dst + (m << 8) + tid, mont_mul(s_hm[m], lo));
+    const Fr lo = s_lo[tid & 255u];
+    const uint32_t m0 = (tid >> 8) * 4u;   // a quarter of the sixteen mid entries per 256 threads
+#pragma unroll
+    for (uint32_t m = m0; m < m0 + 4u; ++m) store_fr(dst + (m << 8) + (tid & 255u), mont_mul(s_hm[m], lo));
 }
 
 __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
@@ -1921,7 +1924,8 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
         hipLaunchKernelGGL(k_prod_reduce, dim3(kProdReduceBlocks, batch), dim3(4 * kProdRecValues), 0, s, partials, blocks, level2);
         hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3(4 * kProdRecValues), 0, s, level2, kProdReduceBlocks, rec, ticket);
     } else if (blocks > 1) {
-        hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((blocks > 256 ? 14 : 4) * kProdRecValues), 0, s, partials, blocks, rec, ticket);
+        // (fourteen threads per value from 32 blocks on: with four a thread's chain of additions was up to 64 long)
+        hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((blocks > 32 ? 14 : 4) * kProdRecValues), 0, s, partials, blocks, rec, ticket);
     }
 }
 
@@ -1982,7 +1986,7 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) 
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
                      hipStream_t s) {
     if (nvars >= 14) {   // many variables: a few products per block, two per entry (k_eq_table_split)
-        hipLaunchKernelGGL(k_eq_table_split, dim3(1u << (nvars - 12u), batch), dim3(256), 0, s, points, stride, first, nvars, out, montgomery ? 1u : 0u);
+        hipLaunchKernelGGL(k_eq_table_split, dim3(1u << (nvars - 12u), batch), dim3(1024), 0, s, points, stride, first, nvars, out, montgomery ? 1u : 0u);
         return;
     }
     hipLaunchKernelGGL(k_eq_table, dim3(blocks_for((size_t)4 << nvars, 4096), batch), dim3(256), 0, s, points, stride, first, nvars, out,
