@@ -1,3 +1,6 @@
+"""Batched proofs of circuits on both sides of the width thresholds, 400 times each, every repeat compared byte for byte with the
+first: the product passes that publish from their last block (arrival counters, one release per block) must never lose a
+partial.   python tools/stress_fused_publish.py   (on the GPU box)"""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from gkr_amd import Context, GKRCircuit, Layer, synth
