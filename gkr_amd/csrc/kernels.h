@@ -264,9 +264,10 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
 // The gate passes with a group of 2^lg lanes per bucket; buckets longer than gate_heavy_threshold() gates are cut into
 // units of gate_heavy_unit() gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
 constexpr uint32_t kHeavyPerLane = 64;    // a lane of a group walks at most this many gates (about eight on average)
-// gates per unit of a heavy bucket (one wave each): sixteen gates per lane where there is plenty of work, four where a layer
-// is small and its one or two heavy buckets -- the constant wires -- are a latency chain on every proof's path
-inline uint32_t gate_heavy_unit(uint64_t gates) { return gates < ((uint64_t)1 << 20) ? 256u : 1024u; }
+// gates per unit of a heavy bucket (one wave each): sixteen gates per lane where there is plenty of work, four or two where a
+// layer is small and its one or two heavy buckets -- the constant wires -- are a latency chain on every proof's path (the
+// 16-circuit step, same box: 10.50 / 10.67 ms with 256 throughout below 2^20 gates, 10.39 / 10.46 with 128 below 2^18, 10.44 / 10.47 with 64)
+inline uint32_t gate_heavy_unit(uint64_t gates) { return gates < ((uint64_t)1 << 18) ? 128u : (gates < ((uint64_t)1 << 20) ? 256u : 1024u); }
 constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the lane-group passes
 uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k);
 uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k);
