@@ -582,6 +582,30 @@ def aggregated_proofs(world, n_inputs):
     ver0 = check(golden["config0"]["digests"] if golden else None, "config0", sample=3) if world.rank == 0 and not os.environ.get("GKR_BENCH_NO_VERIFY") else None
     mine = parallel.shard_units(n_inputs, world.rank, world.size)
     dt, each = measure([synth.mimc7_demo_witness(a, b) for a, b in [synth.demo_proof_inputs(n_inputs)[i] for i in mine]], 5)
+    # one more, untimed step with the library's thread accounts on: where the proving threads' time goes (own hashing pieces,
+    # pieces of other contexts' work taken while waiting for the GPU, spinning with nothing to take, launches and set-up,
+    # and what the threads without an item lent) -- rank 0's figures
+    accounts = None
+    if len(mine) and world.rank == 0:
+        from gkr_amd import _native as N
+        import ctypes
+        lib = N.lib()
+        acc_inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(a, b)) for a, b in [synth.demo_proof_inputs(n_inputs)[i] for i in mine]]))
+        lib.gkr_host_accounting(1)
+        t1 = time.perf_counter()
+        step.prove_raw_many(ctx, acc_inputs, threads)
+        acc_ms = (time.perf_counter() - t1) * 1e3
+        lib.gkr_host_accounting(0)
+        buf = (ctypes.c_double * 7)()
+        lib.gkr_host_accounting_read(buf, 7)
+        own, helped, spin, rest, lent, lent_idle, calls = [float(x) for x in buf]
+        thread_ms = threads * acc_ms
+        accounts = {"step_ms": round(acc_ms, 3), "threads": threads, "proving_calls": int(calls),
+                    "thread_ms": {"own_hashing_pieces": round(own / 1e3, 2), "others_pieces_while_waiting_for_the_gpu": round(helped / 1e3, 2),
+                                  "spinning_on_the_gpu_nothing_to_take": round(spin / 1e3, 2), "launches_setup_copies": round(rest / 1e3, 2),
+                                  "pieces_by_threads_without_an_item": round(lent / 1e3, 2), "those_threads_idle": round(lent_idle / 1e3, 2)},
+                    "busy_fraction_of_threads_x_step": round((own + helped + rest + lent) / 1e3 / thread_ms, 3) if thread_ms else None,
+                    "idle_fraction": round((spin + lent_idle) / 1e3 / thread_ms, 3) if thread_ms else None}
     ver3 = None
     if len(mine) and not os.environ.get("GKR_BENCH_NO_VERIFY"):
         rows = [golden["config3"]["digests"][i] for i in mine] if golden and golden["config3"]["inputs"] == n_inputs else None
@@ -591,6 +615,7 @@ def aggregated_proofs(world, n_inputs):
     out["config3"] = {"inputs": n_inputs, "inputs_per_rank": [len(parallel.shard_units(n_inputs, r, world.size)) for r in range(world.size)],
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt,
                       "ms_each_rank0": each}
+    out["config3"]["host_thread_accounts"] = accounts
     out["config0_three_inputs"]["verified"] = ver0
     out["config3"]["verified"] = dict(ver3 or {}, all_ranks_ok=bad_ranks == 0.0)
     out["verified_ok"] = bad_ranks == 0.0 and (ver0 is None or ver0["ok"]) and (ver3 is None or ver3["ok"])

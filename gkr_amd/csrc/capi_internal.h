@@ -655,6 +655,17 @@ struct ThreadTimeAccount {
     double own_pieces_us = 0, helped_us = 0, spin_us = 0;
 };
 inline thread_local ThreadTimeAccount t_account;
+// gkr_host_accounting (C ABI): the same accounts summed over all threads of the process, for a caller that wants the figures
+// instead of the stderr lines -- bench.py puts them on its line for one extra, untimed proving step
+struct HostAccountTotals {
+    std::atomic<uint64_t> own_ns{0}, helped_ns{0}, spin_ns{0}, rest_ns{0}, lent_ns{0}, lent_idle_ns{0}, calls{0};
+    std::atomic<bool> on{false};
+};
+inline HostAccountTotals& host_account_totals() {
+    static HostAccountTotals t;
+    return t;
+}
+inline bool accounting_on() { return host_account_totals().on.load(std::memory_order_relaxed); }
 inline double now_us_dbg() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline bool help_enabled() {
@@ -670,7 +681,8 @@ static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, b
             while ((*work)()) {
             }
     };
-    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    static const bool dbg_env = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const bool dbg = dbg_env || accounting_on();
     const double t0 = dbg ? now_us_dbg() : 0.0;
     if (several && help_enabled()) {
         gkr::HelpBoard::Posted posted(work, flat ? 0 : priority);
@@ -700,7 +712,8 @@ inline int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint3
         while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
             // this thread has nothing to do until its round lands: a piece of another context's posted host work
             // (a 16-lane hash call, ~30 us) instead of spinning
-            static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+            static const bool dbg_env = getenv("GKR_DEBUG_TIMING") != nullptr;
+            const bool dbg = dbg_env || accounting_on();
             const double th0 = dbg ? now_us_dbg() : 0.0;
             const bool did_help = help && gkr::HelpBoard::instance().help();
             if (!did_help) GKR_CPU_RELAX();

@@ -346,7 +346,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     HIP_TRY(ctx, hipStreamSynchronize(s));
     static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
     const auto tpb0 = std::chrono::steady_clock::now();
-    if (dbg_pb) t_account = ThreadTimeAccount();
+    const bool account = accounting_on();
+    if (dbg_pb || account) t_account = ThreadTimeAccount();
     if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
     if (dbg_pre)
         fprintf(stderr, "[gkr timing] prove, before the layers: input check %.0f us, circuit hash %.0f us, upload + evaluation + Moebius + readback %.0f us\n", us_canon,
@@ -490,6 +491,16 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         fprintf(stderr, "[gkr timing] this thread: own hashing pieces (incl. waiting for helpers) %.0f us, others' pieces %.0f us, spinning with nothing to take %.0f us, "
                         "the rest (launches, set-up, copies) %.0f us\n", t_account.own_pieces_us, t_account.helped_us, t_account.spin_us,
                 us(t_entry, t_end) - t_account.own_pieces_us - t_account.helped_us - t_account.spin_us);
+    }
+    if (account) {
+        HostAccountTotals& tot = host_account_totals();
+        const double all_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count();
+        const double rest = all_us - t_account.own_pieces_us - t_account.helped_us - t_account.spin_us;
+        tot.own_ns.fetch_add((uint64_t)(t_account.own_pieces_us * 1e3), std::memory_order_relaxed);
+        tot.helped_ns.fetch_add((uint64_t)(t_account.helped_us * 1e3), std::memory_order_relaxed);
+        tot.spin_ns.fetch_add((uint64_t)(t_account.spin_us * 1e3), std::memory_order_relaxed);
+        tot.rest_ns.fetch_add((uint64_t)((rest > 0 ? rest : 0) * 1e3), std::memory_order_relaxed);
+        tot.calls.fetch_add(1, std::memory_order_relaxed);
     }
     copier.finish();
     if (copier.err != hipSuccess) return ctx->hip_fail(copier.err, "copy of the d / input_func coefficients to the proof buffers");

@@ -115,8 +115,13 @@ long gkr_host_help_while(const volatile int32_t* busy) {
     if (!busy) return 0;
     long pieces = 0;
     unsigned idle = 0;
+    const bool account = accounting_on();
+    const double t0 = account ? now_us_dbg() : 0.0;
+    double lent_us = 0;
     while (__atomic_load_n(busy, __ATOMIC_ACQUIRE) != 0) {
+        const double th = account ? now_us_dbg() : 0.0;
         if (help_enabled() && gkr::HelpBoard::instance().help()) {
+            if (account) lent_us += now_us_dbg() - th;
             ++pieces;
             idle = 0;
             continue;
@@ -127,7 +132,41 @@ long gkr_host_help_while(const volatile int32_t* busy) {
             idle = 0;
         }
     }
+    if (account) {
+        HostAccountTotals& tot = host_account_totals();
+        const double all = now_us_dbg() - t0;
+        tot.lent_ns.fetch_add((uint64_t)(lent_us * 1e3), std::memory_order_relaxed);
+        tot.lent_idle_ns.fetch_add((uint64_t)((all > lent_us ? all - lent_us : 0) * 1e3), std::memory_order_relaxed);
+    }
     return pieces;
+}
+
+int gkr_host_accounting(int enable) {
+    HostAccountTotals& tot = host_account_totals();
+    if (enable) {
+        tot.own_ns = 0;
+        tot.helped_ns = 0;
+        tot.spin_ns = 0;
+        tot.rest_ns = 0;
+        tot.lent_ns = 0;
+        tot.lent_idle_ns = 0;
+        tot.calls = 0;
+    }
+    tot.on.store(enable != 0, std::memory_order_relaxed);
+    return GKR_OK;
+}
+
+int gkr_host_accounting_read(double* out_us, size_t count) {
+    if (!out_us || count < 7) return GKR_ERR_INVALID;
+    const HostAccountTotals& tot = host_account_totals();
+    out_us[0] = tot.own_ns.load() * 1e-3;
+    out_us[1] = tot.helped_ns.load() * 1e-3;
+    out_us[2] = tot.spin_ns.load() * 1e-3;
+    out_us[3] = tot.rest_ns.load() * 1e-3;
+    out_us[4] = tot.lent_ns.load() * 1e-3;
+    out_us[5] = tot.lent_idle_ns.load() * 1e-3;
+    out_us[6] = (double)tot.calls.load();
+    return GKR_OK;
 }
 
 int gkr_ctx_device_name(const gkr_ctx* ctx, char* buf, size_t len) {

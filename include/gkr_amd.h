@@ -125,6 +125,15 @@ int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
  * (the caller's count of threads still proving) and returns the number of pieces it ran.  GKR_NO_HELP=1 disables
  * the sharing. */
 long gkr_host_help_while(const volatile int32_t *busy);
+/* Where the proving threads' time goes, summed over every thread of the process while enabled (what GKR_DEBUG_TIMING prints
+ * per call, as figures): enable = 1 clears the totals and starts counting, 0 stops.  gkr_host_accounting_read fills, in
+ * microseconds: [0] a thread's own host pieces (hashing, incl. waiting for helpers to finish theirs), [1] pieces of other
+ * contexts' work taken while waiting for its own GPU round, [2] spinning on the GPU with nothing to take, [3] the rest of
+ * its gkr_prove / gkr_prove_batch calls (launches, set-up, copies), [4] pieces run by threads that had no proof left
+ * (gkr_host_help_while), [5] their time with nothing to take, [6] the number of proving calls counted.  count >= 7.
+ * The reference has no counterpart (rayon hides its scheduling); bench.py reports these for its aggregated-proofs leg. */
+int  gkr_host_accounting(int enable);
+int  gkr_host_accounting_read(double *out_us, size_t count);
 
 /* Per-kernel timing with HIP events on the stream each kernel is launched on (bench.py's
  * roofline leg).  enable: 0 off, 1 every kernel, 2 only the bandwidth-bound kernels ("mle_multifold",
