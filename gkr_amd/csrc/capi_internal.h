@@ -595,6 +595,7 @@ struct ProveCrew {
     int finished = 0;             // of the threads (members 1 ..), in the current call
     gkr_prove_item* items = nullptr;
     int32_t busy = 0;             // members still proving (atomic access); the others lend themselves
+    double t_call_us = 0;         // (accounting) when the current call woke the crew
 };
 
 // RAII timing bracket around one launch (only when profiling is on)
@@ -658,7 +659,7 @@ inline thread_local ThreadTimeAccount t_account;
 // gkr_host_accounting (C ABI): the same accounts summed over all threads of the process, for a caller that wants the figures
 // instead of the stderr lines -- bench.py puts them on its line for one extra, untimed proving step
 struct HostAccountTotals {
-    std::atomic<uint64_t> own_ns{0}, helped_ns{0}, spin_ns{0}, rest_ns{0}, lent_ns{0}, lent_idle_ns{0}, calls{0};
+    std::atomic<uint64_t> own_ns{0}, helped_ns{0}, spin_ns{0}, rest_ns{0}, lent_ns{0}, lent_idle_ns{0}, calls{0}, wake_ns{0};
     std::atomic<bool> on{false};
 };
 inline HostAccountTotals& host_account_totals() {

@@ -529,6 +529,7 @@ int gkr_prove_batch(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input
 
 // ---- gkr_prove_many: the items of one aggregation step proven side by side ----------------------------------------
 static void crew_prove_items(ProveCrew* crew, ProveCrew::Member* m) {
+    if (accounting_on()) host_account_totals().wake_ns.fetch_add((uint64_t)((now_us_dbg() - crew->t_call_us) * 1e3), std::memory_order_relaxed);
     for (int idx : m->items) {
         gkr_prove_item& it = crew->items[idx];
         if (!it.circuit || !it.input_values || !it.outs) {
@@ -691,6 +692,7 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         crew->active = want;
         crew->finished = 0;
         __atomic_store_n(&crew->busy, want, __ATOMIC_RELEASE);
+        crew->t_call_us = now_us_dbg();
         ++crew->generation;
     }
     crew->cv_start.notify_all();

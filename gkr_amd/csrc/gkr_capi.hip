@@ -151,6 +151,7 @@ int gkr_host_accounting(int enable) {
         tot.lent_ns = 0;
         tot.lent_idle_ns = 0;
         tot.calls = 0;
+        tot.wake_ns = 0;
     }
     tot.on.store(enable != 0, std::memory_order_relaxed);
     return GKR_OK;
@@ -158,6 +159,7 @@ int gkr_host_accounting(int enable) {
 
 int gkr_host_accounting_read(double* out_us, size_t count) {
     if (!out_us || count < 7) return GKR_ERR_INVALID;
+    if (count >= 8) out_us[7] = host_account_totals().wake_ns.load() * 1e-3;
     const HostAccountTotals& tot = host_account_totals();
     out_us[0] = tot.own_ns.load() * 1e-3;
     out_us[1] = tot.helped_ns.load() * 1e-3;

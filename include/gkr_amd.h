@@ -130,7 +130,8 @@ long gkr_host_help_while(const volatile int32_t *busy);
  * microseconds: [0] a thread's own host pieces (hashing, incl. waiting for helpers to finish theirs), [1] pieces of other
  * contexts' work taken while waiting for its own GPU round, [2] spinning on the GPU with nothing to take, [3] the rest of
  * its gkr_prove / gkr_prove_batch calls (launches, set-up, copies), [4] pieces run by threads that had no proof left
- * (gkr_host_help_while), [5] their time with nothing to take, [6] the number of proving calls counted.  count >= 7.
+ * (gkr_host_help_while), [5] their time with nothing to take, [6] the number of proving calls counted, and with
+ * count >= 8 [7] the time gkr_prove_many's threads took to start on their items after the call woke them.  count >= 7.
  * The reference has no counterpart (rayon hides its scheduling); bench.py reports these for its aggregated-proofs leg. */
 int  gkr_host_accounting(int enable);
 int  gkr_host_accounting_read(double *out_us, size_t count);
