@@ -75,6 +75,13 @@ class World:
         # GKR_BENCH_FORCE_GROUP=1: a process group (and with it RCCL) also for one rank, so that the exchange path of
         # --mode layer-split runs as it does on N GPUs (one MI355X is all a builder's box has)
         self.grouped = self.size > 1 or os.environ.get("GKR_BENCH_FORCE_GROUP") == "1"
+        # eight ranks must never silently share one GPU: a rank's device is its LOCAL_RANK, and it has to exist
+        # (device_count does not initialise the GPU).  Only the single-device test hook above may lift this.
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.size)) or self.size)
+        if self.size > 1 and "GKR_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < local_world:
+            raise SystemExit("bench.py: %d local ranks but %d visible device(s); one process per GPU is the contract "
+                             "(GKR_BENCH_DEVICE=<id> with GKR_BENCH_BACKEND=gloo is the single-device test hook)"
+                             % (local_world, torch.cuda.device_count()))
         if self.grouped:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -539,7 +546,7 @@ def aggregated_proofs(world, n_inputs):
                   "wait, are done or have no item take pieces of the others' host work" % (subs, threads),
            "contexts": threads, "cpus_per_rank": cpus}
 
-    def measure(witnesses, reps):
+    def measure(witnesses, reps, ctx=ctx):
         inputs = step.inputs_for(np.stack([as_limbs(w) for w in witnesses])) if witnesses else None
         if inputs is not None:
             for _ in range(4):
@@ -618,9 +625,31 @@ def aggregated_proofs(world, n_inputs):
                       "proofs": n_inputs * subs, "ms": dt * 1e3, "proofs_per_sec": n_inputs * subs / dt, "inputs_per_sec": n_inputs / dt,
                       "ms_each_rank0": each}
     out["config3"]["host_thread_accounts"] = accounts
+    # configs[3] the way the reference runs it: ONE host process whose par_iter fans prover::prove out
+    # (aggregator.rs:350-355, 411-416) -- here over every device this process can see (gkr_ctx_create_multi: the items of a
+    # gkr_prove_many call dealt over child contexts on all of them).  Only on the N = 1 line: with one rank per GPU the
+    # ranks already hold a device each.
+    if world.size == 1 and os.environ.get("GKR_BENCH_MULTI_DEVICE", "1") != "0":
+        devs = list(range(world.torch.cuda.device_count())) if "GKR_BENCH_DEVICE" not in os.environ else [world.local_rank]
+        try:
+            mctx = Context(devices=devs)
+            dtm, eachm = measure([synth.mimc7_demo_witness(a, b) for a, b in synth.demo_proof_inputs(n_inputs)], 5, ctx=mctx)
+            verm = None
+            if not os.environ.get("GKR_BENCH_NO_VERIFY"):
+                verm = check(golden["config3"]["digests"] if golden and golden["config3"]["inputs"] == n_inputs else None, "config3")
+            out["multi_device"] = {"how": "one process, gkr_ctx_create_multi(%s): one gkr_prove_many call per step deals the %d sub-circuits over "
+                                          "child contexts on every listed device" % (devs, subs),
+                                   "devices_seen": mctx.device_count(), "device_ids": devs, "inputs": n_inputs, "proofs": n_inputs * subs,
+                                   "ms": dtm * 1e3, "proofs_per_sec": n_inputs * subs / dtm, "ms_each": eachm, "verified": verm}
+            if verm and not verm["ok"]:
+                out["multi_device_failed"] = True
+            mctx.close()
+        except Exception as e:   # noqa: BLE001 -- a leg of its own: reported, and it fails the run below
+            out["multi_device"] = {"error": "%s: %s" % (type(e).__name__, e), "device_ids": devs}
+            out["multi_device_failed"] = True
     out["config0_three_inputs"]["verified"] = ver0
     out["config3"]["verified"] = dict(ver3 or {}, all_ranks_ok=bad_ranks == 0.0)
-    out["verified_ok"] = bad_ranks == 0.0 and (ver0 is None or ver0["ok"]) and (ver3 is None or ver3["ok"])
+    out["verified_ok"] = bad_ranks == 0.0 and (ver0 is None or ver0["ok"]) and (ver3 is None or ver3["ok"]) and not out.pop("multi_device_failed", False)
     out["proofs_per_sec"] = out["config3"]["proofs_per_sec"]
     # The same pipeline on an R1CS of the size the reference is FOR (aggregating real circuits): 262 144 constraints -> 16
     # layered circuits with layers of 2^14 .. 2^16 values (round 3's boundary rejected them), one input, every rank alike;
@@ -646,13 +675,15 @@ def aggregated_proofs(world, n_inputs):
         ks_big = [c.get_k_list() for c in big.circuits]
         bad_big = None
         if gold and not os.environ.get("GKR_BENCH_NO_VERIFY"):
+            coeff_gold = gold.get("coeff_digests")
             bad_big = [j for j, (arrs, ks) in enumerate(zip(big._prepared["outs"], ks_big))
-                       if j >= len(gold["digests"]) or ks != gold["k"][j] or synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) != gold["digests"][j]]
+                       if j >= len(gold["digests"]) or ks != gold["k"][j] or synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) != gold["digests"][j]
+                       or (coeff_gold and synth.proof_coeffs_digest(arrs[7][0], arrs[8][0]) != coeff_gold[j])]
         big_bad_ranks = world.max_over_ranks(1.0 if bad_big else 0.0)
         out["large_r1cs"] = {"constraints": 4 * nrounds, "sub_circuits": len(big.circuits), "k_lists": ks_big, "inputs": 1,
                              "compile_ms": big_compile_ms, "ms": dt_big * 1e3, "ms_each": [round(x, 3) for x in each_big],
                              "proofs_per_sec": len(big.circuits) / dt_big, "constraints_per_sec": 4 * nrounds / dt_big,
-                             "verified": None if bad_big is None else {"digests": "tests/golden/large_r1cs_digests.json (compile and proofs by the CPU checker)",
+                             "verified": None if bad_big is None else {"digests": "tests/golden/large_r1cs_digests.json (compile and proofs by the CPU checker; d and input_func %s)" % ("included" if gold.get("coeff_digests") else "not covered"),
                                                                         "proofs": len(big.circuits), "mismatches": bad_big, "ok": not bad_big, "all_ranks_ok": big_bad_ranks == 0.0}}
         if bad_big or big_bad_ranks:
             out["verified_ok"] = False
@@ -749,10 +780,15 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
         products = 2.0 * cnt
         rate = products / (gate_ms * 1e-3) if gate_ms else None
         peak = own["modmul_per_sec"] if own else None
+        dense_accounting = 2 * k <= k_i + 2
         wide = k >= 13   # lane-group passes: the operand table (2^k x 32 B) no longer sits in LDS / L2 -- a gather per gate
         out = {
-            "metric": "BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" % k_i, "value": 25 * (N - 1) * steps / elapsed,
-            "unit": "field-ops/s", "n_gpus": world.size if split else 1, "steps": steps, "warmup": warmup,
+            # a layer with a gate for (nearly) every point of the 2^{2k} hypercube is priced by SURVEY 8d's dense accounting,
+            # 25 (2^{2k} - 1) field-ops per sumcheck; a sparse (circom-shaped, wide) layer is proven in time linear in its GATES,
+            # and 25 * 2^{2k} would be a number about nothing: gates/s there
+            "metric": ("BN254-Fr GKR-layer sumcheck field-ops/sec @ 2^%d gates" if dense_accounting else "BN254-Fr GKR-layer sumcheck gates/sec @ 2^%d gates") % k_i,
+            "value": (25 * (N - 1) if dense_accounting else (1 << k_i)) * steps / elapsed,
+            "unit": "field-ops/s" if dense_accounting else "gates/s", "gates_per_sec": (1 << k_i) * steps / elapsed, "n_gpus": world.size if split else 1, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
             "config": {"workload": "%s: one GKR layer, k_i = %d, k = %d%s" % (
@@ -802,13 +838,18 @@ def wide_prove_leg(world, ks=(18, 20, 20), reps=5):
             each.append((time.perf_counter() - t) * 1e3)
     digest = synth.proof_arrays_digest(list(ks), *[a[0] for a in arrs[:7]])
     want = synth.golden_digest("prove", "k=" + ",".join(map(str, ks)))
+    # d and input_func (the device Moebius transform, copied to the reused buffers by the helper thread on every repetition)
+    coeff_digest = synth.proof_coeffs_digest(arrs[7][0], arrs[8][0])
+    want_coeffs = synth.golden_digest("prove_coeffs", "k=" + ",".join(map(str, ks)))
     dt = world.max_over_ranks(statistics.median(each) / 1e3)
     if world.rank != 0:
         return None
     return {"workload": "gkr_prove of a circuit with k = %s (gates per layer 2^%d, 2^%d; input layer 2^%d values), one witness" % (list(ks), ks[0], ks[1], ks[-1]),
             "ms_per_proof": dt * 1e3, "ms_each": [round(x, 3) for x in each], "first_call_ms": first * 1e3,
             "first_call": "gate arrays uploaded, gate lists sorted, workspaces and proof buffers allocated",
-            "matches_golden_digest": None if want is None else digest == want, "proof_sha256": digest,
+            "matches_golden_digest": None if want is None else (digest == want and (want_coeffs is None or coeff_digest == want_coeffs)),
+            "proof_sha256": digest, "d_and_input_func_sha256": coeff_digest,
+            "digest_covers": "sumcheck_proofs, lengths, sumcheck_r, q, q lengths, z, r" + ("; d and input_func by their own digest" if want_coeffs else "; d and input_func NOT covered (no golden digest)"),
             "outputs_bytes": int(sum(a.nbytes for a in arrs))}
 
 
@@ -1005,6 +1046,66 @@ def emit(obj):
         os.write(_REAL_STDOUT, data)
 
 
+def visible_devices():
+    """GPUs this process would see, counted in a CHILD process (counting must not initialise the GPU in a process that is
+    about to start other programs; -1 when torch cannot say)."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return -1
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: this process has not imported torch or touched the GPU; it
+    starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>` as a CHILD
+    process (never an exec), relays rank 0's one JSON line to the real stdout and returns the child's exit code.  One
+    process per GPU over RCCL -- the multi-GPU twin of the one process whose par_iter fans prover::prove out
+    (rust/src/aggregator.rs:350-355, 411-416)."""
+    import socket
+    import subprocess
+    test_hook = "GKR_BENCH_DEVICE" in os.environ   # several ranks on ONE device (gloo): single-GPU boxes exercising N > 1
+    if not test_hook:
+        seen = visible_devices()
+        if 0 <= seen < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible (set GKR_BENCH_DEVICE=<id> and "
+                             "GKR_BENCH_BACKEND=gloo to run the ranks on one device as a test)\n" % (n, seen))
+            return 3
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, start_new_session=True)
+    try:
+        lines = 0
+        for raw in child.stdout:
+            if raw.lstrip().startswith(b"{") and lines == 0:
+                os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, raw if raw.endswith(b"\n") else raw + b"\n")
+                lines += 1
+            else:
+                sys.stderr.buffer.write(raw)
+        rc = child.wait()
+    except BaseException:
+        import signal
+        try:
+            os.killpg(child.pid, signal.SIGTERM)   # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        raise
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        return 5
+    return rc
+
+
 def main():
     # Libraries below write banners to stdout (RCCL: version / hostname lines at start-up and shutdown; gloo: "Rank n is
     # connected ..."): file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to the saved one.
@@ -1034,7 +1135,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--ref-algo-seconds", type=float, default=20.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = World()
+    if world.size != max(1, args.gpus) and world.size > 1:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world.size))
     try:
         {"mle": run_mle, "proofs": run_proofs, "layer-split": run_layer_split, "mle-split": run_mle_split}[args.mode](args, world)
     finally:

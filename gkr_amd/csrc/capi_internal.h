@@ -22,6 +22,7 @@
 #include "fr64.h"
 #include "hostpool.h"
 #include "kernels.h"
+#include "options.h"
 #include "gate_seg.h"
 #include "keccak.h"
 #include "mimc7.h"
@@ -111,7 +112,7 @@ inline int usable_cpus() {
 // true once the eight-lane IFMA hash is initialised (CPU has avx512ifma and GKR_NO_IFMA is unset)
 inline bool host_ifma_ready() {
     static const bool ready = [] {   // one thread initialises the 52-bit tables, the others wait at the guard
-        if (getenv("GKR_NO_IFMA") || !gkr::gkr_ifma_available()) return false;
+        if (gkr::process_switch("GKR_NO_IFMA") || !gkr::gkr_ifma_available()) return false;
         const gkr::h64::F* cts = host_mimc_constants64();
         static uint64_t canon[gkr::kMimcRounds][4];
         for (int i = 0; i < gkr::kMimcRounds; ++i) {
@@ -127,7 +128,7 @@ inline bool host_ifma_ready() {
 // ONE transcript's hash of a round vector (canonical in, canonical out) on the calling thread: the mulx / adcx / adox
 // code of mimc_adx.cpp where the CPU has it (GKR_NO_ADX unset), the portable 4 x 64-bit code of fr64.h otherwise
 inline gkr::h64::F host_multi_hash(const gkr::h64::F* arr, int n, const gkr::h64::F* cts) {
-    static const bool adx = !getenv("GKR_NO_ADX") && gkr::gkr_adx_available();
+    static const bool adx = !gkr::process_switch("GKR_NO_ADX") && gkr::gkr_adx_available();
     if (!adx) return gkr::h64::mimc7_multi_hash(arr, n, cts, nullptr);
     gkr::h64::F out;
     gkr::gkr_adx_multi_hash(reinterpret_cast<const uint64_t(*)[4]>(arr), n, reinterpret_cast<const uint64_t(*)[4]>(cts), out.l);
@@ -149,148 +150,23 @@ inline void ifma_hash_chunk(const uint64_t (*vec)[3][4], const uint32_t* ln, int
 // (throughput: MI355X + 2 threads, 256 x 2^20: 7.1 ms per step against 8.5), eight otherwise (latency: with 15
 // threads 5.04 ms against 5.19)
 inline int hash_chunk_size(int tables, int threads) {
-    static const int forced = [] {
-        const char* e = getenv("GKR_HASH_CHUNK");
-        const int v = e ? atoi(e) : 0;
-        return v == 8 || v == 16 ? v : 0;
-    }();
-    if (forced) return forced;
+    const long long forced = gkr::opt(gkr::OPT_hash_chunk);   // (called on a context's own thread, before the pieces are posted)
+    if (forced == 8 || forced == 16) return (int)forced;
     return tables >= 32 * threads ? 16 : 8;
 }
 
-// Device allocations of the library: plain hipMalloc.  Two experiment modes stay behind GKR_ALLOC_MODE because the
-// question they answered may come back on other driver versions: whether the streaming kernels' bandwidth depends
-// on how an allocation is mapped (it seemed to: round 1's "allocation modes").  Measured in round 2
-// (profiles/r02/c_placement_map_modes.txt): hipMemAddressReserve does not honour an alignment above 2 MiB here,
-// physical handles of 2 MiB / 64 MiB / 1 GiB / 8 GiB behave like hipMalloc, and the modes were a property of the
-// fold kernel's launch geometry, not of the mapping (kernels.hip, mle_multifold_blocks).
-//   GKR_ALLOC_MODE=malloc      (default) hipMalloc
-//   GKR_ALLOC_MODE=contiguous  hipExtMallocWithFlags(hipDeviceMallocContiguous)
-//   GKR_ALLOC_MODE=vmm         buffers >= 256 MiB: reserved virtual range + physical handles of
-//                              2^GKR_VMM_CHUNK_LOG2 bytes (default 1 GiB), alignment request 2^GKR_VMM_ALIGN_LOG2
-struct VmmAllocation {
-    size_t size = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<size_t> chunk_sizes;
-};
-inline std::mutex g_vmm_mu;
-inline std::map<void*, VmmAllocation> g_vmm;
-
-inline int alloc_mode() {   // 0 malloc, 1 contiguous, 2 vmm
-    static const int mode = [] {
-        if (getenv("GKR_ALLOC_CONTIGUOUS")) return 1;
-        const char* e = getenv("GKR_ALLOC_MODE");
-        if (!e || !strcmp(e, "malloc")) return 0;
-        if (!strcmp(e, "contiguous")) return 1;
-        return !strcmp(e, "vmm") ? 2 : 0;
-    }();
-    return mode;
-}
-constexpr size_t kVmmMin = (size_t)256 << 20;
-
-inline hipError_t vmm_malloc(void** out, size_t bytes) {
-    static const size_t align = (size_t)1 << [] { const char* e = getenv("GKR_VMM_ALIGN_LOG2"); const int v = e ? atoi(e) : 30; return v < 21 ? 21 : (v > 36 ? 36 : v); }();
-    static const size_t chunk = (size_t)1 << [] { const char* e = getenv("GKR_VMM_CHUNK_LOG2"); const int v = e ? atoi(e) : 30; return v < 21 ? 21 : (v > 36 ? 36 : v); }();
-    int dev = 0;
-    hipError_t rc = hipGetDevice(&dev);
-    if (rc != hipSuccess) return rc;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = dev;
-    size_t gran = 0;
-    rc = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-    if (rc != hipSuccess || gran == 0) return rc != hipSuccess ? rc : hipErrorNotSupported;
-    const size_t total = (bytes + gran - 1) / gran * gran;
-    void* va = nullptr;
-    rc = hipMemAddressReserve(&va, total, align, nullptr, 0);
-    if (rc != hipSuccess) return rc;
-    VmmAllocation a;
-    a.size = total;
-    size_t off = 0;
-    while (off < total && rc == hipSuccess) {
-        size_t sz = total - off < chunk ? total - off : chunk;
-        hipMemGenericAllocationHandle_t h;
-        rc = hipMemCreate(&h, sz, &prop, 0);
-        if (rc != hipSuccess) break;
-        rc = hipMemMap(static_cast<char*>(va) + off, sz, 0, h, 0);
-        if (rc != hipSuccess) {
-            (void)hipMemRelease(h);
-            break;
-        }
-        a.handles.push_back(h);
-        a.chunk_sizes.push_back(sz);
-        off += sz;
-    }
-    if (rc == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = dev;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        rc = hipMemSetAccess(va, total, &acc, 1);
-    }
-    if (rc != hipSuccess) {
-        size_t o = 0;
-        for (size_t i = 0; i < a.handles.size(); ++i) {
-            (void)hipMemUnmap(static_cast<char*>(va) + o, a.chunk_sizes[i]);
-            (void)hipMemRelease(a.handles[i]);
-            o += a.chunk_sizes[i];
-        }
-        (void)hipMemAddressFree(va, total);
-        return rc;
-    }
-    {
-        std::lock_guard<std::mutex> g(g_vmm_mu);
-        g_vmm[va] = std::move(a);
-    }
-    *out = va;
-    return hipSuccess;
-}
-
-inline hipError_t device_malloc(void** p, size_t bytes) {
-    const int mode = alloc_mode();
-    if (mode == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
-    if (mode == 2 && bytes >= kVmmMin) {
-        const hipError_t rc = vmm_malloc(p, bytes);
-        if (rc == hipSuccess || rc == hipErrorOutOfMemory) return rc;
-        (void)hipGetLastError();   // the virtual-memory API is not usable here: fall back to the plain allocator
-    }
-    return hipMalloc(p, bytes);
-}
-
-inline hipError_t device_free(void* p) {
-    VmmAllocation a;
-    bool vmm = false;
-    {
-        std::lock_guard<std::mutex> g(g_vmm_mu);
-        auto it = g_vmm.find(p);
-        if (it != g_vmm.end()) {
-            a = std::move(it->second);
-            g_vmm.erase(it);
-            vmm = true;
-        }
-    }
-    if (!vmm) return hipFree(p);
-    hipError_t rc = hipDeviceSynchronize();
-    size_t o = 0;
-    for (size_t i = 0; i < a.handles.size(); ++i) {
-        const hipError_t u = hipMemUnmap(static_cast<char*>(p) + o, a.chunk_sizes[i]);
-        const hipError_t r = hipMemRelease(a.handles[i]);
-        if (rc == hipSuccess) rc = u != hipSuccess ? u : r;
-        o += a.chunk_sizes[i];
-    }
-    const hipError_t f = hipMemAddressFree(p, a.size);
-    return rc != hipSuccess ? rc : f;
-}
+// Device allocations of the library: plain hipMalloc.  (Rounds 1-2 kept two experiment modes here -- contiguous physical
+// memory, and reserved virtual ranges backed by 2 MiB .. 8 GiB handles -- to find out whether the streaming kernels'
+// bandwidth depends on how an allocation is mapped.  It does not: profiles/r02/c_placement_map_modes.txt; what varied
+// was the fold kernel's launch geometry, kernels.hip mle_multifold_blocks.  Retired in round 5.)
+inline hipError_t device_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+inline hipError_t device_free(void* p) { return hipFree(p); }
 
 inline int default_host_threads() {
-    if (const char* e = getenv("GKR_HOST_THREADS")) {
-        int v = atoi(e);
-        if (v >= 1) return v;
-    }
+    if (const int v = gkr::process_int("GKR_HOST_THREADS", 0); v >= 1) return v;
     int cpus = usable_cpus();
     int local = 1;   // one process per GPU: share the host cores between the ranks of this node
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) local = atoi(e) > 0 ? atoi(e) : 1;
+    if (const int ranks = gkr::process_int("LOCAL_WORLD_SIZE", 1); ranks > 0) local = ranks;
     // leave room for the HIP runtime's own threads and the interpreter -- unless the rank's share is so small that
     // the transcript needs all of it (a rank of the 2^20 workload needs ~2 hashing threads to keep its GPU fed)
     const int share = cpus / local;
@@ -416,6 +292,7 @@ struct gkr_ctx {
     int device = 0;
     std::vector<int> devices;                  // gkr_ctx_create_multi: the devices gkr_prove_many's child contexts are dealt over (empty: `device` only)
     int host_threads = 0;                      // 0: from GKR_HOST_THREADS / the usable CPUs; else this many (caller included)
+    gkr::Options options = gkr::Options::from_environment();   // gkr_ctx_set_option; read through gkr::opt() inside GKR_ENTER's scope
     std::vector<std::unique_ptr<PreparedCircuit>> circuits;   // most recently used last; bounded
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;                 // side stream for tiny kernels that only depend on host-written data (lazy)
@@ -496,15 +373,9 @@ struct gkr_ctx {
     // 13.1 ms per 1024 sumchecks).
     hipError_t late_stream(hipStream_t* out) {
         if (!late) {
-            static const bool high = getenv("GKR_LATE_HIGH_PRIORITY") != nullptr;
-            hipError_t rc;
-            if (high) {
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lower = higher priority
-                rc = hipStreamCreateWithPriority(&late, hipStreamNonBlocking, hi);
-            } else {
-                rc = hipStreamCreateWithFlags(&late, hipStreamNonBlocking);
-            }
+            // (normal priority: a HIGH-priority stream, once created in a process, doubled the round latency of every small
+            // kernel launched later on other streams -- DESIGN.md section 3, "Round scheduling")
+            const hipError_t rc = hipStreamCreateWithFlags(&late, hipStreamNonBlocking);
             if (rc != hipSuccess) return rc;
         }
         *out = late;
@@ -624,6 +495,12 @@ struct Timed {
     }
 };
 
+// every compute entry point of the C ABI: the context's device becomes current and the context's options become the
+// calling thread's (options.h) until the entry point returns
+#define GKR_ENTER(ctx)                                        \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device));                \
+    gkr::OptionScope gkr_option_scope_(&(ctx)->options)
+
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
         hipError_t _e = (expr);                              \
@@ -670,11 +547,10 @@ inline bool accounting_on() { return host_account_totals().on.load(std::memory_o
 inline double now_us_dbg() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline bool help_enabled() {
-    static const bool on = getenv("GKR_NO_HELP") == nullptr;
+    static const bool on = !gkr::process_switch("GKR_NO_HELP");
     return on;
 }
 static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, bool several, int priority = 0) {
-    static const bool flat = getenv("GKR_HELP_FLAT") != nullptr;   // A/B: every posted job alike
     auto run = [&] {
         if (pool)
             pool->run_now(work);
@@ -682,11 +558,10 @@ static void run_pieces(gkr::SpinPool* pool, const std::function<bool()>* work, b
             while ((*work)()) {
             }
     };
-    static const bool dbg_env = getenv("GKR_DEBUG_TIMING") != nullptr;
-    const bool dbg = dbg_env || accounting_on();
+    const bool dbg = gkr::debug_timing() || accounting_on();
     const double t0 = dbg ? now_us_dbg() : 0.0;
     if (several && help_enabled()) {
-        gkr::HelpBoard::Posted posted(work, flat ? 0 : priority);
+        gkr::HelpBoard::Posted posted(work, priority);
         run();
     } else {
         run();
@@ -698,11 +573,6 @@ template <typename Rec>
 inline int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint32_t ticket) {
     const auto t0 = std::chrono::steady_clock::now();
     const bool help = help_enabled();
-    static const int wait_mode = [] { const char* e = getenv("GKR_WAIT_MODE"); return e ? atoi(e) : 0; }();
-    if (wait_mode == 1) {   // diagnostic: classic stream synchronisation instead of polling the records
-        hipError_t q = hipStreamSynchronize(ctx->stream);
-        if (q != hipSuccess) return ctx->hip_fail(q, "hipStreamSynchronize");
-    }
     // The stream check and the deadline run every so often whether or not the wait was filled with other contexts'
     // pieces (a faulted stream must be noticed also while the help board stays busy); the deadline counts from this
     // context's last own progress -- a record of ITS round landing -- not from the entry, so time spent on others'
@@ -713,14 +583,13 @@ inline int wait_records(gkr_ctx* ctx, const volatile Rec* recs, int count, uint3
         while (__atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) != ticket) {
             // this thread has nothing to do until its round lands: a piece of another context's posted host work
             // (a 16-lane hash call, ~30 us) instead of spinning
-            static const bool dbg_env = getenv("GKR_DEBUG_TIMING") != nullptr;
-            const bool dbg = dbg_env || accounting_on();
+            const bool dbg = gkr::debug_timing() || accounting_on();
             const double th0 = dbg ? now_us_dbg() : 0.0;
             const bool did_help = help && gkr::HelpBoard::instance().help();
             if (!did_help) GKR_CPU_RELAX();
             if (dbg) (did_help ? t_account.helped_us : t_account.spin_us) += now_us_dbg() - th0;
             if (did_help ? (++helped & 0x3F) == 0 : (++spins & 0xFFFF) == 0) {
-                hipError_t q = wait_mode == 2 ? hipErrorNotReady : hipStreamQuery(ctx->stream);
+                hipError_t q = hipStreamQuery(ctx->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return ctx->hip_fail(q, "stream failed while waiting for a round");
                 if (std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(30)) {
                     if (q == hipSuccess && __atomic_load_n(&recs[b].seq, __ATOMIC_ACQUIRE) == ticket) break;

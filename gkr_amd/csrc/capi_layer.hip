@@ -104,7 +104,7 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
         if (rc_eq) return rc_eq;
     }
     HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
-    static const bool use_atomics = getenv("GKR_PREDICATE_ATOMICS") != nullptr;
+    const bool use_atomics = gkr::opt(gkr::OPT_predicate_atomics) != 0;
     if (!use_atomics || batch > 1) {
         // counting sort by cell, then one modular sum per cell (per proof)
         uint32_t *counts = nullptr, *offsets = nullptr, *cursor = nullptr, *bsums = nullptr, *list = nullptr;
@@ -179,9 +179,9 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
-    const double t_entry_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
     if (!host_tx && batch != 1) return ctx->fail(GKR_ERR_INVALID, "batched proving needs the host transcript");
+    if (k < 1) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
     if (shard && (!host_tx || batch != 1)) return ctx->fail(GKR_ERR_INVALID, "a gate-sharded layer needs the host transcript and one proof");
     // (argument checks come before anything is queued: a rank that returns here has not left its peers inside a collective
     // -- the same arguments fail on every rank)
@@ -196,36 +196,16 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     gkr::FixedMul* d_rtab = nullptr;
     uint32_t *d_len = nullptr, *dep = nullptr;
     gkr::LayerPartial* partials = nullptr;
-    // Three forms of the b-phase (all the same transcript):
-    //   gate lists (default with the host transcript; the only form for k > 13): no 2^{2k}-entry tables at all -- U, V and the
-    //     c-phase row are summed straight from the gates grouped by left / right operand (kernels.hip, k_gate_*);
-    //   dense predicate tables, U, V and the row from two passes over them (layers with more than 2^{2k-2} gates;
-    //     GKR_LAYER_DENSE_TABLES forces it, GKR_LAYER_GATE_LISTS forces the gate lists);
-    //   GKR_LAYER_DENSE_B (and the device transcript): k passes over the dense tables.
-    static const bool dense_b = getenv("GKR_LAYER_DENSE_B") != nullptr;
-    static const bool dense_tables = getenv("GKR_LAYER_DENSE_TABLES") != nullptr;
-    const bool lin_b = host_tx && !dense_b && k >= 1;
-    // gate lists pay when the layer is sparse in its 2^{2k} cells (every circom layer is); for a layer with a gate in
-    // (nearly) every cell the dense tables' counting sort is the cheaper grouping (k_i = 24, k = 12: 8.9 ms against 9.1)
-    static const bool gate_lists_always = getenv("GKR_LAYER_GATE_LISTS") != nullptr;
-    // Small layers (every layer of a circom-sized circuit) can run their whole sumcheck as ONE resident kernel, tables
-    // in LDS, rounds handed over through pinned memory (kernels.hip, k_layer_persistent): GKR_LAYER_PERSISTENT=1.
-    // Opt-in: measured on MI355X it saves the launch per round but a round stays at 70 - 80 us, because what
-    // dominates is the host's 24 - 30 us hash call and ~20 us of PCIe latency per hand-off in either form (64 inputs
-    // x 12 sub-circuits: 63 instead of 75 ms from one context, 19.6 instead of 22 ms from six) -- not enough to make a
-    // kernel that waits on the host the default.
-    static const bool want_persistent = getenv("GKR_LAYER_PERSISTENT") != nullptr;
-    const bool persistent = lin_b && !shard && !dense_tables && want_persistent && !gate_lists_always && k <= (int)gkr::kPersistentMaxK &&
-                            k_i <= k + 4;
-    // gate lists also for dense layers when the block-private sort applies (k <= 12, >= 2^16 gates: 2^24 gates sort in
-    // ~0.5 ms, against 2.7 ms for the dense tables' cell sort)
-    const bool lds_sort = gkr::gate_lists_lds_blocks(span.count, (uint32_t)k) != 0;
-    const bool sparse = shard || persistent || (lin_b && (k > 13 || (!dense_tables && (gate_lists_always || lds_sort || k_i + 2 <= 2 * k))));
+    // Two forms (the same transcript): with the host transcript -- the default -- the layer polynomial is summed in time
+    // linear in the gates: no 2^{2k}-entry tables at all, U, V and the c-phase row come straight from the gates grouped by
+    // left / right operand (kernels.hip, k_gate_* / k_seg_*; kernels_wide.hip for wide layers), and the rounds run as
+    // product passes.  The device transcript works on the dense predicate tables (kernels_layer_dense.hip).
+    const bool sparse = host_tx;
     // Wide layers (2^13 buckets and more per half, each with a few gates): the gate passes run with a group of lanes per
     // bucket and the rare long buckets in units (kernels_wide.hip) -- a block per bucket would be 2^20 blocks for a gate apiece.
-    // GKR_GATE_GROUPS_MIN_K moves the switch (tests run the form on small layers too).
-    static const int wide_min_k = [] { const char* e = getenv("GKR_GATE_GROUPS_MIN_K"); return e ? atoi(e) : (int)gkr::kWideMinK; }();
-    const bool wide = sparse && !persistent && k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
+    // The option gate_groups_min_k moves the switch (tests run the form on small layers too).
+    const int wide_min_k = gkr::opt(gkr::OPT_gate_groups_min_k) >= 0 ? (int)gkr::opt(gkr::OPT_gate_groups_min_k) : (int)gkr::kWideMinK;
+    const bool wide = sparse && k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -237,7 +217,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     WS(ctx, "layer.len", uint32_t, v, d_len);
     WS(ctx, "layer.dep", uint32_t, 32 * (size_t)batch, dep);
     WS(ctx, "layer.partials", gkr::LayerPartial, (size_t)gkr::kMaxLayerBlocks * batch, partials);
-    Fr *U = nullptr, *V = nullptr, *d_eq = nullptr, *collapse = nullptr;
+    Fr *U = nullptr, *V = nullptr, *d_eq = nullptr;
     gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_heavy = nullptr;
@@ -248,12 +228,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     gkr::GateSegs local_segs;
     gkr::GateSegs* segs = cached ? &cached->segs : &local_segs;
     Fr* seg_partials = nullptr;
-    if (lin_b) {
+    if (sparse) {
         WS(ctx, "layer.U", Fr, wlen * batch, U);
         WS(ctx, "layer.V", Fr, wlen * batch, V);
         WS(ctx, "layer.eq", Fr, wlen * batch, d_eq);
-        if (!sparse)
-            WS(ctx, "layer.collapse", Fr, (size_t)2 * batch * gkr::layer_collapse_chunks((uint32_t)k, (uint32_t)batch) * wlen, collapse);
         HIP_TRY(ctx, ctx->pinned_host("layer.u", sizeof(gkr_fr) * (size_t)k * batch, reinterpret_cast<void**>(&h_u)));
     }
     int rc = GKR_OK;
@@ -276,8 +254,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
             // (the dependence flags of a table beyond 2^13 values are found over a grid, not by the prologue's one block)
             const bool dep_wide = k > 13;
-            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, persistent ? nullptr : Wb,
-                                       persistent ? nullptr : Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s);
+            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, Wb, Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s);
             if (dep_wide) {
                 uint32_t* dep_bits = nullptr;
                 WS(ctx, "layer.depbits", uint32_t, (size_t)batch, dep_bits);
@@ -341,18 +318,13 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         gkr::launch_to_mont(d_W, Wc, (uint32_t)(wlen * batch), s);
         gkr::launch_depends(d_W, k, dep, (uint32_t)batch, s);
     }
-    if (persistent) {
-        // U, V, the rounds and the row are all inside the one kernel launched below
-    } else if (sparse) {
+    if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
             gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s,
                                      cached && cached->heavy_known && !lists_fresh ? cached->heavy_hdr : nullptr);
         else
             gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
-    } else if (lin_b) {
-        Timed t(ctx, "layer_uv", (double)N * 2.0 * 32.0 * batch);
-        gkr::launch_layer_uv(A, M, Wc, U, V, (uint32_t)k, lb, s);
     }
 
     // The two tables d_a, d_b (`each` elements) := their sums over all ranks.  One more element travels along: "some rank
@@ -412,17 +384,11 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         if (rc) return rc;
     }
 
-    gkr::LayerHostRec* rec = nullptr;
-    gkr::FixedMul* h_rtab = nullptr;   // pinned, two slots of `batch` tables used alternately
-    const gkr::h64::F* cts64 = host_mimc_constants64();
     const bool ifma = host_ifma_ready();
     gkr::SpinPool* pool = nullptr;
     if (host_tx) {
-        HIP_TRY(ctx, ctx->pinned_host("layer.rec", sizeof(gkr::LayerHostRec) * batch, reinterpret_cast<void**>(&rec)));
-        HIP_TRY(ctx, ctx->pinned_host("layer.rtab", 2 * sizeof(gkr::FixedMul) * batch, reinterpret_cast<void**>(&h_rtab)));
-        // h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record
-        // (the gate-list form's prologue launch wrote it)
-        if (!sparse) gkr::launch_copy_words(dep, h_dep, (size_t)32 * batch, s);
+        // (h_dep is read when round 0 is hashed, i.e. after a LATER kernel of this stream has released that round's record:
+        // the prologue launch wrote it)
         // (gate-sharded with the device exchange: the flag travels with the first exchange and is looked at after the
         // first round's record, on every rank alike -- a rank that left here would leave its peers inside a collective)
         if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
@@ -435,228 +401,18 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         }
         if (batch >= 16) pool = ctx->host_pool();
     }
-    if (persistent) {
-        static const bool dbg_s = getenv("GKR_DEBUG_TIMING") != nullptr;
-        if (dbg_s)
-            fprintf(stderr, "[gkr timing] resident layer set-up (eq upload, gate lists, dep readback): %.0f us\n",
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_entry_us);
-        gkr::LayerChallenge* chal = nullptr;
-        uint32_t* abort_flag = nullptr;
-        HIP_TRY(ctx, ctx->pinned_host("layer.chal", sizeof(gkr::LayerChallenge) * batch, reinterpret_cast<void**>(&chal)));
-        HIP_TRY(ctx, ctx->pinned_host("layer.abort", 64, reinterpret_cast<void**>(&abort_flag)));
-        __atomic_store_n(abort_flag, 0u, __ATOMIC_RELEASE);
-        const uint32_t base = ctx->ticket + 1;
-        ctx->ticket += v;
-        static const bool dbg_p = getenv("GKR_DEBUG_TIMING") != nullptr;
-        const auto tp0 = std::chrono::steady_clock::now();
-        {
-            Timed t(ctx, "layer_persistent", 0.0);
-            gkr::launch_layer_persistent(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, d_gt, d_l, d_r, e_hi, e_lo, kl, d_W,
-                                         rec, chal, abort_flag, base, lb, s);
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        struct AbortGuard {   // whatever path leaves this scope early, the resident kernel is told to stop waiting
-            uint32_t* flag;
-            bool armed = true;
-            ~AbortGuard() {
-                if (armed) __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);
-            }
-        } guard{abort_flag};
-        std::atomic<int> slice_rc{GKR_OK};
-        // a slice of proofs, each advanced independently: whichever records have landed are answered (hashed up to
-        // sixteen at a time), so a proof never waits for another one's block to become resident
-        static const bool dbg_r = getenv("GKR_DEBUG_TIMING") != nullptr;
-        auto run_slice = [&](int first, int count) {
-            std::vector<uint32_t> round(count, 0);
-            int done = 0;
-            double us_gather = 0, us_hash = 0, us_write = 0, us_wait = 0;
-            long calls = 0, lanes = 0;
-            auto t_mark = std::chrono::steady_clock::now();
-            auto lap_us = [&](double& bucket) {
-                const auto t = std::chrono::steady_clock::now();
-                bucket += std::chrono::duration<double, std::micro>(t - t_mark).count();
-                t_mark = t;
-            };
-            auto last_progress = std::chrono::steady_clock::now();
-            uint32_t idle = 0;
-            while (done < count && slice_rc.load(std::memory_order_relaxed) == GKR_OK) {
-                int idx[kHashChunkMax], nr = 0;
-                auto scan = [&] {
-                    nr = 0;
-                    for (int i = 0; i < count && nr < kHashChunkMax; ++i)
-                        if (round[i] < v && __atomic_load_n(&rec[first + i].seq, __ATOMIC_ACQUIRE) == base + round[i]) idx[nr++] = i;
-                };
-                scan();
-                if (nr > 0 && dbg_r) lap_us(us_wait);
-                // A hash call costs the same for one lane as for sixteen (one serial chain of ~1100 products either
-                // way: 24 - 30 us), so answering a few records now and the rest in a second call doubles every proof's
-                // round time -- and the two cohorts then stay out of phase for the rest of the layer.  So a record waits
-                // for the slice's other unfinished proofs, up to about two hash calls' time (blocks that are not resident
-                // yet must not hold the others up for ever).
-                if (nr > 0 && nr < (count - done < kHashChunkMax ? count - done : kHashChunkMax)) {
-                    const int want = count - done < kHashChunkMax ? count - done : kHashChunkMax;
-                    const auto t_gather = std::chrono::steady_clock::now();
-                    while (nr < want && std::chrono::steady_clock::now() - t_gather < std::chrono::microseconds(50)) {
-                        GKR_CPU_RELAX();
-                        scan();
-                    }
-                }
-                if (nr == 0) {
-                    GKR_CPU_RELAX();
-                    // No HIP call in here: another context's thread may sit inside the runtime waiting for work that is
-                    // queued BEHIND this context's resident kernel (streams share hardware queues), and a runtime lock
-                    // taken by this loop would then wait for a kernel that waits for this loop.  Only the clock.
-                    if ((++idle & 0x3FFF) == 0 && std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(30))
-                        slice_rc.store(-2);   // no record for 30 s
-                    continue;
-                }
-                idle = 0;
-                last_progress = std::chrono::steady_clock::now();
-                if (dbg_r) {
-                    lap_us(us_gather);
-                    ++calls;
-                    lanes += nr;
-                }
-                gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
-                uint32_t ln[kHashChunkMax] = {};
-                for (int j = 0; j < nr; ++j) {
-                    const int b = first + idx[j];
-                    gkr::h64::F g1;
-                    memcpy(&c0[j], &rec[b].c0, 32);
-                    memcpy(&g1, &rec[b].g1, 32);
-                    memcpy(&c2[j], &rec[b].c2, 32);
-                    lin[j] = gkr::h64::sub(gkr::h64::sub(g1, c0[j]), c2[j]);
-                    ln[j] = 2u + (h_dep[(size_t)b * 32 + round[idx[j]] % k] ? 1u : 0u);
-                }
-                if (ifma && nr >= 3) {
-                    uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
-                    memset(vec, 0, sizeof vec);
-                    for (int j = 0; j < nr; ++j) {
-                        memcpy(vec[j][0], &c2[j], 32);
-                        memcpy(vec[j][1], &lin[j], 32);
-                        memcpy(vec[j][2], &c0[j], 32);
-                    }
-                    ifma_hash_chunk(vec, ln, nr, out);
-                    for (int j = 0; j < nr; ++j) memcpy(&r[j], out[j], 32);
-                } else {
-                    for (int j = 0; j < nr; ++j) {
-                        gkr::h64::F vec[3] = {c2[j], lin[j], c0[j]};
-                        r[j] = host_multi_hash(vec + (3 - ln[j]), (int)ln[j], cts64);
-                    }
-                }
-                if (dbg_r) lap_us(us_hash);
-                for (int j = 0; j < nr; ++j) {
-                    const int i = idx[j], b = first + i;
-                    const uint32_t rd = round[i];
-                    const gkr::h64::F rm = gkr::h64::to_mont(r[j]);
-                    memcpy(&chal[b].r_mont, &rm, 32);
-                    __atomic_store_n(&chal[b].seq, base + rd, __ATOMIC_RELEASE);   // the device folds while the host writes out
-                    gkr_fr* oc = out_coeffs[b] + (size_t)rd * 3;
-                    memset(&oc[0], 0, 32);
-                    if (ln[j] == 3) memcpy(&oc[0], &c2[j], 32);
-                    memcpy(&oc[1], &lin[j], 32);
-                    memcpy(&oc[2], &c0[j], 32);
-                    out_len[b][rd] = ln[j];
-                    memcpy(&out_r[b][rd], &r[j], 32);
-                    if (++round[i] == v) ++done;
-                }
-                if (dbg_r) lap_us(us_write);
-            }
-            if (dbg_r)
-                fprintf(stderr, "[gkr timing] slice of %d proofs: %ld hash calls, %.1f lanes each; per call: waiting %.1f us, gathering %.1f, hashing %.1f, writing %.1f\n",
-                        count, calls, calls ? (double)lanes / calls : 0.0, calls ? us_wait / calls : 0.0, calls ? us_gather / calls : 0.0,
-                        calls ? us_hash / calls : 0.0, calls ? us_write / calls : 0.0);
-        };
-        if (pool) {
-            const int want = (batch + 15) / 16, most = pool->workers() + 1;
-            const int slices = want < most ? want : most;
-            std::atomic<int> next{0};
-            const std::function<bool()> work = [&]() -> bool {
-                const int sidx = next.fetch_add(1, std::memory_order_relaxed);
-                if (sidx >= slices) return false;
-                const int f = (int)((long long)batch * sidx / slices), e = (int)((long long)batch * (sidx + 1) / slices);
-                run_slice(f, e - f);
-                return true;
-            };
-            gkr::SpinPool::Session session(pool, nullptr);
-            pool->run_now(&work);
-        } else {
-            run_slice(0, batch);
-        }
-        if (const int src = slice_rc.load()) {
-            __atomic_store_n(abort_flag, 1u, __ATOMIC_RELEASE);
-            (void)hipStreamSynchronize(s);
-            (void)src;
-            return ctx->fail(GKR_ERR_HIP, "timed out waiting for the resident layer kernel to publish a round");
-        }
-        guard.armed = false;
-        const auto tp1 = std::chrono::steady_clock::now();
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        ctx->drain_events();
-        if (dbg_p) {
-            const auto tp2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "[gkr timing] resident layer k_i=%d k=%d batch=%d: launch + %u rounds %.0f us, final sync %.0f us\n", k_i, k, batch, v,
-                    std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(tp2 - tp1).count());
-        }
-        return GKR_OK;
-    }
-    // round vectors of up to eight proofs: g = [c2, c1, c0] with c1 = g(1) - c0 - c2, length 2 + dep
-    // (get_univariate_coeff, poly.rs:388-420), hashed together (eight-lane IFMA where available)
-    auto hash_chunk = [&](int first, int count, uint32_t round, gkr::FixedMul* slot) {
-        gkr::h64::F c0[kHashChunkMax], lin[kHashChunkMax], c2[kHashChunkMax], r[kHashChunkMax];
-        uint32_t ln[kHashChunkMax] = {};
-        for (int i = 0; i < count; ++i) {
-            const int b = first + i;
-            gkr::h64::F g1;
-            memcpy(&c0[i], &rec[b].c0, 32);
-            memcpy(&g1, &rec[b].g1, 32);
-            memcpy(&c2[i], &rec[b].c2, 32);
-            lin[i] = gkr::h64::sub(gkr::h64::sub(g1, c0[i]), c2[i]);
-            ln[i] = 2u + (h_dep[(size_t)b * 32 + round % k] ? 1u : 0u);
-        }
-        if (ifma && count >= 3) {
-            uint64_t vec[kHashChunkMax][3][4], out[kHashChunkMax][4];
-            memset(vec, 0, sizeof vec);
-            for (int i = 0; i < count; ++i) {
-                memcpy(vec[i][0], &c2[i], 32);
-                memcpy(vec[i][1], &lin[i], 32);
-                memcpy(vec[i][2], &c0[i], 32);
-            }
-            ifma_hash_chunk(vec, ln, count, out);
-            for (int i = 0; i < count; ++i) memcpy(&r[i], out[i], 32);
-        } else {
-            for (int i = 0; i < count; ++i) {
-                gkr::h64::F vec[3] = {c2[i], lin[i], c0[i]};
-                r[i] = host_multi_hash(vec + (3 - ln[i]), (int)ln[i], cts64);
-            }
-        }
-        for (int i = 0; i < count; ++i) {
-            const int b = first + i;
-            gkr_fr* oc = out_coeffs[b] + (size_t)round * 3;
-            memset(&oc[0], 0, 32);
-            if (ln[i] == 3) memcpy(&oc[0], &c2[i], 32);
-            memcpy(&oc[1], &lin[i], 32);
-            memcpy(&oc[2], &c0[i], 32);
-            out_len[b][round] = ln[i];
-            memcpy(&out_r[b][round], &r[i], 32);
-            gkr::h64::make_fixed_mul(r[i], slot[b].w);
-        }
-    };
     // Product passes (kernels.hip): both phases as sumchecks of W X + Y over three small tables, up to three rounds per
-    // device round trip.  The default for the linear-time form over gate lists; GKR_LAYER_PER_ROUND=1: one round per trip.
-    static const bool per_round = getenv("GKR_LAYER_PER_ROUND") != nullptr;
-    if (lin_b && sparse && (k > 13 || !per_round)) {   // (the per-round kernels' c-phase keeps a row in one block: k <= 13)
+    // device round trip.
+    if (sparse) {
         gkr::ProdPassRec* prec = nullptr;
         Fr *h_pw = nullptr, *d_ppart = nullptr, *Xc = nullptr, *Yc = nullptr;
-        const uint32_t max_blocks = gkr::prod_pass_max_blocks((uint32_t)k);
         HIP_TRY(ctx, ctx->pinned_host("layer.prec", sizeof(gkr::ProdPassRec) * batch, reinterpret_cast<void**>(&prec)));
         HIP_TRY(ctx, ctx->pinned_host("layer.pw", sizeof(Fr) * 8 * batch, reinterpret_cast<void**>(&h_pw)));
         WS(ctx, "layer.ppart", Fr, (size_t)batch * gkr::prod_pass_scratch_values((uint32_t)k), d_ppart);
-        (void)max_blocks;
         WS(ctx, "layer.X", Fr, wlen * batch, Xc);
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
         // (passes of a few blocks per proof publish from their last block: one arrival counter per proof, zero between passes)
-        static const bool no_fused_publish = getenv("GKR_NO_FUSED_PUBLISH") != nullptr;
+        const bool no_fused_publish = gkr::opt(gkr::OPT_no_fused_publish) != 0;
         uint32_t* d_arrivals = nullptr;
         if (!no_fused_publish) {
             WS(ctx, "layer.arrivals", uint32_t, (size_t)(batch < 4096 ? 4096 : batch), d_arrivals);   // (one size for every batch: zeroed once)
@@ -668,25 +424,6 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
         bool second_exchange_done = false;
-        // GKR_LAUNCH_AHEAD=1 (opt-in, <= 8 proofs): the NEXT pass of a phase is queued before this pass's record is waited for and
-        // starts by polling pinned memory for the weights the host is about to write, so that its launch and dispatch gap
-        // overlap the hashing (VERDICT r03 item 7's proposal).  Built and measured on MI355X: NO gain -- the 2^24-gate layer
-        // 1.033 ms per sumcheck either way, the three-input proving step 3.51 against 3.56 ms (profiles/r04/f_launch_ahead_ab.txt):
-        // a waiting block's wake-up (a PCIe read of the flag, then of the weights) costs what the launch it saves does.
-        static const bool want_ahead = getenv("GKR_LAUNCH_AHEAD") != nullptr;
-        const bool ahead = want_ahead && batch <= 8;
-        uint32_t* h_wseq = nullptr;   // pinned: [0] the ticket whose weights are written, [1] "the host gave up"
-        HIP_TRY(ctx, ctx->pinned_host("layer.wseq", 64, reinterpret_cast<void**>(&h_wseq)));
-        __atomic_store_n(h_wseq + 1, 0u, __ATOMIC_RELEASE);
-        struct GiveUp {   // whatever path leaves this scope with a pass still waiting for its weights: it is told to stop waiting
-            uint32_t* flag;
-            bool armed = false;
-            ~GiveUp() {
-                if (armed) __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);
-            }
-        } give_up{h_wseq + 1};
-        bool launched_ahead = false;
-        uint32_t ahead_ticket = 0;
         for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
             Fr *Tw = Wb, *Tx = U, *Ty = V;
             if (phase == 1) {
@@ -723,25 +460,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 // 0.80 ms of product passes per sumcheck, k = 22 1.44 -> 3.33: the second pass then folds into a table four or
                 // two times larger and crosses THAT with J = 3.)
                 const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
-                uint32_t ticket;
-                if (launched_ahead) {   // queued during the previous pass's hashing
-                    ticket = ahead_ticket;
-                    launched_ahead = false;
-                    give_up.armed = false;
-                } else {
-                    ticket = ++ctx->ticket;
+                const uint32_t ticket = ++ctx->ticket;
+                {
                     Timed t(ctx, "layer_prod_pass", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, nullptr, 0, d_arrivals);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals);
                 }
                 m -= jp;
-                if (ahead && rem > J) {   // the phase's next pass, behind this one: it waits for this pass's weights
-                    const uint32_t Jn = rem - J < (uint32_t)gkr::kProdMaxJ ? rem - J : (uint32_t)gkr::kProdMaxJ;
-                    ahead_ticket = ++ctx->ticket;
-                    give_up.armed = true;
-                    Timed t(ctx, "layer_prod_pass_ahead", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, J, h_pw, Jn, d_ppart, (uint32_t)wlen, prec, ahead_ticket, (uint32_t)batch, s, h_wseq, ticket, d_arrivals);
-                    launched_ahead = true;
-                }
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) {
                     rc = ctx->hip_fail(le, "launch of a layer pass");
                     break;
@@ -778,14 +502,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     return true;
                 };
                 run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
-                if (launched_ahead) __atomic_store_n(h_wseq, ticket, __ATOMIC_RELEASE);   // the weights are written: the waiting pass goes
                 jp = J;
                 round0 += J;
                 rem -= J;
             }
         }
         session.close();
-        if (give_up.armed) __atomic_store_n(h_wseq + 1, 1u, __ATOMIC_RELEASE);   // (an error left a pass waiting for weights: it stops before the stream is waited for)
         // a rank that failed between the exchanges still enters the second one (flag set): its peers are waiting in it.
         // (Not when the failure is the travelling flag itself: then every rank is leaving at this very point.)
         if (rc && shard && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
@@ -802,86 +524,17 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         ctx->drain_events();
         return GKR_OK;
     }
-    // The fold with r_j is deferred into the pass that computes round j+1's sums (b-phase: the
-    // fused kernel; c-phase: a separate fold of the single remaining row).
+    // ---- device transcript: rounds over the dense predicate tables (kernels_layer_dense.hip), hashed by one lane per
+    // sumcheck (k_layer_round_hash); one uninterrupted stream of launches, one copy-back.  The fold with r_j is deferred
+    // into the pass that computes round j+1's sums (b-phase: the fused kernel; c-phase: a separate fold of the remaining row).
     const gkr::FixedMul* pending = nullptr;   // challenge tables not yet applied to A, M
-    static const bool no_fused = getenv("GKR_LAYER_NO_FUSED") != nullptr;
-    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
-    double t_launch = 0, t_wait = 0, t_hash = 0, worst_lap = 0;
-    int worst_round = -1, worst_kind = 0, cur_round = 0;
-    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_mark = now_us();
-    auto lap = [&](double& bucket) {
-        const double t = now_us();
-        bucket += t - t_mark;
-        if (t - t_mark > worst_lap) {
-            worst_lap = t - t_mark;
-            worst_round = cur_round;
-            worst_kind = &bucket == &t_launch ? 0 : (&bucket == &t_wait ? 1 : 2);
-        }
-        t_mark = t;
-    };
-    gkr::SpinPool::Session session(pool, nullptr);   // closed on every path out of the round loop
-    bool second_exchange_done = false;
+    const bool no_fused = gkr::opt(gkr::OPT_layer_no_fused) != 0;
     for (uint32_t round = 0; round < v; ++round) {
-        cur_round = (int)round;
         const uint32_t h = (uint32_t)(N >> (round + 1));   // half of the table this round sums over
         const uint32_t phase = round < (uint32_t)k ? 0u : 1u;
         const uint32_t hb = phase == 0 ? (h >> k) : 0u;
         uint32_t nblk = 0;
-        bool published = false;   // the round's kernel wrote the host record itself
-        if (lin_b && round == (uint32_t)k) {
-            // all of b is bound: collapse the rows of A, M at u = (r_1 .. r_k) into the single row the c-phase works on
-            for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
-            gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
-            if (sparse) {
-                {
-                    Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
-                    if (wide)
-                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
-                                                   heavy_partials, s, cached && cached->heavy_known ? cached->heavy_hdr : nullptr);
-                    else
-                        gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq,
-                                              A, M, lb, segs, seg_partials, s);
-                }
-                if (shard) {
-                    second_exchange_done = true;
-                    rc = sum_over_ranks(A, M, wlen, nullptr, GKR_OK);
-                    if (rc) break;
-                }
-            } else {
-                Timed t(ctx, "layer_collapse", (double)N * 2.0 * 32.0 * batch);
-                gkr::launch_layer_collapse(A, M, d_eq, collapse, (uint32_t)k, lb, s);
-            }
-            pending = nullptr;   // U, V are done with; the row is already taken at u
-        }
-        if (phase == 0 && lin_b) {
-            const uint32_t ticket = ++ctx->ticket;
-            {
-                Timed t(ctx, "layer_uv_round", 0.0);
-                gkr::launch_uv_round(pending != nullptr, Wb, U, V, 1u << (k - 1 - (int)round), pending, rec, ticket, lb, s);
-            }
-            pending = nullptr;
-            published = true;
-            lap(t_launch);
-            rc = wait_records(ctx, rec, batch, ticket);
-            if (!rc) rc = xflag_check();
-            lap(t_wait);
-            if (rc) break;
-        } else if (phase == 1 && lin_b && k <= 13) {
-            // the single remaining row: one small block per proof folds it and publishes the round's sums
-            const uint32_t ticket = ++ctx->ticket;
-            {
-                Timed t(ctx, "layer_c_round", 0.0);
-                gkr::launch_c_round(pending != nullptr, A, M, Wc, Wb, h, pending, rec, ticket, lb, s);
-            }
-            pending = nullptr;
-            published = true;
-            lap(t_launch);
-            rc = wait_records(ctx, rec, batch, ticket);
-            lap(t_wait);
-            if (rc) break;
-        } else if (phase == 0 && !no_fused) {
+        if (phase == 0 && !no_fused) {
             Timed t(ctx, "layer_round_fused", (pending ? (double)h * 2.0 * 6.0 : (double)h * 2.0 * 2.0) * 32.0 * batch);
             nblk = gkr::launch_layer_round_b(pending != nullptr, A, M, A, M, hb, (uint32_t)k, pending, Wb, Wc, partials, lb, s);
             pending = nullptr;
@@ -896,64 +549,15 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             Timed t(ctx, "layer_round", (double)h * 4.0 * 32.0 * batch);
             gkr::launch_layer_round(A, M, h, k, phase, hb, Wb, Wc, nblk, partials, lb, s);
         }
-        if (host_tx) {
-            if (!published) {
-                const uint32_t ticket = ++ctx->ticket;
-                {
-                    Timed t(ctx, "layer_round_reduce", 0.0);
-                    gkr::launch_layer_round_reduce(partials, nblk, rec, ticket, lb, s);
-                }
-                lap(t_launch);
-                rc = wait_records(ctx, rec, batch, ticket);
-                lap(t_wait);
-                if (rc) break;
-            }
-            // two sets of pinned tables used alternately: the deferred fold of round j reads set j % 2
-            // while the host already writes round j+1's
-            gkr::FixedMul* slot = h_rtab + (size_t)(round & 1) * batch;
-            const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
-            {
-                std::atomic<int> next{0};
-                const std::function<bool()> work = [&]() -> bool {
-                    const int first = next.fetch_add(chunk, std::memory_order_relaxed);
-                    if (first >= batch) return false;
-                    hash_chunk(first, batch - first < chunk ? batch - first : chunk, round, slot);
-                    return true;
-                };
-                run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round));
-            }
-            lap(t_hash);
-            // fold the W copy bound in this round (rounds 0..k-1 bind b -> Wb, then c -> Wc); the linear-time
-            // round kernels fold W themselves with the pending challenge, except for the last b round, whose
-            // fold leaves the scalar W(u) the c-phase multiplies with
-            const bool fused_w = lin_b && (phase == 0 ? round + 1 < (uint32_t)k : k <= 13);
-            if (!fused_w) gkr::launch_fold_small(phase == 0 ? Wb : Wc, 1u << (k - 1 - (round % k)), slot, lb, s);
-            pending = slot;
-        } else {
-            Timed t(ctx, "layer_round_hash", 0.0);
-            gkr::launch_layer_round_hash(partials, nblk, round, k, dep, ctx->d_cts, d_coeffs, d_len, d_r_out, d_rtab, Wb,
-                                         Wc, s);
-            pending = d_rtab + round;
-        }
-    }
-    session.close();
-    if (rc && shard && lin_b && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
-        (void)sum_over_ranks(A, M, wlen, nullptr, rc);   // the peers are waiting in the second exchange
-    if (dbg)
-        fprintf(stderr, "[gkr timing] layer k=%d batch=%d: %u rounds, launch %.0f us, wait %.0f us, hash %.0f us; longest single step %.0f us (%s, round %d)\n",
-                k, batch, v, t_launch, t_wait, t_hash, worst_lap, worst_kind == 0 ? "launch" : (worst_kind == 1 ? "wait" : "hash"), worst_round);
-    if (rc) {
-        (void)hipStreamSynchronize(s);
-        return rc;
+        Timed t(ctx, "layer_round_hash", 0.0);
+        gkr::launch_layer_round_hash(partials, nblk, round, k, dep, ctx->d_cts, d_coeffs, d_len, d_r_out, d_rtab, Wb, Wc, s);
+        pending = d_rtab + round;
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (!host_tx) {
-        HIP_TRY(ctx, hipMemcpyAsync(out_coeffs[0], d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(out_len[0], d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipMemcpyAsync(out_r[0], d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
-    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_coeffs[0], d_coeffs, (size_t)v * 3 * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out_len[0], d_len, v * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(out_r[0], d_r_out, v * sizeof(Fr), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (const int xr = xflag_check()) return xr;
     ctx->drain_events();
     return GKR_OK;
 }
@@ -1009,7 +613,7 @@ int gkr_sumcheck_layer(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_ty
     int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
     if (rc) return rc;
     if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     DevBuf<uint8_t> dgt;
     DevBuf<uint32_t> dl, dr;
     DevBuf<Fr> dW;
@@ -1034,7 +638,7 @@ int gkr_sumcheck_layer_sharded(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
     // gates are validated on the device (k_gate_count); a bad one fails every rank through the first exchange
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     DevBuf<uint8_t> dgt;
     DevBuf<uint32_t> dl, dr;
     DevBuf<Fr> dW;
@@ -1071,7 +675,7 @@ int gkr_sumcheck_layer_device(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_f
         return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the arrays must hold the whole layer");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
     if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     Fr* dW = nullptr;
     HIP_TRY(ctx, ctx->workspace("layer.Win", sizeof(Fr) << k_next, reinterpret_cast<void**>(&dW)));
     HIP_TRY(ctx, hipMemcpyAsync(dW, W, sizeof(Fr) << k_next, hipMemcpyHostToDevice, ctx->stream));
@@ -1118,7 +722,7 @@ int gkr_resident_layer_create(gkr_ctx* ctx, int k_i, int k_next, uint64_t gate_f
     if (k_next == 0) return ctx->fail(GKR_ERR_DEGENERATE, "k_next == 0: v = 0 underflows in the reference (sumcheck.rs:49)");
     if (k_next < 0 || k_next > kMaxLayerK || k_i > kMaxLayerKi) return ctx->fail(GKR_ERR_INVALID, "k_next must be in [1, GKR_MAX_K_NEXT], k_i in [0, GKR_MAX_K_I]");
     if (gate_first + gate_count > ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "gate range exceeds the layer's 2^k_i gates");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     std::unique_ptr<gkr_resident_layer, void (*)(gkr_resident_layer*)> L(new gkr_resident_layer(), [](gkr_resident_layer* p) {
         gkr_resident_layer_free(nullptr, p);
     });
@@ -1176,7 +780,7 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
     if (!allreduce && (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)))
         return ctx->fail(GKR_ERR_INVALID, "without an exchange hook the layer must be whole");
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     Fr* dW = nullptr;
     if (const int urc = upload_W(ctx, W, k, &dW)) return urc;
     LayerShardArgs sh;
@@ -1203,7 +807,7 @@ int gkr_resident_layer_sumcheck_dev(gkr_ctx* ctx, gkr_resident_layer* layer, con
     if (!layer || !W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z) || !exchange) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     const int k_i = layer->k_i, k = layer->k;
     if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     Fr* dW = nullptr;
     if (const int urc = upload_W(ctx, W, k, &dW)) return urc;
     LayerShardArgs sh;
@@ -1250,7 +854,7 @@ int gkr_predicate_tables(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gate_
     if (!out_A || !out_M) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     int rc = check_layer_args(ctx, k_i, k_next, gate_type, left, right, z);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     const size_t N = (size_t)1 << (2 * k_next);
     DevBuf<uint8_t> dgt;
     DevBuf<uint32_t> dl, dr;
@@ -1277,7 +881,7 @@ int gkr_layer_eval(gkr_ctx* ctx, size_t gates, const uint8_t* gate_type, const u
         if (gate_type[g] > 1 || left[g] >= n_prev || right[g] >= n_prev)
             return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
     if (!all_canonical(prev, n_prev)) return ctx->fail(GKR_ERR_NON_CANONICAL, "prev entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     DevBuf<uint8_t> dgt;
     DevBuf<uint32_t> dl, dr;
     DevBuf<Fr> dprev, dout;
@@ -1355,7 +959,7 @@ int gkr_layer_session_open(gkr_ctx* ctx, int k_i, int k_next, const uint8_t* gat
     if (nshards == 0 || (1u << log_p) != nshards || (int)log_p > k_next || shard >= nshards)
         return ctx->fail(GKR_ERR_INVALID, "shard count must be a power of two <= 2^k_next and shard < count");
     if (!all_canonical(W, (size_t)1 << k_next)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     gkr_layer_session* S = new gkr_layer_session();
     S->k = k_next;
@@ -1404,7 +1008,7 @@ int gkr_layer_session_open_tables(gkr_ctx* ctx, int kc, const gkr_fr* A, const g
     const size_t n = (size_t)1 << kc;
     if (!all_canonical(A, n) || !all_canonical(M, n) || !all_canonical(Wc, n) || !all_canonical(wb, 1))
         return ctx->fail(GKR_ERR_NON_CANONICAL, "tail table entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     gkr_layer_session* S = new gkr_layer_session();
     S->k = kc;           // only c-variables remain: phase 1 from the first round
@@ -1451,7 +1055,7 @@ int gkr_layer_session_rounds(const gkr_layer_session* S, uint32_t* done, uint32_
 int gkr_layer_session_sums(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
     if (!ctx || !S || !out) return GKR_ERR_INVALID;
     if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const uint32_t h = (uint32_t)(S->cells / 2);
     const uint32_t phase = S->round < (uint32_t)S->k ? 0u : 1u;
@@ -1474,7 +1078,7 @@ int gkr_layer_session_bind(gkr_ctx* ctx, gkr_layer_session* S, const gkr_fr* r) 
     if (!ctx || !S || !r) return GKR_ERR_INVALID;
     if (S->round >= S->rounds) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
     if (!all_canonical(r, 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "r >= modulus");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     gkr::h64::F r64;
     memcpy(&r64, r, 32);
@@ -1497,7 +1101,7 @@ int gkr_layer_session_bind(gkr_ctx* ctx, gkr_layer_session* S, const gkr_fr* r) 
 int gkr_layer_session_tail(gkr_ctx* ctx, gkr_layer_session* S, gkr_fr* out) {
     if (!ctx || !S || !out) return GKR_ERR_INVALID;
     if (S->round != S->rounds || S->cells != 1) return ctx->fail(GKR_ERR_INVALID, "session still has rounds to run");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     Fr a, m, wc, wb;
     HIP_TRY(ctx, hipMemcpyAsync(&a, S->A, sizeof(Fr), hipMemcpyDeviceToHost, s));

@@ -64,7 +64,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                          gkr_fr* out_r, const MleTailArgs* tail) {
     using gkr::h64::F;
     const int n_out = tail ? tail->n_total : n, r_off = tail ? tail->round_offset : 0;
-    static const bool dbg = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const bool dbg = gkr::debug_timing();
     const auto dbg_t0 = std::chrono::steady_clock::now();
     auto dbg_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
     double dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_d = 0, dbg_e = 0;
@@ -72,13 +72,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     const size_t len = (size_t)1 << n;
     hipStream_t s = ctx->stream;
     // rounds per pass: up to 5 with the matrix-core fold (fewer passes, ~2.07 N elements moved instead of 2.29 N),
-    // up to 3 with the v_mad_u64_u32 fold (GKR_NO_MFMA_FOLD)
-    static const int jmax = [] {
-        const int cap = getenv("GKR_NO_MFMA_FOLD") ? 3 : gkr::kMlePassMaxRounds;
-        const char* e = getenv("GKR_ROUNDS_PER_PASS");
-        const int v = e ? atoi(e) : cap;
-        return v < 1 ? 1 : (v > cap ? cap : v);
-    }();
+    // up to 3 with the v_mad_u64_u32 fold (option no_mfma_fold)
+    const int jcap = gkr::opt(gkr::OPT_no_mfma_fold) ? 3 : gkr::kMlePassMaxRounds;
+    const int jwant = gkr::opt(gkr::OPT_rounds_per_pass) > 0 ? (int)gkr::opt(gkr::OPT_rounds_per_pass) : jcap;
+    const int jmax = jwant > jcap ? jcap : jwant;
     auto rounds_for = [&](int m) { return mle_pass_rounds(m, n, jmax); };
     const int j_first = rounds_for(n);
     const size_t work_len = len >> j_first;   // the first folded table
@@ -95,7 +92,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // Latency-bound passes (a few sumchecks of moderate size: at most kFusedPublishBytes read per launch) publish from their
     // last block instead of through k_mle_sub_reduce: one launch and one dependent-launch gap less per pass on the round
     // path of a lone sumcheck.  Streaming passes keep the second launch (see mle_publish_from_last_block).
-    static const bool no_fused = getenv("GKR_NO_FUSED_REDUCE") != nullptr;
+    const bool no_fused = gkr::opt(gkr::OPT_no_fused_reduce) != 0;
     constexpr double kFusedPublishBytes = 64.0 * 1024 * 1024;
     uint32_t* d_arrivals = nullptr;
     if (!no_fused && (double)len * 32.0 <= kFusedPublishBytes) {
@@ -116,20 +113,16 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         return true;
     };
     const bool ifma = host_ifma_ready();
-    const bool scalar_book = getenv("GKR_HOST_PASS_SCALAR") != nullptr;   // A/B switch: host_pass_scalar even where the CPU has IFMA
+    static const bool scalar_book = gkr::process_switch("GKR_HOST_PASS_SCALAR");   // A/B switch: host_pass_scalar even where the CPU has IFMA
     std::vector<uint32_t> dep_last(batch, 0);
     gkr::SpinPool* pool = ctx->host_pool();
     // Sumchecks a hashing thread takes at a time, per group: sixteen (full IFMA calls: throughput) when the group has plenty
     // for every thread; otherwise ONE chunk per thread where that fits the sixteen lanes -- a pass's J hashes of a sumcheck
     // are a serial chain, so a group of 128 on 14 threads is done in one chain of 16-lane calls filled to 10 (J x 20 us)
-    // instead of two chains of 8-lane calls (2 x J x 16 us), at the same cost per hash; GKR_HASH_CHUNK forces 8 or 16
+    // instead of two chains of 8-lane calls (2 x J x 16 us), at the same cost per hash; the option hash_chunk forces 8 or 16
     const int hash_threads = pool->workers() + 1;
-    auto group_chunk = [hash_threads](int nb) -> uint32_t {
-        static const int forced = [] {
-            const char* e = getenv("GKR_HASH_CHUNK");
-            const int v = e ? atoi(e) : 0;
-            return v == 8 || v == 16 ? v : 0;
-        }();
+    const int forced = gkr::opt(gkr::OPT_hash_chunk) == 8 || gkr::opt(gkr::OPT_hash_chunk) == 16 ? (int)gkr::opt(gkr::OPT_hash_chunk) : 0;
+    auto group_chunk = [hash_threads, forced](int nb) -> uint32_t {
         if (forced) return (uint32_t)forced;
         if (nb >= 32 * hash_threads) return 16u;
         const int per = (nb + hash_threads - 1) / hash_threads;
@@ -146,13 +139,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // a stream of their own -- pass, the pass's rounds with MiMC7 on eight lanes per element, fold, ... -- without the host;
     // the host hashes the rest as always.  A device-hashed pass takes 0.33 ms per round whatever the number of sumchecks
     // (the chain of 2 x 91 x 4 dependent products), so this is for steps that are bound by the host's hashing: a rank with
-    // two or three host threads, tables so small that the GPU is mostly idle.  GKR_DEVICE_HASH_PERCENT = share of the batch
-    // (0 = none; unset: the rule below).
-    static const int dev_percent_env = [] {
-        const char* e = getenv("GKR_DEVICE_HASH_PERCENT");
-        return e ? (atoi(e) < 0 ? 0 : (atoi(e) > 90 ? 90 : atoi(e))) : -1;
-    }();
-    int dev_percent = dev_percent_env >= 0 ? dev_percent_env : 0;
+    // two or three host threads, tables so small that the GPU is mostly idle.  Option device_hash_percent = share of the batch
+    // (0 = none, the default).
+    const long long dp = gkr::opt(gkr::OPT_device_hash_percent);
+    int dev_percent = dp < 0 ? 0 : (dp > 90 ? 90 : (int)dp);
     int n_dev = 0;
     if (dev_percent > 0 && !tail && batch >= 64 && j_first >= 1) {
         n_dev = (int)((long long)batch * dev_percent / 100) & ~7;
@@ -175,7 +165,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     if (hash_threads <= 3 && host_batch >= 256 && want_groups < 16) want_groups = 16;
     int group_size = host_batch >= 128 ? (host_batch + want_groups - 1) / want_groups : (host_batch >= 16 ? (host_batch + 1) / 2 : host_batch);
     if (n_dev && hash_threads <= 3 && host_batch >= 256) group_size = 64;   // (whole sixteen-lane chunks for both threads, as without a device share)
-    if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
+    if (gkr::opt(gkr::OPT_group_size) > 0) group_size = (int)gkr::opt(gkr::OPT_group_size);
     int groups = (host_batch + group_size - 1) / group_size;
     if (groups > kMaxGroups) groups = kMaxGroups;
     struct Group {
@@ -191,40 +181,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         int index = 0;
         hipStream_t chain = nullptr;   // a device-hashed group: the stream its whole chain runs on
     };
-    // Shares of the batch per group, in per cent (GKR_GROUP_SPLIT="40,30,20,10"): the groups finish in order, and the
-    // LAST one's latency-bound late passes (four host round trips with nothing left to overlap them) are the exposed
-    // tail of the call -- a smaller last group has a shorter tail (fewer hash chunks per round trip).
-    static const std::vector<int> split = [] {
-        std::vector<int> v;
-        if (const char* e = getenv("GKR_GROUP_SPLIT")) {
-            int sum = 0;
-            for (const char* p = e; *p;) {
-                const int x = atoi(p);
-                if (x > 0) {
-                    v.push_back(x);
-                    sum += x;
-                }
-                while (*p && *p != ',') ++p;
-                if (*p == ',') ++p;
-            }
-            if (sum != 100 || v.size() > (size_t)kMaxGroups) v.clear();
-        }
-        return v;
-    }();
-    if (!split.empty() && host_batch >= 16 * (int)split.size()) groups = (int)split.size();
     std::vector<Group> grp(groups);
     HIP_TRY(ctx, ctx->aux_stream(groups));
     {
-        int start = 0, acc = 0;
+        int start = 0;
         for (int g = 0; g < groups; ++g) {
             grp[g].index = g;
-            int end;
-            if (!split.empty() && groups == (int)split.size()) {
-                acc += split[g];
-                end = g + 1 == groups ? host_batch : (int)((long long)host_batch * acc / 100);
-            } else {
-                end = (int)((long long)host_batch * (g + 1) / groups);
-            }
+            const int end = (int)((long long)host_batch * (g + 1) / groups);
             grp[g].b0 = host_b0 + start;
             grp[g].nb = end - start;
             start = end;
@@ -256,7 +219,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st0);
     };
     // a fold pass: bind the jin variables just hashed, produce the sums of the next jout rounds
-    static const bool no_late = getenv("GKR_NO_LATE_STREAM") != nullptr;
+    const bool no_late = gkr::opt(gkr::OPT_no_late_stream) != 0;
     hipStream_t late = s;
     if (!no_late && groups > 1) HIP_TRY(ctx, ctx->late_stream(&late));
     auto launch_fold = [&](Group& G, int jin) {
@@ -287,7 +250,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
             // main stream (busy with another group's pass) pays one event wait, not a launch round trip
             // (one group: nothing else is streaming, and the event between the two streams costs the round path ~10 us
             // more than a second launch on the same stream -- 15 us against 5 between the plan and the fold)
-            static const bool plan_inline = getenv("GKR_PLAN_MAIN") != nullptr;
+            const bool plan_inline = gkr::opt(gkr::OPT_plan_main) != 0;
             if (plan_inline || st != s || groups == 1) {
                 gkr::launch_mle_fold_plan(jin, h_w + (size_t)b0 * gkr::kMleMaxSub, plan, nb, st);
             } else {
@@ -382,10 +345,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
     // (P0 P0 F0 P0 F1 P0 F2 F3 with four groups), and the host's hashing -- which with few threads takes as long as the
     // GPU's work -- is fed from the first millisecond to the last instead of in one burst after all the pass 0s.
     // (All pass 0s first: 2 host threads 19.0 ms per 1024 x 2^20 at 77 % hashing occupancy, 3 threads 15.6 ms at 63 %.)
-    static const int depth_env = [] {
-        const char* e = getenv("GKR_PASS_QUEUE_DEPTH");
-        return e && atoi(e) > 0 ? atoi(e) : 0;
-    }();
+    const int depth_env = gkr::opt(gkr::OPT_pass_queue_depth) > 0 ? (int)gkr::opt(gkr::OPT_pass_queue_depth) : 0;
     const int depth = depth_env ? depth_env : (small_tables ? 4 : 2);
     int next_first = 0;   // groups [next_first, groups): pass 0 still to launch
     if (next_first < groups) launch_first(grp[next_first++]);   // (the host's first sums before the device chain's first pass)
@@ -505,7 +465,7 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
     const size_t len = (size_t)1 << n;
     const size_t rounds = (size_t)batch * n;
     const bool host_tx = ctx->transcript == GKR_TRANSCRIPT_HOST;
-    static const bool per_round = getenv("GKR_MLE_PER_ROUND") != nullptr;
+    const bool per_round = gkr::opt(gkr::OPT_mle_per_round) != 0;
     if (host_tx && !per_round) return run_mle_batch_passes(ctx, d_tables, n, batch, out_coeffs, out_len, out_r);
     Fr *work = nullptr, *d_coeffs = nullptr, *d_r = nullptr;
     uint32_t *d_len = nullptr, *d_dep = nullptr;
@@ -535,9 +495,8 @@ int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* ou
         // Few, large groups: every group-round costs two launches.  A group starts once its
         // predecessor has left the bandwidth-bound rounds (round >= stagger).
         int group_size = batch >= 128 ? (batch + 3) / 4 : (batch >= 16 ? (batch + 1) / 2 : batch);
-        if (const char* e = getenv("GKR_GROUP_SIZE")) group_size = atoi(e) > 0 ? atoi(e) : group_size;
-        int stagger = 0;   // measured on MI355X + 16 host CPUs: starting every group at once is best
-        if (const char* e = getenv("GKR_STAGGER")) stagger = atoi(e);
+        if (gkr::opt(gkr::OPT_group_size) > 0) group_size = (int)gkr::opt(gkr::OPT_group_size);
+        const int stagger = 0;   // measured on MI355X + 16 host CPUs: starting every group at once is best
         int groups = (batch + group_size - 1) / group_size;
         if (groups > kMaxGroups) groups = kMaxGroups;
         struct Group {
@@ -772,7 +731,7 @@ int gkr_sumcheck_mle_batch_device(gkr_ctx* ctx, const void* d_tables, int n, int
     if (!d_tables || !out_coeffs || !out_len || !out_r || batch < 1 || batch > 65535)
         return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of range [1, 65535]");
     if (n < 2 || n > 30) return ctx->fail(GKR_ERR_INVALID, "n must be in [2, 30]");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     return run_mle_batch(ctx, static_cast<const Fr*>(d_tables), n, batch, out_coeffs, out_len, out_r);
 }
 
@@ -782,7 +741,7 @@ int gkr_sumcheck_mle(gkr_ctx* ctx, const gkr_fr* table, int n, gkr_fr* out_coeff
     if (n < 2 || n > 30) return ctx->fail(GKR_ERR_INVALID, "n must be in [2, 30]");
     const size_t len = (size_t)1 << n;
     if (!all_canonical(table, len)) return ctx->fail(GKR_ERR_NON_CANONICAL, "table entry >= r");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     DevBuf<Fr> d;
     HIP_TRY(ctx, d.alloc(len));
     HIP_TRY(ctx, hipMemcpyAsync(d.p, table, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
@@ -821,12 +780,12 @@ int gkr_sumcheck_mle_sharded_dev(gkr_ctx* ctx, const void* d_shards, int n, int 
     if (n < 2 || nl < 1 || nl > GKR_MAX_MLE_N) return ctx->fail(GKR_ERR_INVALID, "n >= 2 and 1 <= n - log2_shards <= GKR_MAX_MLE_N needed");
     if (ctx->transcript != GKR_TRANSCRIPT_HOST) return ctx->fail(GKR_ERR_INVALID, "a sumcheck split over ranks needs the host transcript");
     if (exchange->capacity < gkr_exchange_limbs_mle(n, lp, batch)) return ctx->fail(GKR_ERR_INVALID, "the exchange buffer is smaller than gkr_exchange_limbs_mle(n, log2_shards, batch) int64");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const Fr* shards = static_cast<const Fr*>(d_shards);
     const size_t len = (size_t)1 << nl;
     const int t_stop = nl < kMleShardTailLog2 ? nl : kMleShardTailLog2;   // variables every shard keeps for the gathered tail
-    static const int jmax = getenv("GKR_NO_MFMA_FOLD") ? 3 : gkr::kMlePassMaxRounds;
+    const int jmax = gkr::opt(gkr::OPT_no_mfma_fold) ? 3 : gkr::kMlePassMaxRounds;
     auto rounds_for = [&](int m) {
         int j = mle_pass_rounds(m, nl, jmax);
         if (m - j < t_stop) j = m - t_stop;
@@ -1005,7 +964,7 @@ static void free_mle_session(gkr_mle_session* S) {
 int gkr_mle_session_open(gkr_ctx* ctx, const void* d_table, int n, gkr_mle_session** out) {
     if (!ctx) return GKR_ERR_INVALID;
     if (!d_table || !out || n < 1 || n > 30) return ctx->fail(GKR_ERR_INVALID, "null pointer or n out of [1, 30]");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     gkr_mle_session* S = new gkr_mle_session();
     S->n = n;
     S->input = static_cast<const Fr*>(d_table);
@@ -1028,7 +987,7 @@ int gkr_mle_session_open(gkr_ctx* ctx, const void* d_table, int n, gkr_mle_sessi
 int gkr_mle_session_sums(gkr_ctx* ctx, gkr_mle_session* S, gkr_fr* out, uint32_t* out_dep) {
     if (!ctx || !S || !out) return GKR_ERR_INVALID;
     if ((int)S->round >= S->n) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     if (!S->have_sums) {   // only the very first round computes sums without a fold
         const size_t len = (size_t)1 << S->n;
@@ -1063,7 +1022,7 @@ int gkr_mle_session_bind(gkr_ctx* ctx, gkr_mle_session* S, const gkr_fr* r) {
     if (!ctx || !S || !r) return GKR_ERR_INVALID;
     if ((int)S->round >= S->n) return ctx->fail(GKR_ERR_INVALID, "no round left in this session");
     if (!all_canonical(r, 1)) return ctx->fail(GKR_ERR_NON_CANONICAL, "r >= modulus");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     gkr::h64::F r64;
     memcpy(&r64, r, 32);
@@ -1092,7 +1051,7 @@ int gkr_mle_session_bind(gkr_ctx* ctx, gkr_mle_session* S, const gkr_fr* r) {
 int gkr_mle_session_value(gkr_ctx* ctx, gkr_mle_session* S, gkr_fr* out) {
     if (!ctx || !S || !out) return GKR_ERR_INVALID;
     if ((int)S->round != S->n) return ctx->fail(GKR_ERR_INVALID, "session still has rounds to run");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     Fr v;
     HIP_TRY(ctx, hipMemcpyAsync(&v, S->work, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1109,7 +1068,7 @@ void gkr_mle_session_close(gkr_ctx* ctx, gkr_mle_session* S) {
 // that is a rank bit: compare the shards of ranks p and p ^ 1)
 int gkr_device_tables_differ(gkr_ctx* ctx, const void* d_a, const void* d_b, size_t count, uint32_t* out_differ) {
     if (!ctx || !d_a || !d_b || !out_differ || !count) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     DevBuf<uint32_t> flag;
     HIP_TRY(ctx, flag.alloc(1));
     HIP_TRY(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));

@@ -118,13 +118,13 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     for (uint32_t i = 0; i < L; ++i)
         if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
     const size_t n_in = (size_t)1 << c->k[L];
-    static const bool dbg_pre = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const bool dbg_pre = gkr::debug_timing();
     auto us_since_entry = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(); };
     // (a large input layer is validated where it lands, on the device: the host loop over 2^20 values took 1.6 ms of a 12 ms proof)
     const bool check_on_device = n_in * (size_t)batch >= ((size_t)1 << 16);
     if (!check_on_device && !all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     const double us_canon = us_since_entry();
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
 
     // the circuit on the device: from the context's cache when this circuit was proven before (two independent
@@ -184,7 +184,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
             pc = ctx->circuits.back().get();
             break;
         }
-    static const bool no_cache = getenv("GKR_NO_CIRCUIT_CACHE") != nullptr;
+    const bool no_cache = gkr::opt(gkr::OPT_no_circuit_cache) != 0;
     std::unique_ptr<PreparedCircuit> fresh;
     struct DropFresh {   // an uncached or failed circuit's device arrays do not outlive the call
         gkr_ctx* ctx;
@@ -344,7 +344,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    static const bool dbg_pb = getenv("GKR_DEBUG_TIMING") != nullptr;
+    const bool dbg_pb = gkr::debug_timing();
     const auto tpb0 = std::chrono::steady_clock::now();
     const bool account = accounting_on();
     if (dbg_pb || account) t_account = ThreadTimeAccount();
@@ -582,20 +582,29 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     if ((!items && n_items) || max_concurrent < 0 || n_items > (size_t)1 << 20) return ctx->fail(GKR_ERR_INVALID, "null item list or negative thread count");
     if (n_items == 0) return GKR_OK;
     if (ctx->crew_member) return ctx->fail(GKR_ERR_INVALID, "gkr_prove_many from inside a crew");
+    gkr::OptionScope option_scope(&ctx->options);
+    // (child contexts are created on their devices below, and member 0 may end up without an item: the caller's current
+    // device is put back on every path out)
+    struct RestoreDevice {
+        int prev = -1;
+        RestoreDevice() {
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        }
+        ~RestoreDevice() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } restore_device;
     int want = max_concurrent;
     if (!want) {
         int share = usable_cpus();
-        if (const char* e = getenv("LOCAL_WORLD_SIZE")) {   // ranks of one node share its CPUs
-            const int ranks = atoi(e);
-            if (ranks > 1) share = share / ranks > 1 ? share / ranks : 1;
-        }
+        if (const int ranks = gkr::process_int("LOCAL_WORLD_SIZE", 1); ranks > 1) share = share / ranks > 1 ? share / ranks : 1;   // ranks of one node share its CPUs
         want = share >= 6 ? share - 2 : (share >= 3 ? share - 1 : share);   // two (one, none) left to the runtime's own threads
     }
     // (members beyond the number of items have nothing to prove: they lend themselves from the start -- only if asked for)
     {
         // (members beyond what the items -- cut in two where they are large, below -- can occupy have nothing to prove)
         size_t can_use = n_items;
-        if (getenv("GKR_PROVE_MANY_PIECES"))
+        if (gkr::opt(gkr::OPT_prove_many_pieces) > 0)
             for (size_t i = 0; i < n_items; ++i) can_use += items[i].batch >= 32 ? (size_t)items[i].batch / 32 : 0;
         if (!max_concurrent && (size_t)want > can_use) want = (int)can_use;
     }
@@ -609,6 +618,7 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         ctx->crew->members[0]->ctx = ctx;
     }
     ProveCrew* crew = ctx->crew.get();
+    for (size_t m = 1; m < crew->members.size(); ++m) crew->members[m]->ctx->options = ctx->options;   // (idle between calls)
     while ((int)crew->members.size() < want) {
         gkr_ctx* child = nullptr;
         // member m lives on device devices[m mod #devices] (member 0 = this context, on devices[0])
@@ -617,6 +627,7 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         if (rc) return ctx->fail(rc, "child context of gkr_prove_many");
         child->crew_member = true;
         child->transcript = GKR_TRANSCRIPT_HOST;
+        child->options = ctx->options;
         crew->members.emplace_back(new ProveCrew::Member());
         crew->members.back()->ctx = child;
         const int index = (int)crew->members.size() - 1;
@@ -635,7 +646,7 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
             for (uint32_t l = 1; l <= c->depth; ++l) rounds += 2.0 * c->k[l];
         return rounds * (50.0 + 2.0 * (it.batch > 0 ? it.batch : 1));
     };
-    static const int pieces_env = [] { const char* e = getenv("GKR_PROVE_MANY_PIECES"); return e ? atoi(e) : -1; }();
+    const int pieces_env = (int)gkr::opt(gkr::OPT_prove_many_pieces);
     std::vector<gkr_prove_item> work(items, items + n_items);
     std::vector<int> origin(n_items);
     for (size_t i = 0; i < n_items; ++i) origin[i] = (int)i;

@@ -11,7 +11,6 @@
 // socket, MPI, torch.distributed's store).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -21,15 +20,39 @@
 
 #include "../../include/gkr_amd.h"
 
+// The five entry points and the handful of types of RCCL's C ABI this unit uses, declared HERE: librccl is optional at run
+// time (dlopen), and so is its development header at build time -- the library builds on a ROCm install without RCCL and
+// reports GKR_ERR_UNSUPPORTED when the collective is asked for.  Values as in nccl.h (stable across NCCL 2.x / RCCL);
+// where the header is present the build checks them against it.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define GKR_HAVE_RCCL_HEADER 1
+#endif
+#endif
+namespace rccl_abi {
+typedef int Result;                      // ncclResult_t; ncclSuccess = 0
+struct UniqueId {
+    char internal[128];                  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
+};
+typedef struct CommOpaque* Comm;         // ncclComm_t
+constexpr int kSuccess = 0, kInt64 = 4, kSum = 0;   // ncclSuccess, ncclInt64, ncclSum
+}  // namespace rccl_abi
+#ifdef GKR_HAVE_RCCL_HEADER
+static_assert(sizeof(rccl_abi::UniqueId) == sizeof(ncclUniqueId) && (int)ncclSuccess == rccl_abi::kSuccess && (int)ncclInt64 == rccl_abi::kInt64 &&
+                  (int)ncclSum == rccl_abi::kSum && sizeof(ncclComm_t) == sizeof(rccl_abi::Comm),
+              "the locally declared RCCL ABI differs from <rccl/rccl.h>");
+#endif
+
 namespace {
 
 struct RcclApi {
     void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    rccl_abi::Result (*GetUniqueId)(rccl_abi::UniqueId*) = nullptr;
+    rccl_abi::Result (*CommInitRank)(rccl_abi::Comm*, int, rccl_abi::UniqueId, int) = nullptr;
+    rccl_abi::Result (*CommDestroy)(rccl_abi::Comm) = nullptr;
+    rccl_abi::Result (*AllReduce)(const void*, void*, size_t, int /* ncclDataType_t */, int /* ncclRedOp_t */, rccl_abi::Comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(rccl_abi::Result) = nullptr;
     std::string error;
 };
 
@@ -69,7 +92,7 @@ int fail(int status, const std::string& what) {
 
 struct gkr_rccl_exchange {
     int device = 0, rank = 0, nranks = 1;
-    ncclComm_t comm = nullptr;
+    rccl_abi::Comm comm = nullptr;
     gkr_exchange_dev dev{};
     std::atomic<uint64_t> calls{0};
     std::atomic<int> last_status{0};
@@ -78,9 +101,9 @@ struct gkr_rccl_exchange {
 static int rccl_hook(void* user, size_t count, void* hip_stream) {
     gkr_rccl_exchange* x = static_cast<gkr_rccl_exchange*>(user);
     x->calls.fetch_add(1, std::memory_order_relaxed);
-    const ncclResult_t rc = rccl_api()->AllReduce(x->dev.d_limbs, x->dev.d_limbs, count, ncclInt64, ncclSum, x->comm, static_cast<hipStream_t>(hip_stream));
-    if (rc != ncclSuccess) x->last_status.store((int)rc, std::memory_order_relaxed);
-    return rc == ncclSuccess ? 0 : (int)rc;
+    const rccl_abi::Result rc = rccl_api()->AllReduce(x->dev.d_limbs, x->dev.d_limbs, count, rccl_abi::kInt64, rccl_abi::kSum, x->comm, static_cast<hipStream_t>(hip_stream));
+    if (rc != rccl_abi::kSuccess) x->last_status.store((int)rc, std::memory_order_relaxed);
+    return rc == rccl_abi::kSuccess ? 0 : (int)rc;
 }
 
 extern "C" {
@@ -91,10 +114,10 @@ int gkr_exchange_rccl_unique_id(void* id_out) {
     if (!id_out) return fail(GKR_ERR_INVALID, "null pointer");
     RcclApi* api = rccl_api();
     if (!api->error.empty()) return fail(GKR_ERR_UNSUPPORTED, api->error);
-    static_assert(GKR_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the ABI's id size is RCCL's");
-    ncclUniqueId id;
-    const ncclResult_t rc = api->GetUniqueId(&id);
-    if (rc != ncclSuccess) return fail(GKR_ERR_HIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(rc));
+    static_assert(GKR_RCCL_ID_BYTES == sizeof(rccl_abi::UniqueId), "the ABI's id size is RCCL's");
+    rccl_abi::UniqueId id;
+    const rccl_abi::Result rc = api->GetUniqueId(&id);
+    if (rc != rccl_abi::kSuccess) return fail(GKR_ERR_HIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(rc));
     memcpy(id_out, &id, sizeof id);
     return GKR_OK;
 }
@@ -119,10 +142,13 @@ int gkr_exchange_rccl_create(int device_id, const void* unique_id, int rank, int
         return fail(GKR_ERR_NOMEM, "hipMalloc of the limb buffer");
     }
     (void)hipMemset(buf, 0, capacity_limbs * sizeof(int64_t));
-    ncclUniqueId id;
+    rccl_abi::UniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    const ncclResult_t rc = api->CommInitRank(&x->comm, nranks, id, rank);
-    if (rc != ncclSuccess) {
+    // ncclCommInitRank BLOCKS until all `nranks` ranks have called it with this id (there is no timeout in RCCL's API): a
+    // rank that never arrives leaves the others here.  The host owns that failure mode -- it starts the ranks -- exactly as
+    // with a bare RCCL program; gkr_amd.h says so, tests/test_gpu_sharded.py shows it (the parent kills the waiting child).
+    const rccl_abi::Result rc = api->CommInitRank(&x->comm, nranks, id, rank);
+    if (rc != rccl_abi::kSuccess) {
         (void)hipFree(buf);
         delete x;
         return fail(GKR_ERR_HIP, std::string("ncclCommInitRank: ") + api->GetErrorString(rc));

@@ -33,6 +33,17 @@ int gkr_ctx_create(int device_id, gkr_ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GKR_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= count) return GKR_ERR_INVALID;
+    // the calling thread's current device is the caller's business (a host with several GPUs mixes its own HIP calls
+    // with the library's): whatever it was, it is current again when this returns
+    struct RestoreDevice {
+        int prev = -1;
+        RestoreDevice() {
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        }
+        ~RestoreDevice() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } restore_device;
     if (hipSetDevice(device_id) != hipSuccess) return GKR_ERR_HIP;
     gkr_ctx* c = new gkr_ctx();
     c->device = device_id;
@@ -99,6 +110,36 @@ const char* gkr_last_error(const gkr_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int gkr_ctx_set_transcript(gkr_ctx* ctx, int mode) {
     if (!ctx || (mode != GKR_TRANSCRIPT_DEVICE && mode != GKR_TRANSCRIPT_HOST)) return GKR_ERR_INVALID;
     ctx->transcript = mode;
+    return GKR_OK;
+}
+
+// ---- options (csrc/options.h: the one table of the library's switches) ----
+int gkr_option_count(void) { return (int)gkr::OPT_COUNT; }
+const char* gkr_option_name(int index) { return index >= 0 && index < (int)gkr::OPT_COUNT ? gkr::option_table()[index].name : nullptr; }
+const char* gkr_option_doc(int index) { return index >= 0 && index < (int)gkr::OPT_COUNT ? gkr::option_table()[index].doc : nullptr; }
+const char* gkr_option_env(int index) { return index >= 0 && index < (int)gkr::OPT_COUNT ? gkr::option_table()[index].env : nullptr; }
+
+int gkr_ctx_get_option(const gkr_ctx* ctx, const char* name, long long* value) {
+    const int i = gkr::option_index(name);
+    if (!ctx || !value || i < 0) return GKR_ERR_INVALID;
+    *value = ctx->options.v[i];
+    return GKR_OK;
+}
+
+int gkr_ctx_set_option(gkr_ctx* ctx, const char* name, long long value) {
+    if (!ctx) return GKR_ERR_INVALID;
+    const int i = gkr::option_index(name);
+    if (i < 0) return ctx->fail(GKR_ERR_INVALID, std::string("unknown option: ") + (name ? name : "(null)"));
+    if (ctx->crew_member) return ctx->fail(GKR_ERR_INVALID, "options of a context that is proving are not changed");
+    if (ctx->options.v[i] == value) return GKR_OK;
+    // Cached per-circuit state (gate lists, segment layout) was built under the old value: dropped, rebuilt on next use.
+    // Resident layers (gkr_resident_layer_create) keep the layout they were created with: set options before creating them.
+    if (hipSetDevice(ctx->device) == hipSuccess) {
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (auto& c : ctx->circuits) c->release();
+        ctx->circuits.clear();
+    }
+    ctx->options.v[i] = value;
     return GKR_OK;
 }
 
@@ -582,7 +623,7 @@ int gkr_selftest_wide_sum(const gkr_fr* vals, size_t n, gkr_fr* out) {
 
 int gkr_device_alloc(gkr_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr || !bytes) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipError_t e = device_malloc(d_ptr, bytes);
     if (e == hipErrorOutOfMemory) return ctx->fail(GKR_ERR_NOMEM, "hipMalloc: out of memory");
     HIP_TRY(ctx, e);
@@ -591,14 +632,14 @@ int gkr_device_alloc(gkr_ctx* ctx, size_t bytes, void** d_ptr) {
 
 int gkr_device_free(gkr_ctx* ctx, void* d_ptr) {
     if (!ctx) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     HIP_TRY(ctx, device_free(d_ptr));
     return GKR_OK;
 }
 
 int gkr_device_upload(gkr_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     if (!ctx || !d_dst || !h_src) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GKR_OK;
@@ -606,7 +647,7 @@ int gkr_device_upload(gkr_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
 
 int gkr_device_download(gkr_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (!ctx || !h_dst || !d_src) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GKR_OK;
@@ -614,7 +655,7 @@ int gkr_device_download(gkr_ctx* ctx, void* h_dst, const void* d_src, size_t byt
 
 int gkr_device_fill_table(gkr_ctx* ctx, void* d_table, size_t count, uint64_t seed) {
     if (!ctx || !d_table || !count) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     gkr::launch_fill_table(static_cast<Fr*>(d_table), count, seed, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return GKR_OK;
@@ -624,7 +665,7 @@ int gkr_device_fill_shard(gkr_ctx* ctx, void* d_shard, int n, int log2_shards, i
     if (!ctx || !d_shard || log2_shards < 0 || log2_shards > 16 || n - log2_shards < 1 || n - log2_shards > GKR_MAX_MLE_N || shard < 0 ||
         shard >= (1 << log2_shards))
         return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     gkr::launch_fill_shard(static_cast<Fr*>(d_shard), (size_t)1 << (n - log2_shards), (uint32_t)log2_shards, (uint32_t)shard, seed, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return GKR_OK;
@@ -635,7 +676,7 @@ int gkr_ubench_ceilings(gkr_ctx* ctx, size_t bytes, double* copy_GBps, double* r
     if (!copy_GBps || !read_GBps || !modmul_per_sec) return ctx->fail(GKR_ERR_INVALID, "null pointer");
     if (bytes < ((size_t)64 << 20)) bytes = (size_t)64 << 20;
     bytes &= ~(size_t)4095;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
     char *a = nullptr, *b = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&a), bytes));
@@ -681,7 +722,7 @@ int gkr_ubench_ceilings(gkr_ctx* ctx, size_t bytes, double* copy_GBps, double* r
 
 int gkr_device_synchronize(gkr_ctx* ctx) {
     if (!ctx) return GKR_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GKR_ENTER(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GKR_OK;
 }

@@ -71,14 +71,11 @@ inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_m
 // variables of the previous pass with the 2^jp Montgomery weights at weights + proof * 8 (in place; jp = 0: none), then
 // the cross sums for the next J rounds -> the pinned records (seq = ticket, system-scope release); partials: scratch of
 // batch x prod_pass_blocks(2^(m_in - jp - 1)) x 72 values for passes that span several blocks per proof.
-// wait_seq (pinned host words, may be null): the pass is launched AHEAD of its weights and starts once wait_seq[0] == wait_ticket
-// (the host has written the weights) or wait_seq[1] != 0 (the host gave up).
 // arrivals (may be null): `batch` zeroed words; passes of 2 .. kProdFuseBlocks blocks per proof then publish from their last
 // block instead of a second launch (the words are zero again when the kernel ends).
 constexpr uint32_t kProdFuseBlocks = 64;
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq = nullptr,
-                      uint32_t wait_ticket = 0, uint32_t* arrivals = nullptr);
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals = nullptr);
 // start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
 // the 2^k entries of the rows A, M (gate_rows), per proof
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,
@@ -181,11 +178,27 @@ size_t gate_seg_partial_elems(GateSpan span, uint32_t k_i, uint32_t k);    // Fr
 void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
                        uint32_t* counts, uint32_t* offsets, uint32_t* cursor, uint32_t* block_sums, uint32_t* list, uint32_t* bad,
                        uint32_t* lds_scratch, GateSegs* segs, uint32_t* seg_scratch, hipStream_t s);
+// The sorted gate lists (and gate arrays) of ONE circuit layer on the device, as the passes over the gates read them.  A pass
+// over a batch of proofs of one circuit takes the pointers as launch arguments; a pass over proofs of DIFFERENT circuits whose
+// layers have the same shape (gkr_prove_many's lockstep groups: the reference's par_iter over the (circuit, input) pairs of a
+// step, aggregator.rs:411-416, as ONE launch per pass) takes `sets`, a device table with one entry per proof of the launch,
+// and ignores the pointer arguments.
+struct GateSet {
+    const uint32_t* offsets;      // 2 * 2^k bucket starts
+    const uint32_t* cursor;       // 2 * 2^k bucket ends
+    const uint32_t* list;         // gate indices by bucket; the entries' meta words follow at list + gate_list_words(gates)
+    const uint32_t* heavy;        // the wide layers' work lists (gate_heavy_words; may be null)
+    const uint8_t* gate_type;     // the layer's gate arrays (layer evaluation)
+    const uint32_t* left;
+    const uint32_t* right;
+    uint64_t pad;
+};
+static_assert(sizeof(GateSet) == 64, "one cache line per proof");
 // e_hi / e_lo_mont split at `kl` = gate_seg_shift() when segs->shift != 0 (partials: gate_seg_partial_elems() * batch
 // elements of scratch), else at any kl
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, const GateSegs* segs,
-                    Fr* partials, hipStream_t s);
+                    Fr* partials, hipStream_t s, const GateSet* sets = nullptr);
 // the c-phase's set-up done by the row pass itself (launch_prod_c_setup's arguments; Wb null: not fused)
 struct CPhaseFuse {
     const Fr* Wb = nullptr;
@@ -198,31 +211,7 @@ struct CPhaseFuse {
 // the caller still has to launch_prod_c_setup (the bucket form)
 bool launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse = nullptr);
-// One launch per layer (small layers): the whole layer sumcheck of `batch` proofs as one resident kernel, one block
-// per proof, tables in LDS; rounds are handed to the host and challenges taken back through pinned memory, no
-// launch per round (kernels.hip, k_layer_persistent).
-constexpr uint32_t kPersistentMaxK = 8;      // tables of 2^k <= 256 entries per proof in LDS
-struct LayerChallenge {   // pinned, written by the host: challenge r_j in Montgomery form, then seq = the round's ticket
-    Fr r_mont;
-    uint32_t seq;
-    uint32_t pad[7];
-};
-static_assert(sizeof(LayerChallenge) == 64, "challenge slot layout");
-void launch_layer_persistent(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor,
-                             const uint32_t* list, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
-                             const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, LayerHostRec* host_rec,
-                             const LayerChallenge* challenges, const uint32_t* abort_flag, uint32_t ticket_base, LayerBatch lb,
-                             hipStream_t s);
-// b-phase in linear time (kernels.hip): U, V tables of 2^k entries per proof, their rounds, the row collapse
-void launch_layer_uv(const Fr* A, const Fr* M, const Fr* W, Fr* U, Fr* V, uint32_t k, LayerBatch lb, hipStream_t s);
-void launch_uv_round(bool fold, Fr* W, Fr* U, Fr* V, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec, uint32_t ticket,
-                     LayerBatch lb, hipStream_t s);
-void launch_c_round(bool fold, Fr* A, Fr* M, Fr* Wc, const Fr* Wb, uint32_t h, const FixedMul* rtab, LayerHostRec* host_rec,
-                    uint32_t ticket, LayerBatch lb, hipStream_t s);
-uint32_t layer_collapse_chunks(uint32_t k, uint32_t batch);
-void launch_layer_collapse(Fr* A, Fr* M, const Fr* eq, Fr* scratch, uint32_t k, LayerBatch lb, hipStream_t s);
-
+                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse = nullptr, const GateSet* sets = nullptr);
 void launch_fill_table(Fr* table, size_t count, uint64_t seed, hipStream_t s);
 void launch_fill_shard(Fr* shard_table, size_t count, uint32_t lp, uint32_t shard, uint64_t seed, hipStream_t s);
 // sum over ranks without leaving the device: a, b (each `each` elements) + one flag element <-> (2 each + 1) x 8 int64 limbs
@@ -243,7 +232,7 @@ void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t r
                            uint32_t* dep_last, hipStream_t s);
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
-                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s);
+                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s, const GateSet* sets = nullptr);
 // words 32-bit words src -> dst (16-byte aligned when words >= 4); either side may be pinned host memory
 void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s);
 // out[proof][g] = eq(points[proof * stride + first ..+nvars), g), nvars <= 28; points may be pinned host memory
@@ -276,10 +265,10 @@ size_t gate_heavy_partial_elems(uint64_t gates, uint32_t k);    // Fr elements o
 void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, uint32_t* heavy_words, hipStream_t s);
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                          const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr);
+                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr, const GateSet* sets = nullptr);
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr);
+                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr, const GateSet* sets = nullptr);
 // host_hdr (may be null): the first four words of heavy_words as the host read them back ([2 * half] = heavy buckets of the half)
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)
 void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s);

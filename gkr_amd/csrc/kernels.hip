@@ -17,6 +17,7 @@
 #include <atomic>
 
 #include "kernels.h"
+#include "options.h"
 #include "dev_util.h"
 #include "gate_seg.h"
 #include "mfma_fold.h"
@@ -601,8 +602,14 @@ __global__ void __launch_bounds__(64) k_mle_round_reduce(const MlePartial* __res
 
 __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_type,
                              const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                             const Fr* __restrict__ prev, Fr* __restrict__ out, uint32_t prev_stride) {
-    prev += (size_t)blockIdx.y * prev_stride;   // grid.y = proof of a batch (same gates, its own values)
+                             const Fr* __restrict__ prev, Fr* __restrict__ out, uint32_t prev_stride, const GateSet* __restrict__ sets) {
+    if (sets) {   // proofs of different circuits in one launch: this proof's gate arrays
+        const GateSet gs = sets[blockIdx.y];
+        gate_type = gs.gate_type;
+        left = gs.left;
+        right = gs.right;
+    }
+    prev += (size_t)blockIdx.y * prev_stride;   // grid.y = proof of a batch (its own values)
     out += (size_t)blockIdx.y * gates;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < gates; g += gridDim.x * blockDim.x) {
         Fr a = load_fr(prev + left[g]), b = load_fr(prev + right[g]);
@@ -627,20 +634,9 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
 template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
                                                     const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
-                                                    ProdPassRec* __restrict__ rec, uint32_t ticket, const uint32_t* __restrict__ wait_seq,
-                                                    uint32_t wait_ticket, uint32_t* __restrict__ arrivals) {
+                                                    ProdPassRec* __restrict__ rec, uint32_t ticket, uint32_t* __restrict__ arrivals) {
     __shared__ Fr s_w[8];
     __shared__ uint32_t s_last;
-    // Launched AHEAD of its weights (a lone proof's round path: the launch and its ~6 us dispatch gap overlap the host's
-    // hashing of the previous pass): the block waits until the host has released them -- wait_seq[0] = the previous pass's
-    // ticket (pinned host memory, written after the weights), or wait_seq[1] != 0: the host gave up (every error path sets it).
-    if (wait_seq) {
-        if (threadIdx.x == 0)
-            while (__hip_atomic_load(wait_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != wait_ticket &&
-                   !__hip_atomic_load(wait_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
-                __builtin_amdgcn_s_sleep(4);
-        __syncthreads();
-    }
     __shared__ Fr s_t[3][8][TILE];               // folded tile: table, sub-block, i
     __shared__ Fr s_red[4][kProdRecValues];
     const uint32_t tid = threadIdx.x, proof = blockIdx.y;
@@ -1461,9 +1457,17 @@ __global__ void __launch_bounds__(256) k_gate_uv(const uint32_t* __restrict__ of
                                                  const Fr* __restrict__ e_hi,
                                                  const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                  const Fr* __restrict__ W, Fr* __restrict__ U, Fr* __restrict__ V, uint32_t wstride,
-                                                 uint32_t gate_base) {
+                                                 uint32_t gate_base, const GateSet* __restrict__ sets) {
     __shared__ Acc<9> smem[4 * 2];
     const uint32_t b = blockIdx.x, lmask = (1u << kl) - 1u;
+    if (sets) {   // this proof's circuit (block-uniform: scalar loads)
+        const GateSet gs = sets[blockIdx.y];
+        const ptrdiff_t moff = meta - list;
+        offsets = gs.offsets;
+        cursor = gs.cursor;
+        list = gs.list;
+        meta = gs.list + moff;
+    }
     e_hi += (size_t)blockIdx.y << kh;
     e_lo_mont += (size_t)blockIdx.y << kl;
     W += (size_t)blockIdx.y * wstride;
@@ -1498,9 +1502,17 @@ __global__ void __launch_bounds__(256) k_gate_rows(const uint32_t* __restrict__ 
                                                    const Fr* __restrict__ e_hi,
                                                    const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                    const Fr* __restrict__ eq_mont, Fr* __restrict__ A_row, Fr* __restrict__ M_row,
-                                                   uint32_t k, uint32_t wstride, uint32_t gate_base) {
+                                                   uint32_t k, uint32_t wstride, uint32_t gate_base, const GateSet* __restrict__ sets) {
     __shared__ Acc<9> smem[4 * 2];
     const uint32_t c = blockIdx.x, lmask = (1u << kl) - 1u, bucket = (1u << k) + c;
+    if (sets) {
+        const GateSet gs = sets[blockIdx.y];
+        const ptrdiff_t moff = meta - list;
+        offsets = gs.offsets;
+        cursor = gs.cursor;
+        list = gs.list;
+        meta = gs.list + moff;
+    }
     e_hi += (size_t)blockIdx.y << kh;
     e_lo_mont += (size_t)blockIdx.y << kl;
     eq_mont += (size_t)blockIdx.y * wstride;
@@ -1656,7 +1668,7 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
                                                                   const uint32_t* __restrict__ group_len, const uint32_t* __restrict__ group_off,
                                                                   const uint32_t* __restrict__ packed, const Fr* __restrict__ e_lo_mont, uint32_t shift,
                                                                   const Fr* __restrict__ T, uint32_t tlen, uint32_t tstride, Fr* __restrict__ X,
-                                                                  Fr* __restrict__ Y, uint32_t pstride, uint32_t dbg_mask, uint32_t dbg_nomac) {
+                                                                  Fr* __restrict__ Y, uint32_t pstride) {
     extern __shared__ uint4 s_raw[];
     e_lo_mont += (size_t)blockIdx.y << shift;
     T += (size_t)blockIdx.y * tstride;
@@ -1689,7 +1701,6 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
             idx = order[pos];
             len = items[idx].y & 0xffu;
         }
-        if (dbg_nomac) len = 0;
         const uint32_t* src = packed + (size_t)group_off[slot] * 64u + lane;
         // R0: the accumulator this lane's products go to -- its add gates' sum first, its mult gates' sum after the one
         // exchange at the item's first mult gate (k_seg_pack puts an item's add gates first); R1: the other one
@@ -1698,14 +1709,14 @@ __global__ void __launch_bounds__(LDS_T ? 1024 : 256) k_seg_pass(const uint2* __
         // Entries are requested four steps ahead and E_lo one step ahead: a step's two dependent loads (the entry from
         // HBM, then the gather it addresses) would otherwise cost ~2 us per step with nothing to hide behind.
         const uint32_t last = n - 1u, omask = (1u << (31u - shift)) - 1u;
-        uint32_t ent = src[0] & dbg_mask;
+        uint32_t ent = src[0];
         uint32_t p1 = src[(size_t)(1u < last ? 1u : last) * 64u], p2 = src[(size_t)(2u < last ? 2u : last) * 64u],
                  p3 = src[(size_t)(3u < last ? 3u : last) * 64u];
         Fr e = load_fr(e_lo_mont + (ent & lmask)), t;
         if (!LDS_T) t = load_fr(Tt + ((ent >> shift) & omask));
         for (uint32_t j = 0; j < n; ++j) {
             const uint32_t p4 = src[(size_t)(j + 4u < last ? j + 4u : last) * 64u];
-            const uint32_t ent_n = p1 & dbg_mask;
+            const uint32_t ent_n = p1;
             const Fr e_n = load_fr(e_lo_mont + (ent_n & lmask));   // in flight while this step's products run
             Fr t_n;
             if (LDS_T)
@@ -1871,7 +1882,7 @@ void launch_ubench_modmul(Fr* io, uint32_t entries_pow2, uint32_t waves, int rep
 uint32_t mle_blocks_per_table(uint32_t items, uint32_t batch) {
     // ~1024 items (4 iterations) per block, but enough blocks across the batch to fill the chip;
     // never more than one block per 256 items
-    static const uint32_t per_block = [] { const char* e = getenv("GKR_ITEMS_PER_BLOCK"); return e && atoi(e) >= 256 ? (uint32_t)atoi(e) : 1024u; }();
+    const uint32_t per_block = opt(OPT_items_per_block) >= 256 ? (uint32_t)opt(OPT_items_per_block) : 1024u;
     uint32_t b = (items + per_block - 1) / per_block;
     const uint32_t fill = (2048 + batch - 1) / batch;
     if (b < fill) b = fill;
@@ -1901,22 +1912,21 @@ void launch_mle_round_hash(const MlePartial* partials, uint32_t nblk, uint32_t r
 }
 
 void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t* left, const uint32_t* right,
-                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s) {
+                       const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s, const GateSet* sets) {
     hipLaunchKernelGGL(k_layer_eval, dim3(blocks_for(gates, 4096), batch), dim3(256), 0, s, gates, gate_type, left, right,
-                       prev, out, prev_stride);
+                       prev, out, prev_stride, sets);
 }
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, const uint32_t* wait_seq, uint32_t wait_ticket,
-                      uint32_t* arrivals) {
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals) {
     const uint32_t S = 1u << (m_in - jp - J), blocks = prod_pass_blocks(S);
     uint32_t* fused = (arrivals && blocks > 1 && blocks <= kProdFuseBlocks) ? arrivals : nullptr;   // the last block publishes
     if (prod_pass_tile(S) == kProdTileWide)
         hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           wait_seq, wait_ticket, fused);
+                           fused);
     else
         hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           wait_seq, wait_ticket, fused);
+                           fused);
     if (fused) return;
     if (blocks > 1024) {
         // (the second level's input sits behind the partials: launch_prod_pass's callers size the scratch with prod_pass_scratch_values)
@@ -2003,7 +2013,7 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
 
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,
                              uint32_t batch, hipStream_t s) {
-    static const bool stepwise = getenv("GKR_LINE_STEPWISE") != nullptr;   // (test hook: the wide-layer form at every width)
+    const bool stepwise = opt(OPT_line_stepwise) != 0;   // (test hook: the wide-layer form at every width)
     if (k <= 9 && !stepwise) {
         hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), (size_t)3 * sizeof(Fr) << k, s, W, k, bc, scratch, out, out_len);
         return;
@@ -2087,7 +2097,7 @@ void launch_predicate_sorted(uint32_t k_i, uint32_t k_next, const uint8_t* gate_
 // blocks of the LDS-privatised sort (0: the layer is small or k too large -- use the global-atomic passes), and the
 // scratch it needs: two arrays of 2 * 2^k * blocks counters (histograms, their scan) + the scan's block sums
 uint32_t gate_lists_lds_blocks(uint64_t gates, uint32_t k) {
-    static const bool off = getenv("GKR_GATE_SORT_GLOBAL") != nullptr;
+    const bool off = opt(OPT_gate_sort_global) != 0;
     if (off || k > 12 || gates < ((uint64_t)1 << 16)) return 0;
     uint64_t b = (gates + 16383) / 16384;   // >= 16384 gates per block: the 32 KB histogram flush must stay small beside them
     if (b > 1024) b = 1024;
@@ -2113,12 +2123,12 @@ struct SegPlan {
 };
 static SegPlan seg_plan(GateSpan span, uint32_t k_i, uint32_t k) {
     SegPlan p;
-    static const bool off = getenv("GKR_GATE_SEGMENTS_OFF") != nullptr;
+    const bool off = opt(OPT_gate_segments_off) != 0;
     // (measured, MI355X, gate passes of a layer with k = k_i / 2, ms per pass segment / bucket form: 2^16 gates 0.089 / 0.024,
     // 2^20 0.090 / 0.052, 2^22 0.104 / 0.125, 2^24 0.245 / 0.43 -- the segment form has ~85 us of fixed latency (resident
     // blocks, the one-wave-per-bucket combine); profiles/r03/q_segment_threshold.jsonl)
-    static const uint32_t min_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENTS_MIN_LOG2"); return e ? (uint32_t)atoi(e) : 22u; }();
-    static const uint32_t mean_log2 = [] { const char* e = getenv("GKR_GATE_SEGMENT_LOG2"); return e && atoi(e) >= 2 && atoi(e) <= 8 ? (uint32_t)atoi(e) : kSegMeanLog2; }();
+    const uint32_t min_log2 = (uint32_t)opt(OPT_gate_segments_min_log2);
+    const uint32_t mean_log2 = opt(OPT_gate_segment_log2) >= 2 && opt(OPT_gate_segment_log2) <= 8 ? (uint32_t)opt(OPT_gate_segment_log2) : kSegMeanLog2;
     const uint32_t blocks = gate_lists_lds_blocks(span.count, k);
     if (off || !blocks || span.count < ((uint64_t)1 << min_log2) || span.count > ((uint64_t)1 << 31)) return p;
     const uint64_t per_block = (span.count + blocks - 1) / blocks;
@@ -2239,13 +2249,18 @@ void launch_gate_lists(GateSpan span, uint32_t k_i, uint32_t k, const uint8_t* g
     hipLaunchKernelGGL(k_gate_fill, dim3(gblocks), dim3(256), 0, s, gates, k, gate_type, left, right, cursor, list, list + gate_list_words(gates));
 }
 
+// compute units of the CURRENT device (a process may drive several: gkr_ctx_create_multi), read once per device id
 static uint32_t device_cus() {
-    static const uint32_t n = [] {
-        int dev = 0;
+    static std::atomic<uint32_t> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256u;
+    std::atomic<uint32_t>& slot = cus[dev & 63];
+    uint32_t n = slot.load(std::memory_order_relaxed);
+    if (!n) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 256u;
-        return (uint32_t)prop.multiProcessorCount;
-    }();
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 1) ? (uint32_t)prop.multiProcessorCount : 256u;
+        slot.store(n, std::memory_order_relaxed);
+    }
     return n;
 }
 template <bool ROWS, bool LDS_T>
@@ -2267,16 +2282,12 @@ static void launch_seg_pass_t(const GateSegs& g, uint32_t k, const Fr* e_lo_mont
     }
     // resident blocks: one 1024-thread block per CU with the table in LDS; 256-thread blocks, four per CU, without
     const uint32_t blocks = LDS_T ? device_cus() : 4 * device_cus();
-    // (experiments only -- wrong results: E_lo indices masked so that the gather always hits L1; no arithmetic)
-    static const uint32_t dbg_lo = [] { const char* e = getenv("GKR_DEBUG_SEG_ELO_MASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
-    const uint32_t dbg_mask = dbg_lo | ~((1u << g.shift) - 1u);
-    static const uint32_t dbg_nomac = getenv("GKR_DEBUG_SEG_NO_MAC") ? 1u : 0u;
     hipLaunchKernelGGL((k_seg_pass<ROWS, LDS_T>), dim3(blocks, lb.batch), dim3(LDS_T ? 1024 : 256), lds, s, g.items(), g.order(), g.bucket_begin(),
                        g.nb, g.groups, g.group_len(), g.group_off(), g.packed(), e_lo_mont, g.shift, T, tlen,
-                       (uint32_t)lb.wstride, X, Y, g.half_bound, dbg_mask, dbg_nomac);
+                       (uint32_t)lb.wstride, X, Y, g.half_bound);
 }
 static void launch_seg_pass(bool rows, const GateSegs& g, uint32_t k, const Fr* e_lo_mont, const Fr* T, Fr* X, Fr* Y, LayerBatch lb, hipStream_t s) {
-    static const bool no_lds = getenv("GKR_GATE_SEGMENTS_NO_LDS") != nullptr;
+    const bool no_lds = opt(OPT_gate_segments_no_lds) != 0;
     const bool lds_t = !no_lds && ((size_t)sizeof(Fr) << k) <= 128 * 1024;
     if (rows)
         lds_t ? launch_seg_pass_t<true, true>(g, k, e_lo_mont, T, X, Y, lb, s) : launch_seg_pass_t<true, false>(g, k, e_lo_mont, T, X, Y, lb, s);
@@ -2288,8 +2299,8 @@ static uint32_t bucket_threads(uint64_t gates, uint32_t k) { return (gates >> k)
 
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                     const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, const GateSegs* segs,
-                    Fr* partials, hipStream_t s) {
-    if (segs && segs->shift && partials) {
+                    Fr* partials, hipStream_t s, const GateSet* sets) {
+    if (segs && segs->shift && partials && !sets) {   // (the segment form takes one circuit per launch: callers keep layers that have segments out of groups)
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(false, *segs, k, e_lo_mont, W, X, Y, lb, s);
         hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 0u, 1u << k, X, Y,
@@ -2297,13 +2308,13 @@ void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* off
         return;
     }
     hipLaunchKernelGGL(k_gate_uv, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
-                       list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base);
+                       list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, W, U, V, (uint32_t)lb.wstride, (uint32_t)span.base, sets);
 }
 
 bool launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                       const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse) {
-    if (segs && segs->shift && partials) {
+                      const GateSegs* segs, Fr* partials, hipStream_t s, const CPhaseFuse* fuse, const GateSet* sets) {
+    if (segs && segs->shift && partials && !sets) {
         Fr *X = partials, *Y = partials + (size_t)segs->half_bound * lb.batch;
         launch_seg_pass(true, *segs, k, e_lo_mont, eq_mont, X, Y, lb, s);
         hipLaunchKernelGGL(k_seg_combine, dim3(((1u << k) + 1u) / 2u, lb.batch), dim3(64), 0, s, segs->items(), segs->bucket_begin(), 1u << k, 1u << k, X, Y,
@@ -2312,7 +2323,7 @@ bool launch_gate_rows(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* o
     }
     hipLaunchKernelGGL(k_gate_rows, dim3(1u << k, lb.batch), dim3(bucket_threads(span.count, k)), 0, s, offsets, cursor, list,
                        list + gate_list_words(span.count), e_hi, e_lo_mont, kl, k_i - kl, eq_mont, A_row, M_row, k, (uint32_t)lb.wstride,
-                       (uint32_t)span.base);
+                       (uint32_t)span.base, sets);
     return false;
 }
 
@@ -2346,9 +2357,9 @@ void launch_mle_sub_reduce(const MleSubPartial* partials, uint32_t nblk, uint32_
     hipLaunchKernelGGL(k_mle_sub_reduce, dim3(batch), dim3(512), 0, s, partials, nblk, jout, host_rec, ticket);
 }
 
-// matrix-core form unless GKR_NO_MFMA_FOLD is set or the chunk is not a whole number of 64-entry wave tiles
+// matrix-core form unless the option no_mfma_fold is set or the chunk is not a whole number of 64-entry wave tiles
 bool mle_multifold_uses_mfma(uint32_t S, uint32_t nblk) {
-    static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
+    const bool off = opt(OPT_no_mfma_fold) != 0;
     return !off && nblk > 0 && S % nblk == 0 && (S / nblk) % 64u == 0;
 }
 
@@ -2409,14 +2420,11 @@ void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, si
 // runs at the fast rate (6.1 - 6.5 TB/s in 13 of 13 allocations).  Hence: as many blocks as chunks of
 // GKR_FOLD_MIN_CHUNK (default 256) entries allow, up to GKR_FOLD_BLOCKS (default 65536) over the batch.
 uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch) {
-    static const bool off = getenv("GKR_NO_MFMA_FOLD") != nullptr;
+    const bool off = opt(OPT_no_mfma_fold) != 0;
     if (off) return mle_pass_blocks(S, jout, batch);
-    static const uint32_t target = [] { const char* e = getenv("GKR_FOLD_BLOCKS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 65536u; }();
-    static const uint32_t min_chunk = [] {
-        const char* e = getenv("GKR_FOLD_MIN_CHUNK");
-        const uint32_t v = e ? (uint32_t)atoi(e) : 256u;
-        return v >= 64u && (v & (v - 1u)) == 0 ? v : 256u;
-    }();
+    const uint32_t target = opt(OPT_fold_blocks) > 0 ? (uint32_t)opt(OPT_fold_blocks) : 65536u;
+    const uint32_t mc = (uint32_t)opt(OPT_fold_min_chunk);
+    const uint32_t min_chunk = mc >= 64u && (mc & (mc - 1u)) == 0 ? mc : 256u;
     uint32_t b = 1u << jout;
     while ((uint64_t)b * batch < target && S / (2u * b) >= min_chunk && 2u * b <= kMaxBlocksPerTable) b <<= 1;
     if (b > S) b = S;

@@ -18,6 +18,7 @@
 
 #include "dev_util.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace gkr {
 
@@ -31,7 +32,7 @@ namespace gkr {
 // a whole wave per bucket, 0.52 with four lanes; 2^20 over 2^15 (32 per bucket) 0.216 with 32 lanes, 0.065 with four; 2^20
 // over 2^20 (one per bucket) 0.40 with four lanes, 0.17 with one.
 uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k) {
-    static const int forced = [] { const char* e = getenv("GKR_GATE_GROUP_LANES_LOG2"); return e ? atoi(e) : -1; }();   // (measurement knob)
+    const int forced = (int)opt(OPT_gate_group_lanes_log2);   // (measurement knob)
     if (forced >= 0 && forced <= 6) return (uint32_t)forced;
     const uint64_t mean = gates >> k;
     uint32_t lg = 0;
@@ -113,7 +114,16 @@ __global__ void __launch_bounds__(256) k_gate_group(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
                                                     const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                     const Fr* __restrict__ T, Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t k,
-                                                    uint32_t wstride, uint32_t gate_base, uint32_t lg, uint32_t threshold) {
+                                                    uint32_t wstride, uint32_t gate_base, uint32_t lg, uint32_t threshold,
+                                                    const GateSet* __restrict__ sets) {
+    if (sets) {   // proofs of different circuits in one launch: this proof's lists (block-uniform)
+        const GateSet gs = sets[blockIdx.y];
+        const ptrdiff_t moff = meta - list;
+        offsets = gs.offsets;
+        cursor = gs.cursor;
+        list = gs.list;
+        meta = gs.list + moff;
+    }
     const uint32_t L = 1u << lg, sub = threadIdx.x & (L - 1u), nb = 1u << k;
     const uint32_t bl = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg);   // bucket within the half
     const uint32_t lmask = (1u << kl) - 1u;
@@ -153,7 +163,17 @@ __global__ void __launch_bounds__(256) k_gate_heavy(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
                                                     const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
                                                     const Fr* __restrict__ T, Fr* __restrict__ partials, size_t pstride, uint32_t wstride,
-                                                    uint32_t gate_base, uint32_t unit) {
+                                                    uint32_t gate_base, uint32_t unit, const GateSet* __restrict__ sets) {
+    if (sets) {
+        const GateSet gs = sets[blockIdx.y];
+        const ptrdiff_t moff = meta - list, uoff = units - hdr;
+        offsets = gs.offsets;
+        cursor = gs.cursor;
+        list = gs.list;
+        meta = gs.list + moff;
+        hdr = gs.heavy;
+        units = gs.heavy + uoff;
+    }
     const uint32_t nunits = hdr[2u * half + 1u];
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t lmask = (1u << kl) - 1u;
@@ -183,7 +203,12 @@ __global__ void __launch_bounds__(256) k_gate_heavy(const uint32_t* __restrict__
 // a wave per heavy bucket: the totals of its units -> the bucket's two outputs
 __global__ void __launch_bounds__(256) k_heavy_combine(const uint32_t* __restrict__ hdr, uint32_t half, const uint32_t* __restrict__ buckets,
                                                        uint32_t nb, const Fr* __restrict__ partials, size_t pstride, Fr* __restrict__ out0,
-                                                       Fr* __restrict__ out1, uint32_t wstride) {
+                                                       Fr* __restrict__ out1, uint32_t wstride, const GateSet* __restrict__ sets) {
+    if (sets) {
+        const ptrdiff_t boff = buckets - hdr;
+        hdr = sets[blockIdx.y].heavy;
+        buckets = hdr + boff;
+    }
     const uint32_t nheavy = hdr[2u * half];
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     partials += (size_t)blockIdx.y * pstride;
@@ -216,12 +241,12 @@ void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets,
 template <bool ROWS>
 static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                                 const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
-                                uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
+                                uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
     const uint32_t lg = gate_group_lanes_log2(span.count, k), threshold = gate_heavy_threshold(span.count, k);
     const uint32_t* meta = list + gate_list_words(span.count);
     const uint64_t threads = (uint64_t)1 << (k + lg);
     hipLaunchKernelGGL((k_gate_group<ROWS>), dim3((unsigned)((threads + 255) / 256), lb.batch), dim3(256), 0, s, offsets, cursor, list, meta, e_hi,
-                       e_lo_mont, kl, k_i - kl, T, out0, out1, k, (uint32_t)lb.wstride, (uint32_t)span.base, lg, threshold);
+                       e_lo_mont, kl, k_i - kl, T, out0, out1, k, (uint32_t)lb.wstride, (uint32_t)span.base, lg, threshold, sets);
     const uint32_t half = ROWS ? 1u : 0u;
     // (the work lists' header as the host read it back when the lists were built: a half without a heavy bucket -- most
     // layers -- skips two launches per pass)
@@ -229,20 +254,20 @@ static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const u
     const HeavyView hv = heavy_view(heavy_words, span.count, k, half);
     const size_t pstride = gate_heavy_partial_elems(span.count, k);
     hipLaunchKernelGGL((k_gate_heavy<ROWS>), dim3(512, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.units, offsets, cursor, list, meta, e_hi, e_lo_mont,
-                       kl, k_i - kl, T, heavy_partials, pstride, (uint32_t)lb.wstride, (uint32_t)span.base, gate_heavy_unit(span.count));
+                       kl, k_i - kl, T, heavy_partials, pstride, (uint32_t)lb.wstride, (uint32_t)span.base, gate_heavy_unit(span.count), sets);
     hipLaunchKernelGGL(k_heavy_combine, dim3(64, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.buckets, 1u << k, heavy_partials, pstride, out0, out1,
-                       (uint32_t)lb.wstride);
+                       (uint32_t)lb.wstride, sets);
 }
 
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                          const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
-    launch_gate_group_t<false>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, W, U, V, lb, heavy_words, heavy_partials, s, host_hdr);
+                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
+    launch_gate_group_t<false>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, W, U, V, lb, heavy_words, heavy_partials, s, host_hdr, sets);
 }
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
                            const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr) {
-    launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s, host_hdr);
+                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
+    launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s, host_hdr, sets);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries

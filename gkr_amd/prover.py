@@ -101,6 +101,17 @@ def multi_hash(values, key=0):
     return from_limbs(out)[0]
 
 
+def options():
+    """The library's option table: [(name, environment variable, what it does)] (no GPU needed)."""
+    lib = N.lib()
+    for f in (lib.gkr_option_name, lib.gkr_option_doc, lib.gkr_option_env):
+        f.restype = ctypes.c_char_p
+        f.argtypes = [ctypes.c_int]
+    lib.gkr_option_count.restype = ctypes.c_int
+    return [(lib.gkr_option_name(i).decode(), lib.gkr_option_env(i).decode(), lib.gkr_option_doc(i).decode())
+            for i in range(lib.gkr_option_count())]
+
+
 def host_hash_us(length):
     """(us per hash in sixteen IFMA lanes, us per scalar hash) of a `length`-element round vector on one host thread."""
     a, b = ctypes.c_double(), ctypes.c_double()
@@ -193,8 +204,24 @@ class Context:
         self._check(N.lib().gkr_ctx_device_name(self._h, buf, ctypes.c_size_t(256)))
         return buf.value.decode()
 
+    def device_count(self):
+        """Devices prove_many deals over (1 unless created with devices=[...])."""
+        N.lib().gkr_ctx_device_count.restype = ctypes.c_int
+        return int(N.lib().gkr_ctx_device_count(self._h))
+
     def set_transcript(self, mode):
         self._check(N.lib().gkr_ctx_set_transcript(self._h, ctypes.c_int(mode)))
+
+    def set_option(self, name, value):
+        """One of the library's switches (csrc/options.h; gkr_amd.options() lists them) for THIS context only."""
+        N.lib().gkr_ctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong]
+        self._check(N.lib().gkr_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        N.lib().gkr_ctx_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
+        v = ctypes.c_longlong()
+        self._check(N.lib().gkr_ctx_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def set_host_threads(self, threads):
         """Host threads the context may use for the transcript, the caller included (0 = default)."""

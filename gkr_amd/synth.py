@@ -51,6 +51,12 @@ def proof_arrays_digest(ks, sc, sl, sr, q, ql, z, rr):
     return transcript_digest(sc, sl, sr, q, ql, z, rr)
 
 
+def proof_coeffs_digest(d_coeffs, input_coeffs):
+    """sha256 over one proof's d and input_func coefficient arrays (get_multi_ext, poly.rs:502-536: all 2^k_0 and 2^k_L monomial
+    coefficients, zeros included) in the C ABI's layout."""
+    return transcript_digest(np.ascontiguousarray(d_coeffs), np.ascontiguousarray(input_coeffs))
+
+
 def proof_arrays_from_checker(ref, ks):
     """cdense.prove_raw's dict -> the seven arrays in gkr_proof_buf layout (one proof)."""
     L = len(ks) - 1

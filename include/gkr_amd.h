@@ -117,6 +117,20 @@ int  gkr_ctx_set_transcript(gkr_ctx *ctx, int mode);
  * several contexts from several threads (the reference proves its <= 20 sub-circuits from a rayon par_iter,
  * aggregator.rs:350-355) gives each context its share; 1 = hash on the calling thread, no workers. */
 int  gkr_ctx_set_host_threads(gkr_ctx *ctx, int threads);
+/* The library's switches, per context.  gkr_amd/csrc/options.h holds the ONE table of them (name, default, what it does;
+ * gkr_option_count / _name / _doc / _env enumerate it); a context takes the table's defaults -- or, for a test or an A/B
+ * script that cannot call in, the value of the environment variable named in the table -- when it is created, and
+ * gkr_ctx_set_option changes one value for this context only (cached per-circuit state built under the old value is
+ * dropped; resident layers keep the layout they were created with, so set options first).  `name` is the option's name
+ * ("rounds_per_pass") or its environment variable ("GKR_ROUNDS_PER_PASS").  No option changes a result: each is a choice
+ * between schedules or kernel forms that the parity suite holds bit-exact against each other.  gkr_prove_many's child
+ * contexts prove with the options of the context the call was made on. */
+int  gkr_ctx_set_option(gkr_ctx *ctx, const char *name, long long value);
+int  gkr_ctx_get_option(const gkr_ctx *ctx, const char *name, long long *value);
+int  gkr_option_count(void);
+const char *gkr_option_name(int index);
+const char *gkr_option_doc(int index);
+const char *gkr_option_env(int index);
 int  gkr_ctx_device_name(const gkr_ctx *ctx, char *buf, size_t len);
 /* Contexts proving side by side (one calling thread each -- the reference's par_iter over the (circuit, input) pairs,
  * aggregator.rs:350-355) share their host work: a thread that waits for its own GPU round takes pieces of another
@@ -289,7 +303,19 @@ int  gkr_resident_layer_sumcheck_dev(gkr_ctx *ctx, gkr_resident_layer *layer, co
  * gkr_exchange_dev to pass to gkr_resident_layer_sumcheck_dev / gkr_sumcheck_mle_sharded_dev: its hook queues
  * ncclAllReduce(buf, buf, count, ncclInt64, ncclSum, comm, stream) on the stream the library hands it.  Errors: a status,
  * the text in gkr_exchange_rccl_error() (per thread).  What it stands for in the reference: the rayon reduce at
- * sumcheck.rs:50-63, 97-124 (and :62 for prove_sumcheck), over xGMI instead of over cores. */
+ * sumcheck.rs:50-63, 97-124 (and :62 for prove_sumcheck), over xGMI instead of over cores.
+ *
+ * gkr_exchange_rccl_create BLOCKS until all `nranks` ranks have called it with the same id: RCCL's ncclCommInitRank has no
+ * timeout, and the library adds none -- a rank that never arrives leaves the others waiting, exactly as in a bare RCCL
+ * program; the host that starts the ranks owns that failure mode (tests/test_gpu_sharded.py shows the wait: rank 0 of a
+ * world of two, alone, is still inside the call when its parent ends it).  The unit builds without RCCL's development
+ * header (the few ABI types are declared locally) and returns GKR_ERR_UNSUPPORTED where librccl cannot be loaded.
+ *
+ * STATUS: EXPERIMENTAL beyond one device.  The three multi-device mechanisms -- this exchange, gkr_ctx_create_multi and
+ * gkr_sumcheck_mle_sharded_dev / gkr_resident_layer_sumcheck_dev across ranks -- are proven bit-exact with logical ranks
+ * on one GPU, over gloo with two processes, and through RCCL with ONE rank (torch's communicator and this one); no build
+ * of this library has yet had a second physical device (tests/test_gpu_multi_device.py runs the two-device cases and
+ * skips where fewer than two GPUs are visible). */
 #define GKR_RCCL_ID_BYTES 128
 typedef struct gkr_rccl_exchange gkr_rccl_exchange;
 int  gkr_exchange_rccl_unique_id(void *id_out /* GKR_RCCL_ID_BYTES */);

@@ -102,12 +102,13 @@ def large_r1cs_digests(nrounds=65536, pair=(2, 3)):
     subs = oconv.convert_r1cs_wtns_gkr(r, synth.mimc7_demo_witness(pair[0], pair[1], nrounds=nrounds))
     print("oracle compile: %.0f s, %d sub-circuits" % (time.time() - t, len(subs)), flush=True)
     out = {"what": "sha256 of gkr_amd.synth.proof_arrays_digest per sub-circuit; compile and proofs by the CPU checker",
-           "nrounds": nrounds, "constraints": 4 * nrounds, "input": list(pair), "k": [], "digests": []}
+           "nrounds": nrounds, "constraints": 4 * nrounds, "input": list(pair), "k": [], "digests": [], "coeff_digests": []}
     for sub in subs:
         layers = [(np.asarray(a, dtype=np.uint8), np.asarray(b, dtype=np.uint32), np.asarray(c, dtype=np.uint32)) for a, b, c in sub["layers"]]
         ref = cdense.prove_raw(layers, cdense.to_limbs(sub["input_values"]))
         out["k"].append(list(sub["k"]))
         out["digests"].append(synth.proof_arrays_digest(list(sub["k"]), *synth.proof_arrays_from_checker(ref, list(sub["k"]))))
+        out["coeff_digests"].append(synth.proof_coeffs_digest(cdense.mobius_raw(ref["values"][0], ref["k"][0]), cdense.mobius_raw(ref["values"][-1], ref["k"][-1])))
     return out
 
 
@@ -123,6 +124,20 @@ def main():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "proof_digests.json")
         with open(path, "w") as f:
             json.dump(proof_digests(), f, indent=0, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        return
+    if "--prove-coeffs" in sys.argv:   # only the d / input_func digests of the wide proof, added to the committed file
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
+        cur = json.load(open(path))
+        cur["prove_coeffs"] = {}
+        for ks in ((18, 20, 20),):
+            circuit, raw, wit = synth.wide_circuit(ks)
+            ref = cdense.prove_raw(raw, wit[0])
+            assert cur["prove"]["k=" + ",".join(map(str, ks))] == synth.proof_arrays_digest(list(ks), *synth.proof_arrays_from_checker(ref, list(ks)))
+            cur["prove_coeffs"]["k=" + ",".join(map(str, ks))] = synth.proof_coeffs_digest(cdense.mobius_raw(ref["values"][0], ks[0]), cdense.mobius_raw(ref["values"][-1], ks[-1]))
+        with open(path, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
             f.write("\n")
         print("wrote", path)
         return
@@ -150,6 +165,8 @@ def main():
         circuit, raw, wit = synth.wide_circuit(ks)
         ref = cdense.prove_raw(raw, wit[0])
         out["prove"]["k=" + ",".join(map(str, ks))] = synth.proof_arrays_digest(list(ks), *synth.proof_arrays_from_checker(ref, list(ks)))
+        out["prove_coeffs"] = out.get("prove_coeffs", {})
+        out["prove_coeffs"]["k=" + ",".join(map(str, ks))] = synth.proof_coeffs_digest(cdense.mobius_raw(ref["values"][0], ks[0]), cdense.mobius_raw(ref["values"][-1], ks[-1]))
     for n, seed in ((16, synth.SEED + 1), (20, synth.SEED + 2)):
         C, L, R = cdense.sumcheck_mle_raw(cdense.fill_table(1 << n, seed), n)
         out["mle"]["n=%d,seed=%d" % (n, seed)] = digest(C, L, R)

@@ -51,3 +51,26 @@ def test_layer_split_mode_with_a_process_group_of_one_rank():
              env={"GKR_BENCH_FORCE_GROUP": "1", "MASTER_PORT": "29633", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert d["matches_golden_digest"] is True and d["exchange"]["calls_per_step"] == 2.0 and d["exchange"]["us_per_call"] > 0
     assert d["roofline"]["bound"] == "alu" and d["scaling"] == "strong"
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: the process starts torch.distributed.run itself (a child,
+    before anything touched the GPU), two ranks come up -- here both on the one GPU over gloo, the single-device test
+    hook -- and the one JSON line says n_gpus 2 with every leg verified on every rank."""
+    env = {"GKR_BENCH_BACKEND": "gloo", "GKR_BENCH_DEVICE": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    d = _run("--gpus", "2", "--batch", "32", "--steps", "2", "--warmup", "1", "--proofs", "4", "--layer-k-i", "20", "--layer-k", "10", env=env)
+    assert d["n_gpus"] == 2 and d["collective"]["world_size_seen"] == 2 and d["collective"]["backend"] == "gloo"
+    assert d["verified"]["ok"] is True and d["verified"]["all_ranks_ok"] is True
+    assert d["layer24_split"]["matches_golden_digest"] is True and d["mle_split"]["matches_golden_digest"] is True
+    assert d["aggregated_proofs"]["config3"]["verified"]["all_ranks_ok"] is True
+    assert "multi_device" not in d["aggregated_proofs"]       # (one process over all devices is the N = 1 line's leg)
+
+
+def test_one_process_over_all_devices_leg():
+    """aggregated_proofs.multi_device on the N = 1 line: configs[3] through ONE process and gkr_ctx_create_multi over every
+    visible device, the proofs checked against the committed digests."""
+    d = _run("--batch", "16", "--steps", "1", "--warmup", "1", "--proofs", "4", "--no-extras", "--no-cpu-baseline")
+    m = d["aggregated_proofs"]["multi_device"]
+    assert m["devices_seen"] >= 1 and m["proofs"] == 48 and m["ms"] > 0 and (m["verified"] is None or m["verified"]["ok"] is True)

@@ -34,11 +34,10 @@ def config5_expected(tmp_path_factory):
     return path, (C, L, R)
 
 
-@pytest.mark.parametrize("env", [{}, {"GKR_GATE_SEGMENTS_OFF": "1"}, {"GKR_GATE_SEGMENT_LOG2": "6"},
-                                 {"GKR_GATE_SORT_GLOBAL": "1", "GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"},
-                                 {"GKR_LAYER_DENSE_B": "1"}],
+@pytest.mark.parametrize("env", [{}, {"GKR_GATE_SEGMENTS_OFF": "1"}, {"GKR_GATE_SEGMENT_LOG2": "6"}, {"GKR_GATE_SORT_GLOBAL": "1"},
+                                 {"GKR_GATE_SEGMENTS_NO_LDS": "1"}],
                          ids=["default(gate lists, block-private sort, segment passes)", "bucket passes (no segments)", "segments of 64 gates",
-                              "gate lists, global-atomic sort", "dense tables, linear-time rounds", "dense b-phase passes"])
+                              "gate lists, global-atomic sort", "segment passes gathering from L2"])
 def test_config5_layer_every_form_matches_oracle(config5_expected, env):
     path, _ = config5_expected
     out = subprocess.run([sys.executable, os.path.join(HERE, "config_scale_worker.py"), str(K_I), str(K), path],

@@ -307,19 +307,15 @@ def test_layer_sumcheck_matches_oracle(ctx, seed):
     assert ctx.prove_sumcheck_opt(lay, k, z, w) == cdense.sumcheck_layer(k_i, k, gt, lay.left, lay.right, z, w)
 
 
-@pytest.mark.parametrize("env", [{}, {"GKR_LAYER_GATE_LISTS": "1"}, {"GKR_LAYER_DENSE_TABLES": "1"}, {"GKR_LAYER_DENSE_B": "1"},
-                                 {"GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_LAYER_PERSISTENT": "1"},
-                                 {"GKR_LAYER_DENSE_B": "1", "GKR_LAYER_NO_FUSED": "1"},
-                                 {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_LAYER_PER_ROUND": "1"},
-                                 {"GKR_LAYER_PER_ROUND": "1", "GKR_NO_SMALL_ROUNDS": "1"}, {"GKR_NO_IFMA": "1"}, {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_LINE_STEPWISE": "1"},
-                                 {"GKR_LAUNCH_AHEAD": "1"}, {"GKR_NO_FUSED_PUBLISH": "1"}],
+@pytest.mark.parametrize("env", [{}, {"GKR_NO_CIRCUIT_CACHE": "1"}, {"GKR_HOST_THREADS": "2", "GKR_HASH_CHUNK": "16"}, {"GKR_NO_IFMA": "1"},
+                                 {"GKR_NO_IFMA": "1", "GKR_NO_ADX": "1"}, {"GKR_LINE_STEPWISE": "1"}, {"GKR_NO_FUSED_PUBLISH": "1"},
+                                 {"GKR_GATE_SORT_GLOBAL": "1"}, {"GKR_GATE_GROUPS_MIN_K": "2"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_layer_path_variants_match_oracle(env):
-    """The layer sumcheck has three forms -- linear time over (W, U, V) tables of 2^k entries summed straight from
-    the gate lists (default: product passes, up to three rounds per device round trip; GKR_LAYER_PER_ROUND: one round
-    per trip), the same with U, V taken from dense predicate tables, and k passes over the dense 2^{2k}-entry tables
-    (fused or round + fold kernels): the same transcript from each, single layers and a batch of proofs, IFMA-lane and
-    scalar host passes.  The knobs are read once per process, hence the child."""
+    """The layer sumcheck with the host transcript: linear time over (W, U, V) tables of 2^k entries summed straight from
+    the gate lists, product passes of up to three rounds per device round trip -- under every switch that still reaches
+    it (csrc/options.h), single layers and a batch of proofs, IFMA-lane and scalar host passes.  A child process: the
+    environment seeds a context's options when it is created, and the process switches are read once."""
     import os
     import subprocess
     import sys
@@ -327,6 +323,40 @@ def test_layer_path_variants_match_oracle(env):
     out = subprocess.run([sys.executable, os.path.join(here, "layer_variants_worker.py")], env=dict(os.environ, **env),
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_options_are_per_context():
+    """gkr_ctx_set_option: two contexts of ONE process with different switches give the same transcripts (the options are
+    read per context, not from process-wide statics), an unknown name is an error, and the device transcript's two b-phase
+    forms (layer_no_fused) agree."""
+    from gkr_amd import Context, GkrError
+    rng = random.Random(4242)
+    n = 13
+    table = [rng.randrange(P) for _ in range(1 << n)]
+    k_i, k = 9, 5
+    lay = Layer(k_i, [rng.randint(0, 1) for _ in range(1 << k_i)], [rng.randrange(1 << k) for _ in range(1 << k_i)],
+                [rng.randrange(1 << k) for _ in range(1 << k_i)])
+    z = [rng.randrange(P) for _ in range(k_i)]
+    w = [rng.randrange(P) for _ in range(1 << k)]
+    want_mle = cdense.sumcheck_mle(table, n)
+    want_layer = cdense.sumcheck_layer(k_i, k, lay.gate_type, lay.left, lay.right, z, w)
+    with Context(0) as a, Context(0) as b, Context(0) as c:
+        b.set_option("no_mfma_fold", 1)
+        b.set_option("GKR_ROUNDS_PER_PASS", 2)          # (the variable's name is accepted too)
+        b.set_option("gate_groups_min_k", 1)
+        b.set_option("no_fused_publish", 1)
+        c.set_option("mle_per_round", 1)
+        c.set_option("line_stepwise", 1)
+        assert a.get_option("rounds_per_pass") == 0 and b.get_option("rounds_per_pass") == 2 and c.get_option("mle_per_round") == 1
+        for ctx_ in (a, b, c, a):
+            assert ctx_.prove_sumcheck(table, n) == want_mle
+            assert ctx_.prove_sumcheck_opt(lay, k, z, w) == want_layer
+        with pytest.raises(GkrError):
+            a.set_option("no_such_option", 1)
+        a.set_transcript(N.GKR_TRANSCRIPT_DEVICE)
+        assert a.prove_sumcheck_opt(lay, k, z, w) == want_layer
+        a.set_option("layer_no_fused", 1)
+        assert a.prove_sumcheck_opt(lay, k, z, w) == want_layer
 
 
 def test_layer_sumcheck_length_rule_edges(ctx):

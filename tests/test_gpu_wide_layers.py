@@ -169,14 +169,11 @@ def test_random_circuits_across_the_width_thresholds(ctx, seed):
     _check_proofs(ctx.prove_batch_raw(circuit, np.ascontiguousarray(wit), all_arrays=True), layers, ks, np.ascontiguousarray(wit))
 
 
-@pytest.mark.parametrize("scenario", ["small", "heavy-batch", "per-round"])
+@pytest.mark.parametrize("scenario", ["small", "heavy-batch"])
 def test_lane_group_passes_on_small_layers(scenario):
     """tests/wide_scenarios_worker.py (a child: GKR_GATE_GROUPS_MIN_K is read once per process): the lane-group form of the
-    gate passes and its heavy-bucket units forced onto layers the dense C oracle reaches, also in a batch of proofs and
-    with the per-round kernels after them."""
+    gate passes and its heavy-bucket units forced onto layers the dense C oracle reaches, also in a batch of proofs."""
     env = dict(os.environ, GKR_GATE_GROUPS_MIN_K="1")
-    if scenario == "per-round":
-        env["GKR_LAYER_PER_ROUND"] = "1"
     out = subprocess.run([sys.executable, os.path.join(HERE, "wide_scenarios_worker.py"), scenario], env=env, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr

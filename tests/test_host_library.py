@@ -485,21 +485,51 @@ def test_limits_table_matches_the_code():
         assert name in capi or name == "GKR_MAX_BATCH", name
 
 
-def test_every_environment_knob_is_documented():
-    """INTEGRATION.md section 4 is the table of the library's environment knobs: every getenv("GKR_...") of the sources
-    appears there, and nothing is listed that the sources no longer read."""
+def test_every_switch_is_in_the_one_table():
+    """csrc/options.h is the one place the library reads the environment: no other source calls getenv; INTEGRATION.md
+    section 4 lists exactly the table's options (by name and variable) and the process switches options.h declares; and no
+    switch that produces wrong results exists in the shipped library."""
     import glob
     import re
-    code = set()
-    for path in glob.glob(os.path.join(REPO, "gkr_amd", "csrc", "*")):
+    from gkr_amd.prover import options
+    csrc = os.path.join(REPO, "gkr_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*")):
+        if path.endswith((".hip", ".h", ".cpp")) and os.path.basename(path) != "options.h":
+            assert "getenv" not in open(path).read(), "%s reads the environment itself" % path
+    table = options()
+    assert len(table) >= 20 and len({name for name, _, _ in table}) == len(table)
+    opt_text = open(os.path.join(csrc, "options.h")).read()
+    process = set(re.findall(r"^//   (GKR_[A-Z0-9_]+|LOCAL_WORLD_SIZE)\s", opt_text, flags=re.M))
+    used = set()
+    for path in glob.glob(os.path.join(csrc, "*")):
         if path.endswith((".hip", ".h", ".cpp")):
-            code |= set(re.findall(r'getenv\("(GKR_[A-Z0-9_]+)"\)', open(path).read()))
+            used |= set(re.findall(r'process_(?:switch|int)\("([A-Z0-9_]+)"', open(path).read()))
+    assert used == process, "process switches used %s, declared in options.h %s" % (sorted(used), sorted(process))
     doc_text = open(os.path.join(REPO, "INTEGRATION.md")).read()
-    section = doc_text[doc_text.index("## 4. Environment knobs"):]
-    documented = set(re.findall(r"`(GKR_[A-Z0-9_]+)[`=]", section))
-    assert code - documented == set(), "undocumented knobs: %s" % sorted(code - documented)
-    stale = {k for k in documented - code if not k.startswith(("GKR_TRANSCRIPT", "GKR_BENCH", "GKR_TEST", "GKR_ERR", "GKR_MAX"))}
-    assert stale == set(), "documented but no longer read: %s" % sorted(stale)
+    section = doc_text[doc_text.index("## 4. Options and process switches"):]
+    documented = set(re.findall(r"`(GKR_[A-Z0-9_]+)`", section)) - {"GKR_TRANSCRIPT_DEVICE"}
+    live = {env for _, env, _ in table} | (process - {"LOCAL_WORLD_SIZE"})
+    retired = {"GKR_GROUP_SPLIT", "GKR_STAGGER", "GKR_WAIT_MODE", "GKR_HELP_FLAT"}     # named in the "retired" paragraph
+    assert live - documented == set(), "undocumented: %s" % sorted(live - documented)
+    assert documented - live - retired == set(), "documented but gone: %s" % sorted(documented - live - retired)
+    for name, _, _ in table:
+        assert "`%s`" % name in section, name
+    # the shipped library holds no experiment switch
+    blob = open(N.LIB_PATH, "rb").read()
+    assert b"GKR_DEBUG_SEG" not in blob and b"GKR_DEBUG_" not in blob.replace(b"GKR_DEBUG_TIMING", b"")
+
+
+def test_context_options_without_a_device():
+    """The option table is reachable without a GPU (names, variables, texts); set / get need a context."""
+    from gkr_amd.prover import options
+    names = [n for n, _, _ in options()]
+    for must in ("rounds_per_pass", "no_mfma_fold", "gate_groups_min_k", "prove_many_lockstep", "no_circuit_cache"):
+        assert must in names
+    lib = N.lib()
+    import ctypes
+    v = ctypes.c_longlong()
+    assert lib.gkr_ctx_get_option(None, b"rounds_per_pass", ctypes.byref(v)) == N.GKR_ERR_INVALID
+    assert lib.gkr_ctx_set_option(None, b"rounds_per_pass", ctypes.c_longlong(3)) == N.GKR_ERR_INVALID
 
 
 def test_rccl_exchange_without_a_device_is_an_error_not_a_crash():
