@@ -149,9 +149,14 @@ inline void ifma_hash_chunk(const uint64_t (*vec)[3][4], const uint32_t* ln, int
 // chunk of sumchecks one host thread hashes at a time: sixteen when the host threads are the scarce resource
 // (throughput: MI355X + 2 threads, 256 x 2^20: 7.1 ms per step against 8.5), eight otherwise (latency: with 15
 // threads 5.04 ms against 5.19)
-inline int hash_chunk_size(int tables, int threads) {
+inline int hash_chunk_size(int tables, int threads, int help_share = 0) {
     const long long forced = gkr::opt(gkr::OPT_hash_chunk);   // (called on a context's own thread, before the pieces are posted)
     if (forced == 8 || forced == 16) return (int)forced;
+    // One of a crew's units (gkr_prove_many) with `help_share` threads to itself on average: a FEW proofs in lockstep are a
+    // latency chain -- a lone transcript's scalar hash takes 12 us per round vector, an IFMA call ~25 us whether one lane is
+    // filled or sixteen -- so they go out as pieces of one or two proofs to the threads that have no unit of their own;
+    // many proofs are a throughput problem: whole eight- or sixteen-lane calls.
+    if (help_share > 1 && tables <= 2 * help_share) return tables <= help_share ? 1 : 2;
     return tables >= 32 * threads ? 16 : 8;
 }
 
@@ -227,6 +232,7 @@ struct PreparedCircuit {
     std::vector<uint8_t*> gt;
     std::vector<uint32_t*> l, r;
     std::vector<GateLists> lists;
+    std::vector<unsigned char> retained;   // the gate arrays as they were when the entry was made (all of them, or sampled blocks): compared on a hit
     void release() {
         for (auto p : gt) (void)hipFree(p);
         for (auto p : l) (void)hipFree(p);
@@ -314,6 +320,7 @@ struct gkr_ctx {
     void* mle_arrivals_zeroed = nullptr;       // the same for the plain sumcheck's latency-bound passes
     void* arrivals_zeroed = nullptr;           // the product passes' arrival counters: zeroed once per allocation (every pass leaves them zero)
     bool crew_member = false;                  // one thread of several proving side by side: no workers of its own
+    int help_share = 0;                        // crew threads per proving unit of the current gkr_prove_many call (0: not in one)
     int rounds_ahead = 0;                      // sumcheck rounds left in the proof being proven AFTER the current layer (help priority)
     std::unique_ptr<ProveCrew, void (*)(ProveCrew*)> crew{nullptr, nullptr};   // gkr_prove_many's threads and child contexts (lazy)
     std::map<std::string, std::pair<void*, size_t>> ws;        // grow-only device workspaces
@@ -455,7 +462,7 @@ struct ProveCrew {
     struct Member {
         gkr_ctx* ctx = nullptr;
         std::thread th;
-        std::vector<int> items;   // indices into the current call's item list, in proving order
+        std::vector<int> items;   // indices into the current call's UNIT list, in proving order
     };
     std::vector<std::unique_ptr<Member>> members;
     std::mutex mu;
@@ -465,6 +472,7 @@ struct ProveCrew {
     int active = 0;               // members taking part in the current call (the first `active`)
     int finished = 0;             // of the threads (members 1 ..), in the current call
     gkr_prove_item* items = nullptr;
+    const std::vector<std::vector<int>>* units = nullptr;   // a unit: one item, or the items of a lockstep group (same k list)
     int32_t busy = 0;             // members still proving (atomic access); the others lend themselves
     double t_call_us = 0;         // (accounting) when the current call woke the crew
 };
@@ -646,9 +654,19 @@ struct LayerShardArgs {
     void* user = nullptr;
     const gkr_exchange_dev* dev = nullptr;  // device exchange: limbs widened into the caller's device buffer, summed on the stream
 };
+// A lockstep group (gkr_prove_many): the proofs of a launch belong to DIFFERENT circuits whose layer has this shape; the
+// passes over the gates read each proof's lists through d_sets (one gkr::GateSet per proof, device memory).  heavy_hdr: [2 * half]
+// != 0 when some member has heavy buckets in that half (the wide layers' work lists).
+struct LayerGroup {
+    const gkr::GateSet* d_sets = nullptr;
+    uint32_t heavy_hdr[4] = {0, 0, 0, 0};
+};
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z,
                     const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r, const LayerShardArgs* shard = nullptr,
-                    GateLists* cached = nullptr);
+                    GateLists* cached = nullptr, const LayerGroup* group = nullptr);
+// the cached gate lists of one circuit layer, built and validated as a call of its own (a lone circuit builds them inside its
+// first layer sumcheck; a lockstep group needs every member's before its first launch)
+int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, GateLists* cached);
 int run_layer(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z, const Fr* d_W,
               gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r);
 // ---- defined in capi_prove.hip

@@ -150,14 +150,56 @@ int build_predicates(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const ui
 // b-rounds, the row (a_u, m_u) before the c-rounds -- are completed by the caller's sum-over-ranks hook.
 int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                          const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
-                         const LayerShardArgs* shard, GateLists* cached);
+                         const LayerShardArgs* shard, GateLists* cached, const LayerGroup* group);
+
+// smallest k_next whose layers take the lane-group gate passes of wide layers (kernels_wide.hip)
+static bool layer_is_wide(gkr::GateSpan span, int k_i, int k) {
+    const int wide_min_k = gkr::opt(gkr::OPT_gate_groups_min_k) >= 0 ? (int)gkr::opt(gkr::OPT_gate_groups_min_k) : (int)gkr::kWideMinK;
+    return k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
+}
+
+int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, GateLists* cached) {
+    if (!cached) return ctx->fail(GKR_ERR_INVALID, "no list cache");
+    if (cached->ready) return GKR_OK;
+    const gkr::GateSpan span{0, (uint64_t)1 << k_i};
+    if (gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) != 0) return ctx->fail(GKR_ERR_INVALID, "a layer of the segment form's size in a lockstep group");
+    hipStream_t s = ctx->stream;
+    const bool wide = layer_is_wide(span, k_i, k);
+    const size_t nb2 = (size_t)2 << k;
+    uint32_t *g_counts = nullptr, *g_bsums = nullptr, *bad = nullptr, *lds_scratch = nullptr;
+    WS(ctx, "pred.bad", uint32_t, 1, bad);
+    WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
+    WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
+    if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
+    if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
+    if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
+    if (wide && !cached->heavy) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->heavy), gkr::gate_heavy_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
+    if (const size_t words = gkr::gate_lists_lds_scratch_words(span.count, (uint32_t)k)) WS(ctx, "gates.lds", uint32_t, words, lds_scratch);
+    {
+        Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
+        gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, cached->offsets, cached->cursor, g_bsums, cached->list, bad, lds_scratch,
+                               &cached->segs, nullptr, s);
+        if (wide) gkr::launch_gate_heavy_lists(span, (uint32_t)k, cached->offsets, cached->cursor, cached->heavy, s);
+    }
+    uint32_t hbad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+    if (wide) HIP_TRY(ctx, hipMemcpyAsync(cached->heavy_hdr, cached->heavy, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+    cached->heavy_known = wide;
+    cached->ready = true;
+    return GKR_OK;
+}
 
 // Gate lists that this call built (cached->ready false on entry) count as ready only if the whole call succeeded: a bad
 // gate, a HIP error or a timeout after the sort was queued must not leave half-validated lists marked usable.
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                     const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
-                    const LayerShardArgs* shard, GateLists* cached) {
+                    const LayerShardArgs* shard, GateLists* cached, const LayerGroup* group) {
     const bool was_ready = cached && cached->ready;
+    if (group && (ctx->transcript != GKR_TRANSCRIPT_HOST || shard || !was_ready)) return ctx->fail(GKR_ERR_INVALID, "a lockstep group needs the host transcript and prepared gate lists");
     int rc = GKR_OK;
     if (ctx->transcript != GKR_TRANSCRIPT_HOST && batch > 1 && !shard) {
         // The device transcript hashes on one lane per sumcheck and its round kernels take one proof: the proofs of a
@@ -165,9 +207,9 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
         const size_t wlen = (size_t)1 << k;
         for (int b = 0; b < batch && rc == GKR_OK; ++b)
             rc = run_layer_batch_impl(ctx, 1, k_i, k, d_gt, d_l, d_r, z + (size_t)b * k_i, d_W + (size_t)b * wlen, out_coeffs + b, out_len + b,
-                                      out_r + b, nullptr, cached);
+                                      out_r + b, nullptr, cached, nullptr);
     } else {
-        rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached);
+        rc = run_layer_batch_impl(ctx, batch, k_i, k, d_gt, d_l, d_r, z, d_W, out_coeffs, out_len, out_r, shard, cached, group);
     }
     if (rc && cached && !was_ready) cached->ready = false;
     return rc;
@@ -175,7 +217,7 @@ int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt
 
 int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r,
                          const gkr_fr* z, const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r,
-                         const LayerShardArgs* shard, GateLists* cached) {
+                         const LayerShardArgs* shard, GateLists* cached, const LayerGroup* group) {
     const size_t N = (size_t)1 << (2 * k);
     const size_t wlen = (size_t)1 << k;
     const uint32_t v = 2 * k;
@@ -204,8 +246,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     // Wide layers (2^13 buckets and more per half, each with a few gates): the gate passes run with a group of lanes per
     // bucket and the rare long buckets in units (kernels_wide.hip) -- a block per bucket would be 2^20 blocks for a gate apiece.
     // The option gate_groups_min_k moves the switch (tests run the form on small layers too).
-    const int wide_min_k = gkr::opt(gkr::OPT_gate_groups_min_k) >= 0 ? (int)gkr::opt(gkr::OPT_gate_groups_min_k) : (int)gkr::kWideMinK;
-    const bool wide = sparse && k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
+    const bool wide = sparse && layer_is_wide(span, k_i, k);
+    const gkr::GateSet* sets = group ? group->d_sets : nullptr;   // lockstep group: per-proof gate lists
     const size_t tlen = sparse ? wlen : N;   // entries of A / M per proof: the single c-phase row, or the whole table
     WS(ctx, sparse ? "layer.Arow" : "layer.A", Fr, tlen * batch, A);
     WS(ctx, sparse ? "layer.Mrow" : "layer.M", Fr, tlen * batch, M);
@@ -322,9 +364,9 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
             gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s,
-                                     cached && cached->heavy_known && !lists_fresh ? cached->heavy_hdr : nullptr);
+                                     group ? group->heavy_hdr : (cached && cached->heavy_known && !lists_fresh ? cached->heavy_hdr : nullptr), sets);
         else
-            gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s);
+            gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s, sets);
     }
 
     // The two tables d_a, d_b (`each` elements) := their sums over all ranks.  One more element travels along: "some rank
@@ -437,10 +479,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
                     if (wide)
                         gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
-                                                   heavy_partials, s, cached && cached->heavy_known ? cached->heavy_hdr : nullptr);
+                                                   heavy_partials, s, group ? group->heavy_hdr : (cached && cached->heavy_known ? cached->heavy_hdr : nullptr), sets);
                     else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
-                                                              segs, seg_partials, s, shard ? nullptr : &fuse);
+                                                              segs, seg_partials, s, shard ? nullptr : &fuse, sets);
                 }
                 if (shard) {   // every rank summed its own gates: the rows are complete after one exchange
                     second_exchange_done = true;
@@ -473,7 +515,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 rc = wait_records(ctx, prec, batch, ticket);
                 if (!rc) rc = xflag_check();
                 if (rc) break;
-                const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1);
+                const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1, ctx->crew_member ? ctx->help_share : 0);
                 std::atomic<int> next{0};
                 const std::function<bool()> work = [&]() -> bool {
                     const int first = next.fetch_add(chunk, std::memory_order_relaxed);

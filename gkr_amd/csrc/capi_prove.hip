@@ -96,39 +96,58 @@ int gkr_proof_sizes(const gkr_circuit_desc* c, gkr_proof_sizes_t* out) {
     return GKR_OK;
 }
 
-// `batch` proofs of ONE circuit (different witnesses) advanced together: every layer's sumcheck runs as
-// one batched sumcheck (run_layer_batch), so a round costs one set of launches and one host round trip
-// for all proofs.  This is the multi-proof form of the reference's rayon par_iter over independent
-// (circuit, input) pairs (aggregator.rs:350-355) for the case where the circuits coincide
-// (BASELINE configs[3]: 64 inputs of one circom circuit).
-static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch,
-                            int require_zero_output, gkr_proof_buf* outs) {
-    using gkr::h64::F;
-    const auto t_entry = std::chrono::steady_clock::now();
-    int rc = check_circuit(ctx, c);
-    if (rc) return rc;
-    if (!input_values || !outs || batch < 1 || batch > 4096) return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of [1, 4096]");
-    for (int b = 0; b < batch; ++b) {
-        const gkr_proof_buf* out = &outs[b];
-        if (!out->sumcheck_coeffs || !out->sumcheck_len || !out->sumcheck_r || !out->q || !out->q_len || !out->z || !out->r ||
-            !out->d_coeffs || !out->input_coeffs)
-            return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
+// The circuit on the device: from the context's cache when this circuit was proven before, else validated, uploaded and
+// handed back in `fresh` (the caller caches it when its call succeeds, or drops it).  A cache hit is decided by two
+// independent 64-bit hashes over the k list and the gate arrays AND a comparison with the gate arrays as they were when the
+// entry was made: byte for byte for circuits of up to kExactCompareBytes of gate data (every circom-sized sub-circuit),
+// kSampleBlocks evenly spaced 4 KiB blocks beyond (a wide circuit's 12 MB of gate arrays: a full compare would double the
+// cost of the lookup).  include/gkr_amd.h says what that means for callers that share a context.
+static constexpr size_t kExactCompareBytes = (size_t)1 << 20, kSampleBlock = 4096, kSampleBlocks = 64;
+static void circuit_gate_bytes(const gkr_circuit_desc* c, std::vector<std::pair<const unsigned char*, size_t>>& parts) {
+    for (uint32_t i = 0; i < c->depth; ++i) {
+        const size_t gates = (size_t)1 << c->k[i];
+        parts.push_back({reinterpret_cast<const unsigned char*>(c->gate_type[i]), gates});
+        parts.push_back({reinterpret_cast<const unsigned char*>(c->left[i]), gates * 4});
+        parts.push_back({reinterpret_cast<const unsigned char*>(c->right[i]), gates * 4});
     }
-    const uint32_t L = c->depth;
-    for (uint32_t i = 0; i < L; ++i)
-        if (!c->gate_type[i] || !c->left[i] || !c->right[i]) return ctx->fail(GKR_ERR_INVALID, "null gate array");
-    const size_t n_in = (size_t)1 << c->k[L];
-    const bool dbg_pre = gkr::debug_timing();
-    auto us_since_entry = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(); };
-    // (a large input layer is validated where it lands, on the device: the host loop over 2^20 values took 1.6 ms of a 12 ms proof)
-    const bool check_on_device = n_in * (size_t)batch >= ((size_t)1 << 16);
-    if (!check_on_device && !all_canonical(input_values, n_in * batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
-    const double us_canon = us_since_entry();
-    GKR_ENTER(ctx);
-    hipStream_t s = ctx->stream;
+}
+// the bytes the retained copy holds of one array: all of it, or its sampled blocks
+static void for_each_retained_range(size_t total_bytes, size_t n, const std::function<void(size_t, size_t)>& f) {
+    if (total_bytes <= kExactCompareBytes || n <= kSampleBlock * 2) {
+        f((size_t)0, n);
+        return;
+    }
+    const size_t blocks = n / kSampleBlock < kSampleBlocks ? n / kSampleBlock : kSampleBlocks;
+    for (size_t b = 0; b < blocks; ++b) {
+        const size_t off = b + 1 == blocks ? n - kSampleBlock : (n - kSampleBlock) / (blocks - 1 ? blocks - 1 : 1) * b;
+        f(off, kSampleBlock);
+    }
+}
+static void retain_gate_bytes(const gkr_circuit_desc* c, std::vector<unsigned char>& out) {
+    std::vector<std::pair<const unsigned char*, size_t>> parts;
+    circuit_gate_bytes(c, parts);
+    size_t total = 0;
+    for (auto& p : parts) total += p.second;
+    out.clear();
+    for (auto& p : parts) for_each_retained_range(total, p.second, [&](size_t off, size_t len) { out.insert(out.end(), p.first + off, p.first + off + len); });
+}
+static bool retained_gate_bytes_match(const gkr_circuit_desc* c, const std::vector<unsigned char>& kept) {
+    std::vector<std::pair<const unsigned char*, size_t>> parts;
+    circuit_gate_bytes(c, parts);
+    size_t total = 0, at = 0;
+    for (auto& p : parts) total += p.second;
+    bool same = true;
+    for (auto& p : parts)
+        for_each_retained_range(total, p.second, [&](size_t off, size_t len) {
+            if (at + len > kept.size() || memcmp(kept.data() + at, p.first + off, len) != 0) same = false;
+            at += len;
+        });
+    return same && at == kept.size();
+}
 
-    // the circuit on the device: from the context's cache when this circuit was proven before (two independent
-    // 64-bit hashes over the k list and the gate arrays decide), else validated, uploaded and remembered
+static int find_or_upload_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c, PreparedCircuit** out, std::unique_ptr<PreparedCircuit>& fresh) {
+    const uint32_t L = c->depth;
+    hipStream_t s = ctx->stream;
     uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x9E3779B97F4A7C15ULL;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* q = static_cast<const unsigned char*>(p);
@@ -173,57 +192,182 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         mix(c->left[i], gates * 4);
         mix(c->right[i], gates * 4);
     }
-    const double us_hash = us_since_entry();
-    PreparedCircuit* pc = nullptr;
+    *out = nullptr;
     for (size_t i = 0; i < ctx->circuits.size(); ++i)
         if (ctx->circuits[i]->h1 == h1 && ctx->circuits[i]->h2 == h2 && ctx->circuits[i]->k.size() == L + 1 &&
-            memcmp(ctx->circuits[i]->k.data(), c->k, (L + 1) * sizeof(uint32_t)) == 0) {
+            memcmp(ctx->circuits[i]->k.data(), c->k, (L + 1) * sizeof(uint32_t)) == 0 && retained_gate_bytes_match(c, ctx->circuits[i]->retained)) {
             std::unique_ptr<PreparedCircuit> hit = std::move(ctx->circuits[i]);
             ctx->circuits.erase(ctx->circuits.begin() + i);
             ctx->circuits.push_back(std::move(hit));   // most recently used last
-            pc = ctx->circuits.back().get();
-            break;
+            *out = ctx->circuits.back().get();
+            return GKR_OK;
         }
-    const bool no_cache = gkr::opt(gkr::OPT_no_circuit_cache) != 0;
-    std::unique_ptr<PreparedCircuit> fresh;
-    struct DropFresh {   // an uncached or failed circuit's device arrays do not outlive the call
-        gkr_ctx* ctx;
-        std::unique_ptr<PreparedCircuit>& p;
-        ~DropFresh() {
-            if (p) {
-                (void)hipStreamSynchronize(ctx->stream);
-                p->release();
+    for (uint32_t i = 0; i < L; ++i) {
+        const size_t gates = (size_t)1 << c->k[i];
+        for (size_t g = 0; g < gates; ++g)
+            if (c->gate_type[i][g] > 1 || (c->left[i][g] >> c->k[i + 1]) || (c->right[i][g] >> c->k[i + 1]))
+                return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+    }
+    fresh.reset(new PreparedCircuit());
+    fresh->h1 = h1;
+    fresh->h2 = h2;
+    fresh->k.assign(c->k, c->k + L + 1);
+    fresh->lists.resize(L);
+    retain_gate_bytes(c, fresh->retained);
+    for (uint32_t i = 0; i < L; ++i) {
+        const size_t gates = (size_t)1 << c->k[i];
+        uint8_t* dg = nullptr;
+        uint32_t *dl_ = nullptr, *dr_ = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dg), gates));
+        fresh->gt.push_back(dg);
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dl_), gates * 4));
+        fresh->l.push_back(dl_);
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dr_), gates * 4));
+        fresh->r.push_back(dr_);
+        HIP_TRY(ctx, hipMemcpyAsync(dg, c->gate_type[i], gates, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dl_, c->left[i], gates * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dr_, c->right[i], gates * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // the caller's gate arrays may go away after the call
+    *out = fresh.get();
+    return GKR_OK;
+}
+
+// Can the layers of a circuit with this k list run in a lockstep group (proofs of DIFFERENT circuits in one launch per
+// pass)?  Every form of the gate passes takes per-proof gate lists except the segment form of very large layers.
+static bool k_list_groupable(const uint32_t* k, uint32_t depth) {
+    for (uint32_t i = 0; i < depth; ++i) {
+        const gkr::GateSpan span{0, (uint64_t)1 << k[i]};
+        if (gkr::gate_segs_words(span, k[i], k[i + 1]) != 0) return false;
+    }
+    return true;
+}
+
+// The proofs of `n_members` (circuit, witnesses) pairs advanced together: every layer's sumcheck runs as ONE batched
+// sumcheck (run_layer_batch), so a round costs one set of launches and one host round trip for all proofs.
+//   one member:   `batch` witnesses of ONE circuit -- the multi-proof form of the reference's rayon par_iter over independent
+//                 (circuit, input) pairs (aggregator.rs:350-355) where the circuits coincide (BASELINE configs[3]);
+//   several:      DIFFERENT circuits with the same k list (the <= 20 sub-circuits of one compiled R1CS come in a few shapes:
+//                 aggregator.rs:411-416) -- a LOCKSTEP GROUP: the gate passes and the layer evaluation take a per-proof table
+//                 of gate lists (gkr::GateSet), everything else is indexed by proof anyway.  One chain of launches and
+//                 hand-offs for the whole group instead of one per circuit, its round vectors hashed together.
+static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_members) {
+    using gkr::h64::F;
+    const auto t_entry = std::chrono::steady_clock::now();
+    if (!members || n_members < 1) return ctx->fail(GKR_ERR_INVALID, "no members");
+    const gkr_circuit_desc* c = members[0].circuit;
+    int rc = GKR_OK;
+    int batch = 0;
+    for (int m = 0; m < n_members; ++m) {
+        const gkr_prove_item& it = members[m];
+        rc = check_circuit(ctx, it.circuit);
+        if (rc) return rc;
+        if (!it.input_values || !it.outs || it.batch < 1 || it.batch > 4096) return ctx->fail(GKR_ERR_INVALID, "null pointer or batch out of [1, 4096]");
+        if (it.circuit->depth != c->depth || memcmp(it.circuit->k, c->k, (c->depth + 1) * sizeof(uint32_t)) != 0)
+            return ctx->fail(GKR_ERR_INVALID, "the circuits of a lockstep group must share their k list");
+        batch += it.batch;
+    }
+    if (batch > 4096) return ctx->fail(GKR_ERR_INVALID, "more than 4096 proofs in one group");
+    // per proof: its output buffers, its member
+    std::vector<gkr_proof_buf> outs_v((size_t)batch);
+    std::vector<int> member_of((size_t)batch), first_of((size_t)n_members);
+    {
+        int b = 0;
+        for (int m = 0; m < n_members; ++m) {
+            first_of[m] = b;
+            for (int i = 0; i < members[m].batch; ++i, ++b) {
+                outs_v[b] = members[m].outs[i];
+                member_of[b] = m;
             }
         }
+    }
+    gkr_proof_buf* const outs = outs_v.data();
+    for (int b = 0; b < batch; ++b) {
+        const gkr_proof_buf* out = &outs[b];
+        if (!out->sumcheck_coeffs || !out->sumcheck_len || !out->sumcheck_r || !out->q || !out->q_len || !out->z || !out->r ||
+            !out->d_coeffs || !out->input_coeffs)
+            return ctx->fail(GKR_ERR_INVALID, "null pointer in proof buffers");
+    }
+    const uint32_t L = c->depth;
+    for (int m = 0; m < n_members; ++m)
+        for (uint32_t i = 0; i < L; ++i)
+            if (!members[m].circuit->gate_type[i] || !members[m].circuit->left[i] || !members[m].circuit->right[i])
+                return ctx->fail(GKR_ERR_INVALID, "null gate array");
+    if (n_members > 1 && (ctx->transcript != GKR_TRANSCRIPT_HOST || !k_list_groupable(c->k, L)))
+        return ctx->fail(GKR_ERR_INVALID, "a lockstep group needs the host transcript and layers below the segment form's size");
+    const size_t n_in = (size_t)1 << c->k[L];
+    const bool dbg_pre = gkr::debug_timing();
+    auto us_since_entry = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count(); };
+    // (a large input layer is validated where it lands, on the device: the host loop over 2^20 values took 1.6 ms of a 12 ms proof)
+    const bool check_on_device = n_in * (size_t)batch >= ((size_t)1 << 16);
+    if (!check_on_device)
+        for (int m = 0; m < n_members; ++m)
+            if (!all_canonical(members[m].input_values, n_in * members[m].batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+    const double us_canon = us_since_entry();
+    GKR_ENTER(ctx);
+    hipStream_t s = ctx->stream;
+
+    // every member's circuit on the device (cache, or upload)
+    const bool no_cache = gkr::opt(gkr::OPT_no_circuit_cache) != 0;
+    std::vector<PreparedCircuit*> pcs((size_t)n_members, nullptr);
+    std::vector<std::unique_ptr<PreparedCircuit>> fresh((size_t)n_members);
+    struct DropFresh {   // an uncached or failed circuit's device arrays do not outlive the call
+        gkr_ctx* ctx;
+        std::vector<std::unique_ptr<PreparedCircuit>>& v;
+        ~DropFresh() {
+            bool any = false;
+            for (auto& p : v) any |= (bool)p;
+            if (any) (void)hipStreamSynchronize(ctx->stream);
+            for (auto& p : v)
+                if (p) p->release();
+        }
     } drop_fresh{ctx, fresh};
-    if (!pc) {
+    for (int m = 0; m < n_members; ++m) {
+        // (a member's circuit may be the very circuit of an earlier member: found in `fresh` then, not uploaded twice)
+        for (int e = 0; e < m && !pcs[m]; ++e)
+            if (members[e].circuit == members[m].circuit) pcs[m] = pcs[e];
+        if (pcs[m]) continue;
+        rc = find_or_upload_circuit(ctx, members[m].circuit, &pcs[m], fresh[m]);
+        if (rc) return rc;
+    }
+    PreparedCircuit* pc = pcs[0];
+    const bool any_fresh = [&] {
+        for (auto& p : fresh)
+            if (p) return true;
+        return false;
+    }();
+    const double us_hash = us_since_entry();
+
+    // A lockstep group: every member's gate lists must exist before the group's first launch (a lone circuit builds them
+    // inside its first layer sumcheck), and the passes over the gates get their per-proof table.
+    gkr::GateSet* d_sets = nullptr;            // [layer][proof]
+    std::vector<LayerGroup> groups;
+    if (n_members > 1) {
+        for (int m = 0; m < n_members; ++m)
+            for (uint32_t i = 0; i < L; ++i)
+                if (!pcs[m]->lists[i].ready) {
+                    rc = build_cached_gate_lists(ctx, (int)c->k[i], (int)c->k[i + 1], pcs[m]->gt[i], pcs[m]->l[i], pcs[m]->r[i], &pcs[m]->lists[i]);
+                    if (rc) return rc;
+                }
+        gkr::GateSet* h_sets = nullptr;
+        const size_t n_sets = (size_t)L * batch;
+        HIP_TRY(ctx, ctx->pinned_host("prove.sets", n_sets * sizeof(gkr::GateSet), reinterpret_cast<void**>(&h_sets)));
+        WS(ctx, "prove.dsets", gkr::GateSet, n_sets, d_sets);
+        groups.resize(L);
         for (uint32_t i = 0; i < L; ++i) {
-            const size_t gates = (size_t)1 << c->k[i];
-            for (size_t g = 0; g < gates; ++g)
-                if (c->gate_type[i][g] > 1 || (c->left[i][g] >> c->k[i + 1]) || (c->right[i][g] >> c->k[i + 1]))
-                    return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+            groups[i].d_sets = d_sets + (size_t)i * batch;
+            for (int b = 0; b < batch; ++b) {
+                const PreparedCircuit* p = pcs[member_of[b]];
+                const GateLists& gl = p->lists[i];
+                h_sets[(size_t)i * batch + b] = gkr::GateSet{gl.offsets, gl.cursor, gl.list, gl.heavy, p->gt[i], p->l[i], p->r[i], 0};
+            }
+            for (int m = 0; m < n_members; ++m) {
+                const GateLists& gl = pcs[m]->lists[i];
+                for (int half = 0; half < 2; ++half)
+                    if (!gl.heavy_known || gl.heavy_hdr[2 * half]) groups[i].heavy_hdr[2 * half] = 1;   // some member has heavy buckets in this half
+            }
         }
-        fresh.reset(new PreparedCircuit());
-        fresh->h1 = h1;
-        fresh->h2 = h2;
-        fresh->k.assign(c->k, c->k + L + 1);
-        fresh->lists.resize(L);
-        for (uint32_t i = 0; i < L; ++i) {
-            const size_t gates = (size_t)1 << c->k[i];
-            uint8_t* dg = nullptr;
-            uint32_t *dl_ = nullptr, *dr_ = nullptr;
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dg), gates));
-            fresh->gt.push_back(dg);
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dl_), gates * 4));
-            fresh->l.push_back(dl_);
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dr_), gates * 4));
-            fresh->r.push_back(dr_);
-            HIP_TRY(ctx, hipMemcpyAsync(dg, c->gate_type[i], gates, hipMemcpyHostToDevice, s));
-            HIP_TRY(ctx, hipMemcpyAsync(dl_, c->left[i], gates * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(ctx, hipMemcpyAsync(dr_, c->right[i], gates * 4, hipMemcpyHostToDevice, s));
-        }
-        HIP_TRY(ctx, hipStreamSynchronize(s));   // the caller's gate arrays may go away after the call
-        pc = fresh.get();
+        gkr::launch_copy_words(h_sets, d_sets, n_sets * sizeof(gkr::GateSet) / 4, s);
     }
 
     // forward-evaluate every layer of every proof on the device (calculate_input, convert.rs:787-831)
@@ -239,10 +383,12 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     if (in_bytes <= kKernelCopyLimit) {
         gkr_fr* h_in = nullptr;
         HIP_TRY(ctx, ctx->pinned_host("prove.in", in_bytes, reinterpret_cast<void**>(&h_in)));
-        memcpy(h_in, input_values, in_bytes);
+        for (int m = 0; m < n_members; ++m)
+            memcpy(h_in + (size_t)first_of[m] * n_in, members[m].input_values, n_in * members[m].batch * sizeof(gkr_fr));
         gkr::launch_copy_words(h_in, dW[L], in_bytes / 4, s);
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(dW[L], input_values, in_bytes, hipMemcpyHostToDevice, s));
+        for (int m = 0; m < n_members; ++m)
+            HIP_TRY(ctx, hipMemcpyAsync(dW[L] + (size_t)first_of[m] * n_in, members[m].input_values, n_in * members[m].batch * sizeof(Fr), hipMemcpyHostToDevice, s));
     }
     uint32_t* d_in_flag = nullptr;
     uint32_t h_in_flag = 0;
@@ -253,7 +399,8 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         HIP_TRY(ctx, hipMemcpyAsync(&h_in_flag, d_in_flag, 4, hipMemcpyDeviceToHost, s));
     }
     for (int i = (int)L - 1; i >= 0; --i)
-        gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s);
+        gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s,
+                               n_members > 1 ? groups[i].d_sets : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
     const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
@@ -348,13 +495,13 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     const auto tpb0 = std::chrono::steady_clock::now();
     const bool account = accounting_on();
     if (dbg_pb || account) t_account = ThreadTimeAccount();
-    if (dbg_pb) fprintf(stderr, "[gkr timing] prove: circuit %s, forward evaluation + readback done\n", fresh ? "uploaded" : "from cache");
+    if (dbg_pb) fprintf(stderr, "[gkr timing] prove: %d circuit(s) %s, forward evaluation + readback done\n", n_members, any_fresh ? "uploaded" : "from cache");
     if (dbg_pre)
         fprintf(stderr, "[gkr timing] prove, before the layers: input check %.0f us, circuit hash %.0f us, upload + evaluation + Moebius + readback %.0f us\n", us_canon,
                 us_hash - us_canon, us_since_entry() - us_hash);
     if (h_in_flag) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     for (int b = 0; b < batch; ++b) {
-        if (require_zero_output && !gkr::h64::is_zero(hW0_first ? hW0_first[b] : hW[0][(size_t)b << c->k[0]]))
+        if (members[member_of[b]].require_zero_output && !gkr::h64::is_zero(hW0_first ? hW0_first[b] : hW[0][(size_t)b << c->k[0]]))
             return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
         // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
         std::vector<F> co;
@@ -409,7 +556,7 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
         ctx->rounds_ahead = 0;
         for (uint32_t later = i + 1; later < L; ++later) ctx->rounds_ahead += 2 * (int)c->k[later + 1];
         rc = run_layer_batch(ctx, batch, k_i, k, pc->gt[i], pc->l[i], pc->r[i], z_cur.data(), dW[i + 1], scp.data(), slp.data(),
-                             srp.data(), nullptr, &pc->lists[i]);
+                             srp.data(), nullptr, &pc->lists[i], n_members > 1 ? &groups[i] : nullptr);
         ctx->rounds_ahead = 0;
         if (rc) {
             (void)hipStreamSynchronize(ctx->aux);   // earlier layers' line restrictions still write the pinned q buffers the next call reuses
@@ -504,15 +651,23 @@ static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_f
     }
     copier.finish();
     if (copier.err != hipSuccess) return ctx->hip_fail(copier.err, "copy of the d / input_func coefficients to the proof buffers");
-    if (fresh && !no_cache) {
+    for (auto& f : fresh) {
+        if (!f || no_cache) continue;
         constexpr size_t kMaxCachedCircuits = 64;   // three aggregation steps' worth of sub-circuits
         if (ctx->circuits.size() >= kMaxCachedCircuits) {
+            // (never an entry this call is still using -- a group's members are all in use until here)
             ctx->circuits.front()->release();
             ctx->circuits.erase(ctx->circuits.begin());
         }
-        ctx->circuits.push_back(std::move(fresh));
+        ctx->circuits.push_back(std::move(f));
     }
     return GKR_OK;
+}
+
+static int prove_batch_impl(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int batch, int require_zero_output,
+                            gkr_proof_buf* outs) {
+    gkr_prove_item one{c, input_values, batch, require_zero_output, outs, 0};
+    return prove_group_impl(ctx, &one, 1);
 }
 
 int gkr_prove(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input_values, int require_zero_output,
@@ -530,13 +685,33 @@ int gkr_prove_batch(gkr_ctx* ctx, const gkr_circuit_desc* c, const gkr_fr* input
 // ---- gkr_prove_many: the items of one aggregation step proven side by side ----------------------------------------
 static void crew_prove_items(ProveCrew* crew, ProveCrew::Member* m) {
     if (accounting_on()) host_account_totals().wake_ns.fetch_add((uint64_t)((now_us_dbg() - crew->t_call_us) * 1e3), std::memory_order_relaxed);
-    for (int idx : m->items) {
-        gkr_prove_item& it = crew->items[idx];
-        if (!it.circuit || !it.input_values || !it.outs) {
-            it.status = m->ctx->fail(GKR_ERR_INVALID, "null pointer in a prove item");
+    // threads per unit in this call: how finely a unit cuts its hashing into pieces (capi_layer.hip, the product passes)
+    m->ctx->help_share = crew->units->empty() ? 1 : (crew->active + (int)crew->units->size() - 1) / (int)crew->units->size();
+    for (int u : m->items) {
+        const std::vector<int>& unit = (*crew->units)[u];
+        auto prove_one = [&](int idx) {
+            gkr_prove_item& it = crew->items[idx];
+            if (!it.circuit || !it.input_values || !it.outs) {
+                it.status = m->ctx->fail(GKR_ERR_INVALID, "null pointer in a prove item");
+                return;
+            }
+            it.status = prove_batch_impl(m->ctx, it.circuit, it.input_values, it.batch, it.require_zero_output, it.outs);
+        };
+        if (unit.size() == 1) {
+            prove_one(unit[0]);
             continue;
         }
-        it.status = prove_batch_impl(m->ctx, it.circuit, it.input_values, it.batch, it.require_zero_output, it.outs);
+        // a lockstep group: its items' proofs advance together, one launch per pass
+        std::vector<gkr_prove_item> group;
+        for (int idx : unit) group.push_back(crew->items[idx]);
+        const int rc = prove_group_impl(m->ctx, group.data(), (int)group.size());
+        if (rc == GKR_OK) {
+            for (int idx : unit) crew->items[idx].status = GKR_OK;
+        } else {
+            // something in the group failed (a bad gate, a witness that does not satisfy its circuit ...): the items one by
+            // one, so that every item gets its own status and the others are still proven
+            for (int idx : unit) prove_one(idx);
+        }
     }
     __atomic_fetch_sub(&crew->busy, 1, __ATOMIC_ACQ_REL);
     (void)gkr_host_help_while(&crew->busy);   // out of items: pieces of the others' host work until all are done
@@ -678,12 +853,47 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     const size_t caller_n = n_items;
     items = work.data();
     n_items = work.size();
-    // deal the items out by estimated cost, longest first, each to the member with the least so far (deterministic)
-    std::vector<std::pair<double, int>> cost(n_items);
-    for (size_t i = 0; i < n_items; ++i) {
-        cost[i] = {item_cost(items[i]), (int)i};
-        items[i].status = GKR_OK;
+    // Units: items whose circuits share their k list advance in LOCKSTEP (prove_group_impl) -- the <= 20 sub-circuits of one
+    // compiled R1CS come in a few shapes (the 16 of a 262 144-constraint R1CS: 8 x [14,15,15,15], 7 x [14,15,16,15,15,15], one
+    // other), and 16 chains of one-block kernels are bound by the four hardware queues they share, not by the chip.
+    std::vector<std::vector<int>> units;
+    {
+        const bool lockstep = gkr::opt(gkr::OPT_prove_many_lockstep) != 0;
+        const long long cap_opt = gkr::opt(gkr::OPT_lockstep_max_proofs);
+        const int cap = cap_opt > 0 && cap_opt <= 4096 ? (int)cap_opt : 1024;
+        std::vector<int> unit_proofs;
+        std::vector<bool> taken(n_items, false);
+        for (size_t i = 0; i < n_items; ++i) {
+            if (taken[i]) continue;
+            taken[i] = true;
+            units.push_back({(int)i});
+            unit_proofs.push_back(items[i].batch);
+            const gkr_circuit_desc* c = items[i].circuit;
+            if (!lockstep || !c || !c->k || c->depth < 1 || c->depth > 4096 || !items[i].input_values || !items[i].outs || items[i].batch < 1) continue;
+            if (check_circuit(nullptr, c) != GKR_OK || !k_list_groupable(c->k, c->depth)) continue;
+            for (size_t j = i + 1; j < n_items; ++j) {
+                const gkr_circuit_desc* d = items[j].circuit;
+                if (taken[j] || !d || !d->k || d->depth != c->depth || !items[j].input_values || !items[j].outs || items[j].batch < 1) continue;
+                if (memcmp(d->k, c->k, (c->depth + 1) * sizeof(uint32_t)) != 0) continue;
+                // (the group's proofs: at most `cap`; a member larger than the rest of the room starts a group of its own later)
+                if (unit_proofs.back() + items[j].batch > cap) continue;
+                taken[j] = true;
+                units.back().push_back((int)j);
+                unit_proofs.back() += items[j].batch;
+            }
+        }
     }
+    auto unit_cost = [&](const std::vector<int>& u) {
+        gkr_prove_item all = items[u[0]];
+        for (size_t e = 1; e < u.size(); ++e) all.batch += items[u[e]].batch;
+        return item_cost(all);
+    };
+    // deal the units out by estimated cost, longest first, each to the member with the least so far (deterministic)
+    std::vector<std::pair<double, int>> cost(units.size());
+    for (size_t i = 0; i < n_items; ++i) items[i].status = GKR_OK;
+    for (size_t u = 0; u < units.size(); ++u) cost[u] = {unit_cost(units[u]), (int)u};
+    // (members beyond the number of units prove nothing themselves: they take pieces of the units' host work from the start --
+    // a lockstep group's round vectors are hashed by the whole crew, not by the one thread that launches its kernels)
     std::stable_sort(cost.begin(), cost.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
     std::vector<double> load(want, 0.0);
     for (int m = 0; m < want; ++m) crew->members[m]->items.clear();
@@ -700,6 +910,7 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     {
         std::lock_guard<std::mutex> g(crew->mu);
         crew->items = items;
+        crew->units = &units;
         crew->active = want;
         crew->finished = 0;
         __atomic_store_n(&crew->busy, want, __ATOMIC_RELEASE);
@@ -712,20 +923,22 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
         std::unique_lock<std::mutex> g(crew->mu);
         crew->cv_done.wait(g, [&] { return crew->finished == want - 1; });
         crew->items = nullptr;
+        crew->units = nullptr;
     }
     ctx->crew_member = false;
     ctx->transcript = saved_transcript;
     for (size_t i = 0; i < caller_n; ++i) caller_items[i].status = GKR_OK;
     int first_bad = GKR_OK;
     for (int m = 0; m < want; ++m)
-        for (int idx : crew->members[m]->items)
-            if (items[idx].status != GKR_OK) {
-                if (caller_items[origin[idx]].status == GKR_OK) caller_items[origin[idx]].status = items[idx].status;
-                if (first_bad == GKR_OK) {
-                    if (m) ctx->err = crew->members[m]->ctx->err;
-                    first_bad = items[idx].status;
+        for (int u : crew->members[m]->items)
+            for (int idx : units[u])
+                if (items[idx].status != GKR_OK) {
+                    if (caller_items[origin[idx]].status == GKR_OK) caller_items[origin[idx]].status = items[idx].status;
+                    if (first_bad == GKR_OK) {
+                        if (m) ctx->err = crew->members[m]->ctx->err;
+                        first_bad = items[idx].status;
+                    }
                 }
-            }
     return first_bad;
 }
 
