@@ -154,9 +154,9 @@ inline int hash_chunk_size(int tables, int threads, int help_share = 0) {
     if (forced == 8 || forced == 16) return (int)forced;
     // One of a crew's units (gkr_prove_many) with `help_share` threads to itself on average: a FEW proofs in lockstep are a
     // latency chain -- a lone transcript's scalar hash takes 12 us per round vector, an IFMA call ~25 us whether one lane is
-    // filled or sixteen -- so they go out as pieces of one or two proofs to the threads that have no unit of their own;
+    // filled or sixteen -- so they go out one proof per piece to the threads that have no unit of their own;
     // many proofs are a throughput problem: whole eight- or sixteen-lane calls.
-    if (help_share > 1 && tables <= 2 * help_share) return tables <= help_share ? 1 : 2;
+    if (help_share > 1 && tables <= 3 * help_share) return 1;
     return tables >= 32 * threads ? 16 : 8;
 }
 

@@ -100,9 +100,9 @@ int gkr_proof_sizes(const gkr_circuit_desc* c, gkr_proof_sizes_t* out) {
 // handed back in `fresh` (the caller caches it when its call succeeds, or drops it).  A cache hit is decided by two
 // independent 64-bit hashes over the k list and the gate arrays AND a comparison with the gate arrays as they were when the
 // entry was made: byte for byte for circuits of up to kExactCompareBytes of gate data (every circom-sized sub-circuit),
-// kSampleBlocks evenly spaced 4 KiB blocks beyond (a wide circuit's 12 MB of gate arrays: a full compare would double the
-// cost of the lookup).  include/gkr_amd.h says what that means for callers that share a context.
-static constexpr size_t kExactCompareBytes = (size_t)1 << 20, kSampleBlock = 4096, kSampleBlocks = 64;
+// kSampleBlocks evenly spaced 4 KiB blocks of every gate array beyond (a wide circuit's 12 MB of gate arrays: a full compare
+// would double the cost of the lookup).  include/gkr_amd.h says what that means for callers that share a context.
+static constexpr size_t kExactCompareBytes = (size_t)1 << 20, kSampleBlock = 4096, kSampleBlocks = 8;
 static void circuit_gate_bytes(const gkr_circuit_desc* c, std::vector<std::pair<const unsigned char*, size_t>>& parts) {
     for (uint32_t i = 0; i < c->depth; ++i) {
         const size_t gates = (size_t)1 << c->k[i];
@@ -145,9 +145,9 @@ static bool retained_gate_bytes_match(const gkr_circuit_desc* c, const std::vect
     return same && at == kept.size();
 }
 
-static int find_or_upload_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c, PreparedCircuit** out, std::unique_ptr<PreparedCircuit>& fresh) {
+// two independent 64-bit hashes over the k list and the gate arrays (pure: a group's members are hashed side by side)
+static void circuit_hashes(const gkr_circuit_desc* c, uint64_t* out_h1, uint64_t* out_h2) {
     const uint32_t L = c->depth;
-    hipStream_t s = ctx->stream;
     uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x9E3779B97F4A7C15ULL;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* q = static_cast<const unsigned char*>(p);
@@ -192,6 +192,14 @@ static int find_or_upload_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c, Prepa
         mix(c->left[i], gates * 4);
         mix(c->right[i], gates * 4);
     }
+    *out_h1 = h1;
+    *out_h2 = h2;
+}
+
+static int find_or_upload_circuit(gkr_ctx* ctx, const gkr_circuit_desc* c, uint64_t h1, uint64_t h2, PreparedCircuit** out,
+                                  std::unique_ptr<PreparedCircuit>& fresh) {
+    const uint32_t L = c->depth;
+    hipStream_t s = ctx->stream;
     *out = nullptr;
     for (size_t i = 0; i < ctx->circuits.size(); ++i)
         if (ctx->circuits[i]->h1 == h1 && ctx->circuits[i]->h2 == h2 && ctx->circuits[i]->k.size() == L + 1 &&
@@ -322,12 +330,25 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
                 if (p) p->release();
         }
     } drop_fresh{ctx, fresh};
+    // (hashing a circuit's gate arrays costs ~0.1 ms per MB: the members of a group are hashed side by side, by whichever
+    // threads of the crew have nothing of their own -- one after the other they were 0.9 ms at the head of a 9 ms step)
+    std::vector<uint64_t> hs((size_t)2 * n_members);
+    {
+        std::atomic<int> next{0};
+        const std::function<bool()> work = [&]() -> bool {
+            const int m = next.fetch_add(1, std::memory_order_relaxed);
+            if (m >= n_members) return false;
+            circuit_hashes(members[m].circuit, &hs[2 * (size_t)m], &hs[2 * (size_t)m + 1]);
+            return true;
+        };
+        run_pieces(nullptr, &work, n_members > 1);
+    }
     for (int m = 0; m < n_members; ++m) {
         // (a member's circuit may be the very circuit of an earlier member: found in `fresh` then, not uploaded twice)
         for (int e = 0; e < m && !pcs[m]; ++e)
             if (members[e].circuit == members[m].circuit) pcs[m] = pcs[e];
         if (pcs[m]) continue;
-        rc = find_or_upload_circuit(ctx, members[m].circuit, &pcs[m], fresh[m]);
+        rc = find_or_upload_circuit(ctx, members[m].circuit, hs[2 * (size_t)m], hs[2 * (size_t)m + 1], &pcs[m], fresh[m]);
         if (rc) return rc;
     }
     PreparedCircuit* pc = pcs[0];
@@ -475,7 +496,7 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
             // (of a W_0 whose coefficients come from the device only output 0 of every proof is looked at: "must be zero")
             F* dst = nullptr;
             HIP_TRY(ctx, ctx->pinned_host("prove.hW0first", sizeof(F) * (size_t)batch, reinterpret_cast<void**>(&dst)));
-            for (int b = 0; b < batch; ++b) gkr::launch_copy_words(dW[0] + ((size_t)b << c->k[0]), dst + b, 8, s);
+            gkr::launch_copy_rows(dW[0], (size_t)8 << c->k[0], dst, 8, 8, (uint32_t)batch, s);   // (one launch: 8 words of every proof's table)
             hW0_first = dst;
             continue;
         }

@@ -235,6 +235,8 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
                        const Fr* prev, Fr* out, uint32_t batch, uint32_t prev_stride, hipStream_t s, const GateSet* sets = nullptr);
 // words 32-bit words src -> dst (16-byte aligned when words >= 4); either side may be pinned host memory
 void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s);
+// rows x words: row r from src + r * src_stride_words to dst + r * dst_stride_words (32-bit words)
+void launch_copy_rows(const void* src, size_t src_stride_words, void* dst, size_t dst_stride_words, uint32_t words, uint32_t rows, hipStream_t s);
 // out[proof][g] = eq(points[proof * stride + first ..+nvars), g), nvars <= 28; points may be pinned host memory
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
                      hipStream_t s);

@@ -807,6 +807,17 @@ __global__ void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restr
     for (size_t i = quads * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// `rows` rows of `words` 32-bit words each, row r from src + r * src_stride_words to dst + r * dst_stride_words (the first
+// value of every proof's table in ONE launch: a launch per proof cost a lockstep group seven launches where a lone proof has one)
+__global__ void k_copy_rows(const uint32_t* __restrict__ src, size_t src_stride_words, uint32_t* __restrict__ dst, size_t dst_stride_words,
+                            uint32_t words, uint32_t rows) {
+    const size_t total = (size_t)words * rows;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / words, w = i % words;
+        dst[r * dst_stride_words + w] = src[r * src_stride_words + w];
+    }
+}
+
 // out[proof][g] = eq(point, g) = prod_i (bit_i(g) ? x_i : 1 - x_i) over the `nvars` coordinates x_i = point[first + i] of
 // the proof's point (variable `first` = most significant index bit), canonical or in Montgomery form.  The points are
 // read where the host wrote them (pinned memory): no copy engine, no transfer call on the round path.  Every entry is
@@ -1991,6 +2002,12 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s) 
     if (!words) return;
     hipLaunchKernelGGL(k_copy_words, dim3(blocks_for(words / 4 + 1, 1024)), dim3(256), 0, s, static_cast<const uint32_t*>(src),
                        static_cast<uint32_t*>(dst), words);
+}
+
+void launch_copy_rows(const void* src, size_t src_stride_words, void* dst, size_t dst_stride_words, uint32_t words, uint32_t rows, hipStream_t s) {
+    if (!words || !rows) return;
+    hipLaunchKernelGGL(k_copy_rows, dim3(blocks_for((size_t)words * rows, 1024)), dim3(256), 0, s, static_cast<const uint32_t*>(src), src_stride_words,
+                       static_cast<uint32_t*>(dst), dst_stride_words, words, rows);
 }
 
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
