@@ -317,6 +317,7 @@ struct gkr_ctx {
     std::unique_ptr<gkr::SpinPool> pool;       // host transcript workers (lazy)
     std::unique_ptr<gkr::SpinPool> solo_pool;  // the empty pool a context uses while it is one of a crew (gkr_prove_many)
     std::unique_ptr<AsyncWorker> copier;       // helper thread for a wide proof's coefficient copies (lazy)
+    std::unique_ptr<AsyncWorker> liner;        // helper thread that issues a wide layer's line-restriction launches on the side stream (lazy)
     void* mle_arrivals_zeroed = nullptr;       // the same for the plain sumcheck's latency-bound passes
     void* arrivals_zeroed = nullptr;           // the product passes' arrival counters: zeroed once per allocation (every pass leaves them zero)
     bool crew_member = false;                  // one thread of several proving side by side: no workers of its own

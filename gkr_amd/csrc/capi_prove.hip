@@ -399,13 +399,21 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     }
     // Small transfers go through pinned buffers and a copy kernel, not through the runtime's transfer calls (see
     // k_copy_words); large ones (a 2^20-value input layer) keep the copy engine's bandwidth.
-    constexpr size_t kKernelCopyLimit = (size_t)4 << 20;
+    constexpr size_t kKernelCopyLimit = (size_t)4 << 20, kGroupCopyLimit = (size_t)64 << 20;
     const size_t in_bytes = n_in * batch * sizeof(Fr);
-    if (in_bytes <= kKernelCopyLimit) {
+    if (in_bytes <= (n_members > 1 ? kGroupCopyLimit : kKernelCopyLimit)) {
         gkr_fr* h_in = nullptr;
         HIP_TRY(ctx, ctx->pinned_host("prove.in", in_bytes, reinterpret_cast<void**>(&h_in)));
-        for (int m = 0; m < n_members; ++m)
+        // (a group's members are staged side by side by the crew's free threads: seven 1 MiB input layers one after the other
+        // were 0.3 ms at the head of the group's chain)
+        std::atomic<int> next{0};
+        const std::function<bool()> work = [&]() -> bool {
+            const int m = next.fetch_add(1, std::memory_order_relaxed);
+            if (m >= n_members) return false;
             memcpy(h_in + (size_t)first_of[m] * n_in, members[m].input_values, n_in * members[m].batch * sizeof(gkr_fr));
+            return true;
+        };
+        run_pieces(nullptr, &work, n_members > 1 && in_bytes >= ((size_t)1 << 20));
         gkr::launch_copy_words(h_in, dW[L], in_bytes / 4, s);
     } else {
         for (int m = 0; m < n_members; ++m)
@@ -566,6 +574,15 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     Fr* d_lrbc = nullptr;   // per layer: the next layer's restriction may start before this one's last step has read them
     WS(ctx, "prove.lrbc", Fr, (size_t)L * batch * 2 * kmax, d_lrbc);
     HIP_TRY(ctx, ctx->aux_stream(0));
+    struct LineWorker {   // every path out of the call: the helper has issued what it was handed before the side stream is waited for
+        AsyncWorker* worker = nullptr;
+        bool started = false;
+        void finish() {
+            if (started) worker->wait();
+            started = false;
+        }
+        ~LineWorker() { finish(); }
+    } liner;
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = c->k[i], k = c->k[i + 1];
         for (int b = 0; b < batch; ++b) {
@@ -580,6 +597,7 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
                              srp.data(), nullptr, &pc->lists[i], n_members > 1 ? &groups[i] : nullptr);
         ctx->rounds_ahead = 0;
         if (rc) {
+            liner.finish();
             (void)hipStreamSynchronize(ctx->aux);   // earlier layers' line restrictions still write the pinned q buffers the next call reuses
             return rc;
         }
@@ -588,9 +606,28 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         {
             gkr_fr* lines = h_lines + (size_t)i * batch * 2 * kmax;
             for (int b = 0; b < batch; ++b) memcpy(lines + (size_t)b * 2 * k, srp[b], (size_t)2 * k * sizeof(gkr_fr));
-            Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
-            gkr::launch_line_restriction(dW[i + 1], (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, d_lrbc + (size_t)i * batch * 2 * kmax, d_q + q_off * batch,
-                                         d_qlen + (size_t)i * batch, (uint32_t)batch, ctx->aux);
+            const Fr* Wn = dW[i + 1];
+            Fr* bcm = d_lrbc + (size_t)i * batch * 2 * kmax;
+            Fr* qdst = d_q + q_off * batch;
+            uint32_t* qlen_dst = d_qlen + (size_t)i * batch;
+            hipStream_t aux = ctx->aux;
+            if (k > 12 && ctx->profile == 0) {
+                // A wide layer's restriction is 4 + (k - 6) + 1 launches on the side stream -- output only, but issued by THIS
+                // thread they were ~0.15 ms per layer of launch calls on the proof's round path (five layers of 2^15 values:
+                // 0.7 ms of a 5 ms proof).  A helper thread of the context issues them; the side stream keeps their order.
+                if (!ctx->liner) ctx->liner.reset(new AsyncWorker());
+                liner.worker = ctx->liner.get();
+                liner.started = true;
+                const int device = ctx->device;
+                const uint32_t ub = (uint32_t)batch, uk = (uint32_t)k;
+                ctx->liner->run([=]() {
+                    if (hipSetDevice(device) != hipSuccess) return;
+                    gkr::launch_line_restriction(Wn, uk, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, bcm, qdst, qlen_dst, ub, aux);
+                });
+            } else {
+                Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);
+                gkr::launch_line_restriction(Wn, (uint32_t)k, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, bcm, qdst, qlen_dst, (uint32_t)batch, aux);
+            }
         }
         auto finish = [&](int b) {
             const gkr_fr* sr = srp[b];
@@ -638,6 +675,7 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     {
         HIP_TRY(ctx, hipGetLastError());
         copier.finish();   // (all coefficient copies are queued on the side stream before it is waited for)
+        liner.finish();    // (and all line restrictions)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
         const F* hq = reinterpret_cast<const F*>(d_q);
         const uint32_t* hqlen = d_qlen;

@@ -48,3 +48,32 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def subsets():
+    """gkr_prove_many on subsets of the step's items: every shape's group on its own, then all together."""
+    nrounds = 65536
+    step = ProvingStep(synth.mimc7_demo_r1cs(nrounds=nrounds))
+    inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2, 3, nrounds=nrounds))]))
+    shapes = {}
+    for j, c in enumerate(step.circuits):
+        shapes.setdefault(tuple(c.get_k_list()), []).append(j)
+    with Context(0) as ctx:
+        sets = [("all", list(range(len(step.circuits))))] + [("only k=%s" % list(ks), js) for ks, js in shapes.items()]
+        for threads in (14, 8):
+            for name, js in sets:
+                work = [(step.circuits[j], inputs[j]) for j in js]
+                prepared = ctx.prepare_many(work)
+                for _ in range(3):
+                    ctx.prove_many_raw(prepared, threads)
+                each = []
+                for _ in range(20):
+                    t = time.perf_counter()
+                    ctx.prove_many_raw(prepared, threads)
+                    each.append((time.perf_counter() - t) * 1e3)
+                print({"items": name, "n": len(js), "threads": threads, "median_ms": round(statistics.median(each), 3), "min_ms": round(min(each), 3)}, flush=True)
+    step.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "subsets":
+    subsets()
