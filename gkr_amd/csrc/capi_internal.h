@@ -209,19 +209,16 @@ using namespace gkr_host;
 // the circuit, and an aggregation step proves the same <= 20 circuits for input after input.
 struct GateLists {
     uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
-    uint32_t* heavy = nullptr;   // wide layers: the work lists of the buckets too long for a lane group (kernels_wide.hip)
-    uint32_t heavy_hdr[4] = {0, 0, 0, 0};   // ... and their header as read back when they were built (heavy_known)
-    bool heavy_known = false;
+    uint32_t* plan = nullptr;    // wide layers: the item plan of the gate passes (kernels_wide.hip, launch_gate_plan)
     gkr::GateSegs segs;   // the lists' segments (large layers; segs.words is one more device allocation)
     bool ready = false;
     void release() {
         if (offsets) (void)hipFree(offsets);
         if (cursor) (void)hipFree(cursor);
         if (list) (void)hipFree(list);
-        if (heavy) (void)hipFree(heavy);
+        if (plan) (void)hipFree(plan);
         if (segs.words) (void)hipFree(segs.words);
-        offsets = cursor = list = heavy = nullptr;
-        heavy_known = false;
+        offsets = cursor = list = plan = nullptr;
         segs = gkr::GateSegs();
         ready = false;
     }
@@ -656,11 +653,9 @@ struct LayerShardArgs {
     const gkr_exchange_dev* dev = nullptr;  // device exchange: limbs widened into the caller's device buffer, summed on the stream
 };
 // A lockstep group (gkr_prove_many): the proofs of a launch belong to DIFFERENT circuits whose layer has this shape; the
-// passes over the gates read each proof's lists through d_sets (one gkr::GateSet per proof, device memory).  heavy_hdr: [2 * half]
-// != 0 when some member has heavy buckets in that half (the wide layers' work lists).
+// passes over the gates read each proof's lists through d_sets (one gkr::GateSet per proof, device memory).
 struct LayerGroup {
     const gkr::GateSet* d_sets = nullptr;
-    uint32_t heavy_hdr[4] = {0, 0, 0, 0};
 };
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z,
                     const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r, const LayerShardArgs* shard = nullptr,

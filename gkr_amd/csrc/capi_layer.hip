@@ -173,7 +173,7 @@ int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, c
     if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
     if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
     if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
-    if (wide && !cached->heavy) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->heavy), gkr::gate_heavy_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
+    if (wide && !cached->plan) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->plan), gkr::gate_plan_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));
     HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
     if (const size_t words = gkr::gate_lists_lds_scratch_words(span.count, (uint32_t)k)) WS(ctx, "gates.lds", uint32_t, words, lds_scratch);
@@ -181,14 +181,12 @@ int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, c
         Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
         gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, cached->offsets, cached->cursor, g_bsums, cached->list, bad, lds_scratch,
                                &cached->segs, nullptr, s);
-        if (wide) gkr::launch_gate_heavy_lists(span, (uint32_t)k, cached->offsets, cached->cursor, cached->heavy, s);
+        if (wide) gkr::launch_gate_plan(span, (uint32_t)k, cached->offsets, cached->cursor, cached->list, cached->plan, s);
     }
     uint32_t hbad = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
-    if (wide) HIP_TRY(ctx, hipMemcpyAsync(cached->heavy_hdr, cached->heavy, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
-    cached->heavy_known = wide;
     cached->ready = true;
     return GKR_OK;
 }
@@ -262,8 +260,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     Fr *U = nullptr, *V = nullptr, *d_eq = nullptr;
     gkr_fr* h_u = nullptr;   // pinned: u = (r_1 .. r_k) of every proof, from which the device builds eq(u, .)
     Fr *e_hi = nullptr, *e_lo = nullptr;
-    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_heavy = nullptr;
-    Fr* heavy_partials = nullptr;
+    uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_plan = nullptr;
+    Fr *item_partials = nullptr, *E = nullptr;   // wide layers: the item passes' scratch, eq(z, .) as a table
     // where eq(z, g) is split into E_hi, E_lo: in the middle, or -- large layers, whose gate passes run over segments
     // of the sorted lists (gate_seg.h) -- where the segments are cut
     const uint32_t kl = gkr::gate_seg_shift(span, (uint32_t)k_i, (uint32_t)k);
@@ -303,7 +301,16 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 gkr::launch_depends_wide(d_W, (uint32_t)k, dep_bits, dep, h_dep, (uint32_t)batch, s);
             }
         }
-        if (wide) WS(ctx, "gates.heavypart", Fr, gkr::gate_heavy_partial_elems(span.count, (uint32_t)k) * batch, heavy_partials);
+        if (wide) {
+            // eq(z, g) for every gate index of the layer (of the whole layer also when this rank holds a share of the gates: the
+            // lists carry indices relative to the share's first gate, the passes add it back), canonical
+            WS(ctx, "gates.itempart", Fr, gkr::gate_plan_partial_elems(span.count, (uint32_t)k) * batch, item_partials);
+            WS(ctx, "pred.E", Fr, (size_t)batch << k_i, E);
+            gkr_fr* hz2 = nullptr;
+            HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz2)));
+            Timed t(ctx, "eq_table_z", ((double)batch * 32.0) * (double)((size_t)1 << k_i));
+            gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz2), (uint32_t)k_i, 0u, (uint32_t)k_i, E, false, (uint32_t)batch, s);
+        }
         if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)
         if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
         if (cached && cached->ready) {
@@ -311,8 +318,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             g_offsets = cached->offsets;   // the circuit's lists from an earlier call (validated then)
             g_cursor = cached->cursor;
             g_list = cached->list;
-            g_heavy = cached->heavy;
-            if (wide && !g_heavy) return ctx->fail(GKR_ERR_INVALID, "cached gate lists were built without the wide layer's work lists");
+            g_plan = cached->plan;
+            if (wide && !g_plan) return ctx->fail(GKR_ERR_INVALID, "cached gate lists were built without the wide layer's item plan");
         } else {
             WS(ctx, "gates.counts", uint32_t, nb2, g_counts);
             WS(ctx, "gates.bsums", uint32_t, (nb2 + 2047) / 2048 + 1, g_bsums);
@@ -320,17 +327,17 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 if (!cached->offsets) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->offsets), nb2 * sizeof(uint32_t)));
                 if (!cached->cursor) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->cursor), nb2 * sizeof(uint32_t)));
                 if (!cached->list) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->list), 2 * gkr::gate_list_words(span.count) * sizeof(uint32_t)));
-                if (wide && !cached->heavy)
-                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->heavy), gkr::gate_heavy_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
+                if (wide && !cached->plan)
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&cached->plan), gkr::gate_plan_words(span.count, (uint32_t)k) * sizeof(uint32_t)));
                 g_offsets = cached->offsets;
                 g_cursor = cached->cursor;
                 g_list = cached->list;
-                g_heavy = cached->heavy;
+                g_plan = cached->plan;
             } else {
                 WS(ctx, "gates.offsets", uint32_t, nb2, g_offsets);
                 WS(ctx, "gates.cursor", uint32_t, nb2, g_cursor);
                 WS(ctx, "gates.list", uint32_t, 2 * gkr::gate_list_words(span.count), g_list);
-                if (wide) WS(ctx, "gates.heavy", uint32_t, gkr::gate_heavy_words(span.count, (uint32_t)k), g_heavy);
+                if (wide) WS(ctx, "gates.plan", uint32_t, gkr::gate_plan_words(span.count, (uint32_t)k), g_plan);
             }
             HIP_TRY(ctx, hipMemsetAsync(g_counts, 0, nb2 * sizeof(uint32_t), s));
             uint32_t *lds_scratch = nullptr, *seg_scratch = nullptr;
@@ -346,7 +353,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             Timed t(ctx, "gate_lists", (double)span.count * (9.0 + 4 * 4.0));
             gkr::launch_gate_lists(span, (uint32_t)k_i, (uint32_t)k, d_gt, d_l, d_r, g_counts, g_offsets, g_cursor, g_bsums, g_list, bad, lds_scratch,
                                    segs, seg_scratch, s);
-            if (wide) gkr::launch_gate_heavy_lists(span, (uint32_t)k, g_offsets, g_cursor, g_heavy, s);
+            if (wide) gkr::launch_gate_plan(span, (uint32_t)k, g_offsets, g_cursor, g_list, g_plan, s);
             if (cached) cached->ready = true;   // a bad gate fails the call below and the prepared circuit is dropped
         }
     } else {
@@ -363,8 +370,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
-            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, g_heavy, heavy_partials, s,
-                                     group ? group->heavy_hdr : (cached && cached->heavy_known && !lists_fresh ? cached->heavy_hdr : nullptr), sets);
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, E, Wc, U, V, lb, item_partials, s, sets);
         else
             gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s, sets);
     }
@@ -436,10 +442,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
             uint32_t hbad = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
-            if (wide && cached) HIP_TRY(ctx, hipMemcpyAsync(cached->heavy_hdr, g_heavy, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
-            if (wide && cached) cached->heavy_known = true;
         }
         if (batch >= 16) pool = ctx->host_pool();
     }
@@ -478,8 +482,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
                     if (wide)
-                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb, g_heavy,
-                                                   heavy_partials, s, group ? group->heavy_hdr : (cached && cached->heavy_known ? cached->heavy_hdr : nullptr), sets);
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, E, d_eq, A, M, lb, item_partials, s, sets);
                     else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
                                                               segs, seg_partials, s, shard ? nullptr : &fuse, sets);

@@ -380,12 +380,7 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
             for (int b = 0; b < batch; ++b) {
                 const PreparedCircuit* p = pcs[member_of[b]];
                 const GateLists& gl = p->lists[i];
-                h_sets[(size_t)i * batch + b] = gkr::GateSet{gl.offsets, gl.cursor, gl.list, gl.heavy, p->gt[i], p->l[i], p->r[i], 0};
-            }
-            for (int m = 0; m < n_members; ++m) {
-                const GateLists& gl = pcs[m]->lists[i];
-                for (int half = 0; half < 2; ++half)
-                    if (!gl.heavy_known || gl.heavy_hdr[2 * half]) groups[i].heavy_hdr[2 * half] = 1;   // some member has heavy buckets in this half
+                h_sets[(size_t)i * batch + b] = gkr::GateSet{gl.offsets, gl.cursor, gl.list, gl.plan, p->gt[i], p->l[i], p->r[i], 0};
             }
         }
         gkr::launch_copy_words(h_sets, d_sets, n_sets * sizeof(gkr::GateSet) / 4, s);
@@ -919,7 +914,13 @@ int gkr_prove_many(gkr_ctx* ctx, gkr_prove_item* items, size_t n_items, int max_
     {
         const bool lockstep = gkr::opt(gkr::OPT_prove_many_lockstep) != 0;
         const long long cap_opt = gkr::opt(gkr::OPT_lockstep_max_proofs);
-        const int cap = cap_opt > 0 && cap_opt <= 4096 ? (int)cap_opt : 1024;
+        // Lockstep pays where a chain is LATENCY-bound -- a few proofs per circuit: one launch and one hand-off per pass for the
+        // group, its handful of round vectors hashed side by side by the crew.  Many proofs per item are a THROUGHPUT problem:
+        // the host hashes for a millisecond per pass while the GPU waits and the other way round, and independent chains
+        // overlap each other where one big group cannot (MI355X, 14 threads: 64 inputs x 12 sub-circuits 8.5 ms as twelve
+        // chains, 12.2 ms as two groups of 320 and 448 proofs; 3 inputs x 12: 3.7 against 3.2 ms; the 16 sub-circuits of the
+        // 262 144-constraint R1CS, one input: 10.8 against 7.1 ms -- profiles/r05/a_*).  Hence the cap on a group's proofs.
+        const int cap = cap_opt > 0 && cap_opt <= 4096 ? (int)cap_opt : 32;
         std::vector<int> unit_proofs;
         std::vector<bool> taken(n_items, false);
         for (size_t i = 0; i < n_items; ++i) {

@@ -187,7 +187,7 @@ struct GateSet {
     const uint32_t* offsets;      // 2 * 2^k bucket starts
     const uint32_t* cursor;       // 2 * 2^k bucket ends
     const uint32_t* list;         // gate indices by bucket; the entries' meta words follow at list + gate_list_words(gates)
-    const uint32_t* heavy;        // the wide layers' work lists (gate_heavy_words; may be null)
+    const uint32_t* plan;         // the wide layers' item plan (gate_plan_words; may be null)
     const uint8_t* gate_type;     // the layer's gate arrays (layer evaluation)
     const uint32_t* left;
     const uint32_t* right;
@@ -252,26 +252,20 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
                              uint32_t batch, hipStream_t s);
 
 // ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------
-// The gate passes with a group of 2^lg lanes per bucket; buckets longer than gate_heavy_threshold() gates are cut into
-// units of gate_heavy_unit() gates (work lists built once per circuit by launch_gate_heavy_lists, right after the sort).
-constexpr uint32_t kHeavyPerLane = 64;    // a lane of a group walks at most this many gates (about eight on average)
-// gates per unit of a heavy bucket (one wave each): sixteen gates per lane where there is plenty of work, four or two where a
-// layer is small and its one or two heavy buckets -- the constant wires -- are a latency chain on every proof's path (the
-// 16-circuit step, same box: 10.50 / 10.67 ms with 256 throughout below 2^20 gates, 10.39 / 10.46 with 128 below 2^18, 10.44 / 10.47 with 64)
-inline uint32_t gate_heavy_unit(uint64_t gates) { return gates < ((uint64_t)1 << 18) ? 128u : (gates < ((uint64_t)1 << 20) ? 256u : 1024u); }
-constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the lane-group passes
-uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k);
-uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k);
-size_t gate_heavy_words(uint64_t gates, uint32_t k);            // u32 words of the work lists (both halves)
-size_t gate_heavy_partial_elems(uint64_t gates, uint32_t k);    // Fr elements of pass scratch per proof
-void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, uint32_t* heavy_words, hipStream_t s);
-void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                         const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr, const GateSet* sets = nullptr);
-void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                           const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr = nullptr, const GateSet* sets = nullptr);
-// host_hdr (may be null): the first four words of heavy_words as the host read them back ([2 * half] = heavy buckets of the half)
+// The gate passes over ITEMS: the buckets of the sorted lists cut into pieces of at most sixteen gates, sorted by length, a
+// lane per item; eq(z, .) gathered from a materialised 2^k_i-entry table E (canonical).  The plan (items, their order, the
+// step-major entries) is built once per circuit layer by launch_gate_plan, right after the sort.
+constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the item passes
+size_t gate_plan_words(uint64_t gates, uint32_t k);             // u32 words of the plan (both halves)
+size_t gate_plan_partial_elems(uint64_t gates, uint32_t k);     // Fr elements of pass scratch per proof
+void launch_gate_plan(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list, uint32_t* plan, hipStream_t s);
+// E: batch x 2^k_i entries eq(z, g), canonical; W / eq_mont: batch tables of 2^k entries in Montgomery form (stride lb.wstride)
+void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
+                         hipStream_t s, const GateSet* sets = nullptr);
+void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+                           Fr* partials, hipStream_t s, const GateSet* sets = nullptr);
+// exclusive scan of n 32-bit counts (block_sums: n / 2048 + 1 words of scratch)
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s);
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)
 void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s);
 // dependence flags over a grid: bits = batch zeroed-by-the-launcher words of scratch; dep / host_dep as launch_layer_prologue

@@ -2312,6 +2312,13 @@ static void launch_seg_pass(bool rows, const GateSegs& g, uint32_t k, const Fr* 
         lds_t ? launch_seg_pass_t<false, true>(g, k, e_lo_mont, T, X, Y, lb, s) : launch_seg_pass_t<false, false>(g, k, e_lo_mont, T, X, Y, lb, s);
 }
 
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s) {
+    const uint32_t sblocks = (uint32_t)((n + kScanPerBlock - 1) / kScanPerBlock);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(sblocks), dim3(256), 0, s, in, out, block_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, sblocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(sblocks), dim3(256), 0, s, out, (uint32_t*)nullptr, block_sums, n);
+}
+
 static uint32_t bucket_threads(uint64_t gates, uint32_t k) { return (gates >> k) > 64u ? 256u : 64u; }   // gates per bucket on average
 
 void launch_gate_uv(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,

@@ -6,10 +6,10 @@
 // The linear-time form of kernels.hip has no inherent width limit: U, V, the c-phase row and W are 2^k-entry tables in
 // HBM.  What changes with the width is the SHAPE of the work:
 //   * 2^k buckets of the gate lists with only a few gates each (a circom layer has about as many gates as the next
-//     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here a GROUP of L = 1..64
-//     lanes sums a bucket, about eight gates per lane (k_gate_group), and the few buckets far longer than the rest -- the constant wires every
-//     relay gate reads (convert.rs:307-342) -- are cut into units of 256 / 1024 gates summed a wave per unit (k_gate_heavy,
-//     k_heavy_combine), so that no lane ever walks more than 64 gates;
+//     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here the buckets are cut into
+//     ITEMS of at most sixteen gates, sorted by length and summed a lane per item against a materialised eq(z, .) table
+//     (k_items_pass); the few buckets far longer than the rest -- the constant wires every relay gate reads
+//     (convert.rs:307-342) -- are many items whose partial sums a combine step adds (k_items_combine[_long]);
 //   * tables the one-block helpers cannot walk: the dependence flags (k_depends_wide), the Moebius transform
 //     (k_mobius_pass) and the set-up of the line restriction (k_line_copy, k_line_maxdeg) run over a grid.
 // Same field elements as every other form: bit-exact (tests/test_gpu_wide_layers.py).
@@ -23,251 +23,348 @@
 namespace gkr {
 
 // ---------------------------------------------------------------------------
-// gate passes: a group of lanes per bucket, heavy buckets in units
+// gate passes of wide layers: the buckets of the sorted gate lists cut into ITEMS, a lane per item
 // ---------------------------------------------------------------------------
+// What a gate pass sums (sumcheck.rs:50-63, 97-124 in the linear-time form): per bucket b of the left (U, V) resp. right
+// (a_u, m_u) operand, sum over the bucket's gates of eq(z, g) * T[other operand(g)].  Round 4's form gave a bucket a group of
+// lanes and counted 5560 (2^20 gates over 2^20 values) and 1144 (2^24 over 2^18) wave-instructions per 64 gates against the
+// 128 of the product itself (profiles/r04/q_*): a REDUCED product per gate just to form eq(z, g) = E_hi * E_lo, ~1000
+// instructions of per-lane fixed cost (two reductions, the group's shuffles, two canonical reductions) whether a lane walked
+// one gate or sixteen, and lanes idling on the longest bucket of their wave.  This form:
+//   * eq(z, .) is MATERIALISED per sumcheck as a 2^k_i-entry table (k_eq_table_split, tens of microseconds) and gathered: per
+//     gate ONE unreduced 256 x 256-bit multiply-add;
+//   * a bucket is cut into items of <= kItemMax gates, the items are sorted by length (a counting sort, built once per
+//     circuit) and handled a lane per item, 64 items of (nearly) equal length per wave: every lane of a wave runs the same
+//     number of steps; the items' entries are stored step-major (a wave's step = 512 contiguous bytes);
+//   * a wave whose items hold ONE gate each -- most of a circom layer, where a value feeds one gate -- does one reduced
+//     product per lane and stores: no accumulators, no reductions;
+//   * an item that is its bucket writes the bucket's two outputs itself; buckets of several items (the constant wire half the
+//     relay gates read, convert.rs:307-342: ONE bucket with half the layer) leave partial sums that a second, small kernel
+//     adds per bucket (a lane per bucket; a wave per bucket beyond kLongItems items);
+//   * buckets without gates are items of length zero (their outputs are zero): no memset of the output tables.
+// The same field elements as every other form: integer adds commute, every sum is reduced mod r at the end -- bit-exact.
+constexpr uint32_t kItemMax = 16;
+constexpr uint32_t kLongItems = 64;
+constexpr uint32_t kClasses = kItemMax + 1;   // item lengths 0 .. kItemMax
 
-// Lanes of a wave that sum one bucket: about EIGHT gates per lane.  A lane's fixed cost -- two reductions of its unreduced
-// sums, the group's shuffles, two more reductions -- is ~1000 instructions whether it walked one gate or sixteen; measured on
-// MI355X, ms per gate pass (profiles/r04/h_gate_group_lanes_sweep.txt): 2^24 gates over 2^18 buckets (64 per bucket) 1.74 with
-// a whole wave per bucket, 0.52 with four lanes; 2^20 over 2^15 (32 per bucket) 0.216 with 32 lanes, 0.065 with four; 2^20
-// over 2^20 (one per bucket) 0.40 with four lanes, 0.17 with one.
-uint32_t gate_group_lanes_log2(uint64_t gates, uint32_t k) {
-    const int forced = (int)opt(OPT_gate_group_lanes_log2);   // (measurement knob)
-    if (forced >= 0 && forced <= 6) return (uint32_t)forced;
-    const uint64_t mean = gates >> k;
-    uint32_t lg = 0;
-    while (lg < 6 && ((uint64_t)8 << lg) < mean) ++lg;
-    return lg;
-}
-uint32_t gate_heavy_threshold(uint64_t gates, uint32_t k) { return kHeavyPerLane << gate_group_lanes_log2(gates, k); }   // (at least 64: a lane group's first lane)
-// capacities of one half (left-operand buckets / right-operand buckets)
-static inline size_t heavy_cap_buckets(uint64_t gates, uint32_t k) { return (size_t)(gates / gate_heavy_threshold(gates, k)) + 1; }
-static inline size_t heavy_cap_units(uint64_t gates, uint32_t k) { return (size_t)(gates / gate_heavy_unit(gates)) + heavy_cap_buckets(gates, k); }
-size_t gate_heavy_words(uint64_t gates, uint32_t k) {
-    // header (8 words) | per half: heavy buckets {bucket, first unit, units} (3 words each) | units {bucket, chunk} (2 words each)
-    return 8 + 2 * (3 * heavy_cap_buckets(gates, k) + 2 * heavy_cap_units(gates, k));
-}
-size_t gate_heavy_partial_elems(uint64_t gates, uint32_t k) { return 2 * heavy_cap_units(gates, k); }
-
-struct HeavyView {
-    uint32_t* hdr;        // [2 * half] heavy buckets, [2 * half + 1] units
-    uint32_t* buckets;    // 3 words per heavy bucket of this half
-    uint32_t* units;      // 2 words per unit of this half
+// the plan of ONE half (left-operand buckets / right-operand buckets) as offsets (in u32 words) from the half's base
+struct PlanLayout {
+    uint32_t nb;              // buckets per half
+    uint32_t cap_items, cap_groups, cap_multi, cap_long;
+    size_t cap_packed;        // u64 entries
+    size_t items_per, item_first, item_bucket, sorted, desc, group_len, group_off, scan_sums, multi, longb, packed, half_words;
 };
-static inline HeavyView heavy_view(uint32_t* words, uint64_t gates, uint32_t k, uint32_t half) {
-    const size_t cb = heavy_cap_buckets(gates, k), cu = heavy_cap_units(gates, k);
-    uint32_t* base = words + 8 + (size_t)half * (3 * cb + 2 * cu);
-    return HeavyView{words, base, base + 3 * cb};
+// header of a half: [0] items, [1] groups, [2] buckets of 2 .. kLongItems items, [3] buckets of more, [8 + c] items of length c,
+// [32 + c] the sort's cursors
+constexpr uint32_t kPlanHdrWords = 64;
+static PlanLayout plan_layout(uint64_t gates, uint32_t k) {
+    PlanLayout L;
+    L.nb = 1u << k;
+    const uint64_t nb = L.nb;
+    L.cap_items = (uint32_t)(gates / kItemMax + nb + 64);                 // sum of max(1, ceil(len / kItemMax)) over the buckets
+    L.cap_groups = L.cap_items / 64 + 2;
+    L.cap_multi = (uint32_t)(gates / kItemMax + 1);
+    L.cap_long = (uint32_t)(gates / ((uint64_t)kItemMax * kLongItems) + 1);
+    L.cap_packed = (size_t)gates + 64u * 2u * kItemMax + 64u;              // padding only where the length changes inside a wave
+    size_t w = kPlanHdrWords;
+    auto take = [&](size_t n) { const size_t at = w; w += (n + 3) & ~(size_t)3; return at; };
+    L.items_per = take(nb);
+    L.item_first = take(nb + 1);
+    L.item_bucket = take(L.cap_items);
+    L.sorted = take(L.cap_items);
+    L.desc = take(L.cap_items);
+    L.group_len = take(L.cap_groups);
+    L.group_off = take(L.cap_groups + 1);
+    L.scan_sums = take((L.cap_items > nb ? L.cap_items : nb) / 2048 + 4);
+    L.multi = take(L.cap_multi);
+    L.longb = take(L.cap_long);
+    L.packed = take(2 * L.cap_packed);
+    L.half_words = w;
+    return L;
 }
+size_t gate_plan_words(uint64_t gates, uint32_t k) { return 2 * plan_layout(gates, k).half_words; }
+size_t gate_plan_partial_elems(uint64_t gates, uint32_t k) { return 2 * (size_t)plan_layout(gates, k).cap_items; }   // per proof, one half at a time
 
-// one thread per bucket of both halves: buckets longer than `threshold` go to the half's work lists
-__global__ void __launch_bounds__(256) k_heavy_list(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
-                                                    uint32_t threshold, uint32_t unit, uint32_t* __restrict__ hdr, uint32_t* __restrict__ bucketsL,
-                                                    uint32_t* __restrict__ unitsL, uint32_t* __restrict__ bucketsR, uint32_t* __restrict__ unitsR) {
-    const uint32_t b2 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b2 >= 2u * nb) return;
-    const uint32_t len = cursor[b2] - offsets[b2];
-    if (len <= threshold) return;
-    const uint32_t half = b2 >= nb ? 1u : 0u, nunits = (len + unit - 1u) / unit;
-    const uint32_t slot = atomicAdd(hdr + 2u * half, 1u), first = atomicAdd(hdr + 2u * half + 1u, nunits);
-    uint32_t* hb = (half ? bucketsR : bucketsL) + 3u * (size_t)slot;
-    hb[0] = b2;
-    hb[1] = first;
-    hb[2] = nunits;
-    uint32_t* un = (half ? unitsR : unitsL) + 2u * (size_t)first;
-    for (uint32_t c = 0; c < nunits; ++c) {
-        un[2u * c] = b2;
-        un[2u * c + 1u] = c;
+// packed entry: gate index (28 bits) | other operand (24 bits) << 28 | gate type << 63; all ones = no gate in this step
+constexpr unsigned long long kNoGate = ~0ull;
+
+// one thread per bucket of the half: items of the bucket, and the buckets that need a combine step
+__global__ void __launch_bounds__(256) k_plan_count(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
+                                                    uint32_t* __restrict__ hdr, uint32_t* __restrict__ items_per, uint32_t* __restrict__ multi,
+                                                    uint32_t* __restrict__ longb) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t len = cursor[b] - offsets[b];
+    const uint32_t n = len ? (len + kItemMax - 1u) / kItemMax : 1u;   // (an empty bucket is one item of length zero)
+    items_per[b] = n;
+    if (n > kLongItems)
+        longb[atomicAdd(hdr + 3, 1u)] = b;
+    else if (n > 1u)
+        multi[atomicAdd(hdr + 2, 1u)] = b;
+}
+// one thread per item: its bucket (a search in the buckets' first items), its length class counted
+__global__ void __launch_bounds__(256) k_plan_items(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
+                                                    uint32_t* __restrict__ hdr, const uint32_t* __restrict__ items_per,
+                                                    const uint32_t* __restrict__ item_first, uint32_t* __restrict__ item_bucket) {
+    __shared__ uint32_t s_hist[kClasses];
+    if (threadIdx.x < kClasses) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n_items = item_first[nb - 1u] + items_per[nb - 1u];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u) {
+        hdr[0] = n_items;
+        hdr[1] = (n_items + 63u) / 64u;
     }
-}
-
-// one gate's terms.  e = eq(z, g) (canonical, a reduced product: it is an operand), t = W[right] resp. eq(u, left) in
-// Montgomery form.  The products e t only ever enter a sum: added unreduced, reduced once per lane.
-//   ROWS == false (U, V):      mult gate: P += e t;   add gate: Q += e t and S += e
-//   ROWS == true  (a_u, m_u):  add gate:  P += e t;   mult gate: Q += e t
-template <bool ROWS>
-__device__ __forceinline__ void gate_term(Lazy17& P, Lazy17& Q, Acc<9>& S, uint32_t gg, uint32_t mt, const Fr* __restrict__ e_hi,
-                                          const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t lmask, const Fr* __restrict__ T) {
-    const Fr e = mont_mul(load_fr(e_hi + (gg >> kl)), load_fr(e_lo_mont + (gg & lmask)));
-    const Fr t = load_fr(T + (mt & 0x7fffffffu));
-    const bool mult = (mt >> 31) != 0u;
-    lazy_mac_sel(P, Q, ROWS ? !mult : mult, e, t);
-    if (!ROWS && !mult) acc_add_fr(S, e);
-}
-
-// sum of an accumulator over the 2^lg lanes of a group (lanes of one wave); every lane of the group gets the total
-template <int NL>
-__device__ __forceinline__ Acc<NL> group_sum(Acc<NL> a, uint32_t lg) {
-    for (uint32_t off = 1u; off < (1u << lg); off <<= 1) {
-        Acc<NL> o;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) o.l[i] = __shfl_xor(a.l[i], (int)off, 64);
-        acc_add_acc(a, o);
-    }
-    return a;
-}
-
-// grid = (2^k * L / 256, batch), block = 256: group `tid >> lg` of the grid sums bucket (first_bucket + group).
-// out0 / out1: U, V resp. a_u, m_u (stride wstride per proof).  Buckets longer than `threshold` are left to the units.
-template <bool ROWS>
-__global__ void __launch_bounds__(256) k_gate_group(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
-                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                                                    const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
-                                                    const Fr* __restrict__ T, Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t k,
-                                                    uint32_t wstride, uint32_t gate_base, uint32_t lg, uint32_t threshold,
-                                                    const GateSet* __restrict__ sets) {
-    if (sets) {   // proofs of different circuits in one launch: this proof's lists (block-uniform)
-        const GateSet gs = sets[blockIdx.y];
-        const ptrdiff_t moff = meta - list;
-        offsets = gs.offsets;
-        cursor = gs.cursor;
-        list = gs.list;
-        meta = gs.list + moff;
-    }
-    const uint32_t L = 1u << lg, sub = threadIdx.x & (L - 1u), nb = 1u << k;
-    const uint32_t bl = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lg);   // bucket within the half
-    const uint32_t lmask = (1u << kl) - 1u;
-    e_hi += (size_t)blockIdx.y << kh;
-    e_lo_mont += (size_t)blockIdx.y << kl;
-    T += (size_t)blockIdx.y * wstride;
-    Lazy17 P = lazy_zero(), Q = lazy_zero();
-    Acc<9> S = acc_zero<9>();
-    bool live = bl < nb;
-    uint32_t i = 0, end = 0;
-    if (live) {
-        const uint32_t bucket = ROWS ? nb + bl : bl;
-        i = offsets[bucket];
-        end = cursor[bucket];
-        if (end - i > threshold) {
-            live = false;   // a heavy bucket: its units write it (k_heavy_combine)
-            end = i;
+    if (i < n_items) {
+        uint32_t lo = 0, hi = nb - 1u;   // the last bucket whose first item is <= i
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (item_first[mid] <= i) lo = mid; else hi = mid - 1u;
         }
-        i += sub;
+        item_bucket[i] = lo;
+        const uint32_t len = cursor[lo] - offsets[lo], j = i - item_first[lo];
+        const uint32_t ilen = len - kItemMax * j < kItemMax ? len - kItemMax * j : kItemMax;
+        atomicAdd(&s_hist[ilen], 1u);
     }
-    for (; i < end; i += L) gate_term<ROWS>(P, Q, S, list[i] + gate_base, meta[i], e_hi, e_lo_mont, kl, lmask, T);
-    Acc<9> a0 = S, a1 = acc_zero<9>();
-    acc_add_fr(a0, lazy_reduce(P));
-    acc_add_fr(a1, lazy_reduce(Q));
-    a0 = group_sum(a0, lg);
-    a1 = group_sum(a1, lg);
-    if (live && sub == 0) {
-        store_fr(out0 + (size_t)blockIdx.y * wstride + bl, acc_reduce(a0));
-        store_fr(out1 + (size_t)blockIdx.y * wstride + bl, acc_reduce(a1));
-    }
+    __syncthreads();
+    if (threadIdx.x < kClasses && s_hist[threadIdx.x]) atomicAdd(hdr + 8 + threadIdx.x, s_hist[threadIdx.x]);
 }
-
-// a wave per unit (gate_heavy_unit() gates of a heavy bucket); grid = (blocks, batch), any number of blocks
-template <bool ROWS>
-__global__ void __launch_bounds__(256) k_gate_heavy(const uint32_t* __restrict__ hdr, uint32_t half, const uint32_t* __restrict__ units,
-                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
-                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
-                                                    const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t kl, uint32_t kh,
-                                                    const Fr* __restrict__ T, Fr* __restrict__ partials, size_t pstride, uint32_t wstride,
-                                                    uint32_t gate_base, uint32_t unit, const GateSet* __restrict__ sets) {
-    if (sets) {
-        const GateSet gs = sets[blockIdx.y];
-        const ptrdiff_t moff = meta - list, uoff = units - hdr;
-        offsets = gs.offsets;
-        cursor = gs.cursor;
-        list = gs.list;
-        meta = gs.list + moff;
-        hdr = gs.heavy;
-        units = gs.heavy + uoff;
+// the counting sort by length, longest first: a block reserves a range per class, its items take it in turn
+__global__ void __launch_bounds__(256) k_plan_sort(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
+                                                   uint32_t* __restrict__ hdr, const uint32_t* __restrict__ item_first,
+                                                   const uint32_t* __restrict__ item_bucket, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t s_count[kClasses], s_base[kClasses];
+    if (threadIdx.x < kClasses) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n_items = hdr[0], i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ilen = 0, rank = 0;
+    if (i < n_items) {
+        const uint32_t b = item_bucket[i], len = cursor[b] - offsets[b], j = i - item_first[b];
+        ilen = len - kItemMax * j < kItemMax ? len - kItemMax * j : kItemMax;
+        rank = atomicAdd(&s_count[ilen], 1u);
     }
-    const uint32_t nunits = hdr[2u * half + 1u];
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t lmask = (1u << kl) - 1u;
-    e_hi += (size_t)blockIdx.y << kh;
-    e_lo_mont += (size_t)blockIdx.y << kl;
-    T += (size_t)blockIdx.y * wstride;
-    partials += (size_t)blockIdx.y * pstride;
-    for (uint32_t u = wave; u < nunits; u += nwaves) {
-        const uint32_t bucket = units[2u * u], chunk = units[2u * u + 1u];
-        const uint32_t begin = offsets[bucket] + chunk * unit, stop = cursor[bucket];
-        const uint32_t end = begin + unit < stop ? begin + unit : stop;
-        Lazy17 P = lazy_zero(), Q = lazy_zero();
-        Acc<9> S = acc_zero<9>();
-        for (uint32_t i = begin + lane; i < end; i += 64u) gate_term<ROWS>(P, Q, S, list[i] + gate_base, meta[i], e_hi, e_lo_mont, kl, lmask, T);
-        Acc<9> a0 = S, a1 = acc_zero<9>();
-        acc_add_fr(a0, lazy_reduce(P));
-        acc_add_fr(a1, lazy_reduce(Q));
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            store_fr(partials + 2u * (size_t)u, acc_reduce(a0));
-            store_fr(partials + 2u * (size_t)u + 1u, acc_reduce(a1));
+    __syncthreads();
+    if (threadIdx.x < kClasses) {
+        uint32_t start = 0;   // classes in descending order of length
+        for (uint32_t c = kItemMax; c > threadIdx.x; --c) start += hdr[8 + c];
+        s_base[threadIdx.x] = start + (s_count[threadIdx.x] ? atomicAdd(hdr + 32 + threadIdx.x, s_count[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (i < n_items) sorted[s_base[ilen] + rank] = i;
+}
+// one thread per group of 64 sorted items: its steps = the length of its first (longest) item
+__global__ void __launch_bounds__(256) k_plan_groups(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
+                                                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ item_first,
+                                                     const uint32_t* __restrict__ item_bucket, const uint32_t* __restrict__ sorted,
+                                                     uint32_t* __restrict__ group_len, uint32_t cap_groups) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= cap_groups) return;
+    uint32_t ilen = 0;
+    if (g < hdr[1]) {
+        const uint32_t i = sorted[64u * g], b = item_bucket[i], len = cursor[b] - offsets[b], j = i - item_first[b];
+        ilen = len - kItemMax * j < kItemMax ? len - kItemMax * j : kItemMax;
+    }
+    group_len[g] = ilen;
+}
+// a wave per group: the items' entries step-major, and what a lane needs to know of its item
+//   desc = bucket | (the item is its whole bucket) << 31
+__global__ void __launch_bounds__(256) k_plan_pack(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ meta,
+                                                   const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ items_per,
+                                                   const uint32_t* __restrict__ item_first, const uint32_t* __restrict__ item_bucket,
+                                                   const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ group_len,
+                                                   const uint32_t* __restrict__ group_off, uint32_t* __restrict__ desc,
+                                                   unsigned long long* __restrict__ packed) {
+    const uint32_t lane = threadIdx.x & 63u, g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= hdr[1]) return;
+    const uint32_t pos = 64u * g + lane, steps = group_len[g];
+    uint32_t ilen = 0, base = 0;
+    if (pos < hdr[0]) {
+        const uint32_t i = sorted[pos], b = item_bucket[i], len = cursor[b] - offsets[b], j = i - item_first[b];
+        ilen = len - kItemMax * j < kItemMax ? len - kItemMax * j : kItemMax;
+        base = offsets[b] + kItemMax * j;
+        desc[pos] = b | (items_per[b] == 1u ? 0x80000000u : 0u);
+    }
+    unsigned long long* out = packed + (size_t)group_off[g] * 64u + lane;
+    for (uint32_t t = 0; t < steps; ++t) {
+        unsigned long long e = kNoGate;
+        if (t < ilen) {
+            const uint32_t mt = meta[base + t];
+            e = (unsigned long long)list[base + t] | ((unsigned long long)(mt & 0x7fffffffu) << 28) | ((unsigned long long)(mt >> 31) << 63);
         }
+        out[(size_t)t * 64u] = e;
     }
 }
 
-// a wave per heavy bucket: the totals of its units -> the bucket's two outputs
-__global__ void __launch_bounds__(256) k_heavy_combine(const uint32_t* __restrict__ hdr, uint32_t half, const uint32_t* __restrict__ buckets,
-                                                       uint32_t nb, const Fr* __restrict__ partials, size_t pstride, Fr* __restrict__ out0,
-                                                       Fr* __restrict__ out1, uint32_t wstride, const GateSet* __restrict__ sets) {
-    if (sets) {
-        const ptrdiff_t boff = buckets - hdr;
-        hdr = sets[blockIdx.y].heavy;
-        buckets = hdr + boff;
-    }
-    const uint32_t nheavy = hdr[2u * half];
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    partials += (size_t)blockIdx.y * pstride;
-    for (uint32_t h = wave; h < nheavy; h += nwaves) {
-        const uint32_t bucket = buckets[3u * h], first = buckets[3u * h + 1u], n = buckets[3u * h + 2u];
-        Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
-        for (uint32_t c = lane; c < n; c += 64u) {
-            acc_add_fr(a0, load_fr(partials + 2u * (size_t)(first + c)));
-            acc_add_fr(a1, load_fr(partials + 2u * (size_t)(first + c) + 1u));
-        }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            const uint32_t bl = half ? bucket - nb : bucket;
-            store_fr(out0 + (size_t)blockIdx.y * wstride + bl, acc_reduce(a0));
-            store_fr(out1 + (size_t)blockIdx.y * wstride + bl, acc_reduce(a1));
-        }
-    }
-}
-
-void launch_gate_heavy_lists(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, uint32_t* heavy_words, hipStream_t s) {
-    const uint32_t nb = 1u << k;
-    (void)hipMemsetAsync(heavy_words, 0, 8 * sizeof(uint32_t), s);
-    const HeavyView L = heavy_view(heavy_words, span.count, k, 0), R = heavy_view(heavy_words, span.count, k, 1);
-    hipLaunchKernelGGL(k_heavy_list, dim3((2u * nb + 255u) / 256u), dim3(256), 0, s, offsets, cursor, nb, gate_heavy_threshold(span.count, k),
-                       gate_heavy_unit(span.count), heavy_words,
-                       L.buckets, L.units, R.buckets, R.units);
-}
-
-template <bool ROWS>
-static void launch_gate_group_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                                const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
-                                uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
-    const uint32_t lg = gate_group_lanes_log2(span.count, k), threshold = gate_heavy_threshold(span.count, k);
+void launch_gate_plan(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list, uint32_t* plan, hipStream_t s) {
+    const PlanLayout L = plan_layout(span.count, k);
     const uint32_t* meta = list + gate_list_words(span.count);
-    const uint64_t threads = (uint64_t)1 << (k + lg);
-    hipLaunchKernelGGL((k_gate_group<ROWS>), dim3((unsigned)((threads + 255) / 256), lb.batch), dim3(256), 0, s, offsets, cursor, list, meta, e_hi,
-                       e_lo_mont, kl, k_i - kl, T, out0, out1, k, (uint32_t)lb.wstride, (uint32_t)span.base, lg, threshold, sets);
-    const uint32_t half = ROWS ? 1u : 0u;
-    // (the work lists' header as the host read it back when the lists were built: a half without a heavy bucket -- most
-    // layers -- skips two launches per pass)
-    if (host_hdr && host_hdr[2u * half] == 0u) return;
-    const HeavyView hv = heavy_view(heavy_words, span.count, k, half);
-    const size_t pstride = gate_heavy_partial_elems(span.count, k);
-    hipLaunchKernelGGL((k_gate_heavy<ROWS>), dim3(512, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.units, offsets, cursor, list, meta, e_hi, e_lo_mont,
-                       kl, k_i - kl, T, heavy_partials, pstride, (uint32_t)lb.wstride, (uint32_t)span.base, gate_heavy_unit(span.count), sets);
-    hipLaunchKernelGGL(k_heavy_combine, dim3(64, lb.batch), dim3(256), 0, s, hv.hdr, half, hv.buckets, 1u << k, heavy_partials, pstride, out0, out1,
-                       (uint32_t)lb.wstride, sets);
+    for (uint32_t half = 0; half < 2; ++half) {
+        uint32_t* P = plan + (size_t)half * L.half_words;
+        const uint32_t *off = offsets + (size_t)half * L.nb, *cur = cursor + (size_t)half * L.nb;
+        (void)hipMemsetAsync(P, 0, kPlanHdrWords * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(k_plan_count, dim3((L.nb + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.multi, P + L.longb);
+        launch_exclusive_scan(P + L.items_per, P + L.item_first, P + L.scan_sums, L.nb, s);
+        hipLaunchKernelGGL(k_plan_items, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.item_first, P + L.item_bucket);
+        hipLaunchKernelGGL(k_plan_sort, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, P, P + L.item_first, P + L.item_bucket, P + L.sorted);
+        hipLaunchKernelGGL(k_plan_groups, dim3((L.cap_groups + 255u) / 256u), dim3(256), 0, s, off, cur, P, P + L.item_first, P + L.item_bucket, P + L.sorted,
+                           P + L.group_len, L.cap_groups);
+        launch_exclusive_scan(P + L.group_len, P + L.group_off, P + L.scan_sums, L.cap_groups, s);
+        hipLaunchKernelGGL(k_plan_pack, dim3((L.cap_groups * 64u + 255u) / 256u), dim3(256), 0, s, off, cur, list, meta, P, P + L.items_per, P + L.item_first,
+                           P + L.item_bucket, P + L.sorted, P + L.group_len, P + L.group_off, P + L.desc,
+                           reinterpret_cast<unsigned long long*>(P + L.packed));
+    }
 }
 
-void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                         const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* W, Fr* U, Fr* V, LayerBatch lb, uint32_t* heavy_words,
-                         Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
-    launch_gate_group_t<false>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, W, U, V, lb, heavy_words, heavy_partials, s, host_hdr, sets);
+// value < 2^256 (any representative) -> canonical: 2^256 < 6 r
+__device__ __forceinline__ Fr fr_canonical(Fr x) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) x = fr_reduce_once(x);
+    return x;
 }
-void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list,
-                           const Fr* e_hi, const Fr* e_lo_mont, uint32_t kl, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           uint32_t* heavy_words, Fr* heavy_partials, hipStream_t s, const uint32_t* host_hdr, const GateSet* sets) {
-    launch_gate_group_t<true>(span, k_i, k, offsets, cursor, list, e_hi, e_lo_mont, kl, eq_mont, A_row, M_row, lb, heavy_words, heavy_partials, s, host_hdr, sets);
+
+// The pass: grid = (groups / 4 rounded up, batch), block = 256 = four waves = four groups.
+//   ROWS == false (U, V):      mult gate: P += e t;   add gate: Q += e t and P += e      -> out0 = U, out1 = V
+//   ROWS == true  (a_u, m_u):  add gate:  P += e t;   mult gate: Q += e t               -> out0 = a_u, out1 = m_u
+// e = E[g] = eq(z, g), canonical; t = T[other operand], Montgomery form (W resp. eq(u, .)).
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ E, uint32_t k_i,
+                                                    const Fr* __restrict__ T, uint32_t wstride, Fr* __restrict__ out0, Fr* __restrict__ out1,
+                                                    Fr* __restrict__ partials, size_t pstride, uint32_t gate_base,
+                                                    const GateSet* __restrict__ sets) {
+    if (sets) plan = sets[blockIdx.y].plan;   // proofs of different circuits in one launch: this proof's plan
+    plan += ROWS ? L.half_words : 0;
+    const uint32_t lane = threadIdx.x & 63u, g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= plan[1]) return;
+    const uint32_t pos = 64u * g + lane, steps = plan[L.group_len + g];
+    const bool live = pos < plan[0];
+    const uint32_t d = live ? plan[L.desc + pos] : 0u;
+    const uint32_t bucket = d & 0x7fffffffu;
+    const bool whole = (d >> 31) != 0u;
+    E += (size_t)blockIdx.y << k_i;
+    T += (size_t)blockIdx.y * wstride;
+    out0 += (size_t)blockIdx.y * wstride;
+    out1 += (size_t)blockIdx.y * wstride;
+    const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(plan + L.packed) + (size_t)plan[L.group_off + g] * 64u + lane;
+    if (steps <= 1u) {
+        // items of one gate (or none): one reduced product, no accumulators.  (Sorted by length, such items fill whole waves.)
+        Fr o0 = fr_zero(), o1 = fr_zero();
+        const unsigned long long en = steps ? ent[0] : kNoGate;
+        if (en != kNoGate) {
+            const Fr e = load_fr(E + ((uint32_t)(en & 0xfffffffu) + gate_base));
+            const Fr t = load_fr(T + (uint32_t)((en >> 28) & 0xffffffu));
+            const bool mult = (en >> 63) != 0ull;
+            const Fr et = mont_mul(e, t);
+            if (ROWS) {
+                o0 = mult ? o0 : et;
+                o1 = mult ? et : o1;
+            } else {
+                o0 = mult ? et : e;
+                o1 = mult ? o1 : et;
+            }
+        }
+        if (live) {
+            if (whole) {
+                store_fr(out0 + bucket, o0);
+                store_fr(out1 + bucket, o1);
+            } else {
+                Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)plan[L.sorted + pos];
+                store_fr(part, o0);
+                store_fr(part + 1, o1);
+            }
+        }
+        return;
+    }
+    Lazy17 P = lazy_zero(), Q = lazy_zero();
+    unsigned long long en = ent[0];
+    for (uint32_t st = 0; st < steps; ++st) {
+        const unsigned long long cur = en;
+        if (st + 1u < steps) en = ent[(size_t)(st + 1u) * 64u];   // the next step's entry is on its way while this one's products run
+        if (cur != kNoGate) {
+            const Fr e = load_fr(E + ((uint32_t)(cur & 0xfffffffu) + gate_base));
+            const Fr t = load_fr(T + (uint32_t)((cur >> 28) & 0xffffffu));
+            const bool mult = (cur >> 63) != 0ull;
+            lazy_mac_sel(P, Q, ROWS ? !mult : mult, e, t);
+            if (!ROWS) lazy_add_hi(P, e, !mult);
+        }
+    }
+    // <= kItemMax products and <= kItemMax terms e * 2^256 per accumulator: the 32-term partial reduction applies
+    const Fr rp = lazy_reduce_partial32(P), rq = lazy_reduce_partial32(Q);
+    if (live) {
+        if (whole) {
+            store_fr(out0 + bucket, fr_canonical(rp));
+            store_fr(out1 + bucket, fr_canonical(rq));
+        } else {
+            Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)plan[L.sorted + pos];
+            store_fr(part, rp);
+            store_fr(part + 1, rq);
+        }
+    }
+}
+
+// buckets of 2 .. kLongItems items: a lane per bucket adds its items' partial sums (values below 2^256) and reduces
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ partials, size_t pstride,
+                                                       Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride, const GateSet* __restrict__ sets) {
+    if (sets) plan = sets[blockIdx.y].plan;
+    plan += ROWS ? L.half_words : 0;
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= plan[2]) return;
+    const uint32_t b = plan[L.multi + m], first = plan[L.item_first + b], n = plan[L.items_per + b];
+    const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)first;
+    Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
+    for (uint32_t j = 0; j < n; ++j) {
+        acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
+        acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
+    }
+    store_fr(out0 + (size_t)blockIdx.y * wstride + b, acc_reduce(a0));
+    store_fr(out1 + (size_t)blockIdx.y * wstride + b, acc_reduce(a1));
+}
+// buckets of more items (the constant wires): a wave per bucket
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_items_combine_long(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ partials, size_t pstride,
+                                                            Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride,
+                                                            const GateSet* __restrict__ sets) {
+    if (sets) plan = sets[blockIdx.y].plan;
+    plan += ROWS ? L.half_words : 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t m = wave; m < plan[3]; m += nwaves) {
+        const uint32_t b = plan[L.longb + m], first = plan[L.item_first + b], n = plan[L.items_per + b];
+        const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)first;
+        Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
+        for (uint32_t j = lane; j < n; j += 64u) {
+            acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
+            acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+            store_fr(out0 + (size_t)blockIdx.y * wstride + b, acc_reduce(a0));
+            store_fr(out1 + (size_t)blockIdx.y * wstride + b, acc_reduce(a1));
+        }
+    }
+}
+
+template <bool ROWS>
+static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
+                                Fr* partials, hipStream_t s, const GateSet* sets) {
+    const PlanLayout L = plan_layout(span.count, k);
+    const size_t pstride = gate_plan_partial_elems(span.count, k);
+    // (grids from the plan's capacities: the kernels read the counts the build left on the device, waves beyond them leave at once)
+    hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((L.cap_groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, E, k_i, T, (uint32_t)lb.wstride, out0, out1,
+                       partials, pstride, (uint32_t)span.base, sets);
+    hipLaunchKernelGGL((k_items_combine<ROWS>), dim3((L.cap_multi + 255u) / 256u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
+                       (uint32_t)lb.wstride, sets);
+    hipLaunchKernelGGL((k_items_combine_long<ROWS>), dim3(L.cap_long < 64u ? L.cap_long : 64u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0,
+                       out1, (uint32_t)lb.wstride, sets);
+}
+void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
+                         hipStream_t s, const GateSet* sets) {
+    launch_items_pass_t<false>(span, k_i, k, plan, E, W, U, V, lb, partials, s, sets);
+}
+void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+                           Fr* partials, hipStream_t s, const GateSet* sets) {
+    launch_items_pass_t<true>(span, k_i, k, plan, E, eq_mont, A_row, M_row, lb, partials, s, sets);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries

@@ -34,8 +34,7 @@ namespace gkr {
     X(items_per_block, "items_per_block", "GKR_ITEMS_PER_BLOCK", 0, "entries per block of the first pass (0: 1024)")                 \
     /* ---- layer sumcheck (prove_sumcheck_opt, sumcheck.rs:36-156) ---- */                                                            \
     X(predicate_atomics, "predicate_atomics", "GKR_PREDICATE_ATOMICS", 0, "dense predicate tables by widened-atomic scatter instead of the counting sort") \
-    X(gate_groups_min_k, "gate_groups_min_k", "GKR_GATE_GROUPS_MIN_K", -1, "smallest k_next whose layers take the wide layers' lane-group gate passes (-1: 13)") \
-    X(gate_group_lanes_log2, "gate_group_lanes_log2", "GKR_GATE_GROUP_LANES_LOG2", -1, "lanes (log2) per bucket in the lane-group passes (-1: ~8 gates per lane)") \
+    X(gate_groups_min_k, "gate_groups_min_k", "GKR_GATE_GROUPS_MIN_K", -1, "smallest k_next whose layers take the wide layers' item passes (-1: 13)") \
     X(no_fused_publish, "no_fused_publish", "GKR_NO_FUSED_PUBLISH", 0, "product passes publish through a second launch instead of from their last block") \
     X(gate_sort_global, "gate_sort_global", "GKR_GATE_SORT_GLOBAL", 0, "the gate lists' counting sort with global atomics where the LDS sort applies") \
     X(gate_segments_off, "gate_segments_off", "GKR_GATE_SEGMENTS_OFF", 0, "bucket kernels instead of the segment passes on large layers") \
@@ -48,7 +47,7 @@ namespace gkr {
     X(no_circuit_cache, "no_circuit_cache", "GKR_NO_CIRCUIT_CACHE", 0, "do not keep proven circuits' gate arrays and lists on the device between calls") \
     X(prove_many_pieces, "prove_many_pieces", "GKR_PROVE_MANY_PIECES", 0, "gkr_prove_many: cut the costliest items in two until there are this many")      \
     X(prove_many_lockstep, "prove_many_lockstep", "GKR_PROVE_MANY_LOCKSTEP", 1, "gkr_prove_many: items whose circuits share a k list advance in lockstep, one launch per pass for the group (0: one chain per item)") \
-    X(lockstep_max_proofs, "lockstep_max_proofs", "GKR_LOCKSTEP_MAX_PROOFS", 0, "most proofs one lockstep group may hold (0: 1024)")
+    X(lockstep_max_proofs, "lockstep_max_proofs", "GKR_LOCKSTEP_MAX_PROOFS", 0, "most proofs one lockstep group may hold (0: 32 -- beyond that independent chains overlap better)")
 
 enum OptionId : int {
 #define GKR_OPT_ENUM(id, name, env, def, doc) OPT_##id,

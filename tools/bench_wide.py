@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gkr_amd import Context, parallel, synth  # noqa: E402
 
-KERNELS = ["gate_lists", "gate_uv", "gate_rows", "layer_prod_pass", "exchange"]
+KERNELS = ["gate_lists", "eq_table_z", "gate_uv", "gate_rows", "layer_prod_pass", "exchange"]
 
 
 def main():
