@@ -460,12 +460,13 @@ def run_mle(args, world):
     proofs = None
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
-    layer24 = layer24_split = mle_split_out = wide20 = wide_prove = None
+    layer24 = layer24_split = mle_split_out = wide20 = wide20_circom = wide_prove = None
     split_hung = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
         # a WIDE layer, the shape of a compiled R1CS's big layers (2^20 gates over 2^20 values; round 3 rejected it)
         wide20 = layer_leg(world, 20, 20, steps=5, warmup=2, split=False, ceilings=ceilings) if args.layer_k_i >= 20 else None
+        wide20_circom = layer_leg(world, 20, 20, steps=5, warmup=2, split=False, ceilings=ceilings, shape="circom") if args.layer_k_i >= 20 else None
         wide_prove = wide_prove_leg(world) if args.layer_k_i >= 20 else None
         if world.size > 1:
             # configs[4] as BASELINE words it: the layer's gates split over the ranks, two RCCL all-reduces per sumcheck
@@ -492,6 +493,9 @@ def run_mle(args, world):
         if wide20:
             line["wide20"] = wide20
             verified_ok &= wide20["matches_golden_digest"] is not False
+        if wide20_circom:
+            line["wide20_circom_shaped"] = wide20_circom
+            verified_ok &= wide20_circom["matches_golden_digest"] is not False
         if wide_prove:
             line["wide_prove"] = wide_prove
             verified_ok &= wide_prove["matches_golden_digest"] is not False
@@ -731,7 +735,7 @@ def run_proofs(args, world):
 
 # ------------------------------------------------------------------------------------------------ mode: layer-split
 
-def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
+def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform"):
     """BASELINE configs[4]: ONE GKR layer sumcheck (prove_sumcheck_opt, sumcheck.rs:36-156) with 2^k_i random gates
     over a 2^k-entry next layer, gates and their sorted lists resident in HBM before the timed region, a step = one
     sumcheck (new z, W).  split: the gates are divided over the ranks (two sum-over-ranks exchanges per sumcheck);
@@ -739,7 +743,9 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
     line (on rank 0; None elsewhere).  The transcript is compared with the committed digest of the reference-semantics
     transcript (tests/golden/config_hashes.json)."""
     from gkr_amd import Context, parallel, synth
-    lay, z, W = synth.config5_layer(k_i, k)
+    # shape "circom": the structure the reference's compiler emits (synth.circom_shaped_layer: runs of gates over runs of
+    # values, two wires feeding most of the layer) instead of a uniform draw, which has no locality at all
+    lay, z, W = synth.circom_shaped_layer(k_i, k) if shape == "circom" else synth.config5_layer(k_i, k)
     gt, l, r = lay.arrays()
     first, cnt = parallel.gate_range(k_i, world.rank, world.size) if split else (0, 1 << k_i)
     ctx = Context(world.local_rank)
@@ -761,8 +767,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
     sort_ms = ctx.profile_get("gate_lists")["total_ms"]
     elapsed, each = timed_steps(world, ctx, step, warmup, steps)
     ctx.profile(False)
-    names = ["gate_lists", "gate_uv", "gate_rows", "gate_combine", "predicate_sorted", "layer_uv", "layer_collapse", "layer_prod_pass",
-             "layer_uv_round", "layer_c_round"]
+    names = ["gate_lists", "eq_table_z", "gate_uv", "gate_rows", "gate_combine", "predicate_sorted", "layer_prod_pass"]
     prof = {n_: ctx.profile_get(n_) for n_ in names}
     exch = ctx.profile_get("exchange")
     own = ceilings or (ctx.ceilings(256 << 20) if world.rank == 0 else None)
@@ -770,9 +775,11 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
     if world.rank == 0:
         C, L, R = result[0]
         digest = synth.transcript_digest(C, L, R)
-        want = synth.golden_digest("layer", "k_i=%d,k=%d" % (k_i, k))
+        want = synth.golden_digest("layer", ("circom-shaped," if shape == "circom" else "") + "k_i=%d,k=%d" % (k_i, k))
         N = 1 << (2 * k)
-        passes = [n_ for n_ in ("gate_uv", "gate_rows", "gate_combine") if prof[n_]["launches"]]   # the passes over the gates
+        # the passes over the gates -- for wide layers with the eq(z, .) table they gather from (built once per sumcheck: it
+        # replaced a product per gate, so its time is the passes' time)
+        passes = [n_ for n_ in ("eq_table_z", "gate_uv", "gate_rows", "gate_combine") if prof[n_]["launches"]]
         gate_ms = sum(prof[n_]["total_ms"] for n_ in passes) / steps
         # what a gate pass must do, whatever the schedule: one 254-bit product per gate (eq(z, g) times W[right] resp.
         # eq(u, left)); everything else a form spends (forming eq(z, g) from its two halves per gate, reductions) is
@@ -792,7 +799,8 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
             "config": {"workload": "%s: one GKR layer, k_i = %d, k = %d%s" % (
-                           "BASELINE configs[4]" if (k_i, k) == (24, 12) else "a WIDE layer (beyond round 3's 2^14 cap; the shape of a compiled R1CS's big layers)",
+                           "BASELINE configs[4]" if (k_i, k) == (24, 12) else ("a WIDE layer, gates in the order and with the operand structure the reference's compiler emits (convert.rs:209-214, 278-343)"
+                                                                                if shape == "circom" else "a WIDE layer, gates drawn uniformly (no locality: the worst case for the gathers)"),
                            k_i, k, ", gates split over the ranks, two sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" if split else
                            ", the whole layer on one GPU"),
                        "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z and W per sumcheck)"},
@@ -812,6 +820,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
                                  "plus the 8-byte list entry" % (k, (32 << k) / 2**20),
                         "gathers_per_sec": rate, "GBps_of_40_B_per_gate": rate * 40 / 1e9 if rate else None,
                         "frac_of_hbm_peak": rate * 40 / 1e9 / PEAK_GBPS if rate else None} if wide else None),
+            "product_pass_roofline": product_pass_roofline(k, prof["layer_prod_pass"]["total_ms"] / steps, peak),
             "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
             "collective": collective_info(world, exchange, exch, steps) if split else None,
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},
@@ -819,6 +828,33 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None):
     gates.close()
     ctx.close()
     return out
+
+
+def product_pass_roofline(k, prod_ms, peak_products_per_sec):
+    """The bound of a layer sumcheck's PRODUCT passes (kernels.hip, k_prod_cross: both phases as sumchecks of W X + Y over
+    three tables of 2^k entries, three rounds per pass).  A pass over tables of 2^m entries that binds the previous pass's jp
+    variables and forms the cross sums of the next J rounds costs 3 * 2^m products for the fold (2^jp weights per folded entry,
+    three tables) and 4^J * 2^(m - jp - J) for the cross sums; it reads the three tables once.  Products against the chip's
+    measured rate of dependent 254-bit Montgomery products, bytes against HBM peak -- whichever binds (the products do)."""
+    if not prod_ms:
+        return None
+    products = bytes_ = 0.0
+    for _phase in range(2):
+        m, jp, rem = k, 0, k
+        while rem > 0:
+            J = min(3, rem)
+            bytes_ += 3.0 * 32.0 * (1 << m)
+            if jp:
+                products += 3.0 * (1 << m)
+            m -= jp
+            products += float(1 << (m + J))
+            jp, rem = J, rem - J
+    rate = products / (prod_ms * 1e-3)
+    return {"bound": "alu", "kernel": "k_prod_cross<8|32> (+ k_prod_reduce / k_prod_publish)", "products_per_sumcheck": products,
+            "achieved": rate, "peak": peak_products_per_sec, "unit": "254-bit modular products/s",
+            "frac": rate / peak_products_per_sec if peak_products_per_sec else None, "ms_per_sumcheck": prod_ms,
+            "hbm_bytes_per_sumcheck": bytes_, "hbm_frac_if_it_were_the_bound": bytes_ / (prod_ms * 1e-3) / 1e9 / PEAK_GBPS,
+            "note": "elapsed time of the passes' kernels (HIP events); the hand-offs between them are the host transcript's"}
 
 
 def wide_prove_leg(world, ks=(18, 20, 20), reps=5):

@@ -305,11 +305,13 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             // eq(z, g) for every gate index of the layer (of the whole layer also when this rank holds a share of the gates: the
             // lists carry indices relative to the share's first gate, the passes add it back), canonical
             WS(ctx, "gates.itempart", Fr, gkr::gate_plan_partial_elems(span.count, (uint32_t)k) * batch, item_partials);
-            WS(ctx, "pred.E", Fr, (size_t)batch << k_i, E);
-            gkr_fr* hz2 = nullptr;
-            HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz2)));
-            Timed t(ctx, "eq_table_z", ((double)batch * 32.0) * (double)((size_t)1 << k_i));
-            gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz2), (uint32_t)k_i, 0u, (uint32_t)k_i, E, false, (uint32_t)batch, s);
+            if ((uint32_t)k_i <= gkr::kGateEqTableMaxKi) {
+                WS(ctx, "pred.E", Fr, (size_t)batch << k_i, E);
+                gkr_fr* hz2 = nullptr;
+                HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz2)));
+                Timed t(ctx, "eq_table_z", ((double)batch * 32.0) * (double)((size_t)1 << k_i));
+                gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz2), (uint32_t)k_i, 0u, (uint32_t)k_i, E, false, (uint32_t)batch, s);
+            }
         }
         if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)
         if (const size_t pe = gkr::gate_seg_partial_elems(span, (uint32_t)k_i, (uint32_t)k)) WS(ctx, "gates.segpart", Fr, pe * batch, seg_partials);
@@ -370,7 +372,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
-            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, E, Wc, U, V, lb, item_partials, s, sets);
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, Wc, U, V, lb, item_partials, s, sets);
         else
             gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s, sets);
     }
@@ -482,7 +484,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
                     if (wide)
-                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, E, d_eq, A, M, lb, item_partials, s, sets);
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, d_eq, A, M, lb, item_partials, s, sets);
                     else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
                                                               segs, seg_partials, s, shard ? nullptr : &fuse, sets);

@@ -259,10 +259,20 @@ constexpr uint32_t kWideMinK = 13;        // layers with k_next >= this take the
 size_t gate_plan_words(uint64_t gates, uint32_t k);             // u32 words of the plan (both halves)
 size_t gate_plan_partial_elems(uint64_t gates, uint32_t k);     // Fr elements of pass scratch per proof
 void launch_gate_plan(GateSpan span, uint32_t k, const uint32_t* offsets, const uint32_t* cursor, const uint32_t* list, uint32_t* plan, hipStream_t s);
-// E: batch x 2^k_i entries eq(z, g), canonical; W / eq_mont: batch tables of 2^k entries in Montgomery form (stride lb.wstride)
-void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
+// eq(z, .) for the passes: E (batch x 2^k_i entries, canonical) when materialised, else null and the two half tables of the
+// layer's prologue (e_hi canonical, batch x 2^(k_i - kl); e_lo_mont Montgomery, batch x 2^kl): one reduced product per gate.
+// W / eq_mont: batch tables of 2^k entries in Montgomery form (stride lb.wstride).
+struct GateEq {
+    const Fr* E;
+    const Fr* e_hi;
+    const Fr* e_lo_mont;
+    uint32_t kl;
+};
+// the table is gathered while it stays in the 256 MiB Infinity Cache (k_i <= 22: 128 MiB per proof)
+constexpr uint32_t kGateEqTableMaxKi = 22;
+void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
                          hipStream_t s, const GateSet* sets = nullptr);
-void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
                            Fr* partials, hipStream_t s, const GateSet* sets = nullptr);
 // exclusive scan of n 32-bit counts (block_sums: n / 2048 + 1 words of scratch)
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s);

@@ -54,8 +54,8 @@ struct PlanLayout {
     size_t cap_packed;        // u64 entries
     size_t items_per, item_first, item_bucket, sorted, desc, group_len, group_off, scan_sums, multi, longb, packed, half_words;
 };
-// header of a half: [0] items, [1] groups, [2] buckets of 2 .. kLongItems items, [3] buckets of more, [8 + c] items of length c,
-// [32 + c] the sort's cursors
+// header of a half: [0] items, [1] groups, [2] buckets of 2 .. kLongItems items, [3] buckets of more, [4] groups of two and
+// more steps (sorted by length, they come first), [8 + c] items of length c, [32 + c] the sort's cursors
 constexpr uint32_t kPlanHdrWords = 64;
 static PlanLayout plan_layout(uint64_t gates, uint32_t k) {
     PlanLayout L;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) k_plan_sort(const uint32_t* __restrict__ 
 __global__ void __launch_bounds__(256) k_plan_groups(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor,
                                                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ item_first,
                                                      const uint32_t* __restrict__ item_bucket, const uint32_t* __restrict__ sorted,
-                                                     uint32_t* __restrict__ group_len, uint32_t cap_groups) {
+                                                     uint32_t* __restrict__ group_len, uint32_t cap_groups, uint32_t* __restrict__ hdr_out) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cap_groups) return;
     uint32_t ilen = 0;
@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(256) k_plan_groups(const uint32_t* __restrict_
         ilen = len - kItemMax * j < kItemMax ? len - kItemMax * j : kItemMax;
     }
     group_len[g] = ilen;
+    if (ilen >= 2u) atomicAdd(hdr_out + 4, 1u);
 }
 // a wave per group: the items' entries step-major, and what a lane needs to know of its item
 //   desc = bucket | (the item is its whole bucket) << 31
@@ -208,7 +209,7 @@ void launch_gate_plan(GateSpan span, uint32_t k, const uint32_t* offsets, const 
         hipLaunchKernelGGL(k_plan_items, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.item_first, P + L.item_bucket);
         hipLaunchKernelGGL(k_plan_sort, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, P, P + L.item_first, P + L.item_bucket, P + L.sorted);
         hipLaunchKernelGGL(k_plan_groups, dim3((L.cap_groups + 255u) / 256u), dim3(256), 0, s, off, cur, P, P + L.item_first, P + L.item_bucket, P + L.sorted,
-                           P + L.group_len, L.cap_groups);
+                           P + L.group_len, L.cap_groups, P);
         launch_exclusive_scan(P + L.group_len, P + L.group_off, P + L.scan_sums, L.cap_groups, s);
         hipLaunchKernelGGL(k_plan_pack, dim3((L.cap_groups * 64u + 255u) / 256u), dim3(256), 0, s, off, cur, list, meta, P, P + L.items_per, P + L.item_first,
                            P + L.item_bucket, P + L.sorted, P + L.group_len, P + L.group_off, P + L.desc,
@@ -223,16 +224,34 @@ __device__ __forceinline__ Fr fr_canonical(Fr x) {
     return x;
 }
 
-// The pass: grid = (groups / 4 rounded up, batch), block = 256 = four waves = four groups.
+// eq(z, g): gathered from the materialised table, or -- layers whose table would not stay in the 256 MiB Infinity Cache
+// (a random 32-byte gather from 512 MiB fetched 1.95 GB per pass over 2^24 gates: profiles/r05/b_*) -- one reduced product of
+// the two half tables E_hi (canonical) and E_lo (Montgomery), both a few hundred KiB
+struct EqSource {
+    const Fr* E;          // batch x 2^k_i, or null: the split form
+    const Fr* e_hi;       // batch x 2^(k_i - kl)
+    const Fr* e_lo_mont;  // batch x 2^kl
+    uint32_t k_i, kl;
+};
+__device__ __forceinline__ Fr eq_at(const EqSource& q, uint32_t g) {
+    if (q.E) return load_fr(q.E + ((size_t)blockIdx.y << q.k_i) + g);
+    return mont_mul(load_fr(q.e_hi + ((size_t)blockIdx.y << (q.k_i - q.kl)) + (g >> q.kl)),
+                    load_fr(q.e_lo_mont + ((size_t)blockIdx.y << q.kl) + (g & ((1u << q.kl) - 1u))));
+}
+
+// The passes: grid = (groups / 4 rounded up, batch), block = 256 = four waves = four groups.
 //   ROWS == false (U, V):      mult gate: P += e t;   add gate: Q += e t and P += e      -> out0 = U, out1 = V
 //   ROWS == true  (a_u, m_u):  add gate:  P += e t;   mult gate: Q += e t               -> out0 = a_u, out1 = m_u
-// e = E[g] = eq(z, g), canonical; t = T[other operand], Montgomery form (W resp. eq(u, .)).
+// e = eq(z, g), canonical; t = T[other operand], Montgomery form (W resp. eq(u, .)).
+// Groups whose items hold one gate or none (sorted by length, such items fill whole waves) take a short way: one reduced
+// product per lane, no accumulators.  (As a kernel of its own, with few registers and many waves in flight, that path was
+// SLOWER -- 2^20 gates over 2^20 values 0.095 / 0.102 ms per pass against 0.077 / 0.093: the pass is bound by the 128-byte
+// lines its random 32-byte gathers and stores move, ~400 MB per pass, not by latency; profiles/r05/b_*.)
 template <bool ROWS>
-__global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ E, uint32_t k_i,
-                                                    const Fr* __restrict__ T, uint32_t wstride, Fr* __restrict__ out0, Fr* __restrict__ out1,
-                                                    Fr* __restrict__ partials, size_t pstride, uint32_t gate_base,
-                                                    const GateSet* __restrict__ sets) {
-    if (sets) plan = sets[blockIdx.y].plan;   // proofs of different circuits in one launch: this proof's plan
+__global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__ plan, PlanLayout L, EqSource eq, const Fr* __restrict__ T,
+                                                    uint32_t wstride, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ partials,
+                                                    size_t pstride, uint32_t gate_base, const GateSet* __restrict__ sets) {
+    if (sets) plan = sets[blockIdx.y].plan;
     plan += ROWS ? L.half_words : 0;
     const uint32_t lane = threadIdx.x & 63u, g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (g >= plan[1]) return;
@@ -241,19 +260,17 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
     const uint32_t d = live ? plan[L.desc + pos] : 0u;
     const uint32_t bucket = d & 0x7fffffffu;
     const bool whole = (d >> 31) != 0u;
-    E += (size_t)blockIdx.y << k_i;
     T += (size_t)blockIdx.y * wstride;
     out0 += (size_t)blockIdx.y * wstride;
     out1 += (size_t)blockIdx.y * wstride;
     const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(plan + L.packed) + (size_t)plan[L.group_off + g] * 64u + lane;
     if (steps <= 1u) {
-        // items of one gate (or none): one reduced product, no accumulators.  (Sorted by length, such items fill whole waves.)
         Fr o0 = fr_zero(), o1 = fr_zero();
-        const unsigned long long en = steps ? ent[0] : kNoGate;
-        if (en != kNoGate) {
-            const Fr e = load_fr(E + ((uint32_t)(en & 0xfffffffu) + gate_base));
-            const Fr t = load_fr(T + (uint32_t)((en >> 28) & 0xffffffu));
-            const bool mult = (en >> 63) != 0ull;
+        const unsigned long long en1 = steps ? ent[0] : kNoGate;
+        if (en1 != kNoGate) {
+            const Fr e = eq_at(eq, (uint32_t)(en1 & 0xfffffffu) + gate_base);
+            const Fr t = load_fr(T + (uint32_t)((en1 >> 28) & 0xffffffu));
+            const bool mult = (en1 >> 63) != 0ull;
             const Fr et = mont_mul(e, t);
             if (ROWS) {
                 o0 = mult ? o0 : et;
@@ -281,7 +298,7 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
         const unsigned long long cur = en;
         if (st + 1u < steps) en = ent[(size_t)(st + 1u) * 64u];   // the next step's entry is on its way while this one's products run
         if (cur != kNoGate) {
-            const Fr e = load_fr(E + ((uint32_t)(cur & 0xfffffffu) + gate_base));
+            const Fr e = eq_at(eq, (uint32_t)(cur & 0xfffffffu) + gate_base);
             const Fr t = load_fr(T + (uint32_t)((cur >> 28) & 0xffffffu));
             const bool mult = (cur >> 63) != 0ull;
             lazy_mac_sel(P, Q, ROWS ? !mult : mult, e, t);
@@ -346,25 +363,26 @@ __global__ void __launch_bounds__(256) k_items_combine_long(const uint32_t* __re
 }
 
 template <bool ROWS>
-static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
+static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& ge, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
                                 Fr* partials, hipStream_t s, const GateSet* sets) {
     const PlanLayout L = plan_layout(span.count, k);
     const size_t pstride = gate_plan_partial_elems(span.count, k);
+    const EqSource eq{ge.E, ge.e_hi, ge.e_lo_mont, k_i, ge.kl};
     // (grids from the plan's capacities: the kernels read the counts the build left on the device, waves beyond them leave at once)
-    hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((L.cap_groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, E, k_i, T, (uint32_t)lb.wstride, out0, out1,
+    hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((L.cap_groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, eq, T, (uint32_t)lb.wstride, out0, out1,
                        partials, pstride, (uint32_t)span.base, sets);
     hipLaunchKernelGGL((k_items_combine<ROWS>), dim3((L.cap_multi + 255u) / 256u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
                        (uint32_t)lb.wstride, sets);
     hipLaunchKernelGGL((k_items_combine_long<ROWS>), dim3(L.cap_long < 64u ? L.cap_long : 64u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0,
                        out1, (uint32_t)lb.wstride, sets);
 }
-void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
+void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
                          hipStream_t s, const GateSet* sets) {
-    launch_items_pass_t<false>(span, k_i, k, plan, E, W, U, V, lb, partials, s, sets);
+    launch_items_pass_t<false>(span, k_i, k, plan, eq, W, U, V, lb, partials, s, sets);
 }
-void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const Fr* E, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
+void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
                            Fr* partials, hipStream_t s, const GateSet* sets) {
-    launch_items_pass_t<true>(span, k_i, k, plan, E, eq_mont, A_row, M_row, lb, partials, s, sets);
+    launch_items_pass_t<true>(span, k_i, k, plan, eq, eq_mont, A_row, M_row, lb, partials, s, sets);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries

@@ -31,6 +31,37 @@ def config5_layer(k_i=24, k=12, seed=SEED + 5):
     return lay, z, W
 
 
+def circom_shaped_layer(k_i=20, k=20, seed=SEED + 9):
+    """A WIDE layer with the structure the reference's compiler emits (rust/src/convert.rs:209-214, 278-343; read off the
+    layers gkr_amd.convert compiles from the demo R1CS): gates come in index order of the values they feed on --
+      * a quarter: mult gates, every other one reading ONE hot wire (slot 1: a bucket with an eighth of the layer), the rest a
+        value and its neighbour, in ascending order;
+      * a quarter: add gates over adjacent pairs (2j, 2j + 1);
+      * the rest: relay gates Add(x, zero) carrying values up unchanged, x ascending, ALL reading the zero slot 0 as their
+        right operand (one bucket with half the layer), the tail padding gates Add(0, 0);
+    so a value feeds one gate, runs of gates read runs of values, and two wires feed most of the layer -- unlike
+    config5_layer's uniform draw, which has no locality for a kernel to use.  Random z and W.  2^k >= 2^k_i / 2."""
+    rng = np.random.default_rng(seed)
+    g, m = 1 << k_i, 1 << k
+    q = g >> 2
+    gt = np.zeros(g, dtype=np.uint8)
+    l = np.zeros(g, dtype=np.uint32)
+    r = np.zeros(g, dtype=np.uint32)
+    j = np.arange(q, dtype=np.uint64)
+    gt[:q] = 1
+    l[:q] = np.where(j & 1, 1, 2 + j // 2) % m
+    r[:q] = np.where(j & 1, 2 + j // 2, 2 + j // 2 + (j // 2) % 2) % m
+    base = 2 + q // 2
+    l[q:2 * q] = (base + 2 * j) % m
+    r[q:2 * q] = (base + 2 * j + 1) % m
+    relays = g - 2 * q - (g >> 6)
+    jr = np.arange(relays, dtype=np.uint64)
+    l[2 * q:2 * q + relays] = (base + 2 * q + jr) % m
+    lay = Layer(k_i, gt, l, r)
+    z, W = rand_fr(rng, k_i), rand_fr(rng, 1 << k)
+    return lay, z, W
+
+
 def wide_circuit(ks=(18, 20, 20), seed=SEED + 7):
     """A circuit with WIDE layers (2^k[i] random gates over 2^k[i+1] values) and one witness: what bench.py's wide_prove leg
     and tools/bench_wide_prove.py prove.  -> (GKRCircuit, [(gate_type, left, right)], witness limbs (1, 2^k[-1], 4))."""

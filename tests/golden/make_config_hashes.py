@@ -127,6 +127,18 @@ def main():
             f.write("\n")
         print("wrote", path)
         return
+    if "--circom-shaped" in sys.argv:   # only the compiler-shaped wide layer's digest, added to the committed file
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
+        cur = json.load(open(path))
+        for k_i, k in ((20, 20),):
+            lay, z, W = synth.circom_shaped_layer(k_i, k)
+            C, L, R = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+            cur["layer"]["circom-shaped,k_i=%d,k=%d" % (k_i, k)] = digest(C, L, R)
+        with open(path, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        return
     if "--prove-coeffs" in sys.argv:   # only the d / input_func digests of the wide proof, added to the committed file
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
         cur = json.load(open(path))

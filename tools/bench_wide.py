@@ -16,7 +16,7 @@ def main():
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(20, 15), (22, 16), (24, 18), (20, 20), (22, 22)]
     with Context(0) as ctx:
         for k_i, k in shapes:
-            lay, z, W = synth.config5_layer(k_i, k, seed=1234 + k_i * 100 + k)
+            lay, z, W = (synth.circom_shaped_layer(k_i, k) if os.environ.get("WIDE_SHAPE") == "circom" else synth.config5_layer(k_i, k, seed=1234 + k_i * 100 + k))
             t0 = time.perf_counter()
             ctx.sumcheck_layer_raw(lay, k, z, W)
             t_first = time.perf_counter() - t0
