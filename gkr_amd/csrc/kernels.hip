@@ -1367,17 +1367,56 @@ __global__ void __launch_bounds__(256) k_pred_sum(size_t ncells, const uint32_t*
 // c-phase sum over).  One counting sort over 2 * 2^k buckets -- bucket b = left operand b, bucket 2^k + c = right
 // operand c -- into one list of 2 G entries; shared by all proofs of a batch (same gates).
 // ---------------------------------------------------------------------------
+// One atomic for all the lanes of a wave that hit the same counter as the wave's first (then second) pending lane: the gates
+// of a compiled layer come in runs -- 64 consecutive relay gates all read the zero slot (convert.rs:307-342), every other mult
+// gate one hot wire -- and 2^19 single atomics on ONE address took 2.8 ms where 2^20 over random addresses take 0.13
+// (profiles/r05/b_*).  The lanes that went together get consecutive positions in lane order: a run of gates stays a run in
+// its bucket's list (what the item passes' gathers like).  Called by every lane of the wave; -> the lane's position (its old
+// counter value), meaningless where !active.
+__device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* __restrict__ counters, uint32_t idx, bool active) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t pos = 0;
+    bool pending = active;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long todo = __ballot(pending);
+        if (!todo) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lead_idx = (uint32_t)__shfl((int)idx, leader, 64);
+        const bool mine = pending && idx == lead_idx;
+        const unsigned long long same = __ballot(mine);
+        const uint32_t cnt = (uint32_t)__popcll(same);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(counters + lead_idx, cnt);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) {
+            pos = base + (uint32_t)__popcll(same & below);
+            pending = false;
+        }
+    }
+    if (pending) pos = atomicAdd(counters + idx, 1u);
+    return pos;
+}
+
 __global__ void k_gate_count(uint64_t gates, uint32_t k, const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ left,
                              const uint32_t* __restrict__ right, uint32_t* __restrict__ counts, uint32_t* __restrict__ bad) {
     const uint32_t n = 1u << k;
-    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t l = left[g], r = right[g];
-        if (l >= n || r >= n || gate_type[g] > 1) {
-            atomicOr(bad, 1u);
-            continue;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g0 = blockIdx.x * (uint64_t)blockDim.x; g0 < gates; g0 += stride) {   // (every lane of a wave stays in the loop)
+        const uint64_t g = g0 + threadIdx.x;
+        bool ok = g < gates;
+        uint32_t l = 0, r = 0;
+        if (ok) {
+            l = left[g];
+            r = right[g];
+            if (l >= n || r >= n || gate_type[g] > 1) {
+                atomicOr(bad, 1u);
+                ok = false;
+            }
         }
-        atomicAdd(counts + l, 1u);
-        atomicAdd(counts + n + r, 1u);
+        (void)wave_atomic_inc(counts, l, ok);
+        (void)wave_atomic_inc(counts + n, r, ok);
     }
 }
 
@@ -1385,14 +1424,24 @@ __global__ void k_gate_fill(uint64_t gates, uint32_t k, const uint8_t* __restric
                             const uint32_t* __restrict__ right, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list,
                             uint32_t* __restrict__ meta) {
     const uint32_t n = 1u << k;
-    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < gates; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t l = left[g], r = right[g];
-        if (l >= n || r >= n || gate_type[g] > 1) continue;
-        const uint32_t t = (uint32_t)gate_type[g] << 31, pl = atomicAdd(cursor + l, 1u), pr = atomicAdd(cursor + n + r, 1u);
-        list[pl] = (uint32_t)g;
-        meta[pl] = r | t;   // what the sums over this bucket need of the gate besides its index: the other operand, the type
-        list[pr] = (uint32_t)g;
-        meta[pr] = l | t;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g0 = blockIdx.x * (uint64_t)blockDim.x; g0 < gates; g0 += stride) {
+        const uint64_t g = g0 + threadIdx.x;
+        bool ok = g < gates;
+        uint32_t l = 0, r = 0, t = 0;
+        if (ok) {
+            l = left[g];
+            r = right[g];
+            ok = !(l >= n || r >= n || gate_type[g] > 1);
+            t = ok ? (uint32_t)gate_type[g] << 31 : 0u;
+        }
+        const uint32_t pl = wave_atomic_inc(cursor, l, ok), pr = wave_atomic_inc(cursor + n, r, ok);
+        if (ok) {
+            list[pl] = (uint32_t)g;
+            meta[pl] = r | t;   // what the sums over this bucket need of the gate besides its index: the other operand, the type
+            list[pr] = (uint32_t)g;
+            meta[pr] = l | t;
+        }
     }
 }
 

@@ -46,16 +46,18 @@ namespace gkr {
 constexpr uint32_t kItemMax = 16;
 constexpr uint32_t kLongItems = 64;
 constexpr uint32_t kClasses = kItemMax + 1;   // item lengths 0 .. kItemMax
+constexpr uint32_t kChunkItems = 1024;        // a long bucket's items are summed a wave per chunk of this many, then a wave per bucket
 
 // the plan of ONE half (left-operand buckets / right-operand buckets) as offsets (in u32 words) from the half's base
 struct PlanLayout {
     uint32_t nb;              // buckets per half
-    uint32_t cap_items, cap_groups, cap_multi, cap_long;
+    uint32_t cap_items, cap_groups, cap_multi, cap_long, cap_chunks;
     size_t cap_packed;        // u64 entries
-    size_t items_per, item_first, item_bucket, sorted, desc, group_len, group_off, scan_sums, multi, longb, packed, half_words;
+    size_t items_per, item_first, item_bucket, sorted, desc, group_len, group_off, scan_sums, multi, longb, long_chunk0, chunk_slot, packed, half_words;
 };
-// header of a half: [0] items, [1] groups, [2] buckets of 2 .. kLongItems items, [3] buckets of more, [4] groups of two and
-// more steps (sorted by length, they come first), [8 + c] items of length c, [32 + c] the sort's cursors
+// header of a half: [0] items, [1] groups, [2] buckets of 2 .. kLongItems items, [3] buckets of more ("long"), [4] groups of two
+// and more steps (sorted by length, they come first), [5] chunks of kChunkItems items the long buckets are summed in,
+// [8 + c] items of length c, [32 + c] the sort's cursors
 constexpr uint32_t kPlanHdrWords = 64;
 static PlanLayout plan_layout(uint64_t gates, uint32_t k) {
     PlanLayout L;
@@ -65,6 +67,7 @@ static PlanLayout plan_layout(uint64_t gates, uint32_t k) {
     L.cap_groups = L.cap_items / 64 + 2;
     L.cap_multi = (uint32_t)(gates / kItemMax + 1);
     L.cap_long = (uint32_t)(gates / ((uint64_t)kItemMax * kLongItems) + 1);
+    L.cap_chunks = L.cap_items / kChunkItems + L.cap_long + 1;
     L.cap_packed = (size_t)gates + 64u * 2u * kItemMax + 64u;              // padding only where the length changes inside a wave
     size_t w = kPlanHdrWords;
     auto take = [&](size_t n) { const size_t at = w; w += (n + 3) & ~(size_t)3; return at; };
@@ -78,12 +81,18 @@ static PlanLayout plan_layout(uint64_t gates, uint32_t k) {
     L.scan_sums = take((L.cap_items > nb ? L.cap_items : nb) / 2048 + 4);
     L.multi = take(L.cap_multi);
     L.longb = take(L.cap_long);
+    L.long_chunk0 = take(L.cap_long);
+    L.chunk_slot = take(L.cap_chunks);
     L.packed = take(2 * L.cap_packed);
     L.half_words = w;
     return L;
 }
 size_t gate_plan_words(uint64_t gates, uint32_t k) { return 2 * plan_layout(gates, k).half_words; }
-size_t gate_plan_partial_elems(uint64_t gates, uint32_t k) { return 2 * (size_t)plan_layout(gates, k).cap_items; }   // per proof, one half at a time
+// per proof, one half at a time: two sums per item, and behind them two per chunk of a long bucket
+size_t gate_plan_partial_elems(uint64_t gates, uint32_t k) {
+    const PlanLayout L = plan_layout(gates, k);
+    return 2 * (size_t)L.cap_items + 2 * (size_t)L.cap_chunks;
+}
 
 // packed entry: gate index (28 bits) | other operand (24 bits) << 28 | gate type << 63; all ones = no gate in this step
 constexpr unsigned long long kNoGate = ~0ull;
@@ -91,16 +100,20 @@ constexpr unsigned long long kNoGate = ~0ull;
 // one thread per bucket of the half: items of the bucket, and the buckets that need a combine step
 __global__ void __launch_bounds__(256) k_plan_count(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
                                                     uint32_t* __restrict__ hdr, uint32_t* __restrict__ items_per, uint32_t* __restrict__ multi,
-                                                    uint32_t* __restrict__ longb) {
+                                                    uint32_t* __restrict__ longb, uint32_t* __restrict__ long_chunk0, uint32_t* __restrict__ chunk_slot) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t len = cursor[b] - offsets[b];
     const uint32_t n = len ? (len + kItemMax - 1u) / kItemMax : 1u;   // (an empty bucket is one item of length zero)
     items_per[b] = n;
-    if (n > kLongItems)
-        longb[atomicAdd(hdr + 3, 1u)] = b;
-    else if (n > 1u)
+    if (n > kLongItems) {
+        const uint32_t slot = atomicAdd(hdr + 3, 1u), nch = (n + kChunkItems - 1u) / kChunkItems, c0 = atomicAdd(hdr + 5, nch);
+        longb[slot] = b;
+        long_chunk0[slot] = c0;
+        for (uint32_t c = 0; c < nch; ++c) chunk_slot[c0 + c] = slot;   // (few: a bucket of 2^24 gates has 1024 chunks)
+    } else if (n > 1u) {
         multi[atomicAdd(hdr + 2, 1u)] = b;
+    }
 }
 // one thread per item: its bucket (a search in the buckets' first items), its length class counted
 __global__ void __launch_bounds__(256) k_plan_items(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ cursor, uint32_t nb,
@@ -204,7 +217,8 @@ void launch_gate_plan(GateSpan span, uint32_t k, const uint32_t* offsets, const 
         uint32_t* P = plan + (size_t)half * L.half_words;
         const uint32_t *off = offsets + (size_t)half * L.nb, *cur = cursor + (size_t)half * L.nb;
         (void)hipMemsetAsync(P, 0, kPlanHdrWords * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(k_plan_count, dim3((L.nb + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.multi, P + L.longb);
+        hipLaunchKernelGGL(k_plan_count, dim3((L.nb + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.multi, P + L.longb, P + L.long_chunk0,
+                           P + L.chunk_slot);
         launch_exclusive_scan(P + L.items_per, P + L.item_first, P + L.scan_sums, L.nb, s);
         hipLaunchKernelGGL(k_plan_items, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, L.nb, P, P + L.items_per, P + L.item_first, P + L.item_bucket);
         hipLaunchKernelGGL(k_plan_sort, dim3((L.cap_items + 255u) / 256u), dim3(256), 0, s, off, cur, P, P + L.item_first, P + L.item_bucket, P + L.sorted);
@@ -337,7 +351,33 @@ __global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restric
     store_fr(out0 + (size_t)blockIdx.y * wstride + b, acc_reduce(a0));
     store_fr(out1 + (size_t)blockIdx.y * wstride + b, acc_reduce(a1));
 }
-// buckets of more items (the constant wires): a wave per bucket
+// buckets of more items (the constant wires every relay gate reads: ONE bucket with half the layer), in two steps: a wave per
+// chunk of kChunkItems items, then a wave per bucket over its chunks (one wave over the 32 768 items of a 2^19-gate bucket
+// took 0.15 ms -- longer than the pass itself)
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_items_combine_chunks(const uint32_t* __restrict__ plan, PlanLayout L, Fr* __restrict__ partials, size_t pstride,
+                                                              const GateSet* __restrict__ sets) {
+    if (sets) plan = sets[blockIdx.y].plan;
+    plan += ROWS ? L.half_words : 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    Fr* base = partials + (size_t)blockIdx.y * pstride;
+    for (uint32_t c = wave; c < plan[5]; c += nwaves) {
+        const uint32_t slot = plan[L.chunk_slot + c], b = plan[L.longb + slot], first = plan[L.item_first + b], n = plan[L.items_per + b];
+        const uint32_t lo = (c - plan[L.long_chunk0 + slot]) * kChunkItems, hi = lo + kChunkItems < n ? lo + kChunkItems : n;
+        const Fr* part = base + 2u * (size_t)first;
+        Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
+        for (uint32_t j = lo + lane; j < hi; j += 64u) {
+            acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
+            acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+            store_fr(base + 2u * (size_t)L.cap_items + 2u * (size_t)c, acc_reduce(a0));
+            store_fr(base + 2u * (size_t)L.cap_items + 2u * (size_t)c + 1u, acc_reduce(a1));
+        }
+    }
+}
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_items_combine_long(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ partials, size_t pstride,
                                                             Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride,
@@ -346,10 +386,10 @@ __global__ void __launch_bounds__(256) k_items_combine_long(const uint32_t* __re
     plan += ROWS ? L.half_words : 0;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t m = wave; m < plan[3]; m += nwaves) {
-        const uint32_t b = plan[L.longb + m], first = plan[L.item_first + b], n = plan[L.items_per + b];
-        const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)first;
+        const uint32_t b = plan[L.longb + m], n = plan[L.items_per + b], nch = (n + kChunkItems - 1u) / kChunkItems;
+        const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)L.cap_items + 2u * (size_t)plan[L.long_chunk0 + m];
         Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
-        for (uint32_t j = lane; j < n; j += 64u) {
+        for (uint32_t j = lane; j < nch; j += 64u) {
             acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
             acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
         }
@@ -373,6 +413,8 @@ static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const u
                        partials, pstride, (uint32_t)span.base, sets);
     hipLaunchKernelGGL((k_items_combine<ROWS>), dim3((L.cap_multi + 255u) / 256u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
                        (uint32_t)lb.wstride, sets);
+    hipLaunchKernelGGL((k_items_combine_chunks<ROWS>), dim3(L.cap_chunks < 1024u ? (L.cap_chunks + 3u) / 4u : 256u, lb.batch), dim3(256), 0, s, plan, L, partials,
+                       pstride, sets);
     hipLaunchKernelGGL((k_items_combine_long<ROWS>), dim3(L.cap_long < 64u ? L.cap_long : 64u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0,
                        out1, (uint32_t)lb.wstride, sets);
 }
