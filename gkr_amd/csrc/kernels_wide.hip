@@ -258,54 +258,72 @@ __device__ __forceinline__ Fr eq_at(const EqSource& q, uint32_t g) {
 //   ROWS == true  (a_u, m_u):  add gate:  P += e t;   mult gate: Q += e t               -> out0 = a_u, out1 = m_u
 // e = eq(z, g), canonical; t = T[other operand], Montgomery form (W resp. eq(u, .)).
 // Groups whose items hold one gate or none (sorted by length, such items fill whole waves) take a short way: one reduced
-// product per lane, no accumulators.  (As a kernel of its own, with few registers and many waves in flight, that path was
-// SLOWER -- 2^20 gates over 2^20 values 0.095 / 0.102 ms per pass against 0.077 / 0.093: the pass is bound by the 128-byte
-// lines its random 32-byte gathers and stores move, ~400 MB per pass, not by latency; profiles/r05/b_*.)
+// product per item, no accumulators.  (As a kernel of its own that path was slower: 0.095 / 0.102 ms per pass against
+// 0.077 / 0.093 at 2^20 gates over 2^20 values, profiles/r05/b_*.)
+constexpr uint32_t kSinglePerLane = 4;   // items of one gate (or none) a lane takes in one go
+
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__ plan, PlanLayout L, EqSource eq, const Fr* __restrict__ T,
                                                     uint32_t wstride, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ partials,
                                                     size_t pstride, uint32_t gate_base, const GateSet* __restrict__ sets) {
     if (sets) plan = sets[blockIdx.y].plan;
     plan += ROWS ? L.half_words : 0;
-    const uint32_t lane = threadIdx.x & 63u, g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (g >= plan[1]) return;
-    const uint32_t pos = 64u * g + lane, steps = plan[L.group_len + g];
-    const bool live = pos < plan[0];
-    const uint32_t d = live ? plan[L.desc + pos] : 0u;
-    const uint32_t bucket = d & 0x7fffffffu;
-    const bool whole = (d >> 31) != 0u;
+    const uint32_t lane = threadIdx.x & 63u, w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_items = plan[0], n_groups = plan[1], n_multi = plan[4];   // sorted by length: the first n_multi groups have two and more steps
     T += (size_t)blockIdx.y * wstride;
     out0 += (size_t)blockIdx.y * wstride;
     out1 += (size_t)blockIdx.y * wstride;
-    const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(plan + L.packed) + (size_t)plan[L.group_off + g] * 64u + lane;
-    if (steps <= 1u) {
-        Fr o0 = fr_zero(), o1 = fr_zero();
-        const unsigned long long en1 = steps ? ent[0] : kNoGate;
-        if (en1 != kNoGate) {
-            const Fr e = eq_at(eq, (uint32_t)(en1 & 0xfffffffu) + gate_base);
-            const Fr t = load_fr(T + (uint32_t)((en1 >> 28) & 0xffffffu));
-            const bool mult = (en1 >> 63) != 0ull;
-            const Fr et = mont_mul(e, t);
-            if (ROWS) {
-                o0 = mult ? o0 : et;
-                o1 = mult ? et : o1;
-            } else {
-                o0 = mult ? et : e;
-                o1 = mult ? o1 : et;
-            }
+    partials += (size_t)blockIdx.y * pstride;
+    const unsigned long long* packed = reinterpret_cast<const unsigned long long*>(plan + L.packed);
+    if (w >= n_multi) {
+        // Groups whose items hold one gate or none: one reduced product per item, no accumulators; a lane takes kSinglePerLane
+        // items of as many groups, all their loads in flight together (these waves are two dependent gathers and a store: a
+        // wave per group left the chip waiting for wave launches -- ~900 waves in flight on 1024 SIMDs, profiles/r05/b_*)
+        const uint32_t g0 = n_multi + (w - n_multi) * kSinglePerLane;
+        if (g0 >= n_groups) return;
+        unsigned long long en[kSinglePerLane];
+        uint32_t d[kSinglePerLane], slot[kSinglePerLane];
+        bool live[kSinglePerLane];
+#pragma unroll
+        for (uint32_t q = 0; q < kSinglePerLane; ++q) {
+            const uint32_t g = g0 + q, pos = 64u * g + lane;
+            live[q] = g < n_groups && pos < n_items;
+            const uint32_t steps = g < n_groups ? plan[L.group_len + g] : 0u;
+            en[q] = live[q] && steps ? packed[(size_t)plan[L.group_off + g] * 64u + lane] : kNoGate;
+            d[q] = live[q] ? plan[L.desc + pos] : 0u;
+            slot[q] = live[q] && !(d[q] >> 31) ? plan[L.sorted + pos] : 0u;
         }
-        if (live) {
-            if (whole) {
-                store_fr(out0 + bucket, o0);
-                store_fr(out1 + bucket, o1);
-            } else {
-                Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)plan[L.sorted + pos];
-                store_fr(part, o0);
-                store_fr(part + 1, o1);
+        Fr e[kSinglePerLane], t[kSinglePerLane];
+#pragma unroll
+        for (uint32_t q = 0; q < kSinglePerLane; ++q) {
+            const bool has = en[q] != kNoGate;
+            e[q] = eq_at(eq, has ? (uint32_t)(en[q] & 0xfffffffu) + gate_base : 0u);
+            t[q] = load_fr(T + (has ? (uint32_t)((en[q] >> 28) & 0xffffffu) : 0u));
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kSinglePerLane; ++q) {
+            const bool has = en[q] != kNoGate, mult = (en[q] >> 63) != 0ull;
+            const Fr et = mont_mul(e[q], t[q]);
+            Fr o0, o1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t p = has ? et.l[i] : 0u, ee = has ? e[q].l[i] : 0u;
+                o0.l[i] = ROWS ? (mult ? 0u : p) : (mult ? p : ee);
+                o1.l[i] = ROWS ? (mult ? p : 0u) : (mult ? 0u : p);
+            }
+            if (live[q]) {
+                Fr* dst0 = (d[q] >> 31) ? out0 + (d[q] & 0x7fffffffu) : partials + 2u * (size_t)slot[q];
+                Fr* dst1 = (d[q] >> 31) ? out1 + (d[q] & 0x7fffffffu) : partials + 2u * (size_t)slot[q] + 1u;
+                store_fr(dst0, o0);
+                store_fr(dst1, o1);
             }
         }
         return;
     }
+    const uint32_t g = w, pos = 64u * g + lane, steps = plan[L.group_len + g];
+    const bool live = pos < n_items;
+    const uint32_t d = live ? plan[L.desc + pos] : 0u;
+    const unsigned long long* ent = packed + (size_t)plan[L.group_off + g] * 64u + lane;
     Lazy17 P = lazy_zero(), Q = lazy_zero();
     unsigned long long en = ent[0];
     for (uint32_t st = 0; st < steps; ++st) {
@@ -320,16 +338,17 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
         }
     }
     // <= kItemMax products and <= kItemMax terms e * 2^256 per accumulator: the 32-term partial reduction applies
-    const Fr rp = lazy_reduce_partial32(P), rq = lazy_reduce_partial32(Q);
+    Fr rp = lazy_reduce_partial32(P), rq = lazy_reduce_partial32(Q);
     if (live) {
-        if (whole) {
-            store_fr(out0 + bucket, fr_canonical(rp));
-            store_fr(out1 + bucket, fr_canonical(rq));
-        } else {
-            Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)plan[L.sorted + pos];
-            store_fr(part, rp);
-            store_fr(part + 1, rq);
+        const bool whole = (d >> 31) != 0u;
+        if (whole) {   // (wave-uniform in all but the waves where the buckets' lengths change)
+            rp = fr_canonical(rp);
+            rq = fr_canonical(rq);
         }
+        Fr* dst0 = whole ? out0 + (d & 0x7fffffffu) : partials + 2u * (size_t)plan[L.sorted + pos];
+        Fr* dst1 = whole ? out1 + (d & 0x7fffffffu) : partials + 2u * (size_t)plan[L.sorted + pos] + 1u;
+        store_fr(dst0, rp);
+        store_fr(dst1, rq);
     }
 }
 
