@@ -608,15 +608,23 @@ def aggregated_proofs(world, n_inputs):
         step.prove_raw_many(ctx, acc_inputs, threads)
         acc_ms = (time.perf_counter() - t1) * 1e3
         lib.gkr_host_accounting(0)
-        buf = (ctypes.c_double * 8)()
-        lib.gkr_host_accounting_read(buf, 8)
-        own, helped, spin, rest, lent, lent_idle, calls, wake = [float(x) for x in buf]
+        buf = (ctypes.c_double * 28)()
+        lib.gkr_host_accounting_read(buf, 28)
+        own, helped, spin, rest, lent, lent_idle, calls, wake = [float(x) for x in buf[:8]]
+        n_pieces, piece_us, pass_us = float(buf[8]), float(buf[9]), float(buf[10])
+        lanes_hist = [int(buf[10 + n]) for n in range(1, 17)]
         thread_ms = threads * acc_ms
         accounts = {"step_ms": round(acc_ms, 3), "threads": threads, "proving_calls": int(calls),
                     "thread_ms": {"own_hashing_pieces": round(own / 1e3, 2), "others_pieces_while_waiting_for_the_gpu": round(helped / 1e3, 2),
                                   "spinning_on_the_gpu_nothing_to_take": round(spin / 1e3, 2), "launches_setup_copies": round(rest / 1e3, 2),
                                   "pieces_by_threads_without_an_item": round(lent / 1e3, 2), "those_threads_idle": round(lent_idle / 1e3, 2),
                                   "from_the_call_to_the_threads_first_item": round(wake / 1e3, 2)},
+                    # the hashing pieces themselves: how full the sixteen IFMA lanes were, and what the threads' "piece" time is made of
+                    "pieces": {"count": int(n_pieces), "transcripts_per_piece_histogram_1_to_16": lanes_hist,
+                               "mean_transcripts_per_piece": round(sum((n + 1) * c for n, c in enumerate(lanes_hist)) / max(1.0, n_pieces), 2),
+                               "ms_inside_the_pass_function_hashes_and_field_arithmetic": round(pass_us / 1e3, 2),
+                               "ms_copying_round_vectors_out": round((piece_us - pass_us) / 1e3, 2),
+                               "ms_posting_looking_for_and_waiting_for_pieces": round((own + helped + lent - piece_us) / 1e3, 2)},
                     "busy_fraction_of_threads_x_step": round((own + helped + rest + lent) / 1e3 / thread_ms, 3) if thread_ms else None,
                     "idle_fraction": round((spin + lent_idle) / 1e3 / thread_ms, 3) if thread_ms else None}
     ver3 = None

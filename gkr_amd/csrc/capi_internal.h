@@ -543,6 +543,10 @@ inline thread_local ThreadTimeAccount t_account;
 // instead of the stderr lines -- bench.py puts them on its line for one extra, untimed proving step
 struct HostAccountTotals {
     std::atomic<uint64_t> own_ns{0}, helped_ns{0}, spin_ns{0}, rest_ns{0}, lent_ns{0}, lent_idle_ns{0}, calls{0}, wake_ns{0};
+    // the hashing pieces themselves (whoever ran them): how many, their time, the part of it inside the pass function (the J
+    // hashes of the piece's transcripts in IFMA lanes or on the scalar code, and the field arithmetic between them), and how
+    // many transcripts a piece carried (1 .. 16: the lanes of an IFMA call that were filled)
+    std::atomic<uint64_t> pieces{0}, piece_ns{0}, piece_pass_ns{0}, lanes[17] = {};
     std::atomic<bool> on{false};
 };
 inline HostAccountTotals& host_account_totals() {
@@ -550,6 +554,13 @@ inline HostAccountTotals& host_account_totals() {
     return t;
 }
 inline bool accounting_on() { return host_account_totals().on.load(std::memory_order_relaxed); }
+inline void account_piece(int transcripts, double pass_us, double total_us) {
+    HostAccountTotals& t = host_account_totals();
+    t.pieces.fetch_add(1, std::memory_order_relaxed);
+    t.piece_ns.fetch_add((uint64_t)(total_us * 1e3), std::memory_order_relaxed);
+    t.piece_pass_ns.fetch_add((uint64_t)(pass_us * 1e3), std::memory_order_relaxed);
+    t.lanes[transcripts < 1 ? 1 : (transcripts > 16 ? 16 : transcripts)].fetch_add(1, std::memory_order_relaxed);
+}
 inline double now_us_dbg() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline bool help_enabled() {

@@ -528,11 +528,14 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     const int cnt = batch - first < chunk ? batch - first : chunk;
                     uint64_t c2[gkr::kProdMaxJ][16][4], lin[gkr::kProdMaxJ][16][4], c0[gkr::kProdMaxJ][16][4], rr[gkr::kProdMaxJ][16][4];
                     uint32_t vl[gkr::kProdMaxJ][16];
+                    const bool acct = accounting_on();
+                    const double tp0 = acct ? now_us_dbg() : 0.0;
                     for (uint32_t t = 0; t < J; ++t)
                         for (int i = 0; i < cnt; ++i) vl[t][i] = 2u + (h_dep[(size_t)(first + i) * 32 + (round0 + t) % k] ? 1u : 0u);
                     (ifma && cnt >= 3 ? gkr::gkr_ifma_prod_pass : host_prod_pass_scalar)(
                         reinterpret_cast<const uint64_t*>(prec + first), sizeof(gkr::ProdPassRec) / 8, cnt, (int)J, vl, c2, lin, c0, rr,
                         reinterpret_cast<uint64_t*>(h_pw + (size_t)first * 8), 32);
+                    const double tp1 = acct ? now_us_dbg() : 0.0;
                     for (int i = 0; i < cnt; ++i) {
                         const int b = first + i;
                         for (uint32_t t = 0; t < J; ++t) {
@@ -546,6 +549,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                             memcpy(&out_r[b][round], rr[t][i], 32);
                         }
                     }
+                    if (acct) account_piece(cnt, tp1 - tp0, now_us_dbg() - tp0);
                     return true;
                 };
                 run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));

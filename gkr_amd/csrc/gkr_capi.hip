@@ -193,6 +193,10 @@ int gkr_host_accounting(int enable) {
         tot.lent_idle_ns = 0;
         tot.calls = 0;
         tot.wake_ns = 0;
+        tot.pieces = 0;
+        tot.piece_ns = 0;
+        tot.piece_pass_ns = 0;
+        for (auto& l : tot.lanes) l = 0;
     }
     tot.on.store(enable != 0, std::memory_order_relaxed);
     return GKR_OK;
@@ -209,6 +213,13 @@ int gkr_host_accounting_read(double* out_us, size_t count) {
     out_us[4] = tot.lent_ns.load() * 1e-3;
     out_us[5] = tot.lent_idle_ns.load() * 1e-3;
     out_us[6] = (double)tot.calls.load();
+    if (count >= 28) {   // the hashing pieces: [8] how many, [9] their time, [10] of it inside the pass function, [11 + n] pieces of n + 1 transcripts
+        out_us[8] = (double)tot.pieces.load();
+        out_us[9] = tot.piece_ns.load() * 1e-3;
+        out_us[10] = tot.piece_pass_ns.load() * 1e-3;
+        for (int n = 1; n <= 16; ++n) out_us[10 + n] = (double)tot.lanes[n].load();
+        out_us[27] = 0.0;
+    }
     return GKR_OK;
 }
 

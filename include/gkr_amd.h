@@ -146,6 +146,11 @@ long gkr_host_help_while(const volatile int32_t *busy);
  * its gkr_prove / gkr_prove_batch calls (launches, set-up, copies), [4] pieces run by threads that had no proof left
  * (gkr_host_help_while), [5] their time with nothing to take, [6] the number of proving calls counted, and with
  * count >= 8 [7] the time gkr_prove_many's threads took to start on their items after the call woke them.  count >= 7.
+ * With count >= 28 also the hashing PIECES of the layer sumchecks themselves, whoever ran them: [8] how many, [9] their time,
+ * [10] the part of it inside the pass function (a piece's J hashes per transcript -- in IFMA lanes, or on the scalar code for
+ * fewer than three transcripts -- and the field arithmetic between them; the rest of [9] is copying the round vectors out),
+ * [10 + n] the number of pieces that carried n transcripts (n = 1 .. 16: the lanes of an IFMA call that were filled).
+ * [0] + [1] + [4] - [9] is what the threads spent posting pieces, looking for them and waiting for the last one of a pass.
  * The reference has no counterpart (rayon hides its scheduling); bench.py reports these for its aggregated-proofs leg. */
 int  gkr_host_accounting(int enable);
 int  gkr_host_accounting_read(double *out_us, size_t count);
