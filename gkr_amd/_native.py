@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgkr_amd.so")
+# (GKR_AMD_LIB: another build of the same library -- same-box A/B runs of two source states; never a fallback)
+LIB_PATH = os.environ.get("GKR_AMD_LIB") or os.path.join(_HERE, "lib", "libgkr_amd.so")
 
 GKR_OK = 0
 GKR_ERR_INVALID = 1

@@ -420,12 +420,20 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         WS(ctx, "prove.inflag", uint32_t, 1, d_in_flag);
         HIP_TRY(ctx, hipMemsetAsync(d_in_flag, 0, 4, s));
         gkr::launch_check_canonical(dW[L], n_in * (size_t)batch, d_in_flag, s);
-        HIP_TRY(ctx, hipMemcpyAsync(&h_in_flag, d_in_flag, 4, hipMemcpyDeviceToHost, s));
     }
     for (int i = (int)L - 1; i >= 0; --i)
         gkr::launch_layer_eval(1u << c->k[i], pc->gt[i], pc->l[i], pc->r[i], dW[i + 1], dW[i], (uint32_t)batch, 1u << c->k[i + 1], s,
                                n_members > 1 ? groups[i].d_sets : nullptr);
     HIP_TRY(ctx, hipGetLastError());
+    // Everything below up to the layers is OUTPUT ONLY (d, input_func, "output 0 must be zero", "the inputs were canonical"):
+    // it runs on the side stream behind the evaluation, beside the first layer's sumcheck, and the host looks at it after the
+    // last layer.  (It used to sit on the main stream with a synchronisation before the first layer: 0.14 ms of a lone
+    // 4.6 ms proof, 0.6 ms at the head of a seven-circuit group's chain.)
+    HIP_TRY(ctx, ctx->aux_stream(1));
+    hipStream_t side = ctx->aux;
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_events[0], s));
+    HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->aux_events[0], 0));
+    if (check_on_device) HIP_TRY(ctx, hipMemcpyAsync(&h_in_flag, d_in_flag, 4, hipMemcpyDeviceToHost, side));
     // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
     const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
     const F* hW0_first = nullptr;           // or only output 0 of every proof
@@ -441,8 +449,8 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         const size_t n = (size_t)1 << c->k[i];
         Fr* mono = nullptr;
         HIP_TRY(ctx, ctx->workspace(e ? "prove.monoL" : "prove.mono0", n * batch * sizeof(Fr), reinterpret_cast<void**>(&mono)));
-        HIP_TRY(ctx, hipMemcpyAsync(mono, dW[i], n * batch * sizeof(Fr), hipMemcpyDeviceToDevice, s));
-        gkr::launch_mobius(mono, c->k[i], n, (uint32_t)batch, s);
+        HIP_TRY(ctx, hipMemcpyAsync(mono, dW[i], n * batch * sizeof(Fr), hipMemcpyDeviceToDevice, side));
+        gkr::launch_mobius(mono, c->k[i], n, (uint32_t)batch, side);
         coeff_src[e] = mono;
         coeffs_done[e] = true;
     }
@@ -466,22 +474,17 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         ~CoeffCopier() { finish(); }
     } copier;
     if (coeffs_done[0] || coeffs_done[1]) {
-        HIP_TRY(ctx, ctx->aux_stream(1));
-        hipEvent_t ready = ctx->aux_events[0];
-        HIP_TRY(ctx, hipEventRecord(ready, s));
         const int device = ctx->device;
         const uint32_t k0 = c->k[0], kL = c->k[L];
         // (on the context's side stream, which the line restrictions use later in the call: stream order keeps them apart; a
         // synchronous hipMemcpy on the null stream held every other thread's HIP calls up for its whole duration -- 23 ms)
-        hipStream_t side = ctx->aux;
         if (!ctx->copier) ctx->copier.reset(new AsyncWorker());
         copier.worker = ctx->copier.get();
         copier.side = side;
         copier.started = true;
         CoeffCopier* cp = &copier;
         ctx->copier->run([=]() {
-            hipError_t e = hipSetDevice(device);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side, ready, 0);
+            hipError_t e = hipSetDevice(device);   // (the transforms are queued on the side stream already: stream order)
             for (int which = 0; which < 2 && e == hipSuccess; ++which) {
                 if (!coeff_src[which]) continue;
                 const size_t n = (size_t)1 << (which ? kL : k0);
@@ -499,22 +502,21 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
             // (of a W_0 whose coefficients come from the device only output 0 of every proof is looked at: "must be zero")
             F* dst = nullptr;
             HIP_TRY(ctx, ctx->pinned_host("prove.hW0first", sizeof(F) * (size_t)batch, reinterpret_cast<void**>(&dst)));
-            gkr::launch_copy_rows(dW[0], (size_t)8 << c->k[0], dst, 8, 8, (uint32_t)batch, s);   // (one launch: 8 words of every proof's table)
+            gkr::launch_copy_rows(dW[0], (size_t)8 << c->k[0], dst, 8, 8, (uint32_t)batch, side);   // (one launch: 8 words of every proof's table)
             hW0_first = dst;
             continue;
         }
         if (bytes <= kKernelCopyLimit) {
             F* dst = nullptr;
             HIP_TRY(ctx, ctx->pinned_host(e ? "prove.hWL" : "prove.hW0", bytes, reinterpret_cast<void**>(&dst)));
-            gkr::launch_copy_words(dW[i], dst, bytes / 4, s);
+            gkr::launch_copy_words(dW[i], dst, bytes / 4, side);
             hW[e] = dst;
         } else {
             hW_big[e].resize((size_t)batch << c->k[i]);
-            HIP_TRY(ctx, hipMemcpyAsync(hW_big[e].data(), dW[i], bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipMemcpyAsync(hW_big[e].data(), dW[i], bytes, hipMemcpyDeviceToHost, side));
             hW[e] = hW_big[e].data();
         }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
     const bool dbg_pb = gkr::debug_timing();
     const auto tpb0 = std::chrono::steady_clock::now();
     const bool account = accounting_on();
@@ -523,25 +525,9 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     if (dbg_pre)
         fprintf(stderr, "[gkr timing] prove, before the layers: input check %.0f us, circuit hash %.0f us, upload + evaluation + Moebius + readback %.0f us\n", us_canon,
                 us_hash - us_canon, us_since_entry() - us_hash);
-    if (h_in_flag) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
-    for (int b = 0; b < batch; ++b) {
-        if (members[member_of[b]].require_zero_output && !gkr::h64::is_zero(hW0_first ? hW0_first[b] : hW[0][(size_t)b << c->k[0]]))
-            return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
-        // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
-        std::vector<F> co;
-        if (!coeffs_done[0]) {
-            co.assign(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
-            mobius_msb(co, c->k[0]);
-            memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
-        }
-        if (!coeffs_done[1]) {
-            co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
-            mobius_msb(co, c->k[L]);
-            memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
-        }
-        // z[0] = 0 (prover.rs:16-21)
+    // z[0] = 0 (prover.rs:16-21)
+    for (int b = 0; b < batch; ++b)
         for (uint32_t j = 0; j < c->k[0]; ++j) memset(&outs[b].z[j], 0, sizeof(gkr_fr));
-    }
     std::vector<gkr_fr> z_cur((size_t)batch * (c->k[0] ? c->k[0] : 1));
     memset(z_cur.data(), 0, z_cur.size() * sizeof(gkr_fr));
     std::vector<gkr_fr*> scp(batch), srp(batch);
@@ -672,6 +658,26 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         copier.finish();   // (all coefficient copies are queued on the side stream before it is waited for)
         liner.finish();    // (and all line restrictions)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
+        // what the side stream brought back from before the layers: the checks of the inputs and outputs, and -- for tables
+        // the host transforms -- d and input_func
+        if (h_in_flag) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
+        for (int b = 0; b < batch; ++b) {
+            if (members[member_of[b]].require_zero_output && !gkr::h64::is_zero(hW0_first ? hW0_first[b] : hW[0][(size_t)b << c->k[0]]))
+                return ctx->fail(GKR_ERR_INVALID, "output 0 is not zero (convert.rs:838 asserts d_values[0] == 0)");
+            // monomial forms the Proof carries (get_multi_ext): d = W_0, input_func = W_L
+            std::vector<F> co;
+            if (!coeffs_done[0]) {
+                co.assign(hW[0] + ((size_t)b << c->k[0]), hW[0] + ((size_t)(b + 1) << c->k[0]));
+                mobius_msb(co, c->k[0]);
+                memcpy(outs[b].d_coeffs, co.data(), co.size() * sizeof(F));
+            }
+            if (!coeffs_done[1]) {
+                co.assign(hW[1] + ((size_t)b << c->k[L]), hW[1] + ((size_t)(b + 1) << c->k[L]));
+                mobius_msb(co, c->k[L]);
+                memcpy(outs[b].input_coeffs, co.data(), co.size() * sizeof(F));
+            }
+        }
+
         const F* hq = reinterpret_cast<const F*>(d_q);
         const uint32_t* hqlen = d_qlen;
         size_t off = 0;
