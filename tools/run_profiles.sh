@@ -28,10 +28,15 @@ LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --no-verify --p
 python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20.json 2>/dev/null
 GKR_BENCH_FORCE_GROUP=1 python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20_rccl_one_rank.json 2>/dev/null
 python bench.py --mode mle-split --log2-points 30 --steps 5 > $OUT/bench_mode_mle_split_n30.json 2>/dev/null
-# the default line with two ranks (two processes over gloo sharing the one GPU): every N > 1 field of the line
-GKR_BENCH_BACKEND=gloo GKR_BENCH_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --steps 4 --warmup 2 --batch 256 > $OUT/bench_default_2ranks_gloo_one_gpu.json 2> $OUT/bench_default_2ranks_gloo_one_gpu.err
+# the default line with two ranks (two processes over gloo sharing the one GPU), started by bench.py ITSELF (--gpus 2, no launcher
+# around it): every N > 1 field of the line
+GKR_BENCH_BACKEND=gloo GKR_BENCH_DEVICE=0 python bench.py --gpus 2 --steps 4 --warmup 2 --batch 256 > $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.json 2> $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.err
 python tools/bench_wide.py 20,15 22,16 24,18 20,20 22,22 > $OUT/bench_wide_layers.txt 2>&1
+WIDE_SHAPE=circom python tools/bench_wide.py 20,20 22,22 > $OUT/bench_wide_layers_circom_shaped.txt 2>&1
+bash tools/stats_large_r1cs.sh ${1:-r2x}/large_r1cs_lockstep 10 14 > $OUT/large_r1cs_lockstep_kernel_stats_summary.txt 2>&1
+GKR_PROVE_MANY_LOCKSTEP=0 bash tools/stats_large_r1cs.sh ${1:-r2x}/large_r1cs_one_chain_per_item 10 14 > $OUT/large_r1cs_one_chain_per_item_kernel_stats_summary.txt 2>&1
+python tools/bench_large_r1cs.py 30 14 8 4 > $OUT/large_r1cs_step_by_threads.txt 2>&1
+python tools/config3_accounts.py 64 14 20 > $OUT/config3_thread_and_piece_accounts.txt 2>&1
 bash tools/stats_wide.sh 20,20 24,18 > /dev/null 2>&1; cp gpurun_out/wide_stats_20_20.csv $OUT/kernel_stats_wide_layer_k_i20_k20.csv; cp gpurun_out/wide_stats_24_18.csv $OUT/kernel_stats_wide_layer_k_i24_k18.csv
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
 bash tools/trace_layer_timeline.sh > $OUT/layer24_kernel_timeline.txt 2>&1
