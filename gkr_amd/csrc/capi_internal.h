@@ -210,6 +210,7 @@ using namespace gkr_host;
 struct GateLists {
     uint32_t *offsets = nullptr, *cursor = nullptr, *list = nullptr;
     uint32_t* plan = nullptr;    // wide layers: the item plan of the gate passes (kernels_wide.hip, launch_gate_plan)
+    gkr::GatePlanCounts plan_counts{};   // ... and its counts as read back when it was built (known: exact grids, no empty combine step)
     gkr::GateSegs segs;   // the lists' segments (large layers; segs.words is one more device allocation)
     bool ready = false;
     void release() {
@@ -219,6 +220,7 @@ struct GateLists {
         if (plan) (void)hipFree(plan);
         if (segs.words) (void)hipFree(segs.words);
         offsets = cursor = list = plan = nullptr;
+        plan_counts = gkr::GatePlanCounts{};
         segs = gkr::GateSegs();
         ready = false;
     }
@@ -317,6 +319,7 @@ struct gkr_ctx {
     std::unique_ptr<AsyncWorker> liner;        // helper thread that issues a wide layer's line-restriction launches on the side stream (lazy)
     void* mle_arrivals_zeroed = nullptr;       // the same for the plain sumcheck's latency-bound passes
     void* arrivals_zeroed = nullptr;           // the product passes' arrival counters: zeroed once per allocation (every pass leaves them zero)
+    void* gate_arrive_zeroed = nullptr;        // the same for the wide gate passes' combine step
     bool crew_member = false;                  // one thread of several proving side by side: no workers of its own
     int help_share = 0;                        // crew threads per proving unit of the current gkr_prove_many call (0: not in one)
     int rounds_ahead = 0;                      // sumcheck rounds left in the proof being proven AFTER the current layer (help priority)
@@ -667,6 +670,7 @@ struct LayerShardArgs {
 // passes over the gates read each proof's lists through d_sets (one gkr::GateSet per proof, device memory).
 struct LayerGroup {
     const gkr::GateSet* d_sets = nullptr;
+    gkr::GatePlanCounts plan_counts{};   // the largest counts over the members (known only if every member's are)
 };
 int run_layer_batch(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, const gkr_fr* z,
                     const Fr* d_W, gkr_fr* const* out_coeffs, uint32_t* const* out_len, gkr_fr* const* out_r, const LayerShardArgs* shard = nullptr,

@@ -158,6 +158,15 @@ static bool layer_is_wide(gkr::GateSpan span, int k_i, int k) {
     return k >= wide_min_k && gkr::gate_segs_words(span, (uint32_t)k_i, (uint32_t)k) == 0;
 }
 
+// the counts a plan's build left in its two half headers -> host (queued; valid after the stream has been waited for)
+static hipError_t queue_plan_counts_readback(const uint32_t* plan, uint64_t gates, int k, gkr::GatePlanCounts* out, hipStream_t s) {
+    size_t half1 = 0;
+    gkr::gate_plan_counts_offsets(gates, (uint32_t)k, &half1);
+    hipError_t e = hipMemcpyAsync(out->hdr[0], plan, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->hdr[1], plan + half1, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    return e;
+}
+
 int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, const uint32_t* d_l, const uint32_t* d_r, GateLists* cached) {
     if (!cached) return ctx->fail(GKR_ERR_INVALID, "no list cache");
     if (cached->ready) return GKR_OK;
@@ -185,8 +194,10 @@ int build_cached_gate_lists(gkr_ctx* ctx, int k_i, int k, const uint8_t* d_gt, c
     }
     uint32_t hbad = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+    if (wide) HIP_TRY(ctx, queue_plan_counts_readback(cached->plan, span.count, k, &cached->plan_counts, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+    cached->plan_counts.known = wide;
     cached->ready = true;
     return GKR_OK;
 }
@@ -262,6 +273,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     Fr *e_hi = nullptr, *e_lo = nullptr;
     uint32_t *g_offsets = nullptr, *g_cursor = nullptr, *g_list = nullptr, *g_plan = nullptr;
     Fr *item_partials = nullptr, *E = nullptr;   // wide layers: the item passes' scratch, eq(z, .) as a table
+    uint32_t* gate_arrive = nullptr;             // ... and the combine step's arrival counters (zero between passes)
+    const gkr::GatePlanCounts* plan_counts = group ? &group->plan_counts : (cached && cached->ready ? &cached->plan_counts : nullptr);
     // where eq(z, g) is split into E_hi, E_lo: in the middle, or -- large layers, whose gate passes run over segments
     // of the sorted lists (gate_seg.h) -- where the segments are cut
     const uint32_t kl = gkr::gate_seg_shift(span, (uint32_t)k_i, (uint32_t)k);
@@ -305,6 +318,15 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             // eq(z, g) for every gate index of the layer (of the whole layer also when this rank holds a share of the gates: the
             // lists carry indices relative to the share's first gate, the passes add it back), canonical
             WS(ctx, "gates.itempart", Fr, gkr::gate_plan_partial_elems(span.count, (uint32_t)k) * batch, item_partials);
+            {
+                const size_t words = gkr::gate_plan_arrive_words(span.count, (uint32_t)k) * (size_t)batch;
+                const size_t alloc = words < 4096 ? 4096 : words;   // (one size for the small cases: zeroed once)
+                WS(ctx, "gates.arrive", uint32_t, alloc, gate_arrive);
+                if (ctx->gate_arrive_zeroed != gate_arrive || words > 4096) {
+                    HIP_TRY(ctx, hipMemsetAsync(gate_arrive, 0, alloc * sizeof(uint32_t), s));
+                    ctx->gate_arrive_zeroed = gate_arrive;
+                }
+            }
             if ((uint32_t)k_i <= gkr::kGateEqTableMaxKi) {
                 WS(ctx, "pred.E", Fr, (size_t)batch << k_i, E);
                 gkr_fr* hz2 = nullptr;
@@ -372,7 +394,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
     if (sparse) {
         Timed t(ctx, "gate_uv", (double)span.count * 8.0 * batch);   // HBM: the 8-byte list entry per gate (operands are L2 gathers)
         if (wide)
-            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, Wc, U, V, lb, item_partials, s, sets);
+            gkr::launch_gate_uv_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, Wc, U, V, lb, item_partials, gate_arrive, s, sets, plan_counts);
         else
             gkr::launch_gate_uv(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, Wc, U, V, lb, segs, seg_partials, s, sets);
     }
@@ -444,8 +466,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         if (sparse && lists_fresh && !(shard && shard->dev)) {   // lists found in the circuit cache were validated when they were built
             uint32_t hbad = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+            if (wide && cached) HIP_TRY(ctx, queue_plan_counts_readback(g_plan, span.count, k, &cached->plan_counts, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             if (hbad) return ctx->fail(GKR_ERR_INVALID, "gate type or operand index out of range");
+            if (wide && cached) cached->plan_counts.known = true;
         }
         if (batch >= 16) pool = ctx->host_pool();
     }
@@ -484,7 +508,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
                     const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
                     if (wide)
-                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, d_eq, A, M, lb, item_partials, s, sets);
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, d_eq, A, M, lb, item_partials, gate_arrive, s, sets, plan_counts);
                     else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
                                                               segs, seg_partials, s, shard ? nullptr : &fuse, sets);

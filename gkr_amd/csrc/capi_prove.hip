@@ -377,6 +377,14 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         groups.resize(L);
         for (uint32_t i = 0; i < L; ++i) {
             groups[i].d_sets = d_sets + (size_t)i * batch;
+            groups[i].plan_counts.known = true;
+            for (int m = 0; m < n_members; ++m) {
+                const gkr::GatePlanCounts& pcn = pcs[m]->lists[i].plan_counts;
+                groups[i].plan_counts.known = groups[i].plan_counts.known && pcn.known;
+                for (int half = 0; half < 2; ++half)
+                    for (int w = 0; w < 8; ++w)
+                        if (pcn.hdr[half][w] > groups[i].plan_counts.hdr[half][w]) groups[i].plan_counts.hdr[half][w] = pcn.hdr[half][w];
+            }
             for (int b = 0; b < batch; ++b) {
                 const PreparedCircuit* p = pcs[member_of[b]];
                 const GateLists& gl = p->lists[i];

@@ -270,10 +270,19 @@ struct GateEq {
 };
 // the table is gathered while it stays in the 256 MiB Infinity Cache (k_i <= 22: 128 MiB per proof)
 constexpr uint32_t kGateEqTableMaxKi = 22;
+// The plan's counts as the host read them back when the plan was built (hdr[half]: [1] groups, [2] buckets of 2 .. 64 items, [3]
+// buckets of more, [5] their chunks): exact grids, and no combine launch for a half whose buckets are all one item.  In a lockstep
+// group: the largest count over the members.
+struct GatePlanCounts {
+    uint32_t hdr[2][8];
+    bool known;
+};
+size_t gate_plan_arrive_words(uint64_t gates, uint32_t k);     // zeroed u32 counters per proof (the combine step's long buckets)
+void gate_plan_counts_offsets(uint64_t gates, uint32_t k, size_t* half1_word_offset);   // where the second half's header starts in the plan
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
-                         hipStream_t s, const GateSet* sets = nullptr);
+                         uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           Fr* partials, hipStream_t s, const GateSet* sets = nullptr);
+                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
 // exclusive scan of n 32-bit counts (block_sums: n / 2048 + 1 words of scratch)
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s);
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)

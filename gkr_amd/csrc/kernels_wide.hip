@@ -9,7 +9,7 @@
 //     layer has values) -- a block per bucket would launch 2^20 blocks for one gate apiece.  Here the buckets are cut into
 //     ITEMS of at most sixteen gates, sorted by length and summed a lane per item against a materialised eq(z, .) table
 //     (k_items_pass); the few buckets far longer than the rest -- the constant wires every relay gate reads
-//     (convert.rs:307-342) -- are many items whose partial sums a combine step adds (k_items_combine[_long]);
+//     (convert.rs:307-342) -- are many items whose partial sums a combine step adds (k_items_combine);
 //   * tables the one-block helpers cannot walk: the dependence flags (k_depends_wide), the Moebius transform
 //     (k_mobius_pass) and the set-up of the line restriction (k_line_copy, k_line_maxdeg) run over a grid.
 // Same field elements as every other form: bit-exact (tests/test_gpu_wide_layers.py).
@@ -352,37 +352,43 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
     }
 }
 
-// buckets of 2 .. kLongItems items: a lane per bucket adds its items' partial sums (values below 2^256) and reduces
+// The combine step, ONE launch: blocks [0, multi_blocks) take the buckets of 2 .. kLongItems items, a lane per bucket (it adds
+// its items' partial sums -- values below 2^256 -- and reduces); the blocks behind them take the buckets of more items (the
+// constant wires every relay gate reads: ONE bucket with half the layer) a wave per chunk of kChunkItems items, and the wave
+// that completes a bucket's LAST chunk adds the chunks and writes the bucket (arrive: one zeroed counter per proof and long
+// bucket, left zero again).  One wave over the 32 768 items of a 2^19-gate bucket took 0.15 ms -- longer than the pass itself;
+// three launches (buckets, chunks, long buckets) cost a layer's chain six launches per sumcheck.
 template <bool ROWS>
-__global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ partials, size_t pstride,
-                                                       Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride, const GateSet* __restrict__ sets) {
+__global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restrict__ plan, PlanLayout L, Fr* __restrict__ partials, size_t pstride,
+                                                       Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride, uint32_t multi_blocks,
+                                                       uint32_t* __restrict__ arrive, const GateSet* __restrict__ sets) {
     if (sets) plan = sets[blockIdx.y].plan;
     plan += ROWS ? L.half_words : 0;
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= plan[2]) return;
-    const uint32_t b = plan[L.multi + m], first = plan[L.item_first + b], n = plan[L.items_per + b];
-    const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)first;
-    Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
-    for (uint32_t j = 0; j < n; ++j) {
-        acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
-        acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
-    }
-    store_fr(out0 + (size_t)blockIdx.y * wstride + b, acc_reduce(a0));
-    store_fr(out1 + (size_t)blockIdx.y * wstride + b, acc_reduce(a1));
-}
-// buckets of more items (the constant wires every relay gate reads: ONE bucket with half the layer), in two steps: a wave per
-// chunk of kChunkItems items, then a wave per bucket over its chunks (one wave over the 32 768 items of a 2^19-gate bucket
-// took 0.15 ms -- longer than the pass itself)
-template <bool ROWS>
-__global__ void __launch_bounds__(256) k_items_combine_chunks(const uint32_t* __restrict__ plan, PlanLayout L, Fr* __restrict__ partials, size_t pstride,
-                                                              const GateSet* __restrict__ sets) {
-    if (sets) plan = sets[blockIdx.y].plan;
-    plan += ROWS ? L.half_words : 0;
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     Fr* base = partials + (size_t)blockIdx.y * pstride;
+    out0 += (size_t)blockIdx.y * wstride;
+    out1 += (size_t)blockIdx.y * wstride;
+    if (blockIdx.x < multi_blocks) {
+        const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+        if (m >= plan[2]) return;
+        const uint32_t b = plan[L.multi + m], first = plan[L.item_first + b], n = plan[L.items_per + b];
+        const Fr* part = base + 2u * (size_t)first;
+        Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
+        for (uint32_t j = 0; j < n; ++j) {
+            acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
+            acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
+        }
+        store_fr(out0 + b, acc_reduce(a0));
+        store_fr(out1 + b, acc_reduce(a1));
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = ((blockIdx.x - multi_blocks) * blockDim.x + threadIdx.x) >> 6,
+                   nwaves = ((gridDim.x - multi_blocks) * blockDim.x) >> 6;
+    arrive += (size_t)blockIdx.y * L.cap_long;
+    Fr* chunk_sums = base + 2u * (size_t)L.cap_items;
     for (uint32_t c = wave; c < plan[5]; c += nwaves) {
         const uint32_t slot = plan[L.chunk_slot + c], b = plan[L.longb + slot], first = plan[L.item_first + b], n = plan[L.items_per + b];
-        const uint32_t lo = (c - plan[L.long_chunk0 + slot]) * kChunkItems, hi = lo + kChunkItems < n ? lo + kChunkItems : n;
+        const uint32_t c0 = plan[L.long_chunk0 + slot], nch = (n + kChunkItems - 1u) / kChunkItems;
+        const uint32_t lo = (c - c0) * kChunkItems, hi = lo + kChunkItems < n ? lo + kChunkItems : n;
         const Fr* part = base + 2u * (size_t)first;
         Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
         for (uint32_t j = lo + lane; j < hi; j += 64u) {
@@ -391,59 +397,64 @@ __global__ void __launch_bounds__(256) k_items_combine_chunks(const uint32_t* __
         }
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
+        uint32_t last = 0;
         if (lane == 0) {
-            store_fr(base + 2u * (size_t)L.cap_items + 2u * (size_t)c, acc_reduce(a0));
-            store_fr(base + 2u * (size_t)L.cap_items + 2u * (size_t)c + 1u, acc_reduce(a1));
+            store_fr(chunk_sums + 2u * (size_t)c, acc_reduce(a0));
+            store_fr(chunk_sums + 2u * (size_t)c + 1u, acc_reduce(a1));
+            __threadfence();   // (the chunk's sums cross the XCDs' L2s: written back before the arrival is counted)
+            last = atomicAdd(arrive + slot, 1u) == nch - 1u ? 1u : 0u;
         }
-    }
-}
-template <bool ROWS>
-__global__ void __launch_bounds__(256) k_items_combine_long(const uint32_t* __restrict__ plan, PlanLayout L, const Fr* __restrict__ partials, size_t pstride,
-                                                            Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride,
-                                                            const GateSet* __restrict__ sets) {
-    if (sets) plan = sets[blockIdx.y].plan;
-    plan += ROWS ? L.half_words : 0;
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t m = wave; m < plan[3]; m += nwaves) {
-        const uint32_t b = plan[L.longb + m], n = plan[L.items_per + b], nch = (n + kChunkItems - 1u) / kChunkItems;
-        const Fr* part = partials + (size_t)blockIdx.y * pstride + 2u * (size_t)L.cap_items + 2u * (size_t)plan[L.long_chunk0 + m];
-        Acc<9> a0 = acc_zero<9>(), a1 = acc_zero<9>();
-        for (uint32_t j = lane; j < nch; j += 64u) {
-            acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
-            acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
-        }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            store_fr(out0 + (size_t)blockIdx.y * wstride + b, acc_reduce(a0));
-            store_fr(out1 + (size_t)blockIdx.y * wstride + b, acc_reduce(a1));
+        last = (uint32_t)__shfl((int)last, 0, 64);
+        if (last) {
+            __threadfence();
+            Acc<9> t0 = acc_zero<9>(), t1 = acc_zero<9>();
+            for (uint32_t j = lane; j < nch; j += 64u) {
+                acc_add_fr(t0, load_fr(chunk_sums + 2u * (size_t)(c0 + j)));
+                acc_add_fr(t1, load_fr(chunk_sums + 2u * (size_t)(c0 + j) + 1u));
+            }
+            t0 = wave_sum(t0);
+            t1 = wave_sum(t1);
+            if (lane == 0) {
+                store_fr(out0 + b, acc_reduce(t0));
+                store_fr(out1 + b, acc_reduce(t1));
+                arrive[slot] = 0u;   // (the next pass's waves start after this kernel)
+            }
         }
     }
 }
 
+size_t gate_plan_arrive_words(uint64_t gates, uint32_t k) { return plan_layout(gates, k).cap_long; }   // per proof
+void gate_plan_counts_offsets(uint64_t gates, uint32_t k, size_t* half1_word_offset) { *half1_word_offset = plan_layout(gates, k).half_words; }
+
 template <bool ROWS>
 static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& ge, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
-                                Fr* partials, hipStream_t s, const GateSet* sets) {
+                                Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
     const PlanLayout L = plan_layout(span.count, k);
     const size_t pstride = gate_plan_partial_elems(span.count, k);
     const EqSource eq{ge.E, ge.e_hi, ge.e_lo_mont, k_i, ge.kl};
-    // (grids from the plan's capacities: the kernels read the counts the build left on the device, waves beyond them leave at once)
-    hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((L.cap_groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, eq, T, (uint32_t)lb.wstride, out0, out1,
+    const uint32_t half = ROWS ? 1u : 0u;
+    // Grids from the plan's counts where the host knows them (read back when the plan was built), else from its capacities: the
+    // kernels read the counts the build left on the device, waves beyond them leave at once.
+    const bool known = counts && counts->known;
+    const uint32_t groups = known ? counts->hdr[half][1] : L.cap_groups;
+    const uint32_t n_multi = known ? counts->hdr[half][2] : L.cap_multi, n_long = known ? counts->hdr[half][3] : L.cap_long,
+                   n_chunks = known ? counts->hdr[half][5] : L.cap_chunks;
+    // (waves: one per group of two and more steps, one per kSinglePerLane groups of the rest -- at most `groups`)
+    hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, eq, T, (uint32_t)lb.wstride, out0, out1,
                        partials, pstride, (uint32_t)span.base, sets);
-    hipLaunchKernelGGL((k_items_combine<ROWS>), dim3((L.cap_multi + 255u) / 256u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
-                       (uint32_t)lb.wstride, sets);
-    hipLaunchKernelGGL((k_items_combine_chunks<ROWS>), dim3(L.cap_chunks < 1024u ? (L.cap_chunks + 3u) / 4u : 256u, lb.batch), dim3(256), 0, s, plan, L, partials,
-                       pstride, sets);
-    hipLaunchKernelGGL((k_items_combine_long<ROWS>), dim3(L.cap_long < 64u ? L.cap_long : 64u, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0,
-                       out1, (uint32_t)lb.wstride, sets);
+    if (known && n_multi == 0u && n_long == 0u) return;   // every bucket is one item: nothing to combine
+    const uint32_t multi_blocks = (n_multi + 255u) / 256u;
+    const uint32_t chunk_blocks = n_long ? (n_chunks < 1024u ? (n_chunks + 3u) / 4u : 256u) : 0u;
+    hipLaunchKernelGGL((k_items_combine<ROWS>), dim3(multi_blocks + chunk_blocks, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
+                       (uint32_t)lb.wstride, multi_blocks, arrive, sets);
 }
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
-                         hipStream_t s, const GateSet* sets) {
-    launch_items_pass_t<false>(span, k_i, k, plan, eq, W, U, V, lb, partials, s, sets);
+                         uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
+    launch_items_pass_t<false>(span, k_i, k, plan, eq, W, U, V, lb, partials, arrive, s, sets, counts);
 }
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           Fr* partials, hipStream_t s, const GateSet* sets) {
-    launch_items_pass_t<true>(span, k_i, k, plan, eq, eq_mont, A_row, M_row, lb, partials, s, sets);
+                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
+    launch_items_pass_t<true>(span, k_i, k, plan, eq, eq_mont, A_row, M_row, lb, partials, arrive, s, sets, counts);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries
