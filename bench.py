@@ -864,12 +864,20 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
                          "products_per_launch_pair": products, "gate_pass_ms_per_step": gate_ms,
                          "products_rule": "one product per gate and pass (2 per gate and sumcheck); peak = the chip-wide rate of dependent "
                                           "Montgomery products measured in this process (gkr_ubench_ceilings, 16 waves per SIMD)",
-                         "hbm_bytes_per_gate_and_pass": 8, "note": "not memory-bound: per gate one 8-byte list entry is streamed from HBM, the eq and W "
-                                          "operands are gathers from L2-resident tables"},
-            "gather": ({"bound": "the random 32-byte gather of W[right] / eq(u, left) per gate and pass from a 2^%d-entry table (%.0f MiB: beyond L2), "
-                                 "plus the 8-byte list entry" % (k, (32 << k) / 2**20),
-                        "gathers_per_sec": rate, "GBps_of_40_B_per_gate": rate * 40 / 1e9 if rate else None,
-                        "frac_of_hbm_peak": rate * 40 / 1e9 / PEAK_GBPS if rate else None} if wide else None),
+                         "hbm_bytes_per_gate_and_pass": 8, "note": ("not memory-bound: per gate one 8-byte list entry is streamed from HBM, the eq and W "
+                                          "operands are gathers from L2-resident tables") if not wide else
+                                         ("a WIDE layer's item passes are NOT bound by the products (frac above is what is left of the ALU): they are "
+                                          "bound by the 128-byte lines their random 32-byte accesses move -- see `memory`")},
+            # wide layers (k_next >= 13, kernels_wide.hip): per gate and pass one 8-byte packed entry streamed, eq(z, g) and the operand
+            # gathered (32 B each, random), and per bucket two 32-byte outputs stored -- every one of the random accesses moves a
+            # 128-byte line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch: profiles/r05/b_wide_gate_pass_pmc_*.txt)
+            "memory": ({"bound": "hbm", "algorithmic_bytes_per_step": 2.0 * (cnt * (8 + 32 + 32) + (2 << k) * 32),
+                        "achieved": 2.0 * (cnt * (8 + 32 + 32) + (2 << k) * 32) / (gate_ms * 1e-3) / 1e9 if gate_ms else None, "peak": PEAK_GBPS, "unit": "GB/s",
+                        "frac": 2.0 * (cnt * (8 + 32 + 32) + (2 << k) * 32) / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None,
+                        "line_bytes_per_step_if_every_random_access_moves_128_B": 2.0 * (cnt * (8 + 128 + 128) + (2 << k) * 128),
+                        "frac_in_lines": 2.0 * (cnt * (8 + 128 + 128) + (2 << k) * 128) / (gate_ms * 1e-3) / 1e9 / PEAK_GBPS if gate_ms else None,
+                        "note": "uniform gates: every access is its own line (measured: 0.29 GB fetched + 0.12 GB written per pass at 2^20 gates); "
+                                "compiler-shaped gates: runs of gates read runs of values, the lines are shared"} if wide else None),
             "product_pass_roofline": product_pass_roofline(k, prof["layer_prod_pass"]["total_ms"] / steps, peak),
             "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
             "collective": collective_info(world, exchange, exch, steps) if split else None,
