@@ -329,10 +329,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             }
             if ((uint32_t)k_i <= gkr::kGateEqTableMaxKi) {
                 WS(ctx, "pred.E", Fr, (size_t)batch << k_i, E);
-                gkr_fr* hz2 = nullptr;
-                HIP_TRY(ctx, ctx->pinned_host("pred.z", sizeof(gkr_fr) * (size_t)batch * (k_i ? k_i : 1), reinterpret_cast<void**>(&hz2)));
                 Timed t(ctx, "eq_table_z", ((double)batch * 32.0) * (double)((size_t)1 << k_i));
-                gkr::launch_eq_table(reinterpret_cast<const Fr*>(hz2), (uint32_t)k_i, 0u, (uint32_t)k_i, E, false, (uint32_t)batch, s);
+                gkr::launch_eq_outer(e_hi, e_lo, (uint32_t)k_i, kl, E, (uint32_t)batch, s);   // (the prologue above built the halves)
             }
         }
         if (!(cached && cached->ready)) HIP_TRY(ctx, hipMemsetAsync(bad, 0, 4, s));   // (only the list build writes it)

@@ -283,6 +283,8 @@ void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t
                          uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
                            Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
+// E (batch x 2^k_i, canonical) = the outer product of the prologue's half tables (e_hi canonical, e_lo_mont Montgomery, split at kl)
+void launch_eq_outer(const Fr* e_hi, const Fr* e_lo_mont, uint32_t k_i, uint32_t kl, Fr* E, uint32_t batch, hipStream_t s);
 // exclusive scan of n 32-bit counts (block_sums: n / 2048 + 1 words of scratch)
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s);
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)

@@ -253,6 +253,22 @@ __device__ __forceinline__ Fr eq_at(const EqSource& q, uint32_t g) {
                     load_fr(q.e_lo_mont + ((size_t)blockIdx.y << q.kl) + (g & ((1u << q.kl) - 1u))));
 }
 
+// E[g] = E_hi[g >> kl] * E_lo[g & (2^kl - 1)], canonical: the table the passes gather, from the two half tables the layer's
+// prologue has just built -- one product per entry (building it from the point, k_eq_table_split, was 23 - 34 us on every
+// layer's path; this is ~5 at 2^15 entries).  grid = (blocks, batch), block = 256
+__global__ void __launch_bounds__(256) k_eq_outer(const Fr* __restrict__ e_hi, const Fr* __restrict__ e_lo_mont, uint32_t k_i, uint32_t kl,
+                                                  Fr* __restrict__ E) {
+    const size_t n = (size_t)1 << k_i;
+    e_hi += (size_t)blockIdx.y << (k_i - kl);
+    e_lo_mont += (size_t)blockIdx.y << kl;
+    E += (size_t)blockIdx.y << k_i;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < n; g += (size_t)gridDim.x * blockDim.x)
+        store_fr(E + g, mont_mul(load_fr(e_hi + (g >> kl)), load_fr(e_lo_mont + (g & (((size_t)1 << kl) - 1)))));
+}
+void launch_eq_outer(const Fr* e_hi, const Fr* e_lo_mont, uint32_t k_i, uint32_t kl, Fr* E, uint32_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_eq_outer, dim3(blocks_for((uint64_t)1 << k_i, 16384), batch), dim3(256), 0, s, e_hi, e_lo_mont, k_i, kl, E);
+}
+
 // The passes: grid = (groups / 4 rounded up, batch), block = 256 = four waves = four groups.
 //   ROWS == false (U, V):      mult gate: P += e t;   add gate: Q += e t and P += e      -> out0 = U, out1 = V
 //   ROWS == true  (a_u, m_u):  add gate:  P += e t;   mult gate: Q += e t               -> out0 = a_u, out1 = m_u
