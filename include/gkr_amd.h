@@ -434,6 +434,15 @@ int  gkr_prove_batch(gkr_ctx *ctx, const gkr_circuit_desc *circuit, const gkr_fr
  * hash -- so independent items in flight fill each other's gaps; threads whose items are done, and threads waiting
  * for a round, take pieces of the others' host work (see gkr_host_help_while).  Items are dealt out by estimated cost,
  * the same way for the same list (so a child context finds its circuits in its cache on the next call).
+ * LOCKSTEP GROUPS (round 5; option prove_many_lockstep, default on): items whose circuits share their k list -- the <= 20
+ * sub-circuits of one compiled R1CS come in a few shapes -- are proven as ONE chain: one launch per pass and one hand-off
+ * for the group, the passes over the gates reading each proof's own gate lists through a per-proof table.  A group holds at
+ * most lockstep_max_proofs proofs (default 32: beyond that independent chains overlap better); an item that fails in a
+ * group is proven again on its own, so statuses stay per item.  Same bytes as item by item.
+ * The circuit cache of a context decides a hit by two 64-bit hashes over the k list and the gate arrays AND a comparison
+ * with the gate arrays retained when the entry was made -- byte for byte up to 1 MiB of gate data, sampled 4 KiB blocks of
+ * every array beyond: a context shared with callers that may hand in CRAFTED circuits larger than that should be given
+ * GKR_NO_CIRCUIT_CACHE / no_circuit_cache (the proof would be wrong, not the memory unsafe: indices were range-checked).
  * max_concurrent: threads / child contexts to use at most; 0 = the CPUs this process may use, less two.
  * Every item's `status` is set; the return value is the first status that is not GKR_OK (gkr_last_error has its text). */
 typedef struct {
