@@ -792,6 +792,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
     otherwise every rank proves the whole layer on its own (N = 1 work, MAX over ranks).  -> the dict of the JSON
     line (on rank 0; None elsewhere).  The transcript is compared with the committed digest of the reference-semantics
     transcript (tests/golden/config_hashes.json)."""
+    import numpy as np
     from gkr_amd import Context, parallel, synth
     # shape "circom": the structure the reference's compiler emits (synth.circom_shaped_layer: runs of gates over runs of
     # values, two wires feeding most of the layer) instead of a uniform draw, which has no locality at all
@@ -803,9 +804,15 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
     coll = parallel.TorchCollective() if (split and world.grouped) else None
     exchange = coll.exchange() if coll else None   # one rank: the whole layer, no exchange
     result = [None]
+    # W resident in HBM before the timed region, like the gates (inside prover::prove the next layer's values come from the
+    # forward evaluation and never were host data); the split legs hand W over from the host as their entry points do
+    d_W = None
+    if not split:
+        d_W = ctx.alloc(W.nbytes)
+        ctx.upload(d_W, np.ascontiguousarray(W))
 
     def step():
-        result[0] = gates.sumcheck_raw(k, z, W, exchange)
+        result[0] = gates.sumcheck_raw(k, z, W, exchange) if split else gates.sumcheck_raw_device_w(k, z, d_W)
     # the first sumcheck of a layer pays for the sort of its gates and the segment build as well (z- and W-independent, like
     # the reference's precomputed add_wire / mult_wire; once per circuit): timed on its own, outside the steps
     ctx.profile(1)
@@ -817,6 +824,13 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
     sort_ms = ctx.profile_get("gate_lists")["total_ms"]
     elapsed, each = timed_steps(world, ctx, step, warmup, steps)
     ctx.profile(False)
+    host_w_ms = None
+    if not split and k >= 16:   # the PCIe-inclusive figure (W handed over in host memory every sumcheck): reported, never the value
+        gates.sumcheck_raw(k, z, W, None)
+        t_h = time.perf_counter()
+        for _ in range(3):
+            gates.sumcheck_raw(k, z, W, None)
+        host_w_ms = (time.perf_counter() - t_h) / 3 * 1e3
     names = ["gate_lists", "eq_table_z", "gate_uv", "gate_rows", "gate_combine", "predicate_sorted", "layer_prod_pass"]
     prof = {n_: ctx.profile_get(n_) for n_ in names}
     exch = ctx.profile_get("exchange")
@@ -853,7 +867,9 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
                                                                                 if shape == "circom" else "a WIDE layer, gates drawn uniformly (no locality: the worst case for the gathers)"),
                            k_i, k, ", gates split over the ranks, two sum-over-ranks exchanges of 2 * 2^k field elements per sumcheck" if split else
                            ", the whole layer on one GPU"),
-                       "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z and W per sumcheck)"},
+                       "gates_per_rank": cnt, "gates": "gates and their sorted lists resident in HBM before the timed region (gkr_resident_layer_*: one circuit, a new z per sumcheck)",
+                       "W": "handed over in host memory every sumcheck (the exchange entry points' form)" if split else "resident in HBM (gkr_resident_layer_sumcheck_wdev)"},
+            "ms_per_step_with_W_from_host_memory": host_w_ms,
             "matches_golden_digest": None if want is None else digest == want, "transcript_sha256": digest,
             "one_shot_ms": one_shot_ms, "sort_ms": sort_ms,
             "one_shot_note": "the layer's FIRST sumcheck on this context: gate arrays already in HBM, but the counting sort of the gates, the segment "
@@ -883,6 +899,8 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
             "collective": collective_info(world, exchange, exch, steps) if split else None,
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},
             "step_ms_each": [round(x * 1e3, 3) for x in each]}
+    if d_W is not None:
+        ctx.free(d_W)
     gates.close()
     ctx.close()
     return out

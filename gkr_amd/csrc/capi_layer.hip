@@ -869,6 +869,36 @@ int gkr_resident_layer_sumcheck(gkr_ctx* ctx, gkr_resident_layer* layer, const g
     return rc;
 }
 
+// gkr_resident_layer_sumcheck with W ALREADY in device memory (inside prover::prove the next layer's values come from the
+// forward evaluation, prover.rs:38-43: they never were host data; a host that drives prove_sumcheck_opt itself keeps them on
+// the device the same way): nothing but z and the transcript crosses PCIe.  W is checked where it lies; the status of that
+// check is looked at after the sumcheck (no synchronisation before it).
+int gkr_resident_layer_sumcheck_wdev(gkr_ctx* ctx, gkr_resident_layer* layer, const gkr_fr* z, const void* d_W, gkr_fr* out_coeffs, uint32_t* out_len,
+                                     gkr_fr* out_r) {
+    if (!ctx) return GKR_ERR_INVALID;
+    if (!layer || !d_W || !out_coeffs || !out_len || !out_r || (layer->k_i > 0 && !z)) return ctx->fail(GKR_ERR_INVALID, "null pointer");
+    const int k_i = layer->k_i, k = layer->k;
+    if (layer->first != 0 || layer->count != ((uint64_t)1 << k_i)) return ctx->fail(GKR_ERR_INVALID, "the layer must be whole");
+    if (k_i > 0 && !all_canonical(z, k_i)) return ctx->fail(GKR_ERR_NON_CANONICAL, "z entry >= r");
+    GKR_ENTER(ctx);
+    uint32_t* d_flag = nullptr;
+    uint32_t* h_flag = nullptr;
+    WS(ctx, "layer.Wflag", uint32_t, 1, d_flag);
+    HIP_TRY(ctx, ctx->pinned_host("layer.hWflag", 64, reinterpret_cast<void**>(&h_flag)));
+    *h_flag = 0;
+    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    gkr::launch_check_canonical(static_cast<const Fr*>(d_W), (size_t)1 << k, d_flag, ctx->stream);
+    gkr::launch_copy_words(d_flag, h_flag, 1, ctx->stream);
+    const int rc = run_layer_batch(ctx, 1, k_i, k, layer->gt, layer->l, layer->r, z, static_cast<const Fr*>(d_W), &out_coeffs, &out_len, &out_r, nullptr,
+                                   &layer->lists);
+    if (rc) {
+        layer->lists.ready = false;
+        return rc;
+    }
+    if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE)) return ctx->fail(GKR_ERR_NON_CANONICAL, "W entry >= r");
+    return GKR_OK;
+}
+
 size_t gkr_exchange_limbs(int k_next) {
     if (k_next < 0 || k_next > kMaxLayerK) return 0;
     return (((size_t)2 << k_next) + 1) * 8;

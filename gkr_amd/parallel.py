@@ -389,6 +389,17 @@ class ResidentGates:
         self._ctx._check(rc)
         return C, L, R
 
+    def sumcheck_raw_device_w(self, k_next, z_limbs, d_w):
+        """The same with W (2^k_next values) already in device memory (d_w: a Context.alloc pointer): nothing but z and the
+        transcript crosses PCIe.  Whole layers only."""
+        v = 2 * k_next
+        C = np.zeros((v, 3, 4), dtype=np.uint64)
+        L = np.zeros(v, dtype=np.uint32)
+        R = np.zeros((v, 4), dtype=np.uint64)
+        zl = np.ascontiguousarray(z_limbs, dtype=np.uint64).reshape(-1, 4)
+        self._ctx._check(N.lib().gkr_resident_layer_sumcheck_wdev(self._ctx._h, self._layer(k_next), _ptr(zl), d_w, _ptr(C), _ptr(L), _ptr(R)))
+        return C, L, R
+
     def close(self):
         for h in self._handles.values():
             N.lib().gkr_resident_layer_free(self._ctx._h, h)

@@ -272,6 +272,11 @@ typedef struct gkr_resident_layer gkr_resident_layer;
 int  gkr_resident_layer_create(gkr_ctx *ctx, int k_i, int k_next, uint64_t gate_first, uint64_t gate_count,
                                const uint8_t *gate_type, const uint32_t *left, const uint32_t *right,
                                gkr_resident_layer **out);
+/* ... and with W (2^k_next values, canonical) already in DEVICE memory: what prover::prove has (the next layer's values come
+ * from the forward evaluation, prover.rs:38-43) and what a host that drives prove_sumcheck_opt itself should do -- the
+ * upload of a 2^20-value W is 0.5 ms of PCIe, a quarter of that layer's sumcheck.  Whole layers only (no exchange). */
+int  gkr_resident_layer_sumcheck_wdev(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const void *d_W,
+                                      gkr_fr *out_coeffs, uint32_t *out_len, gkr_fr *out_r);
 int  gkr_resident_layer_sumcheck(gkr_ctx *ctx, gkr_resident_layer *layer, const gkr_fr *z, const gkr_fr *W,
                                  gkr_allreduce_fn allreduce, void *user, gkr_fr *out_coeffs, uint32_t *out_len,
                                  gkr_fr *out_r);

@@ -37,6 +37,31 @@ def test_wide_layer_sumcheck_matches_oracle(ctx, k_i, k):
     assert _same(got, want)
 
 
+def test_resident_layer_with_W_in_device_memory(ctx):
+    """gkr_resident_layer_sumcheck_wdev: W already on the device (what prover::prove has) -- the same transcript as with W
+    handed over in host memory, a non-canonical W entry is reported, and the compiler-shaped layer of the bench's
+    wide20_circom_shaped leg (at a size the test affords) matches the checker."""
+    from gkr_amd import parallel
+    for (k_i, k), shaped in (((16, 15), False), ((17, 17), True), ((9, 5), False)):
+        lay, z, W = (synth.circom_shaped_layer(k_i, k, seed=77) if shaped else synth.config5_layer(k_i, k, seed=4100 + k))
+        gt, l, r = lay.arrays()
+        want = cdense.sumcheck_layer_lin_raw(k_i, k, gt, l, r, z, W)
+        gates = parallel.ResidentGates(ctx, k_i, 0, gt, l, r)
+        assert _same(gates.sumcheck_raw(k, z, W), want)
+        d_W = ctx.alloc(W.nbytes)
+        ctx.upload(d_W, np.ascontiguousarray(W))
+        for _ in range(2):
+            assert _same(gates.sumcheck_raw_device_w(k, z, d_W), want)
+        bad = np.ascontiguousarray(W).copy()
+        bad[3] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)
+        ctx.upload(d_W, bad)
+        with pytest.raises(GkrError) as e:
+            gates.sumcheck_raw_device_w(k, z, d_W)
+        assert e.value.status == 2   # GKR_ERR_NON_CANONICAL
+        ctx.free(d_W)
+        gates.close()
+
+
 def _circom_like_layer(k_i, k, seed):
     """What a compiled layer looks like (convert.rs:278-343): half of the gates are relay gates Add(x, zero) that all read
     the zero slot as their right operand -- ONE bucket with 2^(k_i - 1) gates --, a few hot wires feed thousands of gates,
