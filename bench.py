@@ -742,11 +742,11 @@ def multi_device_in_a_child(n_inputs):
         lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
         if done.returncode == 0 and lines:
             return dict(json.loads(lines[-1]), isolated="ran in a child process of the bench: it cannot fail or hang the line")
-        return {"error": "child exited %d: %s" % (done.returncode, (done.stderr or "")[-400:]), "isolated": True}
+        return {"error": "child exited %d: %s" % (done.returncode, (done.stderr or "")[-400:]), "isolated": True, "device_ids": None}
     except subprocess.TimeoutExpired:
-        return {"error": "no result after 240 s (the child was ended)", "isolated": True}
+        return {"error": "no result after 240 s (the child was ended)", "isolated": True, "device_ids": None}
     except Exception as e:   # noqa: BLE001
-        return {"error": "%s: %s" % (type(e).__name__, e), "isolated": True}
+        return {"error": "%s: %s" % (type(e).__name__, e), "isolated": True, "device_ids": None}
 
 
 # ------------------------------------------------------------------------------------------------ mode: proofs
