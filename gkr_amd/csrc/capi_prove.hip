@@ -263,6 +263,7 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     using gkr::h64::F;
     const auto t_entry = std::chrono::steady_clock::now();
     if (!members || n_members < 1) return ctx->fail(GKR_ERR_INVALID, "no members");
+    GKR_ENTER(ctx);   // (before anything that reads an option: the crew's threads enter their context's scope here)
     const gkr_circuit_desc* c = members[0].circuit;
     int rc = GKR_OK;
     int batch = 0;
@@ -312,7 +313,6 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         for (int m = 0; m < n_members; ++m)
             if (!all_canonical(members[m].input_values, n_in * members[m].batch)) return ctx->fail(GKR_ERR_NON_CANONICAL, "input value >= r");
     const double us_canon = us_since_entry();
-    GKR_ENTER(ctx);
     hipStream_t s = ctx->stream;
 
     // every member's circuit on the device (cache, or upload)
