@@ -21,6 +21,7 @@
 #include "dev_util.h"
 #include "gate_seg.h"
 #include "mfma_fold.h"
+#include "mfma_cross.h"
 #include "mimc7.h"
 
 namespace gkr {
@@ -1979,7 +1980,18 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals) {
-    const uint32_t S = 1u << (m_in - jp - J), blocks = prod_pass_blocks(S);
+    const uint32_t S = 1u << (m_in - jp - J);
+    if (jp == 0u && J == 3u && m_in >= kCrossMinM && !opt(OPT_no_mfma_cross)) {
+        // a wide layer's first pass of a phase: the 64 cross sums as int8 matrix products (mfma_cross.h)
+        const uint32_t kc = cross_pass_kc(S, batch), nblk = S / kc;
+        if (kc == 1024u)
+            hipLaunchKernelGGL(k_prod_cross_mfma<1024>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
+        else
+            hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
+        hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((nblk > 32 ? 14 : 4) * kProdRecValues), 0, s, partials, nblk, rec, ticket);
+        return;
+    }
+    const uint32_t blocks = prod_pass_blocks(S);
     uint32_t* fused = (arrivals && blocks > 1 && blocks <= kProdFuseBlocks) ? arrivals : nullptr;   // the last block publishes
     if (prod_pass_tile(S) == kProdTileWide)
         hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
