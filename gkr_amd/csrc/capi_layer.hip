@@ -481,6 +481,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         WS(ctx, "layer.ppart", Fr, (size_t)batch * gkr::prod_pass_scratch_values((uint32_t)k), d_ppart);
         WS(ctx, "layer.X", Fr, wlen * batch, Xc);
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
+        unsigned char* d_fold_plans = nullptr;   // (wide layers: the later passes' pending folds on the matrix cores)
+        if ((uint32_t)k >= gkr::kProdFoldMinM) WS(ctx, "layer.foldplans", unsigned char, (size_t)batch * gkr::prod_fold_plan_bytes(), d_fold_plans);
         // (passes of a few blocks per proof publish from their last block: one arrival counter per proof, zero between passes)
         const bool no_fused_publish = gkr::opt(gkr::OPT_no_fused_publish) != 0;
         uint32_t* d_arrivals = nullptr;
@@ -532,7 +534,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 const uint32_t ticket = ++ctx->ticket;
                 {
                     Timed t(ctx, "layer_prod_pass", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals);
+                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals, d_fold_plans);
                 }
                 m -= jp;
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) {

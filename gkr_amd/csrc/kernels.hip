@@ -1978,13 +1978,45 @@ void launch_layer_eval(uint32_t gates, const uint8_t* gate_type, const uint32_t*
                        prev, out, prev_stride, sets);
 }
 
+// a wide layer's LATER passes: the pending fold (the previous pass's three variables bound, 2^20 and more entries of three
+// tables read for it) on the matrix cores as the plain sumcheck's fold passes are (mfma_fold.h) -- the weights are constants
+// of the proof -- in place, then the cross sums of the folded tables as a pass with nothing pending.  Three launches for
+// one, where the one spends its time on 8 x 3 products of 254-bit numbers per folded entry.
+// grid = (batch), block = 256
+__global__ void __launch_bounds__(256) k_prod_fold_plan(const Fr* __restrict__ weights, MfmaFoldPlan* __restrict__ plans) {
+    __shared__ __attribute__((aligned(16))) unsigned char digits[32 * 32 * 8];
+    mfma_plan_block<3>(weights + (size_t)blockIdx.x * 8, plans + blockIdx.x, digits);
+}
+// grid = (S / 256, 3 * batch), block = 256: a 64-entry tile per wave (the chunk length the fold passes measured best at)
+__global__ void __launch_bounds__(256) k_prod_fold_mfma(Fr* Wt, Fr* Xt, Fr* Yt, uint32_t S, const MfmaFoldPlan* __restrict__ plans, uint32_t wstride) {
+    __shared__ __attribute__((aligned(16))) unsigned char digits[32 * 32 * 8];
+    const uint32_t table = blockIdx.y % 3u, proof = blockIdx.y / 3u;
+    Fr* T = (table == 0u ? Wt : table == 1u ? Xt : Yt) + (size_t)proof * wstride;
+    const uint32_t chunk = S / gridDim.x, begin = blockIdx.x * chunk;
+    Acc<9> unused = acc_zero<9>();
+    // (in place: an output entry is stored by the wave that read the eight entries it is made of, after it read them)
+    mfma_multifold_block<3>(T, T, S, plans + proof, begin, begin + chunk, blockIdx.x * 5u + blockIdx.y * 3u, unused, digits);
+}
+size_t prod_fold_plan_bytes() { return sizeof(MfmaFoldPlan); }
+
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals) {
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals, void* fold_plans) {
+    const bool mfma = !opt(OPT_no_mfma_cross);
+    if (mfma && fold_plans && jp == 3u && m_in >= kProdFoldMinM) {
+        MfmaFoldPlan* plans = static_cast<MfmaFoldPlan*>(fold_plans);
+        const uint32_t Sf = 1u << (m_in - 3u);
+        hipLaunchKernelGGL(k_prod_fold_plan, dim3(batch), dim3(256), 0, s, weights, plans);
+        hipLaunchKernelGGL(k_prod_fold_mfma, dim3(Sf / 256u, 3u * batch), dim3(256), 0, s, W, X, Y, Sf, plans, wstride);
+        m_in -= 3u;
+        jp = 0u;
+    }
     const uint32_t S = 1u << (m_in - jp - J);
-    if (jp == 0u && J == 3u && m_in >= kCrossMinM && !opt(OPT_no_mfma_cross)) {
-        // a wide layer's first pass of a phase: the 64 cross sums as int8 matrix products (mfma_cross.h)
+    if (mfma && jp == 0u && J == 3u && m_in >= kCrossMinM) {
+        // a wide layer's first pass of a phase (or a later one, folded above): the 64 cross sums as int8 matrix products (mfma_cross.h)
         const uint32_t kc = cross_pass_kc(S, batch), nblk = S / kc;
-        if (kc == 1024u)
+        if (kc == 2048u)
+            hipLaunchKernelGGL(k_prod_cross_mfma<2048>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
+        else if (kc == 1024u)
             hipLaunchKernelGGL(k_prod_cross_mfma<1024>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
         else
             hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);

@@ -33,10 +33,14 @@
 
 namespace gkr {
 
-constexpr uint32_t kCrossKcMax = 1024;       // most entries of every sub-block per block (|C'| <= Kc 2^14 < 2^31)
 constexpr uint32_t kCrossMinM = 17;          // tables of 2^17 entries and more
-// entries of every sub-block per block: 1024, or 512 while that leaves the chip's CUs without a block each
-inline uint32_t cross_pass_kc(uint32_t S, uint32_t batch) { return (size_t)(S / 1024u) * batch >= 256u ? 1024u : 512u; }
+// entries of every sub-block per block: the most (of 2048, 1024, 512) that leaves every CU of the chip a block -- a block's
+// epilogue costs what ~10 k-steps do
+inline uint32_t cross_pass_kc(uint32_t S, uint32_t batch) {
+    for (uint32_t kc = 2048u; kc > 512u; kc >>= 1)
+        if ((size_t)(S / kc) * batch >= 256u) return kc;
+    return 512u;
+}
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
@@ -46,6 +50,24 @@ __device__ __forceinline__ uint32_t cross_tr4(uint32_t own, uint32_t sel1, uint3
     own = __builtin_amdgcn_perm(other, own, sel1);   // even lane: (o0, p0, o2, p2); odd: (p1, o1, p3, o3)
     other = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0x4E, 0xF, 0xF, true);            // quad_perm [2, 3, 0, 1]
     return __builtin_amdgcn_perm(other, own, sel2);  // lanes 0, 1: (o0, o1, p0, p1); lanes 2, 3: (p2, p3, o2, o3)
+}
+
+// (lo, hi) += the same 96-bit number of the lane a DPP control names
+template <int CTRL>
+__device__ __forceinline__ void cross_add96(uint64_t& lo, uint32_t& hi) {
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)lo, CTRL, 0xF, 0xF, true);
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(lo >> 32), CTRL, 0xF, 0xF, true);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, CTRL, 0xF, 0xF, true);
+    const uint64_t n = lo + ((uint64_t)o0 | ((uint64_t)o1 << 32));
+    hi = hi + o2 + (n < lo ? 1u : 0u);
+    lo = n;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void cross_add64(uint64_t& v) {
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xF, 0xF, true);
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+    v += (uint64_t)o0 | ((uint64_t)o1 << 32);
 }
 
 // inclusive prefix sums over the wave's lanes (lane i: the sum of lanes 0 .. i)
@@ -63,7 +85,7 @@ __device__ __forceinline__ int32_t cross_wave_scan(int32_t v, uint32_t lane) {
 template <uint32_t KC>
 __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ Wt, const Fr* __restrict__ Xt, const Fr* __restrict__ Yt,
                                                          uint32_t m, Fr* __restrict__ partials, uint32_t wstride) {
-    static_assert(KC % 128u == 0 && KC <= 1024u, "a block's anti-diagonal sums must stay below 2^32");
+    static_assert(KC % 512u == 0 && KC <= 2048u, "a block's anti-diagonal sums must stay below 2^32: 32 * 2048 * 255^2 < 2^32");
     // [buffer][table][sub-block][digit][entry]: 2 x 2 x 8 x 32 x 32 bytes = 32 KB
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 8 * 32 * 32];
     __shared__ uint32_t s_part[64][8][3];    // [pair][group of eight anti-diagonals]: 96-bit partial totals
@@ -92,7 +114,9 @@ __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ 
     const char* gw = reinterpret_cast<const char*>(W + (size_t)wave * S + i0 + c) + 16u * h;
     const char* gx = reinterpret_cast<const char*>(X + (size_t)wave * S + i0 + c) + 16u * h;
     const char* gy = reinterpret_cast<const char*>(Y + (size_t)wave * S + i0 + c) + 16u * h;
-    constexpr uint32_t kSteps = KC / 32u, PF = 4;   // PF k-steps' half entries in flight per lane (a step is ~0.2 us of MFMA, a load ~1 us)
+    // PF k-steps' half entries in flight per lane; trips of kTrip steps, unrolled in full -- across a loop's back edge the
+    // compiler waits for every load in flight (vmcnt(0)), which left a rolled loop without its prefetch
+    constexpr uint32_t kSteps = KC / 32u, PF = 4, kTrip = kSteps < 32u ? kSteps : 32u;
     mf_v4u rw[PF], rx[PF], ry[PF];
 #pragma unroll
     for (uint32_t u = 0; u < PF; ++u) {
@@ -100,15 +124,16 @@ __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ 
         rx[u] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(gx + (size_t)u * 1024u));
         ry[u] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(gy + (size_t)u * 1024u));
     }
-    // (unrolled in full: across a loop's back edge the compiler waits for every load in flight -- vmcnt(0) once per trip)
+    for (uint32_t trip = 0; trip < kSteps / kTrip; ++trip)
 #pragma unroll
-    for (uint32_t t0 = 0; t0 < kSteps; t0 += PF)
+    for (uint32_t t0 = 0; t0 < kTrip; t0 += PF)
 #pragma unroll
     for (uint32_t u = 0; u < PF; ++u) {
-        const uint32_t t = t0 + u;
+        const uint32_t t = t0 + u;   // (the step within the trip)
         const mf_v4u cw = rw[u] ^ 0x80808080u, cx = rx[u] ^ 0x80808080u, cy = ry[u];
-        {   // (the last PF steps load the last step's entries again rather than branch: the ring's indices stay static)
-            const uint32_t tn = t + PF < kSteps ? t + PF : kSteps - 1u;
+        if (kSteps == kTrip ? t + PF < kTrip : true) {   // (compile-time.  One trip: nothing past its end.  Several: the last
+            // steps of the last trip load its last step again -- no branch, the counts of loads in flight stay static)
+            const uint32_t tn = kSteps == kTrip ? t + PF : (trip * kTrip + t + PF < kSteps ? trip * kTrip + t + PF : kSteps - 1u);
             rw[u] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(gw + (size_t)tn * 1024u));
             rx[u] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(gx + (size_t)tn * 1024u));
             ry[u] = __builtin_nontemporal_load(reinterpret_cast<const mf_v4u*>(gy + (size_t)tn * 1024u));
@@ -157,18 +182,31 @@ __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);   // (the steps stay apart: moved across them, the loads' registers overflow the file)
     }
     // ---- epilogue ----
-    {   // Y: the wave's total of its sub-block's pieces (half h of an entry: limbs 4 h .. 4 h + 3)
-        Acc<9> ysum = acc_zero<9>();
-        uint64_t carry = 0;
+    {   // Y: the wave's total of its sub-block's pieces.  The columns first, within the wave's halves (half h of an entry is
+        // limbs 4 h .. 4 h + 3): four DPP stages and one lane permute each, then lane 0 puts the two halves' columns together.
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            carry += ycol[q];
-            if (h) ysum.l[4 + q] = (uint32_t)carry; else ysum.l[q] = (uint32_t)carry;
-            carry >>= 32;
+            cross_add64<0xB1>(ycol[q]);    // quad_perm [1, 0, 3, 2]
+            cross_add64<0x4E>(ycol[q]);    // quad_perm [2, 3, 0, 1]
+            cross_add64<0x141>(ycol[q]);   // row_half_mirror
+            cross_add64<0x140>(ycol[q]);   // row_mirror: the sixteen lanes' total in all of them
+            ycol[q] += __shfl_xor(ycol[q], 16, 64);
         }
-        if (h) ysum.l[8] = (uint32_t)carry; else ysum.l[4] = (uint32_t)carry;
-        ysum = wave_sum(ysum);
-        if (lane == 0) s_y[wave] = ysum;
+        uint64_t upper[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) upper[q] = __shfl(ycol[q], 32, 64);
+        if (lane == 0) {
+            Acc<9> ysum;
+            uint64_t carry = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                carry += q < 4 ? ycol[q] : upper[q - 4];
+                ysum.l[q] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            ysum.l[8] = (uint32_t)carry;
+            s_y[wave] = ysum;
+        }
     }
     // The corrections' share of the anti-diagonal sums, modulo 2^32: lane s gets 128 sum_{d + e = s} A_d -- the sum of A over
     // the window max(0, s - 31) <= d <= min(31, s), a difference of two prefix sums -- likewise for B; the 128^2 n of every
@@ -191,34 +229,35 @@ __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ 
         const int32_t below = __shfl(pre, (int)((lane - 32u) & 63u), 64);
         corrB[y] = 128u * (uint32_t)(pre - (lane >= 32u ? below : 0));
     }
-    // The 64 sums sum_s D_s 256^s, a pair at a time: lane s collects the anti-diagonal d + e = s of C' (accumulator register
-    // r of lane (c, h) is C'[d = 8 (r >> 2) + 4 h + (r & 3)][e = c]: 32 lane permutes, no LDS round trip), eight lanes'
-    // diagonals make a number below 2^96, the eight of those go to LDS for the pair's thread below.
+    // The 64 sums sum_s D_s 256^s, a pair at a time.  Accumulator register r of lane (c, h) is C'[d][e = c] with
+    // d = 8 (r >> 2) + (r & 3) + 4 h, a term of anti-diagonal d + c.  One lane permute per register moves all 64 of them:
+    // lane (l, h) takes the term of row d whose diagonal is l modulo 32 -- column (l - d) mod 32, diagonal l if l >= d, else
+    // l + 32 -- so a pair costs 16 permutes, every one of them full; the two halves then exchange what they hold of each
+    // other's diagonal, and lane s has D_s.  No LDS round trip.
+    const int32_t lh = (int32_t)c - 4 * (int32_t)h;   // l - 4 h: row d = d0 + 4 h has l >= d where lh >= d0
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            uint32_t D = corrA[x] + corrB[y];
+            uint32_t low = 0, all = 0;   // this lane's terms of diagonal l, and of both l and l + 32
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (uint32_t hs = 0; hs < 2u; ++hs) {
-                    const uint32_t d = 8u * ((uint32_t)r >> 2) + 4u * hs + ((uint32_t)r & 3u);
-                    const uint32_t src = ((lane - d) & 31u) | (32u * hs);
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), acc[x][y][r]);
-                    D += (lane >= d && lane - d < 32u) ? v : 0u;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int32_t d0 = 8 * (r >> 2) + (r & 3);
+                const uint32_t src = ((uint32_t)(lh - d0) & 31u) | (32u * h);
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), acc[x][y][r]);
+                low += lh >= d0 ? v : 0u;
+                all += v;
+            }
+            const uint32_t give = h ? low : all - low;                  // the other half's diagonal
+            const uint32_t D = (h ? all - low : low) + __shfl_xor(give, 32, 64) + corrA[x] + corrB[y];
             const uint32_t sh = 8u * (lane & 7u);
             uint64_t plo = (uint64_t)D << sh;
             uint32_t phi = sh > 32u ? D >> (64u - sh) : 0u;
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                const uint64_t olo = __shfl_xor(plo, off, 64);
-                const uint32_t ohi = __shfl_xor(phi, off, 64);
-                const uint64_t nlo = plo + olo;
-                phi = phi + ohi + (nlo < plo ? 1u : 0u);
-                plo = nlo;
-            }
+            // (the eight lanes' total in all of them: quad exchanges and a mirror of the eight, on the VALU -- the LDS pipe
+            // is what this loop is bound by, 16 permutes per pair and wave)
+            cross_add96<0xB1>(plo, phi);    // quad_perm [1, 0, 3, 2]
+            cross_add96<0x4E>(plo, phi);    // quad_perm [2, 3, 0, 1]
+            cross_add96<0x141>(plo, phi);   // row_half_mirror: lane i of the eight <-> lane 7 - i (the other quad's total)
             if ((lane & 7u) == 0u) {
                 uint32_t* pp = s_part[(a0 + x) * 8u + b0 + y][lane >> 3];
                 pp[0] = (uint32_t)plo;

@@ -37,6 +37,32 @@ def test_wide_layer_sumcheck_matches_oracle(ctx, k_i, k):
     assert _same(got, want)
 
 
+@pytest.mark.parametrize("k_i,k,edge", [(12, 17, "random"), (14, 19, "random"), (16, 20, "random"), (10, 20, "extremes"), (8, 17, "zeros"),
+                                        (18, 21, "random")])
+def test_matrix_core_product_passes_match_the_checker_and_the_valu_form(k_i, k, edge):
+    """Product passes over tables of 2^17 entries and more run on int8 MFMA (mfma_cross.h: the 64 cross sums as byte-digit
+    matrix products in blocks of 512, 1024 or 2048 entries per sub-block -- k = 17, 19/20, 21 -- and, from 2^19 entries, the
+    pending fold of a phase's second pass through the fold passes' digit matrices).  The same bytes as the checker and as
+    the option's other value; W of zeros, and W of r - 1 and 2^253-ish entries (every byte digit at its extremes, the
+    anti-diagonal sums at their largest)."""
+    lay, z, W = synth.config5_layer(k_i, k, seed=9100 + 10 * k_i + k)
+    W = np.ascontiguousarray(W).copy()
+    if edge == "zeros":
+        W[:] = 0
+        W[5] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    elif edge == "extremes":
+        r_minus_1 = np.array([0x43E1F593F0000000, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029], dtype=np.uint64)
+        all_ff = np.array([0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0x2FFFFFFFFFFFFFFF], dtype=np.uint64)
+        W[0::2] = r_minus_1
+        W[1::4] = all_ff
+    want = cdense.sumcheck_layer_lin_raw(k_i, k, lay.gate_type, lay.left, lay.right, z, W)
+    with Context(0) as a, Context(0) as b:
+        b.set_option("no_mfma_cross", 1)
+        assert a.get_option("no_mfma_cross") == 0
+        assert _same(a.sumcheck_layer_raw(lay, k, z, W), want)
+        assert _same(b.sumcheck_layer_raw(lay, k, z, W), want)
+
+
 def test_resident_layer_with_W_in_device_memory(ctx):
     """gkr_resident_layer_sumcheck_wdev: W already on the device (what prover::prove has) -- the same transcript as with W
     handed over in host memory, a non-canonical W entry is reported, and the compiler-shaped layer of the bench's

@@ -28,11 +28,12 @@ int main() {
         const uint32_t S = 1u << (m - 3);
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (uint32_t kc : {512u, 1024u}) {
+        for (uint32_t kc : {512u, 1024u, 2048u}) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipEventRecord(e0, 0));
                 if (kc == 512u) hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
+                else if (kc == 2048u) hipLaunchKernelGGL(k_prod_cross_mfma<2048>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
                 else hipLaunchKernelGGL(k_prod_cross_mfma<1024>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
