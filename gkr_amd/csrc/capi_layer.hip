@@ -482,7 +482,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         WS(ctx, "layer.X", Fr, wlen * batch, Xc);
         WS(ctx, "layer.Y", Fr, wlen * batch, Yc);
         unsigned char* d_fold_plans = nullptr;   // (wide layers: the later passes' pending folds on the matrix cores)
-        if ((uint32_t)k >= gkr::kProdFoldMinM) WS(ctx, "layer.foldplans", unsigned char, (size_t)batch * gkr::prod_fold_plan_bytes(), d_fold_plans);
+        if (k >= 14) WS(ctx, "layer.foldplans", unsigned char, (size_t)batch * gkr::prod_fold_plan_bytes(), d_fold_plans);
         // (passes of a few blocks per proof publish from their last block: one arrival counter per proof, zero between passes)
         const bool no_fused_publish = gkr::opt(gkr::OPT_no_fused_publish) != 0;
         uint32_t* d_arrivals = nullptr;

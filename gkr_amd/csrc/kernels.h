@@ -76,7 +76,7 @@ inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_m
 // fold_plans (may be null): batch * prod_fold_plan_bytes() of device memory; passes with three variables pending over tables
 // of 2^kProdFoldMinM entries and more then fold on the matrix cores first (unless the option no_mfma_cross is set).
 constexpr uint32_t kProdFuseBlocks = 64;
-constexpr uint32_t kProdFoldMinM = 19;
+constexpr uint32_t kProdFoldMinM = 17;
 size_t prod_fold_plan_bytes();
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals = nullptr, void* fold_plans = nullptr);

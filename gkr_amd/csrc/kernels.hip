@@ -2002,7 +2002,8 @@ size_t prod_fold_plan_bytes() { return sizeof(MfmaFoldPlan); }
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals, void* fold_plans) {
     const bool mfma = !opt(OPT_no_mfma_cross);
-    if (mfma && fold_plans && jp == 3u && m_in >= kProdFoldMinM) {
+    const uint32_t fold_min = opt(OPT_prod_fold_min_log2) > 0 ? (uint32_t)opt(OPT_prod_fold_min_log2) : kProdFoldMinM;
+    if (mfma && fold_plans && jp == 3u && m_in >= fold_min && m_in >= 14u) {
         MfmaFoldPlan* plans = static_cast<MfmaFoldPlan*>(fold_plans);
         const uint32_t Sf = 1u << (m_in - 3u);
         hipLaunchKernelGGL(k_prod_fold_plan, dim3(batch), dim3(256), 0, s, weights, plans);
@@ -2014,6 +2015,8 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
     if (mfma && jp == 0u && J == 3u && m_in >= kCrossMinM) {
         // a wide layer's first pass of a phase (or a later one, folded above): the 64 cross sums as int8 matrix products (mfma_cross.h)
         const uint32_t kc = cross_pass_kc(S, batch), nblk = S / kc;
+        // (publishing from the last block to arrive, as the small passes do, was measured and is slower here: its 37 dependent
+        // additions per value over partials in other XCDs' memory cost more than the launch they save)
         if (kc == 2048u)
             hipLaunchKernelGGL(k_prod_cross_mfma<2048>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
         else if (kc == 1024u)
