@@ -912,11 +912,15 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
 
 
 def product_pass_roofline(k, prod_ms, peak_products_per_sec):
-    """The bound of a layer sumcheck's PRODUCT passes (kernels.hip, k_prod_cross: both phases as sumchecks of W X + Y over
-    three tables of 2^k entries, three rounds per pass).  A pass over tables of 2^m entries that binds the previous pass's jp
-    variables and forms the cross sums of the next J rounds costs 3 * 2^m products for the fold (2^jp weights per folded entry,
-    three tables) and 4^J * 2^(m - jp - J) for the cross sums; it reads the three tables once.  Products against the chip's
-    measured rate of dependent 254-bit Montgomery products, bytes against HBM peak -- whichever binds (the products do)."""
+    """The bound of a layer sumcheck's PRODUCT passes (kernels.hip: both phases as sumchecks of W X + Y over three tables of 2^k
+    entries, three rounds per pass).  Since round 5 the passes over tables of 2^17 entries and more run on the matrix cores
+    (mfma_cross.h, mfma_fold.h: the 254-bit products as int8 digit-matrix products, exact), which leaves them bound by the
+    bytes they move: a first pass reads its three tables once; a later pass folds the previous pass's three variables (reads
+    three tables of 2^m entries, writes them an eighth as long) and reads the folded tables for its cross sums.  Below 2^17
+    entries the passes stay on v_mad_u64_u32 and are latency chains between two hashes (a few us of work each).  `achieved`
+    is all of those bytes over the elapsed time of ALL the passes' kernels -- the small ones included, which is why the
+    fraction is low; the large kernels alone: profiles/r05 (k_prod_cross_mfma 96 MiB in 30 us at k = 20).  The modular-product
+    count and the chip's measured rate of such products on the VALU -- the bound before round 5 -- stay beside it."""
     if not prod_ms:
         return None
     products = bytes_ = 0.0
@@ -924,17 +928,23 @@ def product_pass_roofline(k, prod_ms, peak_products_per_sec):
         m, jp, rem = k, 0, k
         while rem > 0:
             J = min(3, rem)
-            bytes_ += 3.0 * 32.0 * (1 << m)
+            bytes_ += 3.0 * 32.0 * (1 << m)                       # the tables as they stand: read once
             if jp:
                 products += 3.0 * (1 << m)
+                bytes_ += 3.0 * 32.0 * (1 << (m - jp))             # the folded tables: written
+                if m >= 17:
+                    bytes_ += 3.0 * 32.0 * (1 << (m - jp))         # ... and read again by the cross-sum kernel
             m -= jp
             products += float(1 << (m + J))
             jp, rem = J, rem - J
     rate = products / (prod_ms * 1e-3)
-    return {"bound": "alu", "kernel": "k_prod_cross<8|32> (+ k_prod_reduce / k_prod_publish)", "products_per_sumcheck": products,
-            "achieved": rate, "peak": peak_products_per_sec, "unit": "254-bit modular products/s",
-            "frac": rate / peak_products_per_sec if peak_products_per_sec else None, "ms_per_sumcheck": prod_ms,
-            "hbm_bytes_per_sumcheck": bytes_, "hbm_frac_if_it_were_the_bound": bytes_ / (prod_ms * 1e-3) / 1e9 / PEAK_GBPS,
+    gbps = bytes_ / (prod_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_prod_cross_mfma + k_prod_fold_mfma (2^17 entries and more), k_prod_cross<8|32> below, k_prod_publish",
+            "hbm_bytes_per_sumcheck": bytes_, "achieved": gbps, "peak": PEAK_GBPS, "unit": "GB/s", "frac": gbps / PEAK_GBPS,
+            "ms_per_sumcheck": prod_ms,
+            "modular_products_per_sumcheck": products, "modular_products_per_sec": rate,
+            "valu_product_rate_of_the_chip": peak_products_per_sec,
+            "frac_of_the_valu_product_rate": rate / peak_products_per_sec if peak_products_per_sec else None,
             "note": "elapsed time of the passes' kernels (HIP events); the hand-offs between them are the host transcript's"}
 
 

@@ -710,9 +710,19 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
             __threadfence();
             const uint32_t q = tid / (uint32_t)kProdRecValues, val = tid % (uint32_t)kProdRecValues;   // three threads per value
             if (q < 3u) {
+                // (eight partials requested before the first is added: they sit in other XCDs' memory, ~1 us each when one
+                // load waits for the addition before it)
                 const Fr* pp = partials + (size_t)proof * gridDim.x * kProdRecValues + val;
                 Fr v = fr_zero();
-                for (uint32_t b = q; b < gridDim.x; b += 3u) v = fr_add(v, load_fr(pp + (size_t)b * kProdRecValues));
+                for (uint32_t b0 = q; b0 < gridDim.x; b0 += 24u) {
+                    Fr in[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j)
+                        if (b0 + 3u * j < gridDim.x) in[j] = load_fr(pp + (size_t)(b0 + 3u * j) * kProdRecValues);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j)
+                        if (b0 + 3u * j < gridDim.x) v = fr_add(v, in[j]);
+                }
                 s_red[q][val] = v;
             }
             __syncthreads();
@@ -2021,8 +2031,12 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
             hipLaunchKernelGGL(k_prod_cross_mfma<2048>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
         else if (kc == 1024u)
             hipLaunchKernelGGL(k_prod_cross_mfma<1024>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
-        else
+        else if (kc == 512u)
             hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
+        else if (kc == 256u)
+            hipLaunchKernelGGL(k_prod_cross_mfma<256>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
+        else
+            hipLaunchKernelGGL(k_prod_cross_mfma<128>, dim3(nblk, batch), dim3(512), 0, s, W, X, Y, m_in, partials, wstride);
         hipLaunchKernelGGL(k_prod_publish, dim3(batch), dim3((nblk > 32 ? 14 : 4) * kProdRecValues), 0, s, partials, nblk, rec, ticket);
         return;
     }

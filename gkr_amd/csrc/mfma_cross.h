@@ -34,12 +34,12 @@
 namespace gkr {
 
 constexpr uint32_t kCrossMinM = 17;          // tables of 2^17 entries and more
-// entries of every sub-block per block: the most (of 2048, 1024, 512) that leaves every CU of the chip a block -- a block's
-// epilogue costs what ~10 k-steps do
+// entries of every sub-block per block: the most (of 2048 .. 128) that leaves every CU of the chip a block -- a block's
+// epilogue costs what ~10 k-steps do, but a table of 2^17 entries in blocks of 512 is 32 blocks on 256 CUs
 inline uint32_t cross_pass_kc(uint32_t S, uint32_t batch) {
-    for (uint32_t kc = 2048u; kc > 512u; kc >>= 1)
+    for (uint32_t kc = 2048u; kc > 128u; kc >>= 1)
         if ((size_t)(S / kc) * batch >= 256u) return kc;
-    return 512u;
+    return 128u;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -85,7 +85,7 @@ __device__ __forceinline__ int32_t cross_wave_scan(int32_t v, uint32_t lane) {
 template <uint32_t KC>
 __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ Wt, const Fr* __restrict__ Xt, const Fr* __restrict__ Yt,
                                                          uint32_t m, Fr* __restrict__ partials, uint32_t wstride) {
-    static_assert(KC % 512u == 0 && KC <= 2048u, "a block's anti-diagonal sums must stay below 2^32: 32 * 2048 * 255^2 < 2^32");
+    static_assert(KC % 128u == 0 && KC <= 2048u, "a block's anti-diagonal sums must stay below 2^32: 32 * 2048 * 255^2 < 2^32");
     // [buffer][table][sub-block][digit][entry]: 2 x 2 x 8 x 32 x 32 bytes = 32 KB
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 8 * 32 * 32];
     __shared__ uint32_t s_part[64][8][3];    // [pair][group of eight anti-diagonals]: 96-bit partial totals

@@ -17,7 +17,7 @@ __global__ void k_fill(uint32_t* p, size_t words) {
 
 int main() {
     using namespace gkr;
-    for (uint32_t m : {20u, 22u}) {
+    for (uint32_t m : {17u, 18u, 20u, 22u}) {
         const size_t n = (size_t)1 << m;
         Fr *W, *X, *Y, *part;
         CK(hipMalloc(&W, n * 32)); CK(hipMalloc(&X, n * 32)); CK(hipMalloc(&Y, n * 32)); CK(hipMalloc(&part, (size_t)8192 * 72 * 32));
@@ -28,11 +28,14 @@ int main() {
         const uint32_t S = 1u << (m - 3);
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (uint32_t kc : {512u, 1024u, 2048u}) {
+        for (uint32_t kc : {128u, 256u, 512u, 1024u, 2048u}) {
+            if (S / kc < 16u || S / kc > 2048u) continue;
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipEventRecord(e0, 0));
-                if (kc == 512u) hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
+                if (kc == 128u) hipLaunchKernelGGL(k_prod_cross_mfma<128>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
+                else if (kc == 256u) hipLaunchKernelGGL(k_prod_cross_mfma<256>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
+                else if (kc == 512u) hipLaunchKernelGGL(k_prod_cross_mfma<512>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
                 else if (kc == 2048u) hipLaunchKernelGGL(k_prod_cross_mfma<2048>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
                 else hipLaunchKernelGGL(k_prod_cross_mfma<1024>, dim3(S / kc, 1), dim3(512), 0, 0, W, X, Y, m, part, (uint32_t)n);
                 CK(hipEventRecord(e1, 0));
