@@ -62,6 +62,41 @@ void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count
     }
 }
 
+// The HOST TAIL of a phase's product passes.  Once the tables are small (2^host_tail_log2 entries and fewer) a device pass is a
+// latency chain -- launch, ~15 us of kernel for a few hundred products, the record's way back -- and costs more than the
+// products do on one host core.  The last device pass of the phase therefore also leaves the three tables in pinned memory
+// (k_prod_cross's `tail`), and the host does what the later passes' kernels would: binds the previous pass's variables
+// (T'[i] = sum_b w_b T[b S + i], the weights in Montgomery form) and forms the next rounds' record (m[a][b] and the sub-block
+// sums of Y, as k_prod_cross defines them) -- exact field arithmetic, the same canonical values.  W is in Montgomery form and
+// stays so; X and Y are canonical.
+// tables: [3][stride] (W, X, Y) of 2^m entries each, folded in place to 2^(m - jp); rec: the record's 72 values
+void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec) {
+    using namespace gkr::h64;
+    const uint32_t mf = m - jp, len = 1u << mf;
+    if (jp) {
+        for (int t = 0; t < 3; ++t) {
+            F* T = tables + (size_t)t * stride;
+            for (uint32_t i = 0; i < len; ++i) {
+                F v = mont_mul(T[i], weights[0]);
+                for (uint32_t b = 1; b < (1u << jp); ++b) v = add(v, mont_mul(T[((size_t)b << mf) + i], weights[b]));
+                T[i] = v;
+            }
+        }
+    }
+    const uint32_t nsub = 1u << J, S = len >> J;
+    const F *W = tables, *X = tables + stride, *Y = tables + 2 * stride;
+    for (uint32_t a = 0; a < nsub; ++a) {
+        for (uint32_t b = 0; b < nsub; ++b) {
+            F v = mont_mul(W[a * S], X[b * S]);
+            for (uint32_t i = 1; i < S; ++i) v = add(v, mont_mul(W[a * S + i], X[b * S + i]));
+            rec[a * 8 + b] = v;
+        }
+        F y = Y[a * S];
+        for (uint32_t i = 1; i < S; ++i) y = add(y, Y[a * S + i]);
+        rec[64 + a] = y;
+    }
+}
+
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the
 // 2^J sub-block sums of the current table; the host runs J rounds on them (J <= 5 hashes in a row,
 // eight or sixteen sumchecks per IFMA call), derives the 2^J fold weights, and the next pass binds all J
@@ -493,11 +528,27 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 ctx->arrivals_zeroed = d_arrivals;
             }
         }
+        // the host tail (host_tail_pass above): for batches of a few proofs -- where a step waits for its chain of hand-offs, not
+        // for its hashing throughput -- the passes over tables of 2^tail_log2 entries and fewer run on the host
+        const long long tail_opt = gkr::opt(gkr::OPT_host_tail_log2), tail_batch_opt = gkr::opt(gkr::OPT_host_tail_max_batch);
+        const uint32_t tail_log2 = tail_opt < 0 ? 0u : tail_opt == 0 ? 6u : (uint32_t)(tail_opt > 12 ? 12 : tail_opt);
+        const bool tail_on = tail_log2 >= 3u && batch <= (tail_batch_opt > 0 ? tail_batch_opt : 8);
+        Fr* h_tail = nullptr;
+        if (tail_on) HIP_TRY(ctx, ctx->pinned_host("layer.tail", sizeof(Fr) * 3 * ((size_t)batch << tail_log2), reinterpret_cast<void**>(&h_tail)));
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
-        bool second_exchange_done = false;
+        bool second_exchange_done = false, tail_active = false;
+        const size_t tail_stride = (size_t)1 << tail_log2;
+        uint32_t tail_m = 0;   // log2 of the host tables' length (before the pending fold), while the tail is active
         for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
             Fr *Tw = Wb, *Tx = U, *Ty = V;
+            if (phase == 1 && tail_active) {
+                // what is left of Wb -- the 2^jp entries the last pass's weights bind into W(u) -- is on the host: back to the device,
+                // where the c-phase's set-up reads it
+                for (int b = 0; b < batch; ++b)
+                    HIP_TRY(ctx, hipMemcpyAsync(Wb + (size_t)b * wlen, h_tail + (size_t)b * 3 * tail_stride, sizeof(Fr) << jp, hipMemcpyHostToDevice, s));
+            }
+            tail_active = false;
             if (phase == 1) {
                 // all of b is bound: the rows of a, m at u = (r_1 .. r_k), then the c-phase's tables X = a_u + W(u) m_u,
                 // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
@@ -531,19 +582,26 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 // 0.80 ms of product passes per sumcheck, k = 22 1.44 -> 3.33: the second pass then folds into a table four or
                 // two times larger and crosses THAT with J = 3.)
                 const uint32_t J = rem < (uint32_t)gkr::kProdMaxJ ? rem : (uint32_t)gkr::kProdMaxJ;
-                const uint32_t ticket = ++ctx->ticket;
-                {
-                    Timed t(ctx, "layer_prod_pass", 0.0);
-                    gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals, d_fold_plans);
+                const bool on_host = tail_active;
+                // (this pass exports the tables if they are small enough and a later pass of the phase is there to be saved)
+                const bool exports = tail_on && !on_host && m - jp <= tail_log2 && rem > J;
+                if (!on_host) {
+                    const uint32_t ticket = ++ctx->ticket;
+                    {
+                        Timed t(ctx, "layer_prod_pass", 0.0);
+                        gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals, d_fold_plans,
+                                              exports ? h_tail : nullptr, (uint32_t)tail_stride);
+                    }
+                    if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+                        rc = ctx->hip_fail(le, "launch of a layer pass");
+                        break;
+                    }
+                    rc = wait_records(ctx, prec, batch, ticket);
+                    if (!rc) rc = xflag_check();
+                    if (rc) break;
                 }
+                const uint32_t m_before = on_host ? tail_m : 0u, jp_before = jp;
                 m -= jp;
-                if (hipError_t le = hipGetLastError(); le != hipSuccess) {
-                    rc = ctx->hip_fail(le, "launch of a layer pass");
-                    break;
-                }
-                rc = wait_records(ctx, prec, batch, ticket);
-                if (!rc) rc = xflag_check();
-                if (rc) break;
                 const int chunk = hash_chunk_size(batch, pool ? pool->workers() + 1 : 1, ctx->crew_member ? ctx->help_share : 0);
                 std::atomic<int> next{0};
                 const std::function<bool()> work = [&]() -> bool {
@@ -554,6 +612,11 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     uint32_t vl[gkr::kProdMaxJ][16];
                     const bool acct = accounting_on();
                     const double tp0 = acct ? now_us_dbg() : 0.0;
+                    if (on_host)   // (the weights of the previous pass are still in h_pw: the pass function below replaces them)
+                        for (int i = 0; i < cnt; ++i)
+                            host_tail_pass(reinterpret_cast<gkr::h64::F*>(h_tail + (size_t)(first + i) * 3 * tail_stride), tail_stride, m_before, jp_before,
+                                           reinterpret_cast<const gkr::h64::F*>(h_pw + (size_t)(first + i) * 8), J,
+                                           reinterpret_cast<gkr::h64::F*>(&prec[first + i].v[0]));
                     for (uint32_t t = 0; t < J; ++t)
                         for (int i = 0; i < cnt; ++i) vl[t][i] = 2u + (h_dep[(size_t)(first + i) * 32 + (round0 + t) % k] ? 1u : 0u);
                     (ifma && cnt >= 3 ? gkr::gkr_ifma_prod_pass : host_prod_pass_scalar)(
@@ -577,6 +640,8 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     return true;
                 };
                 run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
+                if (exports) tail_active = true;
+                if (exports || on_host) tail_m = m;   // (the host's tables: 2^m entries, this pass's J variables pending)
                 jp = J;
                 round0 += J;
                 rem -= J;

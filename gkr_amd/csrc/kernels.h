@@ -73,13 +73,17 @@ inline size_t prod_pass_scratch_values(uint32_t k) { return ((size_t)prod_pass_m
 // batch x prod_pass_blocks(2^(m_in - jp - 1)) x 72 values for passes that span several blocks per proof.
 // arrivals (may be null): `batch` zeroed words; passes of 2 .. kProdFuseBlocks blocks per proof then publish from their last
 // block instead of a second launch (the words are zero again when the kernel ends).
+// tail (may be null; pinned host memory, batch x 3 tables x tail_stride entries): the pass also leaves there the tables its
+// rounds work on (2^(m_in - jp) <= tail_stride entries each, the pending fold applied) -- the host runs the rest of the
+// phase's passes itself (capi_layer.hip, host tail).
 // fold_plans (may be null): batch * prod_fold_plan_bytes() of device memory; passes with three variables pending over tables
 // of 2^kProdFoldMinM entries and more then fold on the matrix cores first (unless the option no_mfma_cross is set).
 constexpr uint32_t kProdFuseBlocks = 64;
 constexpr uint32_t kProdFoldMinM = 17;
 size_t prod_fold_plan_bytes();
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals = nullptr, void* fold_plans = nullptr);
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals = nullptr, void* fold_plans = nullptr,
+                      Fr* tail = nullptr, uint32_t tail_stride = 0);
 // start of the c-phase: W(u) = sum_b w_b Wb[b] over the 2^jp entries left of Wb, then X = A + W(u) M, Y = W(u) A over
 // the 2^k entries of the rows A, M (gate_rows), per proof
 void launch_prod_c_setup(const Fr* Wb, uint32_t jp, const Fr* weights, const Fr* A, const Fr* M, Fr* X, Fr* Y, uint32_t k, uint32_t wstride,

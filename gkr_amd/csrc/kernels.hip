@@ -635,7 +635,8 @@ __global__ void k_layer_eval(uint32_t gates, const uint8_t* __restrict__ gate_ty
 template <uint32_t TILE>
 __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __restrict__ Xt, Fr* __restrict__ Yt, uint32_t m_in, uint32_t jp,
                                                     const Fr* __restrict__ weights, uint32_t J, Fr* __restrict__ partials, uint32_t wstride,
-                                                    ProdPassRec* __restrict__ rec, uint32_t ticket, uint32_t* __restrict__ arrivals) {
+                                                    ProdPassRec* __restrict__ rec, uint32_t ticket, uint32_t* __restrict__ arrivals,
+                                                    Fr* __restrict__ tail, uint32_t tail_stride) {
     __shared__ Fr s_w[8];
     __shared__ uint32_t s_last;
     __shared__ Fr s_t[3][8][TILE];               // folded tile: table, sub-block, i
@@ -670,7 +671,10 @@ __global__ void __launch_bounds__(256) k_prod_cross(Fr* __restrict__ Wt, Fr* __r
             v = load_fr(T[t] + idx);
         }
         s_t[t][a][i] = v;
+        // (the host takes the rest of the phase over from here: the tables as this pass's rounds find them, into pinned memory)
+        if (tail) store_fr(tail + ((size_t)proof * 3u + t) * tail_stride + idx, v);
     }
+    if (tail) __threadfence_system();   // (before the barrier the record's release stands behind)
     __syncthreads();
     const uint32_t p = tid & 63u, sub = tid >> 6, a = p >> 3, b = p & 7u;
     Fr acc = fr_zero(), accy = fr_zero();
@@ -2010,7 +2014,8 @@ __global__ void __launch_bounds__(256) k_prod_fold_mfma(Fr* Wt, Fr* Xt, Fr* Yt, 
 size_t prod_fold_plan_bytes() { return sizeof(MfmaFoldPlan); }
 
 void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr* weights, uint32_t J, Fr* partials, uint32_t wstride,
-                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals, void* fold_plans) {
+                      ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals, void* fold_plans, Fr* tail,
+                      uint32_t tail_stride) {
     const bool mfma = !opt(OPT_no_mfma_cross);
     const uint32_t fold_min = opt(OPT_prod_fold_min_log2) > 0 ? (uint32_t)opt(OPT_prod_fold_min_log2) : kProdFoldMinM;
     if (mfma && fold_plans && jp == 3u && m_in >= fold_min && m_in >= 14u) {
@@ -2044,10 +2049,10 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
     uint32_t* fused = (arrivals && blocks > 1 && blocks <= kProdFuseBlocks) ? arrivals : nullptr;   // the last block publishes
     if (prod_pass_tile(S) == kProdTileWide)
         hipLaunchKernelGGL(k_prod_cross<kProdTileWide>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           fused);
+                           fused, tail, tail_stride);
     else
         hipLaunchKernelGGL(k_prod_cross<kProdTile>, dim3(blocks, batch), dim3(256), 0, s, W, X, Y, m_in, jp, weights, J, partials, wstride, rec, ticket,
-                           fused);
+                           fused, tail, tail_stride);
     if (fused) return;
     if (blocks > 1024) {
         // (the second level's input sits behind the partials: launch_prod_pass's callers size the scratch with prod_pass_scratch_values)

@@ -460,6 +460,34 @@ def test_prove_wide_layers_match_oracle(ctx):
             assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"]
 
 
+@pytest.mark.parametrize("tail_log2,max_batch", [(-1, 0), (0, 0), (3, 0), (9, 0), (12, 0), (6, 2), (8, 64)])
+def test_host_tail_of_the_product_passes(tail_log2, max_batch):
+    """host_tail_log2 / host_tail_max_batch: a phase's passes over small tables run on the host (capi_layer.hip, host_tail_pass)
+    from tables the last device pass leaves in pinned memory -- from the phase's FIRST pass on when the layer is that small, never
+    (-1), for a batch above the limit not at all.  One proof, a batch of three (constant and 0/1 witnesses: short round
+    vectors) and a batch of nine against the checker, layers of 2^2 .. 2^11 values; every proof passes through both phases'
+    hand-over (the c-phase's set-up reads what is left of W from the device)."""
+    rng = random.Random(5150 + tail_log2)
+    ks = [2, 10, 11, 7, 4, 9]
+    layers = []
+    for i in range(len(ks) - 1):
+        g, n = 1 << ks[i], 1 << ks[i + 1]
+        layers.append(([rng.randint(0, 1) for _ in range(g)], [rng.randrange(n) for _ in range(g)],
+                       [rng.randrange(n) for _ in range(g)]))
+    witnesses = [[rng.randrange(P) for _ in range(1 << ks[-1])], [(i >> 7) + 3 for i in range(1 << ks[-1])],
+                 [rng.randrange(2) for _ in range(1 << ks[-1])]] + [[rng.randrange(P) for _ in range(1 << ks[-1])] for _ in range(6)]
+    refs = [cdense.prove(layers, w) for w in witnesses]
+    circuit = _circuit(layers, 1 << ks[-1])
+    with Context(0) as c:
+        c.set_option("host_tail_log2", tail_log2)
+        c.set_option("host_tail_max_batch", max_batch)
+        for got, want in (([c.prove(circuit, witnesses[0])], refs[:1]), (c.prove_batch(circuit, witnesses[:3]), refs[:3]),
+                          (c.prove_batch(circuit, witnesses), refs)):
+            for pr, ref in zip(got, want):
+                assert pr.sumcheck_proofs == ref["sumcheck_proofs"] and pr.sumcheck_r == ref["sumcheck_r"]
+                assert pr.q == ref["q"] and pr.z == ref["z"] and pr.r == ref["r"] and pr.k == ref["k"]
+
+
 def test_prove_batch_equals_single_proofs_and_oracle(ctx):
     """gkr_prove_batch: proofs of one circuit for many witnesses advanced together (host transcript), or layer by
     layer one after the other with no host in the loop (device transcript)."""
