@@ -70,6 +70,43 @@ __device__ __forceinline__ void cross_add64(uint64_t& v) {
     v += (uint64_t)o0 | ((uint64_t)o1 << 32);
 }
 
+// A block's sum of KC <= 2^11 products of values below r, as 17 limbs -> its value over 2^256 mod r, canonical: lazy_reduce's
+// eight Montgomery steps leave (x + M r) / 2^256 < 2^263 + r, which the fold pass's short reduction finishes (a quotient
+// estimate and one product with r: mfma_fold.h) where acc_reduce spends a whole product on the top limbs.
+__device__ __forceinline__ Fr cross_reduce(const Lazy17& x) {
+    constexpr uint32_t p[8] = GKR_MOD_LIMBS;
+    uint32_t t[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = x.l[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t m = t[k] * GKR_INV32;
+        uint64_t a2 = t[k];
+        uint32_t e2 = 0;
+        mac96_s(a2, e2, m, p[0]);
+        a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+        e2 = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            a2 += t[k + j];
+            mac96_s(a2, e2, m, p[j]);
+            t[k + j] = (uint32_t)a2;
+            a2 = (a2 >> 32) | ((uint64_t)e2 << 32);
+            e2 = 0;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 17; ++j) {   // (no carry out of limb 16: the sum stays below 2^520 + 2^256 r)
+            a2 += t[j];
+            t[j] = (uint32_t)a2;
+            a2 >>= 32;
+        }
+    }
+    uint32_t hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hi[i] = t[8 + i];
+    return mf_reduce_274(hi);
+}
+
 // inclusive prefix sums over the wave's lanes (lane i: the sum of lanes 0 .. i)
 __device__ __forceinline__ int32_t cross_wave_scan(int32_t v, uint32_t lane) {
 #pragma unroll
@@ -283,9 +320,9 @@ __global__ void __launch_bounds__(512) k_prod_cross_mfma(const Fr* __restrict__ 
             prev_hi = s_part[tid][q][2];
         }
         v.l[16] = (uint32_t)(prev_hi + carry);   // (the sum is below KC 2^512)
-        store_fr(out + tid, lazy_reduce(v));
+        store_fr(out + tid, cross_reduce(v));
     } else if (tid < 128u && lane < 8u) {   // (a second wave, beside the first)
-        store_fr(out + 64 + lane, acc_reduce(s_y[lane]));
+        store_fr(out + 64 + lane, mf_reduce_274(s_y[lane].l));   // (a sum of KC values below r: below 2^265)
     }
 }
 
