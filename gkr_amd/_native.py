@@ -29,7 +29,7 @@ SYMBOLS = [
     "gkr_strerror", "gkr_version", "gkr_ctx_create", "gkr_ctx_create_multi", "gkr_ctx_device_count", "gkr_ctx_destroy", "gkr_last_error",
     "gkr_ctx_set_transcript", "gkr_ctx_set_host_threads", "gkr_ctx_set_option", "gkr_ctx_get_option", "gkr_option_count", "gkr_option_name", "gkr_option_doc", "gkr_option_env", "gkr_host_help_while", "gkr_host_accounting", "gkr_host_accounting_read", "gkr_prove_many", "gkr_ctx_device_name", "gkr_ctx_profile", "gkr_ctx_profile_get", "gkr_ctx_profile_samples",
     "gkr_ctx_profile_reset", "gkr_mimc7_multi_hash", "gkr_mimc7_hash", "gkr_mimc7_constant",
-    "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_host_prod_pass", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_selftest_seg_item", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
+    "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_host_prod_pass", "gkr_selftest_host_tail", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_selftest_seg_item", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
     "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_sumcheck_wdev", "gkr_resident_layer_free", "gkr_exchange_limbs", "gkr_resident_layer_sumcheck_dev", "gkr_exchange_limbs_mle", "gkr_sumcheck_mle_sharded_dev", "gkr_exchange_rccl_unique_id", "gkr_exchange_rccl_create", "gkr_exchange_rccl_dev",
     "gkr_exchange_rccl_calls", "gkr_exchange_rccl_destroy", "gkr_exchange_rccl_error", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
     "gkr_circom_meta", "gkr_circom_input_json", "gkr_circom_verifier_source", "gkr_circom_inject",

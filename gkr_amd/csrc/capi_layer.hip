@@ -73,13 +73,13 @@ void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count
 void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec) {
     using namespace gkr::h64;
     const uint32_t mf = m - jp, len = 1u << mf;
-    if (jp) {
+    if (jp) {   // (sums of 2^jp products with one reduction each: wide_mac / wide_reduce, fr64.h)
         for (int t = 0; t < 3; ++t) {
             F* T = tables + (size_t)t * stride;
             for (uint32_t i = 0; i < len; ++i) {
-                F v = mont_mul(T[i], weights[0]);
-                for (uint32_t b = 1; b < (1u << jp); ++b) v = add(v, mont_mul(T[((size_t)b << mf) + i], weights[b]));
-                T[i] = v;
+                Wide acc = wide_zero();
+                for (uint32_t b = 0; b < (1u << jp); ++b) wide_mac(acc, T[((size_t)b << mf) + i], weights[b]);
+                T[i] = wide_reduce(acc);
             }
         }
     }
@@ -87,9 +87,9 @@ void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp,
     const F *W = tables, *X = tables + stride, *Y = tables + 2 * stride;
     for (uint32_t a = 0; a < nsub; ++a) {
         for (uint32_t b = 0; b < nsub; ++b) {
-            F v = mont_mul(W[a * S], X[b * S]);
-            for (uint32_t i = 1; i < S; ++i) v = add(v, mont_mul(W[a * S + i], X[b * S + i]));
-            rec[a * 8 + b] = v;
+            Wide acc = wide_zero();
+            for (uint32_t i = 0; i < S; ++i) wide_mac(acc, W[a * S + i], X[b * S + i]);
+            rec[a * 8 + b] = wide_reduce(acc);
         }
         F y = Y[a * S];
         for (uint32_t i = 1; i < S; ++i) y = add(y, Y[a * S + i]);

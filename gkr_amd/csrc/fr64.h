@@ -101,6 +101,63 @@ inline F mont_mul(const F& a, const F& b) {
     return out;
 }
 
+// Sums of products with ONE reduction (the device's lazy_mac_v / lazy_reduce on 64-bit limbs): a product of two values below
+// 2^256 is added as a 512-bit integer into a 576-bit accumulator -- 2^64 products fit -- and the sum is reduced once:
+// four Montgomery steps, then a quotient estimate from the top bits (the sum over 2^256 is below 2^274 for up to 2^18
+// products of values below r) and one product with r.  wide_reduce(sum of a_i b_i) == the modular sum of mont_mul(a_i, b_i).
+struct Wide {
+    uint64_t l[9];
+};
+inline Wide wide_zero() { return Wide{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
+inline void wide_mac(Wide& acc, const F& a, const F& b) {
+    for (int i = 0; i < 4; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; ++j) {
+            const u128 p = (u128)a.l[j] * b.l[i] + acc.l[i + j] + carry;
+            acc.l[i + j] = (uint64_t)p;
+            carry = (uint64_t)(p >> 64);
+        }
+        for (int j = i + 4; j < 9 && carry; ++j) {
+            const u128 s = (u128)acc.l[j] + carry;
+            acc.l[j] = (uint64_t)s;
+            carry = (uint64_t)(s >> 64);
+        }
+    }
+}
+inline F wide_reduce(const Wide& x) {
+    uint64_t t[9];
+    for (int i = 0; i < 9; ++i) t[i] = x.l[i];
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = t[i] * kInv;
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; ++j) {
+            const u128 p = (u128)m * kMod[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)p;
+            carry = (uint64_t)(p >> 64);
+        }
+        for (int j = i + 4; j < 9 && carry; ++j) {
+            const u128 s = (u128)t[j] + carry;
+            t[j] = (uint64_t)s;
+            carry = (uint64_t)(s >> 64);
+        }
+    }
+    // y = t[4 .. 8] < 2^274: q = floor((y >> 224) * mu / 2^61) with mu = floor(2^61 / ((r >> 224) + 1)) never exceeds y / r and
+    // falls short of it by less than 2 (mfma_fold.h, mf_reduce_274): y - q r is in [0, 2r)
+    const uint64_t top = (t[8] << 32) | (t[7] >> 32);
+    const uint64_t q = (uint64_t)(((u128)top * 0xa948e8c4ull) >> 61);
+    F out;
+    uint64_t carry = 0, borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        const u128 p = (u128)q * kMod[i] + carry;
+        carry = (uint64_t)(p >> 64);
+        const u128 d = (u128)t[4 + i] - (uint64_t)p - borrow;
+        out.l[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+    if (geq_mod(out)) sub_mod(out);
+    return out;
+}
+
 inline F to_mont(const F& a) { return mont_mul(a, kR2); }
 inline F from_mont(const F& a) {
     const F one = {{1, 0, 0, 0}};

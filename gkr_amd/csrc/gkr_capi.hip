@@ -437,6 +437,29 @@ int gkr_selftest_host_prod_pass(const gkr_fr* recs, int count, int J, const uint
     return GKR_OK;
 }
 
+// the host tail of a phase's product passes (capi_layer.hip, host_tail_pass) on tables the caller gives: W, X, Y of 2^m canonical
+// entries each, the previous pass's 2^jp canonical weights (jp = 0: none), the next pass's J rounds -> the 72 values of the
+// record the device pass would have left (cross sums of the folded tables' 2^J sub-blocks, then the sub-block sums of Y)
+int gkr_selftest_host_tail(const gkr_fr* tables, int m, int jp, const gkr_fr* weights, int J, gkr_fr* rec) {
+    using gkr::h64::F;
+    if (!tables || !rec || m < 0 || m > 12 || jp < 0 || jp > gkr::kProdMaxJ || jp > m || J < 1 || J > gkr::kProdMaxJ || J > m - jp || (jp && !weights))
+        return GKR_ERR_INVALID;
+    const size_t len = (size_t)1 << m;
+    if (!all_canonical(tables, 3 * len) || (jp && !all_canonical(weights, (size_t)1 << jp))) return GKR_ERR_NON_CANONICAL;
+    std::vector<F> t(3 * len);
+    memcpy(t.data(), tables, sizeof(F) * 3 * len);
+    for (size_t i = 0; i < len; ++i) t[i] = gkr::h64::to_mont(t[i]);   // W is in Montgomery form on the device, and stays so
+    F w[8] = {};
+    for (int b = 0; jp && b < (1 << jp); ++b) {   // (jp = 0: nothing pending, no weights)
+        memcpy(&w[b], &weights[b], sizeof(F));
+        w[b] = gkr::h64::to_mont(w[b]);
+    }
+    F out[gkr::kProdRecValues] = {};
+    host_tail_pass(t.data(), len, (uint32_t)m, (uint32_t)jp, w, (uint32_t)J, out);
+    memcpy(rec, out, sizeof out);
+    return GKR_OK;
+}
+
 // eight right-aligned round vectors (3 slots each, the last len[k] slots count) hashed the way the
 // host transcript does: the eight-lane IFMA code when the CPU has it (*used_ifma = 1; its sixteen-lane
 // form is cross-checked on the way), else scalar

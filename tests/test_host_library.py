@@ -237,6 +237,38 @@ def test_host_pass_matches_big_integers():
         == N.GKR_ERR_NON_CANONICAL
 
 
+def test_host_tail_pass_forms_the_records_a_device_pass_would():
+    """capi_layer.hip's host tail: the fold of the previous pass's variables and the cross sums of the next rounds, as sums of
+    products with one reduction each (fr64.h wide_mac / wide_reduce) -- against plain integer arithmetic, with random tables,
+    tables of r - 1 (the largest sums) and of zeros"""
+    lib = N.lib()
+    rng = random.Random(606)
+    for m, jp, J, kind in ((6, 3, 3, "random"), (9, 3, 3, "random"), (5, 0, 3, "random"), (5, 3, 2, "random"), (3, 0, 3, "random"),
+                           (12, 3, 3, "max"), (9, 3, 3, "max"), (4, 2, 2, "zero"), (6, 0, 1, "random"), (8, 3, 3, "random")):
+        n = 1 << m
+        draw = {"random": lambda: rng.randrange(P), "max": lambda: P - 1, "zero": lambda: 0}[kind]
+        Wt, Xt, Yt = ([draw() for _ in range(n)] for _ in range(3))
+        w = [draw() if kind != "zero" else rng.randrange(P) for _ in range(1 << jp)]
+        mf = m - jp
+        fold = lambda T: [sum(w[b] * T[(b << mf) + i] for b in range(1 << jp)) % P for i in range(1 << mf)] if jp else list(T)
+        Wf, Xf, Yf = fold(Wt), fold(Xt), fold(Yt)
+        S = (1 << mf) >> J
+        want = [0] * 72
+        for a in range(1 << J):
+            for b in range(1 << J):
+                want[a * 8 + b] = sum(Wf[a * S + i] * Xf[b * S + i] for i in range(S)) % P
+            want[64 + a] = sum(Yf[a * S + i] for i in range(S)) % P
+        rec = np.zeros((72, 4), dtype=np.uint64)
+        T, Wl = to_limbs(Wt + Xt + Yt), to_limbs(w)          # (kept alive across the call)
+        rc = lib.gkr_selftest_host_tail(_p(T), ctypes.c_int(m), ctypes.c_int(jp), _p(Wl) if jp else None, ctypes.c_int(J), _p(rec))
+        assert rc == N.GKR_OK, (m, jp, J, kind)
+        assert from_limbs(rec) == want, (m, jp, J, kind)
+    bad, zeros, rec = to_limbs([0] * 24), to_limbs([0] * 24), np.zeros((72, 4), dtype=np.uint64)
+    bad[5] = 0xFFFFFFFFFFFFFFFF
+    assert lib.gkr_selftest_host_tail(_p(bad), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(3), _p(rec)) == N.GKR_ERR_NON_CANONICAL
+    assert lib.gkr_selftest_host_tail(_p(zeros), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(4), _p(rec)) == N.GKR_ERR_INVALID
+
+
 def test_host_prod_pass_matches_a_direct_product_sumcheck():
     """the host's share of a product pass of the layer sumcheck: the cross-sum matrix of random tables W, X, Y is built
     here, and the coefficients / challenges / weights the library derives from it alone (scalar and IFMA lanes) must
