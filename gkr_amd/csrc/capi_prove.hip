@@ -146,51 +146,71 @@ static bool retained_gate_bytes_match(const gkr_circuit_desc* c, const std::vect
 }
 
 // two independent 64-bit hashes over the k list and the gate arrays (pure: a group's members are hashed side by side)
-static void circuit_hashes(const gkr_circuit_desc* c, uint64_t* out_h1, uint64_t* out_h2) {
+// The cache key of a circuit: two 64-bit hashes over its k list and gate arrays.  The arrays are hashed in SEGMENTS of at most
+// kHashSegment bytes, each on its own (seeded by its position), and the segments' hashes are folded in order -- so that the
+// megabytes of a wide circuit (12 MB for k = 18, 20, 20: 0.54 ms on one core, an eighth of the proof) can be hashed by several
+// threads at once.  circuit_hash_segments lists them, hash_segment hashes one, fold_segment_hashes makes the key.
+constexpr size_t kHashSegment = (size_t)256 << 10;
+struct HashSegment {
+    const void* p;
+    size_t n;
+};
+static void circuit_hash_segments(const gkr_circuit_desc* c, std::vector<HashSegment>& out) {
     const uint32_t L = c->depth;
-    uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x9E3779B97F4A7C15ULL;
-    auto mix = [&](const void* p, size_t n) {
-        const unsigned char* q = static_cast<const unsigned char*>(p);
-        size_t i = 0;
-        if (n >= 4096) {
-            // long arrays (the gate lists of a wide layer: megabytes per call): four independent multiply chains over
-            // 32-byte blocks, folded into the two running hashes at the end -- the single chain below is latency-bound
-            // (1.8 ms for 12 MB of gate arrays per proof)
-            uint64_t a[4] = {h1, h1 ^ 0x9E3779B97F4A7C15ULL, h1 + 0x632BE59BD9B4E019ULL, ~h1}, b[4] = {h2, ~h2, h2 ^ 0xD6E8FEB86659FD93ULL, h2 + 1};
-            for (; i + 32 <= n; i += 32) {
-                uint64_t w[4];
-                memcpy(w, q + i, 32);
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = (a[t] ^ w[t]) * 0x100000001b3ULL;
-                    b[t] = (b[t] + w[t]) * 0xBF58476D1CE4E5B9ULL;
-                    b[t] ^= b[t] >> 29;
-                }
-            }
-            for (int t = 0; t < 4; ++t) {
-                h1 = (h1 ^ a[t]) * 0x100000001b3ULL;
-                h2 = (h2 + b[t]) * 0xBF58476D1CE4E5B9ULL;
-                h2 ^= h2 >> 29;
-            }
-        }
-        for (; i + 8 <= n; i += 8) {
-            uint64_t w;
-            memcpy(&w, q + i, 8);
-            h1 = (h1 ^ w) * 0x100000001b3ULL;
-            h2 = (h2 + w) * 0xBF58476D1CE4E5B9ULL;
-            h2 ^= h2 >> 29;
-        }
-        for (; i < n; ++i) {
-            h1 = (h1 ^ q[i]) * 0x100000001b3ULL;
-            h2 = (h2 + q[i]) * 0x94D049BB133111EBULL;
-        }
-    };
-    mix(&L, sizeof L);
-    mix(c->k, (L + 1) * sizeof(uint32_t));
+    out.push_back({c->k, (L + 1) * sizeof(uint32_t)});
     for (uint32_t i = 0; i < L; ++i) {
         const size_t gates = (size_t)1 << c->k[i];
-        mix(c->gate_type[i], gates);
-        mix(c->left[i], gates * 4);
-        mix(c->right[i], gates * 4);
+        const void* arrays[3] = {c->gate_type[i], c->left[i], c->right[i]};
+        const size_t bytes[3] = {gates, gates * 4, gates * 4};
+        for (int a = 0; a < 3; ++a)
+            for (size_t off = 0; off < bytes[a]; off += kHashSegment)
+                out.push_back({static_cast<const unsigned char*>(arrays[a]) + off, bytes[a] - off < kHashSegment ? bytes[a] - off : kHashSegment});
+    }
+}
+static void hash_segment(const HashSegment& seg, uint64_t index, uint64_t* out_h1, uint64_t* out_h2) {
+    uint64_t h1 = 0xcbf29ce484222325ULL ^ (index * 0x9E3779B97F4A7C15ULL), h2 = 0x9E3779B97F4A7C15ULL + index;
+    const unsigned char* q = static_cast<const unsigned char*>(seg.p);
+    const size_t n = seg.n;
+    size_t i = 0;
+    if (n >= 4096) {
+        // long arrays: four independent multiply chains over 32-byte blocks, folded into the two running hashes at the end -- a
+        // single chain is latency-bound (1.8 ms for 12 MB of gate arrays per proof)
+        uint64_t a[4] = {h1, h1 ^ 0x9E3779B97F4A7C15ULL, h1 + 0x632BE59BD9B4E019ULL, ~h1}, b[4] = {h2, ~h2, h2 ^ 0xD6E8FEB86659FD93ULL, h2 + 1};
+        for (; i + 32 <= n; i += 32) {
+            uint64_t w[4];
+            memcpy(w, q + i, 32);
+            for (int t = 0; t < 4; ++t) {
+                a[t] = (a[t] ^ w[t]) * 0x100000001b3ULL;
+                b[t] = (b[t] + w[t]) * 0xBF58476D1CE4E5B9ULL;
+                b[t] ^= b[t] >> 29;
+            }
+        }
+        for (int t = 0; t < 4; ++t) {
+            h1 = (h1 ^ a[t]) * 0x100000001b3ULL;
+            h2 = (h2 + b[t]) * 0xBF58476D1CE4E5B9ULL;
+            h2 ^= h2 >> 29;
+        }
+    }
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, q + i, 8);
+        h1 = (h1 ^ w) * 0x100000001b3ULL;
+        h2 = (h2 + w) * 0xBF58476D1CE4E5B9ULL;
+        h2 ^= h2 >> 29;
+    }
+    for (; i < n; ++i) {
+        h1 = (h1 ^ q[i]) * 0x100000001b3ULL;
+        h2 = (h2 + q[i]) * 0x94D049BB133111EBULL;
+    }
+    *out_h1 = h1;
+    *out_h2 = h2;
+}
+static void fold_segment_hashes(uint32_t depth, const uint64_t* seg_hashes, size_t n_segments, uint64_t* out_h1, uint64_t* out_h2) {
+    uint64_t h1 = 0xcbf29ce484222325ULL ^ depth, h2 = 0x9E3779B97F4A7C15ULL + n_segments;
+    for (size_t i = 0; i < n_segments; ++i) {
+        h1 = (h1 ^ seg_hashes[2 * i]) * 0x100000001b3ULL;
+        h2 = (h2 + seg_hashes[2 * i + 1]) * 0xBF58476D1CE4E5B9ULL;
+        h2 ^= h2 >> 29;
     }
     *out_h1 = h1;
     *out_h2 = h2;
@@ -334,14 +354,32 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     // threads of the crew have nothing of their own -- one after the other they were 0.9 ms at the head of a 9 ms step)
     std::vector<uint64_t> hs((size_t)2 * n_members);
     {
-        std::atomic<int> next{0};
+        // (the segments of all members' arrays in one list: a piece is a segment -- the members of a group, and the megabytes of one
+        // wide circuit, are hashed by whichever threads are free: the crew's, or the context's own pool when it proves alone)
+        std::vector<HashSegment> segs;
+        std::vector<size_t> first_seg((size_t)n_members + 1, 0);
+        size_t total_bytes = 0;
+        for (int m = 0; m < n_members; ++m) {
+            circuit_hash_segments(members[m].circuit, segs);
+            first_seg[(size_t)m + 1] = segs.size();
+        }
+        for (const HashSegment& sg : segs) total_bytes += sg.n;
+        std::vector<uint64_t> seg_hashes(2 * segs.size());
+        std::atomic<size_t> next{0};
         const std::function<bool()> work = [&]() -> bool {
-            const int m = next.fetch_add(1, std::memory_order_relaxed);
-            if (m >= n_members) return false;
-            circuit_hashes(members[m].circuit, &hs[2 * (size_t)m], &hs[2 * (size_t)m + 1]);
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= segs.size()) return false;
+            const size_t m = (size_t)(std::upper_bound(first_seg.begin(), first_seg.end(), i) - first_seg.begin()) - 1;
+            hash_segment(segs[i], i - first_seg[m], &seg_hashes[2 * i], &seg_hashes[2 * i + 1]);
             return true;
         };
-        run_pieces(nullptr, &work, n_members > 1);
+        gkr::SpinPool* hash_pool = (!ctx->crew_member && total_bytes >= ((size_t)2 << 20)) ? ctx->host_pool() : nullptr;
+        gkr::SpinPool::Session session(hash_pool, nullptr);
+        run_pieces(hash_pool, &work, segs.size() > (size_t)n_members);
+        session.close();
+        for (int m = 0; m < n_members; ++m)
+            fold_segment_hashes(members[m].circuit->depth, &seg_hashes[2 * first_seg[m]], first_seg[(size_t)m + 1] - first_seg[m], &hs[2 * (size_t)m],
+                                &hs[2 * (size_t)m + 1]);
     }
     for (int m = 0; m < n_members; ++m) {
         // (a member's circuit may be the very circuit of an earlier member: found in `fresh` then, not uploaded twice)
@@ -579,6 +617,23 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
             slp[b] = outs[b].sumcheck_len + row_off;
             srp[b] = outs[b].sumcheck_r + row_off;
         }
+        // The LAST layer's line restriction has no later sumcheck to run beside: the part of it that needs W alone (the copy, the
+        // Moebius transform, the largest degree: 0.1 ms of the 0.3 at 2^20 values) is issued before the layer's sumcheck, on the
+        // side stream, behind the previous layer's restriction.
+        const bool line_prepared = i + 1 == L && k > 12 && ctx->profile == 0;
+        if (line_prepared) {
+            if (!ctx->liner) ctx->liner.reset(new AsyncWorker());
+            liner.worker = ctx->liner.get();
+            liner.started = true;
+            const int device = ctx->device;
+            const Fr* Wn = dW[i + 1];
+            const uint32_t ub = (uint32_t)batch, uk = (uint32_t)k;
+            hipStream_t aux = ctx->aux;
+            ctx->liner->run([=]() {
+                if (hipSetDevice(device) != hipSuccess) return;
+                gkr::launch_line_restriction(Wn, uk, nullptr, d_lr, d_lrdeg, nullptr, nullptr, nullptr, ub, aux, gkr::LinePart::prepare);
+            });
+        }
         const auto tl0 = std::chrono::steady_clock::now();
         ctx->rounds_ahead = 0;
         for (uint32_t later = i + 1; later < L; ++later) ctx->rounds_ahead += 2 * (int)c->k[later + 1];
@@ -611,7 +666,8 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
                 const uint32_t ub = (uint32_t)batch, uk = (uint32_t)k;
                 ctx->liner->run([=]() {
                     if (hipSetDevice(device) != hipSuccess) return;
-                    gkr::launch_line_restriction(Wn, uk, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, bcm, qdst, qlen_dst, ub, aux);
+                    gkr::launch_line_restriction(Wn, uk, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, bcm, qdst, qlen_dst, ub, aux,
+                                                 line_prepared ? gkr::LinePart::finish : gkr::LinePart::all);
                 });
             } else {
                 Timed t(ctx, "line_restriction", 0.0, ctx->aux, true);

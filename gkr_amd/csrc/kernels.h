@@ -256,8 +256,11 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
 // q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, deg_scratch batch
 // words (device), out batch x (k + 1) highest degree first, out_len batch
 // bcm: batch * 2k elements of device scratch (the line's coefficients in Montgomery form; unused for k <= 9)
+// part (layers of more than 2^12 values only; smaller ones ignore it and must be called with `all`): `prepare` issues what needs
+// W alone (the copy, the Moebius transform, the largest degree), `finish` the rest (the line's coefficients, the steps, q).
+enum class LinePart { all, prepare, finish };
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,
-                             uint32_t batch, hipStream_t s);
+                             uint32_t batch, hipStream_t s, LinePart part = LinePart::all);
 
 // ---- wide layers (kernels_wide.hip): next-layer tables of 2^14 values and more -------------------------------------------
 // The gate passes over ITEMS: the buckets of the sorted lists cut into pieces of at most sixteen gates, sorted by length, a

@@ -2144,7 +2144,7 @@ void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t
 }
 
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,
-                             uint32_t batch, hipStream_t s) {
+                             uint32_t batch, hipStream_t s, LinePart part) {
     const bool stepwise = opt(OPT_line_stepwise) != 0;   // (test hook: the wide-layer form at every width)
     if (k <= 9 && !stepwise) {
         hipLaunchKernelGGL(k_line_restriction, dim3(batch), dim3(256), (size_t)3 * sizeof(Fr) << k, s, W, k, bc, scratch, out, out_len);
@@ -2156,8 +2156,11 @@ void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch,
         // wide layers: the set-up over a grid (kernels_wide.hip), one launch per variable while the table is large, the last
         // six variables, q and its length in one block per proof -- 4 + (k - 6) + 1 launches instead of 2 k + 6 (the proving
         // thread issues them between two layers' sumchecks)
+        // (the set-up needs W only, the rest the line: a caller that has W before it has the line -- the last layer of a proof,
+        // whose restriction nothing else overlaps -- issues the two parts apart)
+        if (part != LinePart::finish) launch_line_setup_wide(W, k, scratch, deg_scratch, batch, s);
+        if (part == LinePart::prepare) return;
         hipLaunchKernelGGL(k_line_coeffs, dim3(batch), dim3(64), 0, s, k, bc, bcm);
-        launch_line_setup_wide(W, k, scratch, deg_scratch, batch, s);
         const uint32_t j0 = k - 6u;
         for (uint32_t j = 0; j < j0; ++j) {
             const uint32_t items = (1u << (k - j - 1u)) * (j + 2u);
