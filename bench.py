@@ -544,7 +544,7 @@ def aggregated_proofs(world, n_inputs):
     compile_ms = (time.perf_counter() - t0) * 1e3
     subs = len(step.circuits)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    threads = cpus - 2 if cpus >= 6 else (cpus - 1 if cpus >= 3 else cpus)   # two (one, none) left to the runtime's own threads
+    threads = transcript_threads()   # (the library's own default: gkr_capi.hip, default_host_threads)
     ctx = Context(world.local_rank)
     out = {"circuit": "R1CS equivalent to rust/t.circom (MiMC7-91, 364 constraints) -> %d layered circuits, k lists %s"
                       % (subs, [c.get_k_list() for c in step.circuits]),
@@ -765,7 +765,7 @@ def run_proofs(args, world):
     subs = len(step_obj.circuits)
     mine = parallel.shard_units(args.proofs, world.rank, world.size)
     cpus = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    threads = cpus - 2 if cpus >= 6 else (cpus - 1 if cpus >= 3 else cpus)   # two (one, none) left to the runtime's own threads
+    threads = transcript_threads()   # (the library's own default: gkr_capi.hip, default_host_threads)
     ctx = Context(world.local_rank)
     inputs = step_obj.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(2 + i, 3 + (i % 5))) for i in mine])) if len(mine) else None
 
