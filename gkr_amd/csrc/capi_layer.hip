@@ -535,6 +535,9 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         const bool tail_on = tail_log2 >= 3u && batch <= (tail_batch_opt > 0 ? tail_batch_opt : 8);
         Fr* h_tail = nullptr;
         if (tail_on) HIP_TRY(ctx, ctx->pinned_host("layer.tail", sizeof(Fr) * 3 * ((size_t)batch << tail_log2), reinterpret_cast<void**>(&h_tail)));
+        const bool dbg_sections = gkr::debug_timing();
+        double us_launch = 0, us_wait = 0, us_pieces = 0, us_phase1 = 0;
+        const double t_passes0 = dbg_sections ? now_us_dbg() : 0.0;
         gkr::SpinPool::Session session(pool, nullptr);
         uint32_t round0 = 0, jp = 0;
         bool second_exchange_done = false, tail_active = false;
@@ -549,6 +552,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     HIP_TRY(ctx, hipMemcpyAsync(Wb + (size_t)b * wlen, h_tail + (size_t)b * 3 * tail_stride, sizeof(Fr) << jp, hipMemcpyHostToDevice, s));
             }
             tail_active = false;
+            const double t_ph1 = dbg_sections ? now_us_dbg() : 0.0;
             if (phase == 1) {
                 // all of b is bound: the rows of a, m at u = (r_1 .. r_k), then the c-phase's tables X = a_u + W(u) m_u,
                 // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
@@ -575,6 +579,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 Ty = Yc;
                 jp = 0;
             }
+            if (dbg_sections && phase == 1) us_phase1 += now_us_dbg() - t_ph1;
             uint32_t m = (uint32_t)k;   // log2 of the tables' length before the pending fold
             for (uint32_t rem = (uint32_t)k; rem > 0 && rc == GKR_OK;) {
                 // (the rounds that do not fill a pass of three come LAST.  First -- so that the pass over the whole table forms
@@ -587,6 +592,7 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                 const bool exports = tail_on && !on_host && m - jp <= tail_log2 && rem > J;
                 if (!on_host) {
                     const uint32_t ticket = ++ctx->ticket;
+                    const double tl0 = dbg_sections ? now_us_dbg() : 0.0;
                     {
                         Timed t(ctx, "layer_prod_pass", 0.0);
                         gkr::launch_prod_pass(Tw, Tx, Ty, m, jp, h_pw, J, d_ppart, (uint32_t)wlen, prec, ticket, (uint32_t)batch, s, d_arrivals, d_fold_plans,
@@ -596,7 +602,12 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                         rc = ctx->hip_fail(le, "launch of a layer pass");
                         break;
                     }
+                    const double tl1 = dbg_sections ? now_us_dbg() : 0.0;
                     rc = wait_records(ctx, prec, batch, ticket);
+                    if (dbg_sections) {
+                        us_launch += tl1 - tl0;
+                        us_wait += now_us_dbg() - tl1;
+                    }
                     if (!rc) rc = xflag_check();
                     if (rc) break;
                 }
@@ -639,7 +650,9 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
                     if (acct) account_piece(cnt, tp1 - tp0, now_us_dbg() - tp0);
                     return true;
                 };
+                const double tw0 = dbg_sections ? now_us_dbg() : 0.0;
                 run_pieces(pool, &work, batch > chunk, ctx->rounds_ahead + (int)(v - round0));
+                if (dbg_sections) us_pieces += now_us_dbg() - tw0;
                 if (exports) tail_active = true;
                 if (exports || on_host) tail_m = m;   // (the host's tables: 2^m entries, this pass's J variables pending)
                 jp = J;
@@ -648,6 +661,10 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             }
         }
         session.close();
+        if (dbg_sections)
+            fprintf(stderr, "[gkr timing] layer k_i=%d k=%d batch=%d passes: %.0f us = launch calls %.0f + waiting for records %.0f + hashing pieces %.0f + c-phase set-up calls %.0f + other %.0f\n",
+                    k_i, k, batch, now_us_dbg() - t_passes0, us_launch, us_wait, us_pieces, us_phase1,
+                    now_us_dbg() - t_passes0 - us_launch - us_wait - us_pieces - us_phase1);
         // a rank that failed between the exchanges still enters the second one (flag set): its peers are waiting in it.
         // (Not when the failure is the travelling flag itself: then every rank is leaving at this very point.)
         if (rc && shard && !second_exchange_done && !(h_xflag && __atomic_load_n(h_xflag, __ATOMIC_ACQUIRE)))
