@@ -913,7 +913,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
 
 def product_pass_roofline(k, prod_ms, peak_products_per_sec):
     """The bound of a layer sumcheck's PRODUCT passes (kernels.hip: both phases as sumchecks of W X + Y over three tables of 2^k
-    entries, three rounds per pass).  Since round 5 the passes over tables of 2^17 entries and more run on the matrix cores
+    entries, three rounds per pass).  Since round 5 the passes over tables of 2^15 (cross sums) / 2^17 (pending folds) entries and more run on the matrix cores
     (mfma_cross.h, mfma_fold.h: the 254-bit products as int8 digit-matrix products, exact), which leaves them bound by the
     bytes they move: a first pass reads its three tables once; a later pass folds the previous pass's three variables (reads
     three tables of 2^m entries, writes them an eighth as long) and reads the folded tables for its cross sums.  Below 2^17
@@ -939,7 +939,7 @@ def product_pass_roofline(k, prod_ms, peak_products_per_sec):
             jp, rem = J, rem - J
     rate = products / (prod_ms * 1e-3)
     gbps = bytes_ / (prod_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_prod_cross_mfma + k_prod_fold_mfma (2^17 entries and more), k_prod_cross<8|32> below, k_prod_publish",
+    return {"bound": "hbm", "kernel": "k_prod_cross_mfma (2^15 entries and more) + k_prod_fold_mfma (2^17 and more), k_prod_cross<8|32> below, k_prod_publish",
             "hbm_bytes_per_sumcheck": bytes_, "achieved": gbps, "peak": PEAK_GBPS, "unit": "GB/s", "frac": gbps / PEAK_GBPS,
             "ms_per_sumcheck": prod_ms,
             "modular_products_per_sumcheck": products, "modular_products_per_sec": rate,

@@ -2027,7 +2027,8 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
         jp = 0u;
     }
     const uint32_t S = 1u << (m_in - jp - J);
-    if (mfma && jp == 0u && J == 3u && m_in >= kCrossMinM) {
+    const uint32_t cross_min = opt(OPT_prod_cross_min_log2) > 0 ? (uint32_t)opt(OPT_prod_cross_min_log2) : kCrossMinM;
+    if (mfma && jp == 0u && J == 3u && m_in >= cross_min && m_in >= 13u) {
         // a wide layer's first pass of a phase (or a later one, folded above): the 64 cross sums as int8 matrix products (mfma_cross.h)
         const uint32_t kc = cross_pass_kc(S, batch), nblk = S / kc;
         // (publishing from the last block to arrive, as the small passes do, was measured and is slower here: its 37 dependent

@@ -33,7 +33,7 @@
 
 namespace gkr {
 
-constexpr uint32_t kCrossMinM = 17;          // tables of 2^17 entries and more
+constexpr uint32_t kCrossMinM = 15;          // tables of 2^15 entries and more (32 blocks of 128: 14 us where k_prod_cross<32> takes 15-33)
 // entries of every sub-block per block: the most (of 2048 .. 128) that leaves every CU of the chip a block -- a block's
 // epilogue costs what ~10 k-steps do, but a table of 2^17 entries in blocks of 512 is 32 blocks on 256 CUs
 inline uint32_t cross_pass_kc(uint32_t S, uint32_t batch) {

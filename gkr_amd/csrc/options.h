@@ -41,7 +41,8 @@ namespace gkr {
     X(gate_segments_min_log2, "gate_segments_min_log2", "GKR_GATE_SEGMENTS_MIN_LOG2", 22, "smallest layer (log2 gates) that takes the segment passes") \
     X(gate_segment_log2, "gate_segment_log2", "GKR_GATE_SEGMENT_LOG2", 0, "log2 of the segments' mean length (0: 4)")              \
     X(gate_segments_no_lds, "gate_segments_no_lds", "GKR_GATE_SEGMENTS_NO_LDS", 0, "the segment pass gathers its table from L2 instead of LDS") \
-    X(no_mfma_cross, "no_mfma_cross", "GKR_NO_MFMA_CROSS", 0, "wide layers' product passes over tables of 2^17 entries and more on v_mad_u64_u32 instead of int8 MFMA") \
+    X(no_mfma_cross, "no_mfma_cross", "GKR_NO_MFMA_CROSS", 0, "wide layers' product passes over tables of 2^15 entries and more on v_mad_u64_u32 instead of int8 MFMA") \
+    X(prod_cross_min_log2, "prod_cross_min_log2", "GKR_PROD_CROSS_MIN_LOG2", 0, "smallest tables (log2 entries, at least 13) whose cross sums of a product pass run on the matrix cores (0: 15)") \
     X(prod_fold_min_log2, "prod_fold_min_log2", "GKR_PROD_FOLD_MIN_LOG2", 0, "smallest tables (log2 entries) whose pending fold of a product pass runs on the matrix cores (0: 17)") \
     X(host_tail_log2, "host_tail_log2", "GKR_HOST_TAIL_LOG2", 0, "a phase's product passes over tables of 2^this entries and fewer run on the host (0: 6; -1: none; at most 12)") \
     X(host_tail_max_batch, "host_tail_max_batch", "GKR_HOST_TAIL_MAX_BATCH", 0, "largest batch (proofs advancing together) whose small product passes run on the host (0: 8)") \

@@ -37,12 +37,12 @@ def test_wide_layer_sumcheck_matches_oracle(ctx, k_i, k):
     assert _same(got, want)
 
 
-@pytest.mark.parametrize("k_i,k,edge", [(12, 17, "random"), (14, 19, "random"), (16, 20, "random"), (10, 20, "extremes"), (8, 17, "zeros"),
+@pytest.mark.parametrize("k_i,k,edge", [(12, 15, "random"), (13, 16, "extremes"), (12, 17, "random"), (14, 19, "random"), (16, 20, "random"), (10, 20, "extremes"), (8, 17, "zeros"),
                                         (18, 21, "random")])
 def test_matrix_core_product_passes_match_the_checker_and_the_valu_form(k_i, k, edge):
-    """Product passes over tables of 2^17 entries and more run on int8 MFMA (mfma_cross.h: the 64 cross sums as byte-digit
-    matrix products in blocks of 512, 1024 or 2048 entries per sub-block -- k = 17, 19/20, 21 -- and, from 2^19 entries, the
-    pending fold of a phase's second pass through the fold passes' digit matrices).  The same bytes as the checker and as
+    """Product passes over tables of 2^15 entries and more run on int8 MFMA (mfma_cross.h: the 64 cross sums as byte-digit
+    matrix products in blocks of 128 .. 2048 entries per sub-block -- k = 15 .. 21 -- and, from 2^17 entries, the pending fold
+    of a phase's later passes through the fold passes' digit matrices).  The same bytes as the checker and as
     the option's other value; W of zeros, and W of r - 1 and 2^253-ish entries (every byte digit at its extremes, the
     anti-diagonal sums at their largest)."""
     lay, z, W = synth.config5_layer(k_i, k, seed=9100 + 10 * k_i + k)
