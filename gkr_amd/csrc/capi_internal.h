@@ -656,6 +656,7 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
 int run_mle_batch(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr_fr* out_coeffs, uint32_t* out_len, gkr_fr* out_r);
 // ---- defined in capi_layer.hip
 void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec);
+void host_tail_pass_scalar(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec);
 void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16], uint64_t (*c2)[16][4],
                            uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4], uint64_t* weights, size_t w_row_words);
 // One rank's share of a layer split across GPUs by GATES (gkr_sumcheck_layer_sharded): the device gate arrays hold

@@ -70,7 +70,7 @@ void host_prod_pass_scalar(const uint64_t* recs, size_t rec_row_words, int count
 // sums of Y, as k_prod_cross defines them) -- exact field arithmetic, the same canonical values.  W is in Montgomery form and
 // stays so; X and Y are canonical.
 // tables: [3][stride] (W, X, Y) of 2^m entries each, folded in place to 2^(m - jp); rec: the record's 72 values
-void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec) {
+void host_tail_pass_scalar(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec) {
     using namespace gkr::h64;
     const uint32_t mf = m - jp, len = 1u << mf;
     if (jp) {   // (sums of 2^jp products with one reduction each: wide_mac / wide_reduce, fr64.h)
@@ -95,6 +95,14 @@ void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp,
         for (uint32_t i = 1; i < S; ++i) y = add(y, Y[a * S + i]);
         rec[64 + a] = y;
     }
+}
+
+// (eight products per instruction group where the CPU has AVX-512 IFMA: mimc_ifma.cpp, gkr_ifma_tail_pass -- the same values)
+void host_tail_pass(gkr::h64::F* tables, size_t stride, uint32_t m, uint32_t jp, const gkr::h64::F* weights, uint32_t J, gkr::h64::F* rec) {
+    if (host_ifma_ready())
+        gkr::gkr_ifma_tail_pass(&tables[0].l[0], stride, m, jp, weights ? &weights[0].l[0] : nullptr, J, &rec[0].l[0]);
+    else
+        host_tail_pass_scalar(tables, stride, m, jp, weights, J, rec);
 }
 
 // Host transcript, default schedule (kernels.hip "Multi-round passes"): a pass hands the host the

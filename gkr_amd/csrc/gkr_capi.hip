@@ -440,7 +440,7 @@ int gkr_selftest_host_prod_pass(const gkr_fr* recs, int count, int J, const uint
 // the host tail of a phase's product passes (capi_layer.hip, host_tail_pass) on tables the caller gives: W, X, Y of 2^m canonical
 // entries each, the previous pass's 2^jp canonical weights (jp = 0: none), the next pass's J rounds -> the 72 values of the
 // record the device pass would have left (cross sums of the folded tables' 2^J sub-blocks, then the sub-block sums of Y)
-int gkr_selftest_host_tail(const gkr_fr* tables, int m, int jp, const gkr_fr* weights, int J, gkr_fr* rec) {
+int gkr_selftest_host_tail(const gkr_fr* tables, int m, int jp, const gkr_fr* weights, int J, gkr_fr* rec, int* used_ifma) {
     using gkr::h64::F;
     if (!tables || !rec || m < 0 || m > 12 || jp < 0 || jp > gkr::kProdMaxJ || jp > m || J < 1 || J > gkr::kProdMaxJ || J > m - jp || (jp && !weights))
         return GKR_ERR_INVALID;
@@ -455,7 +455,24 @@ int gkr_selftest_host_tail(const gkr_fr* tables, int m, int jp, const gkr_fr* we
         w[b] = gkr::h64::to_mont(w[b]);
     }
     F out[gkr::kProdRecValues] = {};
-    host_tail_pass(t.data(), len, (uint32_t)m, (uint32_t)jp, w, (uint32_t)J, out);
+    const bool ifma = host_ifma_ready();
+    if (used_ifma) *used_ifma = ifma ? 1 : 0;
+    if (ifma) {   // the eight-lane form beside the scalar one: the same record and the same folded tables
+        std::vector<F> t2(t);
+        F out2[gkr::kProdRecValues] = {};
+        gkr::gkr_ifma_tail_pass(&t2[0].l[0], len, (uint32_t)m, (uint32_t)jp, &w[0].l[0], (uint32_t)J, &out2[0].l[0]);
+        host_tail_pass_scalar(t.data(), len, (uint32_t)m, (uint32_t)jp, w, (uint32_t)J, out);
+        const size_t folded = (size_t)1 << (m - jp);
+        for (int tb = 0; tb < 3; ++tb)
+            if (memcmp(&t[(size_t)tb * len], &t2[(size_t)tb * len], folded * sizeof(F)) != 0) return GKR_ERR_INVALID;
+        const int n = 1 << J;
+        for (int a = 0; a < n; ++a) {
+            if (memcmp(&out[a * 8], &out2[a * 8], sizeof(F) * n) != 0) return GKR_ERR_INVALID;
+            if (memcmp(&out[64 + a], &out2[64 + a], sizeof(F)) != 0) return GKR_ERR_INVALID;
+        }
+    } else {
+        host_tail_pass_scalar(t.data(), len, (uint32_t)m, (uint32_t)jp, w, (uint32_t)J, out);
+    }
     memcpy(rec, out, sizeof out);
     return GKR_OK;
 }

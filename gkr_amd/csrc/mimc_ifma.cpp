@@ -73,6 +73,7 @@ static void dbl_mod(uint64_t x[4]) {
     memcpy(x, t, 32);
 }
 
+static uint64_t g_r264_52[5];   // 2^264 mod p: a 4x64-Montgomery operand (x 2^256) times this, through mont_mul (/ 2^260), is that operand's value x 2^260
 static uint64_t g_p52[5], g_pinv52, g_r2_52[5], g_one52[5], g_r256_52[5];   // g_r256: 2^256 mod p (the 4x64-bit code's Montgomery one)
 static uint64_t g_cts52[91][5];   // MiMC constants, Montgomery (radix 2^260)
 static bool g_ready = false;
@@ -284,6 +285,10 @@ static void init_constants(const uint64_t (*cts_canonical)[4]) {
     uint64_t r256[4] = {1, 0, 0, 0};
     for (int i = 0; i < 256; ++i) dbl_mod(r256);
     to52(r256, g_r256_52);
+    uint64_t r264[4];
+    memcpy(r264, r256, sizeof r264);
+    for (int i = 0; i < 8; ++i) dbl_mod(r264);
+    to52(r264, g_r264_52);
     g_ready = true;   // mont_mul usable from here
     const V r2 = splat(g_r2_52);
     for (int base = 0; base < 91; base += 8) {
@@ -752,6 +757,54 @@ void gkr_ifma_prod_pass(const uint64_t* recs, size_t rec_row_words, int count, i
         ifma::prod_pass_w<2>(recs, rec_row_words, count, J, vec_len, c2, lin, c0, r, weights, w_row_words);
     else
         ifma::prod_pass_w<1>(recs, rec_row_words, count, J, vec_len, c2, lin, c0, r, weights, w_row_words);
+}
+
+// The host tail of a phase's product passes (capi_layer.hip, host_tail_pass), eight field products per instruction group: the
+// fold of the previous pass's 2^jp variables over eight consecutive entries at a time, the cross sums with the eight sub-blocks of
+// X in the lanes.  tables: W (x 2^256), X, Y of 2^m entries each, `stride` elements apart, folded in place to 2^(m - jp) entries;
+// weights: 2^jp values x 2^256; rec: 72 values (m[a * 8 + b], the sub-block sums of Y at 64 + a).  All canonical 4 x 64-bit.
+// mont_mul divides by 2^260, the 4x64-bit code's Montgomery form carries 2^256: a weight goes in times 2^264 / 2^260 (then
+// weight x entry is the entry's fold term in the entry's own form), and a cross sum of (W x 2^256) X / 2^260 comes out times
+// 2^264 / 2^260 again.
+void gkr_ifma_tail_pass(uint64_t* tables, size_t stride, uint32_t m, uint32_t jp, const uint64_t* weights, uint32_t J, uint64_t* rec) {
+    using namespace ifma;
+    const uint32_t mf = m - jp, len = 1u << mf, nsub = 1u << J, S = len >> J;
+    const V c264 = splat(g_r264_52);
+    if (jp) {
+        V w[8];
+        for (uint32_t b = 0; b < (1u << jp); ++b) {
+            uint64_t l[5];
+            to52(weights + 4 * b, l);
+            w[b] = mont_mul(splat(l), c264);
+        }
+        for (int t = 0; t < 3; ++t) {
+            uint64_t* T = tables + (size_t)t * stride * 4;
+            for (uint32_t i = 0; i < len; i += 8) {
+                const int count = len - i < 8 ? (int)(len - i) : 8;
+                const __m512i off = lane_offsets(4, count);
+                V acc = mont_mul(gather8(T + (size_t)i * 4, off), w[0]);
+                for (uint32_t b = 1; b < (1u << jp); ++b) acc = add_mod(acc, mont_mul(gather8(T + (((size_t)b << mf) + i) * 4, off), w[b]));
+                scatter8(acc, T + (size_t)i * 4, off, (__mmask8)((1u << count) - 1u));
+            }
+        }
+    }
+    const uint64_t *W = tables, *X = tables + stride * 4, *Y = tables + 2 * stride * 4;
+    const __m512i sub_off = lane_offsets((size_t)S * 4, (int)nsub);     // lane b: sub-block b (lanes beyond nsub read sub-block 0's)
+    const __mmask8 sub_lanes = (__mmask8)((1u << nsub) - 1u);
+    const __m512i rec_off = lane_offsets(4, (int)nsub);
+    uint64_t zero52[5] = {0, 0, 0, 0, 0};
+    for (uint32_t a = 0; a < nsub; ++a) {
+        V acc = splat(zero52);
+        for (uint32_t i = 0; i < S; ++i) {
+            uint64_t l[5];
+            to52(W + ((size_t)a * S + i) * 4, l);
+            acc = add_mod(acc, mont_mul(splat(l), gather8(X + (size_t)i * 4, sub_off)));
+        }
+        scatter8(mont_mul(acc, c264), rec + (size_t)a * 8 * 4, rec_off, sub_lanes);
+    }
+    V ysum = splat(zero52);
+    for (uint32_t i = 0; i < S; ++i) ysum = add_mod(ysum, gather8(Y + (size_t)i * 4, sub_off));
+    scatter8(ysum, rec + 64 * 4, rec_off, sub_lanes);
 }
 
 // The host's share of one multi-round pass of `count` <= 16 plain sumchecks (lanes), J <= 5 rounds:

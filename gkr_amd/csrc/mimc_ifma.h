@@ -15,4 +15,6 @@ void gkr_ifma_pass(const uint64_t* sums, size_t sums_row_words, int count, int J
 // the host's share of one product pass of the layer sumcheck, `count` <= 16 sumchecks side by side (see mimc_ifma.cpp)
 void gkr_ifma_prod_pass(const uint64_t* recs, size_t rec_row_words, int count, int J, const uint32_t (*vec_len)[16], uint64_t (*c2)[16][4],
                         uint64_t (*lin)[16][4], uint64_t (*c0)[16][4], uint64_t (*r)[16][4], uint64_t* weights, size_t w_row_words);
+// the host tail of a phase's product passes on eight lanes (see mimc_ifma.cpp; capi_layer.hip, host_tail_pass, is its scalar twin)
+void gkr_ifma_tail_pass(uint64_t* tables, size_t stride, uint32_t m, uint32_t jp, const uint64_t* weights, uint32_t J, uint64_t* rec);
 }  // namespace gkr

@@ -191,8 +191,9 @@ int  gkr_selftest_host_pass(const gkr_fr *sums, int count, int J, const uint32_t
 /* the host tail of a phase's product passes (once the tables are down to 2^host_tail_log2 entries the host forms the passes'
  * records itself, from tables the last device pass leaves in pinned memory): tables = W, X, Y of 2^m <= 2^12 canonical entries each,
  * weights = the previous pass's 2^jp canonical weights (jp = 0: none pending), J = the rounds of the pass -> rec: the 72 values
- * the device pass would have left (m[a*8 + b] of the folded tables' 2^J sub-blocks, the sub-block sums of Y at 64 + a). */
-int  gkr_selftest_host_tail(const gkr_fr *tables, int m, int jp, const gkr_fr *weights, int J, gkr_fr *rec);
+ * the device pass would have left (m[a*8 + b] of the folded tables' 2^J sub-blocks, the sub-block sums of Y at 64 + a).  Scalar code;
+ * its eight-lane IFMA form runs beside it when the CPU has it (*used_ifma = 1) and must agree. */
+int  gkr_selftest_host_tail(const gkr_fr *tables, int m, int jp, const gkr_fr *weights, int J, gkr_fr *rec, int *used_ifma);
 /* the host's share of one product pass of the layer sumcheck (h = W X + Y over three tables): `count` <= 16 sumchecks,
  * recs: 72 values each -- the cross sums m[a*8 + b] = sum_i W[aS+i] X[bS+i] of the 2^J <= 8 sub-blocks, then the Y sums
  * at 64 + a; vec_len[t*count + k] = 2 or 3 -> per round t < J (index t*count + k) the coefficients of

@@ -260,13 +260,13 @@ def test_host_tail_pass_forms_the_records_a_device_pass_would():
             want[64 + a] = sum(Yf[a * S + i] for i in range(S)) % P
         rec = np.zeros((72, 4), dtype=np.uint64)
         T, Wl = to_limbs(Wt + Xt + Yt), to_limbs(w)          # (kept alive across the call)
-        rc = lib.gkr_selftest_host_tail(_p(T), ctypes.c_int(m), ctypes.c_int(jp), _p(Wl) if jp else None, ctypes.c_int(J), _p(rec))
+        rc = lib.gkr_selftest_host_tail(_p(T), ctypes.c_int(m), ctypes.c_int(jp), _p(Wl) if jp else None, ctypes.c_int(J), _p(rec), None)
         assert rc == N.GKR_OK, (m, jp, J, kind)
         assert from_limbs(rec) == want, (m, jp, J, kind)
     bad, zeros, rec = to_limbs([0] * 24), to_limbs([0] * 24), np.zeros((72, 4), dtype=np.uint64)
     bad[5] = 0xFFFFFFFFFFFFFFFF
-    assert lib.gkr_selftest_host_tail(_p(bad), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(3), _p(rec)) == N.GKR_ERR_NON_CANONICAL
-    assert lib.gkr_selftest_host_tail(_p(zeros), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(4), _p(rec)) == N.GKR_ERR_INVALID
+    assert lib.gkr_selftest_host_tail(_p(bad), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(3), _p(rec), None) == N.GKR_ERR_NON_CANONICAL
+    assert lib.gkr_selftest_host_tail(_p(zeros), ctypes.c_int(3), ctypes.c_int(0), None, ctypes.c_int(4), _p(rec), None) == N.GKR_ERR_INVALID
 
 
 def test_host_prod_pass_matches_a_direct_product_sumcheck():
