@@ -1,9 +1,10 @@
-// The FIRST product pass of a wide layer's phase on the matrix cores (device code, gfx950).
+// The cross sums of a wide layer's product passes on the matrix cores (device code, gfx950): a pass with nothing pending -- a
+// phase's first, or a later one whose pending fold ran through mfma_fold.h first (kernels.hip, launch_prod_pass).
 //
 // A product pass (kernels.hip, k_prod_cross) hands the host, for the next J = 3 rounds, the cross sums
 //     m[a][b] = sum_{i < S} W[a S + i] * X[b S + i]      (a, b < 8;  S = 2^(m - 3) entries per sub-block)
 // of two tables of 2^m entries -- 64 products of two 254-bit numbers per index i, 8.4 * 10^6 products for tables of 2^20
-// entries: on v_mad_u64_u32 that pass runs at the chip's product rate (86 us) where its 96 MiB are 16 us of HBM.  Both
+// entries: on v_mad_u64_u32 that pass runs at the chip's product rate (86 us) where its 96 MiB are 12 us of HBM.  Both
 // operands vary with i, so the fold pass's trick (mfma_fold.h: one operand a per-sumcheck constant, its digit matrix the
 // shared MFMA operand) does not apply as it stands; what does is the same exactness argument one level up.  Over the
 // BYTES w_d, x_e of the entries (W = sum_d w_d 256^d, X = sum_e x_e 256^e)
@@ -17,12 +18,12 @@
 // Bytes are unsigned, the instruction signed: w = w' + 128 (the top bit flipped), so
 //     C[d][e] = C'[d][e] + 128 (A_d + B_e) + 128^2 n,      A_d = sum_i w'_d,  B_e = sum_i x'_e,
 // the digit sums accumulated beside the MFMAs with v_dot4_i32_i8.  What the 512-bit sum needs of C are its anti-diagonal
-// sums D_s = sum_{d + e = s} C[d][e] <= 32 n 255^2 < 2^32 (n <= 1024): every term is added modulo 2^32 -- the signed C',
+// sums D_s = sum_{d + e = s} C[d][e] <= 32 n 255^2 < 2^32 (n <= 2048): every term is added modulo 2^32 -- the signed C',
 // the window sums of A and B -- and the result is the exact D_s.  Every quantity is an exact integer; the sum
-// sum_s D_s 256^s is reduced mod r once per block and pair (lazy_reduce: the Montgomery form of W makes that the product's
+// sum_s D_s 256^s is reduced mod r once per block and pair (cross_reduce: the Montgomery form of W makes that the product's
 // value) -- the same field elements as the VALU form, bit for bit.
 //
-// A block takes KC <= 1024 entries of every sub-block (|C'| <= KC * 2^14 < 2^31) and leaves one partial record
+// A block takes KC = 128 .. 2048 entries of every sub-block (|C'| <= KC * 2^14 < 2^31) and leaves one partial record
 // (72 values) like a block of k_prod_cross; 512 threads = 8 waves, wave w: sub-blocks a in {2 (w & 3), +1} x b in
 // {4 (w >> 2) .. +3} -- eight 32 x 32 int32 tiles, 128 accumulator registers.
 #pragma once
