@@ -2017,8 +2017,12 @@ void launch_prod_pass(Fr* W, Fr* X, Fr* Y, uint32_t m_in, uint32_t jp, const Fr*
                       ProdPassRec* rec, uint32_t ticket, uint32_t batch, hipStream_t s, uint32_t* arrivals, void* fold_plans, Fr* tail,
                       uint32_t tail_stride) {
     const bool mfma = !opt(OPT_no_mfma_cross);
+    // (the threshold counts a lockstep group's proofs in: k_prod_cross<8> over 64 blocks x 7 proofs takes 43 us where one proof's
+    // takes 26, the fold kernels a few us either way)
+    uint32_t log_batch = 0;
+    while ((2u << log_batch) <= batch) ++log_batch;
     const uint32_t fold_min = opt(OPT_prod_fold_min_log2) > 0 ? (uint32_t)opt(OPT_prod_fold_min_log2) : kProdFoldMinM;
-    if (mfma && fold_plans && jp == 3u && m_in >= fold_min && m_in >= 14u) {
+    if (mfma && fold_plans && jp == 3u && m_in + log_batch >= fold_min && m_in >= 14u) {
         MfmaFoldPlan* plans = static_cast<MfmaFoldPlan*>(fold_plans);
         const uint32_t Sf = 1u << (m_in - 3u);
         hipLaunchKernelGGL(k_prod_fold_plan, dim3(batch), dim3(256), 0, s, weights, plans);

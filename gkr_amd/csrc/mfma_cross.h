@@ -35,12 +35,13 @@
 namespace gkr {
 
 constexpr uint32_t kCrossMinM = 15;          // tables of 2^15 entries and more (32 blocks of 128: 14 us where k_prod_cross<32> takes 15-33)
-// entries of every sub-block per block: the most (of 2048 .. 128) that leaves every CU of the chip a block -- a block's
-// epilogue costs what ~10 k-steps do, but a table of 2^17 entries in blocks of 512 is 32 blocks on 256 CUs
+// entries of every sub-block per block: the fewest (of 128 .. 2048) that still give every block of the launch a CU of its own --
+// a block's epilogue costs what ~10 k-steps do, so blocks should be long, but a second round of blocks costs a whole block's
+// time (a table of 2^16 entries for seven proofs: 448 blocks of 128 took 37 us, 224 of 256 take 17)
 inline uint32_t cross_pass_kc(uint32_t S, uint32_t batch) {
-    for (uint32_t kc = 2048u; kc > 128u; kc >>= 1)
-        if ((size_t)(S / kc) * batch >= 256u) return kc;
-    return 128u;
+    for (uint32_t kc = 128u; kc < 2048u; kc <<= 1)
+        if ((size_t)(S / kc) * batch <= 256u) return kc;
+    return 2048u;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
