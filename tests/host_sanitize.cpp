@@ -264,6 +264,36 @@ static void hashes(std::mt19937_64& rng) {
             gkr::gkr_ifma_multi_hash8(hv, hl, 3, ho);
             for (int k = 0; k < lanes; ++k) CHECK(memcmp(ho[k], &r[(size_t)k * 4], 32) == 0);
         }
+        // the host tail of the product passes on eight lanes: tables of EXACTLY 3 x 2^m entries, weights of exactly 2^jp, a record of
+        // exactly 72 -- every fold depth and round count, against the scalar sums of products (fr64.h wide_mac / wide_reduce)
+        for (uint32_t m = 1; m <= 9; ++m)
+            for (uint32_t jp = 0; jp <= 3 && jp <= m; ++jp)
+                for (uint32_t J = 1; J <= 3 && J + jp <= m; ++J) {
+                    const size_t len = (size_t)1 << m;
+                    std::vector<uint64_t> tabs(3 * len * 4), w((size_t)(1u << jp) * 4), rec(72 * 4, 0);
+                    for (size_t i = 0; i < tabs.size(); ++i) tabs[i] = (i % 4 == 3) ? rng() >> 4 : rng();
+                    for (size_t i = 0; i < w.size(); ++i) w[i] = (i % 4 == 3) ? rng() >> 4 : rng();
+                    std::vector<uint64_t> want_tabs(tabs);
+                    gkr::gkr_ifma_tail_pass(tabs.data(), len, m, jp, jp ? w.data() : nullptr, J, rec.data());
+                    using gkr::h64::F;
+                    F* T = reinterpret_cast<F*>(want_tabs.data());
+                    const F* wf = reinterpret_cast<const F*>(w.data());
+                    const uint32_t mf = m - jp, flen = 1u << mf, S = flen >> J;
+                    for (int t = 0; t < 3 && jp; ++t)
+                        for (uint32_t i = 0; i < flen; ++i) {
+                            gkr::h64::Wide acc = gkr::h64::wide_zero();
+                            for (uint32_t b = 0; b < (1u << jp); ++b) gkr::h64::wide_mac(acc, T[(size_t)t * len + ((size_t)b << mf) + i], wf[b]);
+                            T[(size_t)t * len + i] = gkr::h64::wide_reduce(acc);
+                        }
+                    for (int t = 0; t < 3; ++t) CHECK(memcmp(&T[(size_t)t * len], &tabs[(size_t)t * len * 4], (size_t)flen * 32) == 0);
+                    for (uint32_t a = 0; a < (1u << J); ++a)
+                        for (uint32_t b = 0; b < (1u << J); ++b) {
+                            gkr::h64::Wide acc = gkr::h64::wide_zero();
+                            for (uint32_t i = 0; i < S; ++i) gkr::h64::wide_mac(acc, T[a * S + i], T[len + b * S + i]);
+                            const F v = gkr::h64::wide_reduce(acc);
+                            CHECK(memcmp(&v, &rec[(size_t)(a * 8 + b) * 4], 32) == 0);
+                        }
+                }
     } else {
         printf("(no AVX-512 IFMA on this CPU: lane hash skipped)\n");
     }
