@@ -827,7 +827,16 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
     step()
     one_shot_ms = (time.perf_counter() - t_first) * 1e3
     sort_ms = ctx.profile_get("gate_lists")["total_ms"]
+    # the steps on the line run WITHOUT the per-kernel events (a pair of event records around every timed launch leaves ~6 us of
+    # idle device between two kernels of a chain: ~40 us of a 1.4 ms sumcheck); the kernels' own times come from a second pass
+    # of the same steps with the events on
+    ctx.profile(False)
     elapsed, each = timed_steps(world, ctx, step, warmup, steps)
+    ctx.profile(1)
+    ctx.profile_reset()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
     ctx.profile(False)
     host_w_ms = None
     if not split and k >= 16:   # the PCIe-inclusive figure (W handed over in host memory every sumcheck): reported, never the value
@@ -903,6 +912,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
             "exchange": {"calls_per_step": exch["launches"] / steps, "us_per_call": exch["total_ms"] * 1e3 / exch["launches"]} if exch["launches"] else None,
             "collective": collective_info(world, exchange, exch, steps) if split else None,
             "kernel_ms_per_step": {n_: prof[n_]["total_ms"] / steps for n_ in names if prof[n_]["launches"]},
+            "kernel_ms_source": "HIP events around the launches in a second pass of the same %d steps (the timed steps run without them)" % steps,
             "step_ms_each": [round(x * 1e3, 3) for x in each]}
     if d_W is not None:
         ctx.free(d_W)
