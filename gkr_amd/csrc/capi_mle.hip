@@ -180,9 +180,19 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         int pass = 0;
         int index = 0;
         hipStream_t chain = nullptr;   // a device-hashed group: the stream its whole chain runs on
+        bool on_host = false;          // the host tail: the group's tables (2^m entries each) are in h_tail, the device is done with them
     };
     std::vector<Group> grp(groups);
     HIP_TRY(ctx, ctx->aux_stream(groups));
+    // The host tail: the last fold pass of a sumcheck works on a table of 2^7 entries and fewer -- 128 products, and ~30 us as a
+    // device pass (launch, 15 us of kernel, the record's way back).  For a few sumchecks at a time (a latency chain, not a
+    // throughput problem) the pass before it leaves its folded table in pinned memory as well, and the host binds the remaining
+    // variables itself: exact field arithmetic, the same canonical sums.
+    constexpr uint32_t kMleTailLog2 = 7;
+    const bool tail_on = gkr::opt(gkr::OPT_host_tail_log2) >= 0 && n_dev == 0 &&
+                         batch <= (gkr::opt(gkr::OPT_host_tail_max_batch) > 0 ? gkr::opt(gkr::OPT_host_tail_max_batch) : 8);
+    Fr* h_tail = nullptr;
+    if (tail_on) HIP_TRY(ctx, ctx->pinned_host("mlep.tail", sizeof(Fr) * ((size_t)batch << kMleTailLog2), reinterpret_cast<void**>(&h_tail)));
     {
         int start = 0;
         for (int g = 0; g < groups; ++g) {
@@ -237,9 +247,13 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         G.ticket = ++ctx->ticket;
         const double bytes = (double)nb * ((double)src_len + (double)S) * 32.0;
         if (S <= gkr::kSmallPassEntries) {
+            // (the table it leaves is small enough for the host to finish, and there is a pass left to save)
+            const bool exports = tail_on && !G.chain && S <= ((size_t)1 << kMleTailLog2) && G.m - G.j > 0;
             Timed t(ctx, "mle_pass_small", bytes, st, true);
             gkr::launch_mle_multifold_small(jin, src, src_stride, dst, work_len, (uint32_t)S, (uint32_t)G.j, nb,
-                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, st);
+                                            h_w + (size_t)b0 * gkr::kMleMaxSub, rec + b0, G.ticket, st,
+                                            exports ? h_tail + ((size_t)b0 << kMleTailLog2) : nullptr, 1u << kMleTailLog2);
+            G.on_host = exports;
             return;
         }
         const uint32_t nblk = gkr::mle_multifold_blocks((uint32_t)S, (uint32_t)G.j, nb);
@@ -274,6 +288,33 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
         if (fused) return;
         Timed t(ctx, "mle_sub_reduce", 0.0, st, true);
         gkr::launch_mle_sub_reduce(part, nblk, (uint32_t)G.j, nb, rec + b0, G.ticket, st);
+    };
+    // the same pass on the host (the group's tables are in h_tail): T'[i] = sum_t w_t T[t S + i], then the sub-block sums of the
+    // next rounds into the record the device pass would have written
+    auto host_fold = [&](Group& G, int jin) {
+        using gkr::h64::F;
+        const size_t S = ((size_t)1 << G.m) >> jin;
+        G.m -= jin;
+        G.round0 += jin;
+        G.j = rounds_for(G.m);
+        G.ticket = ++ctx->ticket;
+        const size_t nsub = (size_t)1 << G.j, sub = S >> G.j;
+        for (int b = G.b0; b < G.b0 + G.nb; ++b) {
+            F* T = reinterpret_cast<F*>(h_tail + ((size_t)b << kMleTailLog2));
+            const F* w = reinterpret_cast<const F*>(h_w + (size_t)b * gkr::kMleMaxSub);
+            for (size_t i = 0; i < S; ++i) {
+                gkr::h64::Wide acc = gkr::h64::wide_zero();
+                for (size_t t = 0; t < ((size_t)1 << jin); ++t) gkr::h64::wide_mac(acc, T[t * S + i], w[t]);
+                T[i] = gkr::h64::wide_reduce(acc);
+            }
+            F* sums = reinterpret_cast<F*>(rec[b].sums);
+            for (size_t a = 0; a < nsub; ++a) {
+                F v = T[a * sub];
+                for (size_t i = 1; i < sub; ++i) v = gkr::h64::add(v, T[a * sub + i]);
+                sums[a] = v;
+            }
+            __atomic_store_n(&rec[b].seq, G.ticket, __ATOMIC_RELEASE);
+        }
     };
     // the J rounds of up to sixteen sumchecks whose sub-block sums have landed
     auto process_chunk = [&](const Group& G, int b_first, int count) {
@@ -399,7 +440,10 @@ int run_mle_batch_passes(gkr_ctx* ctx, const Fr* d_tables, int n, int batch, gkr
                 G.claim.store(0, std::memory_order_release);
                 if (G.m - G.j > 0) {
                     const bool first_fold = G.m == n;
-                    launch_fold(G, G.j);
+                    if (G.on_host)
+                        host_fold(G, G.j);
+                    else
+                        launch_fold(G, G.j);
                     G.state = 0;
                     if (first_fold && next_first < groups) launch_first(grp[next_first++]);
                 } else {

@@ -133,8 +133,10 @@ void launch_mle_multifold(int jin, const Fr* src, size_t src_stride, Fr* dst, si
 void launch_mle_pass_hash_lanes(const MleHostRecSub* rec, uint32_t count, uint32_t J, uint32_t round0, uint32_t n_out, bool final_pass,
                                 bool first_pass, const Fr* cts, uint32_t* dep_last, Fr* weights, Fr* out_coeffs, uint32_t* out_len, Fr* out_r,
                                 hipStream_t s);
+// tail (may be null; pinned host memory, tail_stride entries per sumcheck): the folded table (S <= tail_stride entries) is left there
+// too -- the host binds the remaining variables itself (capi_mle.hip, the host tail of a lone sumcheck).
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
-                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s);
+                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s, Fr* tail = nullptr, uint32_t tail_stride = 0);
 void launch_layer_round_reduce(const LayerPartial* partials, uint32_t nblk, LayerHostRec* host_rec, uint32_t ticket,
                                LayerBatch lb, hipStream_t s);
 void launch_fold_small(Fr* W, uint32_t hw, const FixedMul* rtab, LayerBatch lb, hipStream_t s);

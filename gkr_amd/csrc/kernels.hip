@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) k_mle_sums_small(const Fr* __restrict__ s
 __global__ void __launch_bounds__(1024) k_mle_multifold_small(const Fr* __restrict__ src, size_t src_stride, Fr* __restrict__ dst,
                                                               size_t dst_stride, uint32_t S, uint32_t jin, uint32_t jout,
                                                               const Fr* __restrict__ weights, MleHostRecSub* __restrict__ host_rec,
-                                                              uint32_t ticket) {
+                                                              uint32_t ticket, Fr* __restrict__ tail, uint32_t tail_stride) {
     __shared__ Fr s_w[kMleMaxSub];
     __shared__ Fr s_y[1024];       // partial sums [q][i], then (the first S) the outputs
     __shared__ Acc<9> s_part[kMleMaxSub];
@@ -486,7 +486,10 @@ __global__ void __launch_bounds__(1024) k_mle_multifold_small(const Fr* __restri
         for (uint32_t g = 0; g < groups; ++g) acc_add_fr(tot, s_y[g * S + threadIdx.x]);
         y = acc_reduce(tot);
         store_fr(d + threadIdx.x, y);
+        // (the host finishes the sumcheck from here: the folded table into pinned memory, released with the record below)
+        if (tail) store_fr(tail + (size_t)b * tail_stride + threadIdx.x, y);
     }
+    if (tail) __threadfence_system();
     __syncthreads();   // every partial has been read
     if (threadIdx.x < S) s_y[threadIdx.x] = y;
     __syncthreads();
@@ -2579,13 +2582,13 @@ uint32_t mle_multifold_blocks(uint32_t S, uint32_t jout, uint32_t batch) {
 }
 
 void launch_mle_multifold_small(int jin, const Fr* src, size_t src_stride, Fr* dst, size_t dst_stride, uint32_t S, uint32_t jout,
-                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s) {
+                                uint32_t batch, const Fr* weights, MleHostRecSub* host_rec, uint32_t ticket, hipStream_t s, Fr* tail, uint32_t tail_stride) {
     dim3 grid(batch);
     if (jin == 0)
         hipLaunchKernelGGL(k_mle_sums_small, grid, dim3(256), 0, s, src, src_stride, S, jout, host_rec, ticket);
     else
         hipLaunchKernelGGL(k_mle_multifold_small, grid, dim3(1024), 0, s, src, src_stride, dst, dst_stride, S, (uint32_t)jin, jout, weights,
-                           host_rec, ticket);
+                           host_rec, ticket, tail, tail_stride);
 }
 
 void launch_mle_round_reduce(const MlePartial* partials, uint32_t nblk, uint32_t batch, MleHostRec* host_rec,

@@ -347,6 +347,7 @@ def test_options_are_per_context():
         b.set_option("no_fused_publish", 1)
         c.set_option("mle_per_round", 1)
         c.set_option("line_stepwise", 1)
+        b.set_option("host_tail_log2", -1)             # (no host tail: the plain sumcheck's last fold pass and the layers' last product passes on the device)
         assert a.get_option("rounds_per_pass") == 0 and b.get_option("rounds_per_pass") == 2 and c.get_option("mle_per_round") == 1
         for ctx_ in (a, b, c, a):
             assert ctx_.prove_sumcheck(table, n) == want_mle
