@@ -770,9 +770,17 @@ __global__ void __launch_bounds__(1024) k_prod_publish(const Fr* __restrict__ pa
                    val = tid % (uint32_t)kProdRecValues;
     ProdPassRec* r = rec + blockIdx.x;
     if (q < Q) {
+        // (four partials requested before the first is added: a load per addition, each waiting for the one before, was ~0.5 us a
+        // term; eight at a time do not fit the 64 registers a block of 1024 threads leaves a lane)
         const Fr* p = partials + (size_t)blockIdx.x * blocks * kProdRecValues + val;
         Fr v = fr_zero();
-        for (uint32_t k = q; k < blocks; k += Q) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
+        uint32_t k = q;
+        for (; k + 3u * Q < blocks; k += 4u * Q) {
+            const Fr a = load_fr(p + (size_t)k * kProdRecValues), b = load_fr(p + (size_t)(k + Q) * kProdRecValues);
+            const Fr c = load_fr(p + (size_t)(k + 2u * Q) * kProdRecValues), d = load_fr(p + (size_t)(k + 3u * Q) * kProdRecValues);
+            v = fr_add(fr_add(v, a), fr_add(fr_add(b, c), d));
+        }
+        for (; k < blocks; k += Q) v = fr_add(v, load_fr(p + (size_t)k * kProdRecValues));
         s_q[q][val] = v;
     }
     __syncthreads();
