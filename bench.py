@@ -461,7 +461,7 @@ def run_mle(args, world):
     if args.proofs > 0:
         proofs = aggregated_proofs(world, args.proofs)
     layer24 = layer24_split = mle_split_out = wide20 = wide20_circom = wide_prove = None
-    split_hung = False
+    split_hung = split_failed = False
     if not args.no_extras and args.layer_k_i > 0:
         layer24 = layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=False, ceilings=ceilings)
         # a WIDE layer, the shape of a compiled R1CS's big layers (2^20 gates over 2^20 values; round 3 rejected it)
@@ -473,6 +473,8 @@ def run_mle(args, world):
             # (device exchange).  Under a watchdog: a rank stuck in a collective must not cost the whole line.
             def split_leg():
                 world.torch.cuda.set_device(world.local_rank)
+                if os.environ.get("GKR_BENCH_FAIL_SPLIT") == "1":     # (test hook: what a failing split leg does to the exit code)
+                    raise RuntimeError("GKR_BENCH_FAIL_SPLIT=1")
                 return layer_leg(world, args.layer_k_i, args.layer_k, steps=10, warmup=3, split=True, ceilings=ceilings)
             layer24_split, err, split_hung = guarded(split_leg, 180)
             if err:
@@ -518,14 +520,25 @@ def run_mle(args, world):
             line["cpu_baseline"] = cpu_dense(n, args.cpu_seconds)
             line["cpu_ref_algo"] = cpu_ref_algo(args.ref_algo_seconds)
             line["cpu_pipeline"] = cpu_pipeline()
-        line["exit"] = {"code": 4 if split_hung else (1 if (not verified_ok or ranks_failed) else 0),
-                        "why": ("a secondary leg's collective did not return (the headline above was timed and verified first)" if split_hung else
-                                ("WRONG RESULTS: an output of a timed step failed its check" if (not verified_ok or ranks_failed) else "ok"))}
+        # exit code: 1 = an output of a timed step failed its check; 4 = a split leg's collective did not return; 2 = a split leg
+        # (the only legs with a real N > 1 data path) raised -- the line is still emitted and says which
+        split_errors = {name: leg["error"] for name, leg in (("layer24_split", layer24_split), ("mle_split", mle_split_out))
+                        if isinstance(leg, dict) and "error" in leg}
+        wrong = not verified_ok or ranks_failed
+        code = 1 if wrong else (4 if split_hung else (2 if split_errors else 0))
+        why = ("WRONG RESULTS: an output of a timed step failed its check" if wrong else
+               "a split leg's collective did not return (the headline above was timed and verified first)" if split_hung else
+               "a split leg failed: " + "; ".join("%s: %s" % kv for kv in split_errors.items()) if split_errors else "ok")
+        line["exit"] = {"code": code, "why": why[:400]}
+        split_failed = bool(split_errors)
         emit(line)
     if split_hung:
         os._exit(4)    # a thread of this process sits in a collective that will not return: no orderly shutdown possible
     if not verified_ok or ranks_failed:
         raise SystemExit("WRONG RESULTS: the outputs of the timed steps failed their check (see \"verified\" / \"layer24\" / \"n16\")")
+    if world.rank == 0 and split_failed:
+        sys.stderr.write("bench.py: a split leg failed (see the line's `exit`)\n")
+        raise SystemExit(2)
 
 
 def aggregated_proofs(world, n_inputs):
@@ -1171,16 +1184,120 @@ def cpu_pipeline():
 
 
 _REAL_STDOUT = None
+DETAIL_PATH = os.environ.get("GKR_BENCH_DETAIL", os.path.join(REPO, "bench_detail.json"))
+LINE_LIMIT = 6000   # bytes of the ONE stdout line (a 20 KB line was not parsed by the driver)
+
+_CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config")
+_ROOFLINE = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
+             "launches", "copy_GBps_measured", "frac_of_copy", "traffic_source")
+_CPU = ("value", "unit", "cores", "kind", "sample")
+
+
+def _short(v, limit=200):
+    """A scalar as it goes on the stdout line: floats to 6 significant digits, strings cut to `limit` characters."""
+    if isinstance(v, float):
+        return float("%.9g" % v)
+    if isinstance(v, str) and len(v) > limit:
+        return v[:limit - 3] + "..."
+    return v
+
+
+def _leg(v):
+    """One secondary leg as {ms, ok, ...}: its step time, whether its outputs passed their check, its roofline fraction."""
+    out = {}
+    for k in ("ms_per_step", "ms", "ms_per_proof"):
+        if isinstance(v.get(k), (int, float)):
+            out["ms"] = _short(float(v[k]))
+            break
+    ok = v.get("matches_golden_digest", v.get("whole_batch_digest"))
+    ver = v.get("verified")
+    if ok is None and isinstance(ver, dict):
+        ok = ver.get("ok")
+    if "error" in v:
+        ok, out["error"] = False, _short(str(v["error"]), 160)
+    out["ok"] = ok
+    for k in ("value", "proofs_per_sec", "compile_ms"):
+        if isinstance(v.get(k), (int, float)):
+            out[k] = _short(float(v[k]))
+    if isinstance(v.get("unit"), str) and "value" in out:
+        out["unit"] = v["unit"]
+    r = v.get("roofline")
+    if isinstance(r, dict) and isinstance(r.get("frac"), (int, float)):
+        out["roofline_frac"] = _short(float(r["frac"]))
+        out["bound"] = "host-hash" if str(r.get("bound")).startswith("host transcript") else _short(str(r.get("bound")), 24)
+    return out
+
+
+def compact_line(full):
+    """The stdout line: the contract's keys, `roofline` and `cpu_baseline` with scalar fields only, `verified.ok`, and a flat
+    `legs` summary {name: {ms, ok, ...}} of everything else; the whole of `full` goes to bench_detail.json and stderr."""
+    line = {k: full[k] for k in _CONTRACT if k in full}
+    if isinstance(line.get("dtype"), str):
+        line["dtype"] = line["dtype"].split(" ")[0]
+    line = {k: (_short(v) if not isinstance(v, dict) else {a: _short(b, 160) for a, b in v.items() if not isinstance(b, (dict, list))})
+            for k, v in line.items()}
+    if isinstance(full.get("roofline"), dict):
+        line["roofline"] = {k: _short(full["roofline"].get(k), 120) for k in _ROOFLINE if k in full["roofline"]}
+        line["roofline"].setdefault("traffic", None)
+    if isinstance(full.get("cpu_baseline"), dict):
+        line["cpu_baseline"] = {k: _short(full["cpu_baseline"].get(k), 160) for k in _CPU}
+    ver = full.get("verified")
+    if isinstance(ver, dict):
+        line["verified"] = {k: ver[k] for k in ("ok", "all_ranks_ok", "tables_matching_their_digest", "whole_batch_digest") if k in ver}
+    elif "matches_golden_digest" in full:
+        line["verified"] = {"ok": full["matches_golden_digest"] is not False and full.get("all_ranks_match") is not False}
+    legs = {}
+    for name, v in full.items():
+        if name in line or not isinstance(v, dict) or name in ("exit", "host_threads", "host_transcript", "kernel_ms", "collective",
+                                                               "kernel_ms_per_step", "exchange", "memory", "product_pass_roofline"):
+            continue
+        if name == "aggregated_proofs":
+            for sub, sv in v.items():
+                if isinstance(sv, dict) and ("ms" in sv or "error" in sv):
+                    legs[{"config0_three_inputs": "config0", "config3": "config3"}.get(sub, sub)] = _leg(sv)
+        else:
+            legs[name] = _leg(v)
+    if legs:
+        line["legs"] = legs
+    for k in ("exchange", "collective"):
+        if isinstance(full.get(k), dict):
+            line[k] = {a: _short(b, 80) for a, b in full[k].items() if not isinstance(b, (dict, list))}
+    if "exit" in full:
+        line["exit"] = full["exit"]
+    line["detail"] = os.path.basename(DETAIL_PATH)
+    for drop in ("collective", "exchange", "legs"):       # (never reached with today's legs: ~3 KB)
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def emit_raw(obj):
+    """A child leg's result for its parent (bench.py --mode multi-device): the whole object on stdout, no detail file."""
+    data = (json.dumps(obj) + "\n").encode()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, data)
 
 
 def emit(obj):
-    """The ONE JSON line of the contract, on the process's real stdout (see main)."""
-    data = (json.dumps(obj) + "\n").encode()
+    """The ONE JSON line of the contract, on the process's real stdout (see main): at most LINE_LIMIT bytes.  Every other
+    figure of the run goes to bench_detail.json beside this file (GKR_BENCH_DETAIL overrides the path) and to stderr."""
+    full = json.dumps(obj, indent=1)
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s (%s)\n" % (DETAIL_PATH, e))
+    sys.stderr.write("bench.py detail (also in %s): %s\n" % (DETAIL_PATH, json.dumps(obj)))
+    sys.stderr.flush()
+    data = (json.dumps(compact_line(obj)) + "\n").encode()
+    assert len(data) < LINE_LIMIT, len(data)
     if _REAL_STDOUT is None:
         sys.stdout.write(data.decode())
         sys.stdout.flush()
     else:
-        os.write(_REAL_STDOUT, data)
+        while data:                      # (a pipe may take the line in pieces)
+            data = data[os.write(_REAL_STDOUT, data):]
 
 
 def visible_devices():
@@ -1245,12 +1362,13 @@ def launch_ranks(n):
     if rc == 0 and lines != 1:
         sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
         return 5
-    if rc != 0 and lines == 1 and relayed_exit == 4 and os.environ.get("GKR_BENCH_STRICT_EXIT") != "1":
-        # The line is out and says what happened (`exit`): the headline was timed and verified on every rank, then a SECONDARY leg
-        # (layer24_split / mle_split: their first real multi-device collective) did not come back and the ranks left through
-        # os._exit(4) -- the launcher reports failure, the line does not deserve it.  Wrong results (exit code 1) stay fatal.
-        sys.stderr.write("bench.py: a secondary leg hung after the verified headline (see the line's `exit`); exit code 0\n")
+    if rc != 0 and lines == 1 and relayed_exit in (2, 4) and os.environ.get("GKR_BENCH_LENIENT_EXIT") == "1":
+        # Opt-in only: the line is out and says what happened (`exit`), a split leg failed (2) or hung (4) after the verified
+        # headline.  By default that IS the run's exit code: a broken RCCL path must go red on the first multi-GPU box.
+        sys.stderr.write("bench.py: a split leg failed after the verified headline (see the line's `exit`); GKR_BENCH_LENIENT_EXIT=1: exit code 0\n")
         return 0
+    if rc == 0 and relayed_exit not in (None, 0):
+        return int(relayed_exit)
     return rc
 
 
@@ -1284,7 +1402,7 @@ def main():
     ap.add_argument("--ref-algo-seconds", type=float, default=20.0)
     args = ap.parse_args()
     if args.mode == "multi-device":   # (the default line's multi_device leg, run as its child)
-        emit(multi_device_leg(args.proofs))
+        emit_raw(multi_device_leg(args.proofs))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))

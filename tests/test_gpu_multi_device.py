@@ -83,12 +83,8 @@ def test_the_callers_current_device_survives_every_call():
                 assert np.array_equal(a, b)
 
 
-# The two tests below have NEVER run: no builder's box had a second GPU.  Where one is visible they run and report (x = failed,
-# X = passed) without being able to turn the suite red -- a first contact with hardware is a measurement, not yet a gate.
-FIRST_CONTACT = pytest.mark.xfail(strict=False, reason="first contact with a second device: these cases have never run on hardware")
-
-
-@FIRST_CONTACT
+# The two tests below need a second GPU (no builder's box had one): they skip where there is none and FAIL like any other test
+# where there is one -- a broken RCCL or multi-device path must turn the first multi-GPU run red.
 @pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
 def test_native_rccl_exchange_with_two_ranks_on_two_devices(tmp_path):
     """gkr_exchange_rccl_create with nranks = 2, a process per GPU, the id handed over in a file: the gate-sharded layer
@@ -108,7 +104,6 @@ def test_native_rccl_exchange_with_two_ranks_on_two_devices(tmp_path):
         assert k.returncode == 0 and ("OK rank %d" % r) in so, so[-2000:] + se[-3000:]
 
 
-@FIRST_CONTACT
 @pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
 def test_prove_many_over_two_devices_matches_one_device():
     """gkr_ctx_create_multi([0, 1]): the items of one gkr_prove_many call dealt over child contexts on BOTH devices (pinned
