@@ -297,6 +297,26 @@ def verify_mle_outputs(ctx, tables, n, batch, out, rank, sample=32, evaluations=
     return res, bool(ok)
 
 
+def native_verify_all(circuits, outs, threads=None):
+    """gkr_verify (the library's C++ verifier: python/gkr.py:202-231 + python/sumcheck.py:55-70 on the gkr_proof_buf) on EVERY
+    proof of a timed step: outs[j] = the nine output arrays of circuit j (first axis = proof).  Small proofs are spread over a
+    thread pool (ctypes releases the GIL), each verified single-threaded; a lone wide proof gets all the threads itself.
+    -> {"proofs", "accepted", "rejected": [(circuit, proof, layer, check)], "ms"}"""
+    from concurrent.futures import ThreadPoolExecutor
+    from gkr_amd.dropin import verify_native
+    threads = threads or max(1, usable_cpus() - 1)
+    jobs = [(j, b) for j, arrs in enumerate(outs) for b in range(arrs[0].shape[0])]
+    t0 = time.perf_counter()
+    if len(jobs) <= 2:
+        res = [verify_native(circuits[j], outs[j], index=b, threads=threads) for j, b in jobs]
+    else:
+        with ThreadPoolExecutor(threads) as pool:
+            res = list(pool.map(lambda jb: verify_native(circuits[jb[0]], outs[jb[0]], index=jb[1], threads=1), jobs))
+    bad = [(j, b, r[1], r[2]) for (j, b), r in zip(jobs, res) if not r[0]]
+    return {"verifier": "gkr_verify (csrc/dropin.cpp) on every proof of the last timed step", "proofs": len(jobs), "accepted": len(jobs) - len(bad),
+            "rejected": bad[:8], "ms": round((time.perf_counter() - t0) * 1e3, 2), "ok": not bad}
+
+
 # ------------------------------------------------------------------------------------------------ mode: mle
 
 def run_mle(args, world):
@@ -604,8 +624,9 @@ def aggregated_proofs(world, n_inputs):
                     verified += 1
                     if not verify(pr, circuit):
                         bad.append((i, j, "verifier"))
+        native = native_verify_all(step.circuits, step._prepared["outs"])
         res.update({"proofs": total, "digests": "tests/golden/proof_digests.json[%s]" % tag if golden_rows is not None else None,
-                    "mismatches": bad[:8], "verifier_accepts": verified, "ok": not bad})
+                    "mismatches": bad[:8], "python_verifier_accepts": verified, "gkr_verify": native, "ok": not bad and native["ok"]})
         return res
     golden = synth.proof_digests() if not os.environ.get("GKR_BENCH_NO_VERIFY") else None
     ver0 = check(golden["config0"]["digests"] if golden else None, "config0", sample=3) if world.rank == 0 and not os.environ.get("GKR_BENCH_NO_VERIFY") else None
@@ -693,12 +714,16 @@ def aggregated_proofs(world, n_inputs):
             bad_big = [j for j, (arrs, ks) in enumerate(zip(big._prepared["outs"], ks_big))
                        if j >= len(gold["digests"]) or ks != gold["k"][j] or synth.proof_arrays_digest(ks, *[a[0] for a in arrs[:7]]) != gold["digests"][j]
                        or (coeff_gold and synth.proof_coeffs_digest(arrs[7][0], arrs[8][0]) != coeff_gold[j])]
+        big_native = native_verify_all(big.circuits, big._prepared["outs"]) if not os.environ.get("GKR_BENCH_NO_VERIFY") else None
+        if big_native is not None and not big_native["ok"]:
+            bad_big = (bad_big or []) + ["gkr_verify"]
         big_bad_ranks = world.max_over_ranks(1.0 if bad_big else 0.0)
         out["large_r1cs"] = {"constraints": 4 * nrounds, "sub_circuits": len(big.circuits), "k_lists": ks_big, "inputs": 1,
                              "compile_ms": big_compile_ms, "ms": dt_big * 1e3, "ms_each": [round(x, 3) for x in each_big],
                              "proofs_per_sec": len(big.circuits) / dt_big, "constraints_per_sec": 4 * nrounds / dt_big,
                              "verified": None if bad_big is None else {"digests": "tests/golden/large_r1cs_digests.json (compile and proofs by the CPU checker; d and input_func %s)" % ("included" if gold.get("coeff_digests") else "not covered"),
-                                                                        "proofs": len(big.circuits), "mismatches": bad_big, "ok": not bad_big, "all_ranks_ok": big_bad_ranks == 0.0}}
+                                                                        "proofs": len(big.circuits), "mismatches": bad_big, "ok": not bad_big, "all_ranks_ok": big_bad_ranks == 0.0,
+                                                                        "gkr_verify": big_native}}
         if bad_big or big_bad_ranks:
             out["verified_ok"] = False
         big.close()
@@ -722,15 +747,25 @@ def multi_device_leg(n_inputs):
     step = ProvingStep(synth.mimc7_demo_r1cs())
     subs = len(step.circuits)
     inputs = step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(a, b)) for a, b in synth.demo_proof_inputs(n_inputs)]))
-    with Context(devices=devs) as mctx:
-        for _ in range(4):
+    # The same step through a plain context on devs[0] and through the multi-device context, ALTERNATING in this one process (a
+    # fresh process proves ~5 % slower than the long-running one of the default line whatever the path -- same-box A/B
+    # profiles/r06/a_multi_device_ab.txt -- so the comparison that says what gkr_ctx_create_multi costs is made here).
+    direct_step = ProvingStep(synth.mimc7_demo_r1cs())
+    direct_inputs = direct_step.inputs_for(np.stack([as_limbs(synth.mimc7_demo_witness(a, b)) for a, b in synth.demo_proof_inputs(n_inputs)]))
+    with Context(devs[0]) as one, Context(devices=devs) as mctx:
+        for _ in range(6):
+            direct_step.prove_raw_many(one, direct_inputs, 0)
             step.prove_raw_many(mctx, inputs, 0)
-        each = []
-        for _ in range(5):
+        each, each_direct = [], []
+        for _ in range(8):
+            t = time.perf_counter()
+            direct_step.prove_raw_many(one, direct_inputs, 0)
+            each_direct.append(round((time.perf_counter() - t) * 1e3, 3))
             t = time.perf_counter()
             step.prove_raw_many(mctx, inputs, 0)
             each.append(round((time.perf_counter() - t) * 1e3, 3))
         seen = mctx.device_count()
+    direct_step.close()
     golden = synth.proof_digests()
     rows = golden["config3"]["digests"] if golden and golden["config3"]["inputs"] == n_inputs else None
     bad = total = 0
@@ -745,6 +780,8 @@ def multi_device_leg(n_inputs):
                    "on every listed device (the reference: one process whose par_iter fans prover::prove out, aggregator.rs:350-355)" % (devs, subs),
             "devices_seen": seen, "device_ids": devs, "inputs": n_inputs, "proofs": n_inputs * subs, "ms": dt * 1e3,
             "proofs_per_sec": n_inputs * subs / dt, "ms_each": each,
+            "direct_ms_same_process": statistics.median(each_direct), "direct_ms_each": each_direct,
+            "ms_over_direct": dt * 1e3 / statistics.median(each_direct),
             "verified": {"proofs": total, "digests": "tests/golden/proof_digests.json[config3]" if rows is not None else None, "mismatches": bad, "ok": bad == 0}}
 
 
@@ -994,10 +1031,12 @@ def wide_prove_leg(world, ks=(18, 20, 20), reps=5):
     dt = world.max_over_ranks(statistics.median(each) / 1e3)
     if world.rank != 0:
         return None
-    return {"workload": "gkr_prove of a circuit with k = %s (gates per layer 2^%d, 2^%d; input layer 2^%d values), one witness" % (list(ks), ks[0], ks[1], ks[-1]),
+    native = native_verify_all([circuit], [arrs]) if not os.environ.get("GKR_BENCH_NO_VERIFY") else None
+    return {"verified_by_gkr_verify": native,
+            "workload": "gkr_prove of a circuit with k = %s (gates per layer 2^%d, 2^%d; input layer 2^%d values), one witness" % (list(ks), ks[0], ks[1], ks[-1]),
             "ms_per_proof": dt * 1e3, "ms_each": [round(x, 3) for x in each], "first_call_ms": first * 1e3,
             "first_call": "gate arrays uploaded, gate lists sorted, workspaces and proof buffers allocated",
-            "matches_golden_digest": None if want is None else (digest == want and (want_coeffs is None or coeff_digest == want_coeffs)),
+            "matches_golden_digest": None if want is None else (digest == want and (want_coeffs is None or coeff_digest == want_coeffs) and (native is None or native["ok"])),
             "proof_sha256": digest, "d_and_input_func_sha256": coeff_digest,
             "digest_covers": "sumcheck_proofs, lengths, sumcheck_r, q, q lengths, z, r" + ("; d and input_func by their own digest" if want_coeffs else "; d and input_func NOT covered (no golden digest)"),
             "outputs_bytes": int(sum(a.nbytes for a in arrs))}
@@ -1217,7 +1256,7 @@ def _leg(v):
     if "error" in v:
         ok, out["error"] = False, _short(str(v["error"]), 160)
     out["ok"] = ok
-    for k in ("value", "proofs_per_sec", "compile_ms"):
+    for k in ("value", "proofs_per_sec", "compile_ms", "direct_ms_same_process", "ms_over_direct"):
         if isinstance(v.get(k), (int, float)):
             out[k] = _short(float(v[k]))
     if isinstance(v.get("unit"), str) and "value" in out:

@@ -134,12 +134,29 @@ int gkr_ctx_set_option(gkr_ctx* ctx, const char* name, long long value) {
     if (ctx->options.v[i] == value) return GKR_OK;
     // Cached per-circuit state (gate lists, segment layout) was built under the old value: dropped, rebuilt on next use.
     // Resident layers (gkr_resident_layer_create) keep the layout they were created with: set options before creating them.
-    if (hipSetDevice(ctx->device) == hipSuccess) {
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-        for (auto& c : ctx->circuits) c->release();
-        ctx->circuits.clear();
-    }
+    // gkr_prove_many's child contexts (idle between calls: crew_member stays set on them, their threads wait for the next call)
+    // hold PreparedCircuits built under the old value as well, and prove with the options of this context: theirs go too,
+    // each on its own device (only the calling context's cache was dropped -- a changed gate_segment_log2 then met
+    // cached segment lists of the old shift).
+    int prev_device = -1;
+    if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
+    auto drop_cache = [](gkr_ctx* c) {
+        if (hipSetDevice(c->device) != hipSuccess) return;
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->aux) (void)hipStreamSynchronize(c->aux);
+        for (auto& pc : c->circuits) pc->release();
+        c->circuits.clear();
+    };
+    drop_cache(ctx);
     ctx->options.v[i] = value;
+    if (ctx->crew)
+        for (size_t m = 1; m < ctx->crew->members.size(); ++m) {
+            gkr_ctx* child = ctx->crew->members[m]->ctx;
+            if (!child) continue;
+            drop_cache(child);
+            child->options = ctx->options;
+        }
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
     return GKR_OK;
 }
 

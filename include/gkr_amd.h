@@ -466,6 +466,54 @@ typedef struct {
 } gkr_prove_item;
 int  gkr_prove_many(gkr_ctx *ctx, gkr_prove_item *items, size_t n_items, int max_concurrent);
 
+/* ---- the reference's own argument types at `prove` (host only) ----------------------------------------------------
+ * prover::prove(&GKRCircuit<S>, &Input<S>) (prover.rs:6-9) does not receive gate arrays and evaluation tables: a Layer
+ * holds its wiring as `wire: (Vec<Vec<S>>, Vec<Vec<S>>)` (gkr.rs:35-51) -- per add gate and per mult gate one vector of
+ * k_i + 2 k_next field elements 0 / 1, the bits of `gate || left || right`, most significant first (convert.rs:715-767,
+ * convert_binary_to_vec) -- and Input.w[i] (gkr.rs:21-33) is layer i's multilinear extension as a TERM LIST: rows
+ * [coeff, e_1 .. e_k] with exponents 0 / 1 (get_multi_ext, poly.rs:502-536; non-zero coefficients only, any order).
+ * These three turn the one form into the other, so a binding can sit at `prove` itself without touching convert.rs
+ * (INTEGRATION.md writes it out; tests/capi_dropin.c drives it from C):
+ *   gkr_layer_from_wires   add_wire: n_add rows, mult_wire: n_mult rows of (k_i + 2 k_next) elements -> gate_type / left /
+ *                          right of 2^k_i entries.  n_add + n_mult must be 2^k_i and every gate index appear once (every
+ *                          slot of a compiled layer is a gate, convert.rs:209-214); an entry that is neither 0 nor 1, a gate
+ *                          named twice or a count that does not fill the layer -> GKR_ERR_INVALID.
+ *   gkr_values_from_terms  n_terms rows of (1 + k) elements -> the 2^k evaluations over the hypercube (index = the bit
+ *                          string, variable 1 most significant): the inverse of get_multi_ext.  Equal monomials add up
+ *                          (add_poly); an exponent other than 0 / 1 -> GKR_ERR_INVALID; n_terms = 0 gives the zero table.
+ *   gkr_terms_from_coeffs  a table of 2^k monomial coefficients (gkr_proof_buf.d_coeffs / input_coeffs) -> the term list
+ *                          Proof.d / Proof.input_func holds: the non-zero coefficients, ascending monomial index, rows of
+ *                          (1 + k) elements.  *n_terms = how many there are; out_terms == NULL only counts;
+ *                          GKR_ERR_NOMEM if capacity_terms is too small. */
+int  gkr_layer_from_wires(int k_i, int k_next, const gkr_fr *add_wire, size_t n_add, const gkr_fr *mult_wire, size_t n_mult,
+                          uint8_t *gate_type, uint32_t *left, uint32_t *right);
+int  gkr_values_from_terms(int k, const gkr_fr *terms, size_t n_terms, gkr_fr *out_values);
+int  gkr_terms_from_coeffs(int k, const gkr_fr *coeffs, gkr_fr *out_terms, size_t capacity_terms, size_t *n_terms);
+
+/* ---- verifier (host only, no device) ------------------------------------------------------------------------------
+ * The relations the reference's verifier checks (python/gkr.py:202-231 with python/sumcheck.py:55-70; verifier.circom:39-71
+ * holds the same inside a circuit) on the Rust prover's Proof, which carries no `f` / `add` / `mult` fields: per layer
+ * every round's g_j(0) + g_j(1) = the running claim and r_j = multi_hash(g_j); the last claim =
+ * add_i(z, b*, c*) (q(0) + q(1)) + mult_i(z, b*, c*) q(0) q(1) with the wiring predicates summed over the circuit's gates
+ * (eq tables, O(gates) products on `threads` host threads; 0 = the CPUs this process may use); r* = multi_hash of the last
+ * round vector; z[i+1] = l(r*); finally q(r*) of the last layer = input_func(z[L]).  z[0] must be zero (prover.rs:16-21).
+ * *accept = 1 / 0; on a rejection *failed_layer / *failed_check (either may be NULL) name the first relation that failed.
+ * The return value is a status of the CALL (GKR_ERR_INVALID: null pointers, a gate operand out of range), not the verdict. */
+enum {
+    GKR_VERIFY_OK = 0,
+    GKR_VERIFY_SHAPE = 1,          /* a round vector / q length outside its range */
+    GKR_VERIFY_NON_CANONICAL = 2,  /* a proof element >= r */
+    GKR_VERIFY_Z0 = 3,             /* z[0] is not the zero vector */
+    GKR_VERIFY_ROUND_SUM = 4,      /* g_j(0) + g_j(1) != claim */
+    GKR_VERIFY_CHALLENGE = 5,      /* r_j != multi_hash(g_j) */
+    GKR_VERIFY_FINAL_CLAIM = 6,    /* g_v(r_v) != add (q0 + q1) + mult q0 q1 */
+    GKR_VERIFY_R_STAR = 7,         /* r* != multi_hash(last round vector) */
+    GKR_VERIFY_NEXT_Z = 8,         /* z[i+1] != b* + r* (c* - b*) */
+    GKR_VERIFY_INPUT = 9           /* q(r*) of the last layer != input_func(z[L]) */
+};
+int  gkr_verify(const gkr_circuit_desc *circuit, const gkr_proof_buf *proof, int threads, int *accept, uint32_t *failed_layer,
+                uint32_t *failed_check);
+
 /* ---- the proof as input signals of verifier.circom (host only) -----------
  * What the reference does with a Proof right after the path: pad its ragged vectors to the dimensions of
  * the generated verifier component (get_meta aggregator.rs:92-146, modify_proof_for_circom :148-213), print

@@ -129,3 +129,23 @@ def test_sixteen_sub_circuit_step_in_groups_matches_the_committed_digests():
         for threads in (0, 4):
             _assert_same(ctx.prove_many_raw(ctx.prepare_many(work), threads), want, ("r1cs", threads))
     step.close()
+
+
+def test_option_changes_between_calls_reach_the_child_contexts_caches():
+    """gkr_prove_many keeps child contexts (one per thread) with their own circuit caches between calls.  An option that
+    changes the layout of cached gate lists -- gate_groups_min_k decides which layers get the wide-layer item plan,
+    gate_segment_log2 / gate_segments_min_log2 the segment form's shift -- set on the PARENT between two calls must drop the
+    children's caches too (only the caller's was dropped; the children then proved with lists of the old layout)."""
+    rng = np.random.default_rng(4321)
+    work = []
+    for j, ks in enumerate([[9, 13, 14], [9, 13, 14], [10, 15], [8, 12, 12], [8, 12, 12]]):
+        c, _ = _circuit(ks, 700 + j, circom_like=(j % 2 == 1))
+        work.append((c, np.ascontiguousarray(synth.rand_fr(rng, 1 << ks[-1]).reshape(1, 1 << ks[-1], 4))))
+    with Context(0) as ctx:
+        want = _one_by_one(ctx, work)
+        ctx.set_option("prove_many_lockstep", 0)           # one chain per item: every child context caches circuits of its own
+        _assert_same(ctx.prove_many_raw(ctx.prepare_many(work), 4), want, "defaults")
+        for name, value in (("gate_groups_min_k", 12), ("gate_groups_min_k", 16), ("gate_segments_min_log2", 8),
+                            ("gate_segment_log2", 2), ("gate_segments_off", 1)):
+            ctx.set_option(name, value)
+            _assert_same(ctx.prove_many_raw(ctx.prepare_many(work), 4), want, (name, value))
