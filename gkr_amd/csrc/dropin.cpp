@@ -24,6 +24,7 @@
 
 #include "../../include/gkr_amd.h"
 #include "fr64.h"
+#include "host_cpus.h"
 
 namespace {
 
@@ -75,19 +76,8 @@ void parallel_for(size_t n, int threads, size_t min_chunk, Fn fn) {
 }
 
 int default_threads() {
-    unsigned n = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {      // a container's CPU quota (the GPU box: 16 of 256)
-        char q[32];
-        double period = 0;
-        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-            const double quota = atof(q) / period;
-            if (quota >= 1 && quota < n) n = (unsigned)quota;
-        }
-        fclose(f);
-    }
-    return n < 1 ? 1 : (n > 64 ? 64 : (int)n);
+    const int n = gkr::usable_cpus();
+    return n > 64 ? 64 : n;
 }
 
 // eq(point, .) over 2^k indices, variable 1 = most significant index bit; point and table in Montgomery form

@@ -132,6 +132,7 @@ struct OptionScope {
 //   GKR_HOST_PASS_SCALAR  the plain sumcheck's host pass on the scalar code (A/B against the IFMA lanes)
 //   GKR_NO_HELP        contexts proving side by side do not share their host work
 //   GKR_HOST_THREADS   host threads a context's transcript may use (gkr_ctx_set_host_threads overrides per context)
+//   GKR_COMPILE_THREADS  threads of gkr_r1cs_compile (0 / unset: the CPUs this process may use, at most 32)
 //   LOCAL_WORLD_SIZE   ranks sharing this host's CPUs (set by torch.distributed.run)
 inline bool process_switch(const char* env) { return getenv(env) != nullptr; }
 inline int process_int(const char* env, int def) {

@@ -39,6 +39,18 @@ def test_worker_pool_under_thread_sanitizer():
         assert out.returncode == 0 and "bad=0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
 
 
+def test_r1cs_compiler_parallel_stages_under_thread_sanitizer():
+    """`make tsan_r1cs`: gkr_r1cs_compile's parallel tree building (sharded arena) and group compilation under
+    -fsanitize=thread, 1 / 3 / 8 / 2 threads on one R1CS -- identical circuits every time, no race report
+    (tests/r1cs_compile_race.cpp)."""
+    build = subprocess.run(["make", "-C", os.path.join(REPO, "gkr_amd", "csrc"), "tsan_r1cs"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + build.stderr[-200:])
+    exe = os.path.join(REPO, "gkr_amd", "build_san", "r1cs_compile_race_tsan")
+    out = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0 and "bad=0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr[-3000:]
+
+
 def test_first_use_of_the_transcript_tables_under_thread_sanitizer():
     """tests/build_host_tsan.sh builds the library's whole host side with -fsanitize=thread (libgkr_tsan.so) and
     tests/first_use_race.cpp: 32 threads make the FIRST call into the MiMC7 constant tables and the IFMA initialisation

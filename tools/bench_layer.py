@@ -87,7 +87,9 @@ def main():
     out["transcript_sha256"] = synth.transcript_digest(C, L, R)
     out["matches_golden_digest"] = None if want is None else (out["transcript_sha256"] == want)
     ctx.close()
-    if not out["verifier_relations_ok"] or out["matches_golden_digest"] is False:
+    if os.environ.get("GKR_EXPERIMENT_WRONG_RESULTS_OK") == "1":    # (a variant library built to time a kernel with a piece removed)
+        out["EXPERIMENT"] = "results not checked: timing of a deliberately broken variant"
+    elif not out["verifier_relations_ok"] or out["matches_golden_digest"] is False:
         raise SystemExit("WRONG TRANSCRIPT (relations ok: %s, golden digest match: %s) -- no timing reported"
                          % (out["verifier_relations_ok"], out["matches_golden_digest"]))
     print(json.dumps(out))
