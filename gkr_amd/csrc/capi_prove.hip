@@ -477,13 +477,22 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
     // 4.6 ms proof, 0.6 ms at the head of a seven-circuit group's chain.)
     HIP_TRY(ctx, ctx->aux_stream(1));
     hipStream_t side = ctx->aux;
+    // The side stream's copies below land in locals of this call (h_in_flag, hW_big) and in the caller's buffers: whatever path
+    // leaves the call -- the HIP_TRY / WS early returns included -- waits for the stream first.  Declared after those locals'
+    // storage, so it runs before they go.
+    std::vector<F> hW_big[2];
+    struct SideDrain {
+        hipStream_t st;
+        ~SideDrain() {
+            if (st) (void)hipStreamSynchronize(st);
+        }
+    } side_drain{side};
     HIP_TRY(ctx, hipEventRecord(ctx->aux_events[0], s));
     HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->aux_events[0], 0));
     if (check_on_device) HIP_TRY(ctx, hipMemcpyAsync(&h_in_flag, d_in_flag, 4, hipMemcpyDeviceToHost, side));
     // the host needs the outputs and the inputs (d, input_func); the layers in between stay on the device
     const F* hW[2] = {nullptr, nullptr};   // [0]: W_0, [1]: W_L
     const F* hW0_first = nullptr;           // or only output 0 of every proof
-    std::vector<F> hW_big[2];
     // d and input_func are the monomial forms of W_0 and W_L (get_multi_ext, poly.rs:502-536): tables beyond 2^12 values are
     // transformed on the device (k launches over a grid) and land in the proof buffers directly; small ones on the host
     constexpr uint32_t kDeviceMobiusMinK = 13;
@@ -529,7 +538,9 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
         copier.side = side;
         copier.started = true;
         CoeffCopier* cp = &copier;
+        const gkr::Options* const call_options = &ctx->options;
         ctx->copier->run([=]() {
+            gkr::OptionScope option_scope(call_options);
             hipError_t e = hipSetDevice(device);   // (the transforms are queued on the side stream already: stream order)
             for (int which = 0; which < 2 && e == hipSuccess; ++which) {
                 if (!coeff_src[which]) continue;
@@ -629,7 +640,9 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
             const Fr* Wn = dW[i + 1];
             const uint32_t ub = (uint32_t)batch, uk = (uint32_t)k;
             hipStream_t aux = ctx->aux;
+            const gkr::Options* const call_options = &ctx->options;
             ctx->liner->run([=]() {
+                gkr::OptionScope option_scope(call_options);   // (the helper thread proves with the context's options, not the process defaults)
                 if (hipSetDevice(device) != hipSuccess) return;
                 gkr::launch_line_restriction(Wn, uk, nullptr, d_lr, d_lrdeg, nullptr, nullptr, nullptr, ub, aux, gkr::LinePart::prepare);
             });
@@ -664,7 +677,9 @@ static int prove_group_impl(gkr_ctx* ctx, const gkr_prove_item* members, int n_m
                 liner.started = true;
                 const int device = ctx->device;
                 const uint32_t ub = (uint32_t)batch, uk = (uint32_t)k;
+                const gkr::Options* const call_options = &ctx->options;
                 ctx->liner->run([=]() {
+                    gkr::OptionScope option_scope(call_options);
                     if (hipSetDevice(device) != hipSuccess) return;
                     gkr::launch_line_restriction(Wn, uk, reinterpret_cast<const Fr*>(lines), d_lr, d_lrdeg, bcm, qdst, qlen_dst, ub, aux,
                                                  line_prepared ? gkr::LinePart::finish : gkr::LinePart::all);

@@ -1,6 +1,6 @@
 # SQ counters of the segment gate passes (k_seg_pass<uv>, <rows>, k_seg_combine) on the GPU box, one rocprofv3 --pmc pass per
 # counter group, per-launch means:  bash tools/pmc_gate_passes.sh > gpurun_out/seg_pass_pmc_counters.txt
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY"; do
   D=/tmp/pmc_$(echo $G | tr ' ' '_' | cut -c1-40)

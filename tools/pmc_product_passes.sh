@@ -4,7 +4,7 @@
 #   bash tools/pmc_product_passes.sh 20,20 > gpurun_out/product_pass_pmc_20_20.txt
 # FETCH_SIZE / WRITE_SIZE: KiB, FETCH_SIZE doubled for the gfx950 wide-read under-count, as MI355X_MICROARCH.md's HBM section
 # prescribes (printed raw and converted).
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SHAPE=${1:-20,20}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pst

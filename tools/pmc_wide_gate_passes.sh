@@ -1,7 +1,7 @@
 # Counters of the wide layers' gate passes (k_items_pass<uv>, <rows> and their combine steps; kernels_wide.hip) on the GPU box: one rocprofv3 --pmc pass
 # per counter group over tools/bench_wide.py at the given shape, per-launch means, with the kernel's average duration from a
 # separate --kernel-trace --stats run:   bash tools/pmc_wide_gate_passes.sh 24,18 > gpurun_out/wide_gate_pass_pmc_24_18.txt
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SHAPE=${1:-24,18}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/wst

@@ -6,7 +6,7 @@ OUT=gpurun_out/${1:-r2x}
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $OUT/gpu_tests.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-verify --proofs 0 > /tmp/stats_bench.json 2>/dev/null
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) $R/$OUT/kernel_stats.csv
