@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -80,22 +81,64 @@ int default_threads() {
     return n > 64 ? 64 : n;
 }
 
-// eq(point, .) over 2^k indices, variable 1 = most significant index bit; point and table in Montgomery form
-void eq_table(const std::vector<F>& point_m, std::vector<F>& out) {
-    const int k = (int)point_m.size();
-    out.assign((size_t)1 << k, F{{0, 0, 0, 0}});
-    const F one_m = mont_one();
-    out[0] = one_m;
-    size_t have = 1;
-    for (int i = 0; i < k; ++i) {
-        // entry j of the table over variables 1..i becomes entries 2j (x_{i+1} = 0) and 2j + 1 (x_{i+1} = 1)
-        for (size_t j = have; j-- > 0;) {
-            const F hi = gkr::h64::mont_mul(out[j], point_m[i]);
-            out[2 * j] = gkr::h64::sub(out[j], hi);
-            out[2 * j + 1] = hi;
+// eq(point, .) over 2^k indices, variable 1 = most significant index bit; point and table in Montgomery form.  The table of
+// the first t variables is built by doublings on the calling thread; every thread then expands its own slice of those 2^t
+// prefixes by the remaining k - t variables (entry j of a level becomes entries 2j and 2j + 1 of the next, so a prefix's
+// descendants are a contiguous block of every later level).
+// a table whose storage is kept between layers and never zero-filled (every entry is written before it is read)
+struct Table {
+    std::unique_ptr<F[]> p;
+    size_t cap = 0;
+    F* get(size_t n) {
+        if (n > cap) {
+            p.reset(new F[n]);
+            cap = n;
         }
-        have <<= 1;
+        return p.get();
     }
+};
+
+void eq_table(const std::vector<F>& point_m, Table& table, int threads) {
+    const int k = (int)point_m.size();
+    F* out = table.get((size_t)1 << k);
+    out[0] = mont_one();
+    auto expand = [&](size_t base, size_t have, int from, int to) {   // the block out[base .. base + have) of level `from` -> level `to`, in place at base << (to - from)
+        for (int i = from; i < to; ++i) {
+            const size_t b0 = base << (i - from), b1 = base << (i + 1 - from);
+            for (size_t j = have; j-- > 0;) {
+                const F v = out[b0 + j];
+                const F hi = gkr::h64::mont_mul(v, point_m[i]);
+                out[b1 + 2 * j] = gkr::h64::sub(v, hi);
+                out[b1 + 2 * j + 1] = hi;
+            }
+            have <<= 1;
+        }
+    };
+    int t = 0;
+    while (t < k && ((size_t)1 << t) < (size_t)threads * 4) ++t;
+    if (k < 14 || threads <= 1) t = k;
+    expand(0, 1, 0, t);
+    if (t == k) return;
+    // level t sits in out[0 .. 2^t); prefix p's block of level k is out[p << (k - t) .. (p + 1) << (k - t)).  Highest prefix first
+    // within a thread would overwrite nothing it still needs only if blocks never overlap their sources: copy level t aside.
+    const std::vector<F> prefixes(out, out + ((size_t)1 << t));
+    parallel_for((size_t)1 << t, threads, 1, [&](int, size_t a, size_t b) {
+        for (size_t p = a; p < b; ++p) {
+            const size_t base = p << (k - t);
+            out[base] = prefixes[p];
+            // (expand works on "block at base of the current level": re-based so that the prefix is entry 0 of its own sub-table)
+            size_t have = 1;
+            for (int i = t; i < k; ++i) {
+                for (size_t j = have; j-- > 0;) {
+                    const F v = out[base + j];
+                    const F hi = gkr::h64::mont_mul(v, point_m[i]);
+                    out[base + 2 * j] = gkr::h64::sub(v, hi);
+                    out[base + 2 * j + 1] = hi;
+                }
+                have <<= 1;
+            }
+        }
+    });
 }
 
 // Horner, highest degree first (poly.rs:260-267); coefficients canonical, x Montgomery -> canonical
@@ -109,16 +152,50 @@ F horner(const gkr_fr* c, int n, const F& x_m) {
 // the variables are bound one by one, last variable first (c[rest,0] + x c[rest,1]); canonical in, x Montgomery, canonical out
 F eval_monomial_table(const gkr_fr* coeffs, int k, const std::vector<F>& x_m, int threads) {
     if (k == 0) return load(coeffs[0]);
-    std::vector<F> cur((size_t)1 << (k - 1));
-    const F& last = x_m[k - 1];
-    parallel_for(cur.size(), threads, 4096, [&](int, size_t a, size_t b) {
-        for (size_t i = a; i < b; ++i) cur[i] = gkr::h64::add(load(coeffs[2 * i]), gkr::h64::mont_mul(load(coeffs[2 * i + 1]), last));
+    // every thread folds its own contiguous slice of the table down to one value per slice-prefix (the leading variables index
+    // the slices), the calling thread folds those
+    int t = 0;
+    while (t < k - 10 && ((size_t)1 << t) < (size_t)threads * 2) ++t;
+    if (threads <= 1) t = 0;
+    std::vector<F> top((size_t)1 << t);
+    parallel_for((size_t)1 << t, threads, 1, [&](int, size_t a, size_t b) {
+        std::vector<F> cur;
+        for (size_t p = a; p < b; ++p) {
+            const int kk = k - t;                                 // the slice's own variables: t + 1 .. k
+            const gkr_fr* c = coeffs + (p << kk);
+            if (kk == 0) {
+                top[p] = load(c[0]);
+                continue;
+            }
+            cur.resize((size_t)1 << (kk - 1));
+            const F& last = x_m[k - 1];
+            for (size_t i = 0; i < cur.size(); ++i) cur[i] = gkr::h64::add(load(c[2 * i]), gkr::h64::mont_mul(load(c[2 * i + 1]), last));
+            for (int v = kk - 2; v >= 0; --v) {
+                const size_t half = (size_t)1 << v;
+                const F& x = x_m[t + v];
+                for (size_t i = 0; i < half; ++i) cur[i] = gkr::h64::add(cur[2 * i], gkr::h64::mont_mul(cur[2 * i + 1], x));
+            }
+            top[p] = cur[0];
+        }
     });
-    for (int v = k - 2; v >= 0; --v) {
+    for (int v = t - 1; v >= 0; --v) {
         const size_t half = (size_t)1 << v;
-        for (size_t i = 0; i < half; ++i) cur[i] = gkr::h64::add(cur[2 * i], gkr::h64::mont_mul(cur[2 * i + 1], x_m[v]));
+        for (size_t i = 0; i < half; ++i) top[i] = gkr::h64::add(top[2 * i], gkr::h64::mont_mul(top[2 * i + 1], x_m[v]));
     }
-    return cur[0];
+    return top[0];
+}
+
+// every element of a table below r?  (on the threads: a 2^20-entry table is 32 MiB)
+bool all_canonical_par(const gkr_fr* v, size_t n, int threads) {
+    std::atomic<int> bad{0};
+    parallel_for(n, threads, 1 << 15, [&](int, size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i)
+            if (!canonical(v[i])) {
+                bad.store(1);
+                return;
+            }
+    });
+    return !bad.load();
 }
 
 }  // namespace
@@ -214,11 +291,10 @@ int gkr_verify(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, int 
         if (!is_zero(z[j])) return reject(0, GKR_VERIFY_Z0);
         zi_m[j] = zero;
     }
-    for (size_t i = 0; i < ((size_t)1 << circuit->k[0]); ++i)
-        if (!canonical(proof->d_coeffs[i])) return reject(0, GKR_VERIFY_NON_CANONICAL);
+    if (!all_canonical_par(proof->d_coeffs, (size_t)1 << circuit->k[0], threads)) return reject(0, GKR_VERIFY_NON_CANONICAL);
     F m = eval_monomial_table(proof->d_coeffs, (int)circuit->k[0], zi_m, threads);
     size_t row = 0, qo = 0, zo = circuit->k[0];
-    std::vector<F> eq_z, eq_b, eq_c;
+    Table tab_z, tab_b, tab_c;
     for (uint32_t i = 0; i < L; ++i) {
         const int k_i = (int)circuit->k[i], k = (int)circuit->k[i + 1];
         const size_t gates = (size_t)1 << k_i;
@@ -252,9 +328,10 @@ int gkr_verify(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, int 
         F q1 = zero;
         for (uint32_t t = 0; t < qlen; ++t) q1 = gkr::h64::add(q1, load(q[t]));
         std::vector<F> b_m(rs_m.begin(), rs_m.begin() + k), c_m(rs_m.begin() + k, rs_m.end());
-        eq_table(zi_m, eq_z);
-        eq_table(b_m, eq_b);
-        eq_table(c_m, eq_c);
+        eq_table(zi_m, tab_z, threads);
+        eq_table(b_m, tab_b, threads);
+        eq_table(c_m, tab_c, threads);
+        const F *eq_z = tab_z.p.get(), *eq_b = tab_b.p.get(), *eq_c = tab_c.p.get();
         const uint8_t* gt = circuit->gate_type[i];
         const uint32_t *lf = circuit->left[i], *rt = circuit->right[i];
         const uint32_t limit = (uint32_t)1 << k;
@@ -269,6 +346,10 @@ int gkr_verify(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, int 
                     if (lf[g] >= limit || rt[g] >= limit || gt[g] > 1) {
                         bad_gate.store(1);
                         return;
+                    }
+                    if (g + 12 < end && lf[g + 12] < limit && rt[g + 12] < limit) {   // (the operands' eq entries are random reads of 32 MiB tables)
+                        __builtin_prefetch(&eq_b[lf[g + 12]]);
+                        __builtin_prefetch(&eq_c[rt[g + 12]]);
                     }
                     const F bc = gkr::h64::mont_mul(eq_b[lf[g]], eq_c[rt[g]]);
                     gkr::h64::wide_mac(gt[g] ? wm : wa, eq_z[g], bc);
@@ -308,8 +389,7 @@ int gkr_verify(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, int 
         qo += (size_t)k + 1;
         zo += (size_t)k;
     }
-    for (size_t i = 0; i < ((size_t)1 << circuit->k[L]); ++i)
-        if (!canonical(proof->input_coeffs[i])) return reject(L, GKR_VERIFY_NON_CANONICAL);
+    if (!all_canonical_par(proof->input_coeffs, (size_t)1 << circuit->k[L], threads)) return reject(L, GKR_VERIFY_NON_CANONICAL);
     if (!same(m, eval_monomial_table(proof->input_coeffs, (int)circuit->k[L], zi_m, threads))) return reject(L, GKR_VERIFY_INPUT);
     (void)one_m;
     (void)layer_out;

@@ -284,3 +284,33 @@ def test_limits_are_reported(ctx):
     with pytest.raises(GkrError) as e:
         ctx.sumcheck_layer_raw(lay, 25, np.zeros((2, 4), dtype=np.uint64), np.zeros((1 << 25, 4), dtype=np.uint64))
     assert "GKR_MAX_K_NEXT" in str(e.value)
+
+
+def test_library_verifier_on_gpu_proofs_through_wide_layers(ctx):
+    """gkr_verify (csrc/dropin.cpp; the relations of python/gkr.py:202-231 on the gkr_proof_buf) accepts what gkr_prove_batch
+    produced for a circuit with layers of 2^13 .. 2^15 values -- the interpreted verifier cannot follow at that size -- for
+    every proof of a batch of three, with one and with many threads; a changed round coefficient, challenge, q entry, r*, z
+    entry, input coefficient or gate type is refused with the check that names it."""
+    from gkr_amd.dropin import verify_native
+    ks = [12, 14, 15, 13]
+    circuit, layers, _ = synth.wide_circuit(ks, seed=4242)
+    rng = np.random.default_rng(8)
+    wit = np.ascontiguousarray(synth.rand_fr(rng, 3 << ks[-1]).reshape(3, 1 << ks[-1], 4))
+    arrs = [a.copy() for a in ctx.prove_batch_raw(circuit, wit, all_arrays=True)]
+    for b in range(3):
+        for threads in (1, 0):
+            assert verify_native(circuit, arrs, index=b, threads=threads) == (True, 0, 0), (b, threads)
+    rows1 = 2 * ks[1]                      # rounds of layer 0; layer 1's rows follow
+    for name, arr, index, check, layer in (("round coefficient", 0, (1, rows1 + 5, 2, 0), 4, 1), ("challenge", 2, (1, 3, 0), 5, 0),
+                                           ("q", 3, (1, ks[1] + 1 + 4, 0), 6, 1), ("r*", 6, (1, 2, 0), 7, 2), ("z", 5, (1, ks[0] + 1, 0), 8, 0),
+                                           ("input_func", 8, (1, 77, 0), 9, 3)):
+        bad = [a.copy() for a in arrs]
+        bad[arr][index] ^= np.uint64(1)
+        ok, at, why = verify_native(circuit, bad, index=1, threads=0)
+        assert not ok and why == check and at == layer, (name, ok, at, why)
+        assert verify_native(circuit, bad, index=0, threads=0)[0]          # (the other proofs of the batch are untouched)
+    flipped = [(gt.copy(), l, r) for gt, l, r in layers]
+    flipped[2][0][123] ^= 1
+    from gkr_amd import GKRCircuit, Layer
+    wrong = GKRCircuit([Layer(ks[i], *flipped[i]) for i in range(3)], ks[-1])
+    assert verify_native(wrong, arrs, index=2, threads=0)[:1] == (False,)
