@@ -5,9 +5,10 @@ set -x
 OUT=gpurun_out/${1:-r2x}
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $OUT/gpu_tests.txt
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+GKR_BENCH_DETAIL=$OUT/bench_default_detail.json python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err   # (the driver's exact command)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
+export GKR_BENCH_DETAIL=/tmp/bench_detail_scratch.json   # (only the runs that name their own keep a detail file)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-verify --proofs 0 > /tmp/stats_bench.json 2>/dev/null
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) $R/$OUT/kernel_stats.csv
 cp /tmp/stats_bench.json $R/$OUT/stats_bench.json
@@ -21,16 +22,16 @@ cd $R
 python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write 1024 20 > $OUT/pmc_traffic.json
 PROBE_REPS=60 PROBE_THREADS=14,12 python tools/proof_many_probe.py 64 > $OUT/proof_many_probe_64.txt 2>/dev/null
 PROBE_REPS=60 PROBE_THREADS=14 python tools/proof_many_probe.py 3 > $OUT/proof_many_probe_3.txt 2>/dev/null
-python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split.json 2>/dev/null
+GKR_BENCH_DETAIL=$OUT/bench_mode_layer_split_detail.json python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split.json 2>/dev/null
 GKR_BENCH_FORCE_GROUP=1 python bench.py --mode layer-split --steps 10 --warmup 3 > $OUT/bench_mode_layer_split_rccl_one_rank.json 2>/dev/null
-python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
+GKR_BENCH_DETAIL=$OUT/bench_mode_proofs_detail.json python bench.py --mode proofs --steps 10 --warmup 3 > $OUT/bench_mode_proofs.json 2>/dev/null
 LOCAL_WORLD_SIZE=8 python bench.py --no-cpu-baseline --no-extras --no-verify --proofs 0 > $OUT/bench_emulated_8_ranks.json 2>/dev/null
 python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20.json 2>/dev/null
 GKR_BENCH_FORCE_GROUP=1 python bench.py --mode mle-split --log2-points 20 > $OUT/bench_mode_mle_split_n20_rccl_one_rank.json 2>/dev/null
 python bench.py --mode mle-split --log2-points 30 --steps 5 > $OUT/bench_mode_mle_split_n30.json 2>/dev/null
 # the default line with two ranks (two processes over gloo sharing the one GPU), started by bench.py ITSELF (--gpus 2, no launcher
 # around it): every N > 1 field of the line
-GKR_BENCH_BACKEND=gloo GKR_BENCH_DEVICE=0 python bench.py --gpus 2 --steps 4 --warmup 2 --batch 256 > $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.json 2> $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.err
+GKR_BENCH_DETAIL=$OUT/bench_default_gpus2_self_launched_gloo_one_gpu_detail.json GKR_BENCH_BACKEND=gloo GKR_BENCH_DEVICE=0 python bench.py --gpus 2 --steps 4 --warmup 2 --batch 256 > $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.json 2> $OUT/bench_default_gpus2_self_launched_gloo_one_gpu.err
 python tools/bench_wide.py 20,15 22,16 24,18 20,20 22,22 > $OUT/bench_wide_layers.txt 2>&1
 WIDE_SHAPE=circom python tools/bench_wide.py 20,20 22,22 > $OUT/bench_wide_layers_circom_shaped.txt 2>&1
 bash tools/stats_large_r1cs.sh ${1:-r2x}/large_r1cs_lockstep 10 14 > $OUT/large_r1cs_lockstep_kernel_stats_summary.txt 2>&1
