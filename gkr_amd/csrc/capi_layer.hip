@@ -350,12 +350,13 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
             memcpy(hz, z, sizeof(gkr_fr) * (size_t)batch * k_i);
             // (the dependence flags of a table beyond 2^13 values are found over a grid, not by the prologue's one block)
             const bool dep_wide = k > 13;
-            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, Wb, Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s);
-            if (dep_wide) {
-                uint32_t* dep_bits = nullptr;
-                WS(ctx, "layer.depbits", uint32_t, (size_t)batch, dep_bits);
-                gkr::launch_depends_wide(d_W, (uint32_t)k, dep_bits, dep, h_dep, (uint32_t)batch, s);
-            }
+            uint32_t* dep_bits = nullptr;
+            if (dep_wide) WS(ctx, "layer.depbits", uint32_t, (size_t)batch, dep_bits);
+            gkr::launch_layer_prologue(reinterpret_cast<const Fr*>(hz), (uint32_t)k_i, (uint32_t)kh, kl, e_hi, e_lo, d_W, Wb, Wc, (uint32_t)k, dep_wide ? nullptr : dep, h_dep, (uint32_t)batch, s,
+                                       dep_bits);
+            // (the prologue's last block has stored what the table's first 256 entries show: a generic table's grid scan finds
+            // every bit set and leaves at once)
+            if (dep_wide) gkr::launch_depends_wide(d_W, (uint32_t)k, dep_bits, dep, h_dep, (uint32_t)batch, s, true);
         }
         if (wide) {
             // eq(z, g) for every gate index of the layer (of the whole layer also when this rank holds a share of the gates: the

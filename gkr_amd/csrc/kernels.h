@@ -254,7 +254,7 @@ void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t
 // trailing ones), the two Montgomery copies of W (Wb null: none) and the 32 dependence flags per proof, in dep and -- when not null -- in
 // pinned host memory host_dep (k_layer_prologue)
 void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,
-                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
+                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s, uint32_t* wide_bits = nullptr);
 // q(t) = W(b + t (c - b)) per proof: W batch x 2^k, bc batch x 2k (b then c), scratch batch x 3 * 2^k, deg_scratch batch
 // words (device), out batch x (k + 1) highest degree first, out_len batch
 // bcm: batch * 2k elements of device scratch (the line's coefficients in Montgomery form; unused for k <= 9)
@@ -302,8 +302,9 @@ void launch_eq_outer(const Fr* e_hi, const Fr* e_lo_mont, uint32_t k_i, uint32_t
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t* block_sums, size_t n, hipStream_t s);
 // *flag |= 1 if some entry of t[0 .. n) is >= r (flag zeroed by the caller)
 void launch_check_canonical(const Fr* t, size_t n, uint32_t* flag, hipStream_t s);
-// dependence flags over a grid: bits = batch zeroed-by-the-launcher words of scratch; dep / host_dep as launch_layer_prologue
-void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s);
+// dependence flags over a grid: bits = one word of scratch per proof, zeroed by the launcher unless `bits_preset` (the layer's
+// prologue stored what a first look found: launch_layer_prologue's wide_bits); dep / host_dep as launch_layer_prologue
+void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s, bool bits_preset = false);
 // in-place Moebius transform (evaluations -> monomial coefficients, MSB-first) of `batch` tables of 2^k, `stride` apart
 void launch_mobius(Fr* tables, uint32_t k, size_t stride, uint32_t batch, hipStream_t s);
 void launch_line_setup_wide(const Fr* W, uint32_t k, Fr* scratch, uint32_t* maxdeg_scratch, uint32_t batch, hipStream_t s);

@@ -955,7 +955,8 @@ __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points,
 __global__ void __launch_bounds__(256) k_layer_prologue(const Fr* __restrict__ points, uint32_t k_i, uint32_t kh, uint32_t kl,
                                                         Fr* __restrict__ e_hi, Fr* __restrict__ e_lo, const Fr* __restrict__ W,
                                                         Fr* __restrict__ Wb, Fr* __restrict__ Wc, uint32_t k, uint32_t* __restrict__ dep,
-                                                        uint32_t* __restrict__ host_dep, uint32_t nb_hi, uint32_t nb_lo, uint32_t nb_mont) {
+                                                        uint32_t* __restrict__ host_dep, uint32_t nb_hi, uint32_t nb_lo, uint32_t nb_mont,
+                                                        uint32_t* __restrict__ wide_bits) {
     const uint32_t bx = blockIdx.x, proof = blockIdx.y, n = 1u << k;
     if (bx < nb_hi) {
         eq_table_part(points, k_i, 0u, kh, e_hi, 0u, bx, nb_hi, proof);
@@ -970,7 +971,29 @@ __global__ void __launch_bounds__(256) k_layer_prologue(const Fr* __restrict__ p
             store_fr(Wc + base + i, m);
         }
     } else {
-        if (!dep) return;   // (a wide table's flags are found over a grid: launch_depends_wide)
+        if (!dep) {
+            // A wide table's flags are found over a grid (launch_depends_wide) -- but only a table that does NOT depend on some
+            // variable needs the whole scan: that it does depend is shown by any one pair.  This block looks at the pairs of
+            // the table's first 256 entries and STORES what it finds in the grid kernel's word (no memset before it): for a
+            // generic table that is every bit, and the grid kernel's blocks leave at once (23.7 -> ~4 us at 2^20 values).
+            if (!wide_bits) return;
+            __shared__ uint32_t s_found;
+            if (threadIdx.x == 0) s_found = 0;
+            __syncthreads();
+            const Fr* w = W + ((size_t)proof << k);
+            uint32_t bits = 0;
+            if (threadIdx.x < n) {
+                const Fr a = load_fr(w + threadIdx.x);
+                for (uint32_t b = 0; b < k; ++b) {
+                    const uint32_t bit = 1u << (k - 1 - b);
+                    if (!(threadIdx.x & bit) && !fr_eq(a, load_fr(w + (threadIdx.x ^ bit)))) bits |= 1u << b;
+                }
+            }
+            if (bits) atomicOr(&s_found, bits);
+            __syncthreads();
+            if (threadIdx.x == 0) wide_bits[proof] = s_found;
+            return;
+        }
         __shared__ uint32_t s_dep;
         if (threadIdx.x == 0) s_dep = 0;
         __syncthreads();
@@ -2152,11 +2175,11 @@ void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t
 }
 
 void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,
-                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s) {
+                           uint32_t k, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s, uint32_t* wide_bits) {
     const uint32_t nb_hi = blocks_for((size_t)4 << kh, 4096), nb_lo = blocks_for((size_t)4 << kl, 4096);
     const uint32_t nb_mont = Wb ? blocks_for((size_t)1 << k, 1024) : 0u;
     hipLaunchKernelGGL(k_layer_prologue, dim3(nb_hi + nb_lo + nb_mont + 1, batch), dim3(256), 0, s, points, k_i, kh, kl, e_hi, e_lo, W, Wb,
-                       Wc, k, dep, host_dep, nb_hi, nb_lo, nb_mont);
+                       Wc, k, dep, host_dep, nb_hi, nb_lo, nb_mont, wide_bits);
 }
 
 void launch_line_restriction(const Fr* W, uint32_t k, const Fr* bc, Fr* scratch, uint32_t* deg_scratch, Fr* bcm, Fr* out, uint32_t* out_len,

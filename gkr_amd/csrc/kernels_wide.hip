@@ -495,7 +495,9 @@ __global__ void __launch_bounds__(256) k_depends_wide(const Fr* __restrict__ W, 
     if (threadIdx.x == 0) s_bits = 0u;
     __syncthreads();
     const uint32_t all = k >= 32u ? 0xffffffffu : (1u << k) - 1u;
-    uint32_t mine = __hip_atomic_load(bits + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what other blocks found already
+    const uint32_t known = __hip_atomic_load(bits + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what other blocks (or the layer's prologue) found already
+    if (known == all) return;   // (uniform over the block)
+    uint32_t mine = known;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n && mine != all; i += gridDim.x * blockDim.x) {
         const Fr a = load_fr(w + i);
         for (uint32_t b = 0; b < k; ++b) {
@@ -503,7 +505,7 @@ __global__ void __launch_bounds__(256) k_depends_wide(const Fr* __restrict__ W, 
             if (!((mine >> b) & 1u) && !(i & bit) && !fr_eq(a, load_fr(w + (i ^ bit)))) mine |= 1u << b;
         }
     }
-    if (mine) atomicOr(&s_bits, mine);
+    if (mine & ~known) atomicOr(&s_bits, mine);
     __syncthreads();
     if (threadIdx.x == 0 && s_bits) atomicOr(bits + blockIdx.y, s_bits);
 }
@@ -513,8 +515,8 @@ __global__ void k_dep_publish(const uint32_t* __restrict__ bits, uint32_t* __res
     dep[(size_t)blockIdx.x * 32 + threadIdx.x] = f;
     if (host_dep) host_dep[(size_t)blockIdx.x * 32 + threadIdx.x] = f;
 }
-void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s) {
-    (void)hipMemsetAsync(bits, 0, sizeof(uint32_t) * batch, s);
+void launch_depends_wide(const Fr* W, uint32_t k, uint32_t* bits, uint32_t* dep, uint32_t* host_dep, uint32_t batch, hipStream_t s, bool bits_preset) {
+    if (!bits_preset) (void)hipMemsetAsync(bits, 0, sizeof(uint32_t) * batch, s);
     hipLaunchKernelGGL(k_depends_wide, dim3(blocks_for((uint64_t)1 << k, 1024), batch), dim3(256), 0, s, W, k, bits);
     hipLaunchKernelGGL(k_dep_publish, dim3(batch), dim3(32), 0, s, bits, dep, host_dep);
 }
