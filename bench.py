@@ -43,6 +43,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_GBPS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md; measured copy ceiling 6.29 TB/s)
+# The chip's rate of dependent 254-bit Montgomery products on v_mad_u64_u32 chains (16 waves per SIMD), as a CONSTANT: what
+# gkr_ubench_ceilings measured on every box of rounds 3-6 (1.184 - 1.199 * 10^11).  The legs bound by it quote their fraction
+# of this figure beside the fraction of what the box of the run itself measures, so that a slow box does not lower the bar.
+PEAK_PRODUCTS_PER_SEC = 1.19e11
 
 
 def usable_cpus():
@@ -945,6 +949,7 @@ def layer_leg(world, k_i, k, steps, warmup, split, ceilings=None, shape="uniform
             "roofline": {"bound": "alu", "kernel": " + ".join("k_" + p_ for p_ in passes) + " (the two passes over this rank's gates: U, V before the b rounds; the row a_u, m_u before the c rounds)",
                          "achieved": rate, "peak": peak, "unit": "254-bit modular products/s",
                          "frac": rate / peak if rate and peak else None, "traffic": None,
+                         "peak_fixed": PEAK_PRODUCTS_PER_SEC, "frac_of_fixed_peak": rate / PEAK_PRODUCTS_PER_SEC if rate else None,
                          "products_per_launch_pair": products, "gate_pass_ms_per_step": gate_ms,
                          "products_rule": "one product per gate and pass (2 per gate and sumcheck); peak = the chip-wide rate of dependent "
                                           "Montgomery products measured in this process (gkr_ubench_ceilings, 16 waves per SIMD)",
@@ -1009,6 +1014,7 @@ def product_pass_roofline(k, prod_ms, peak_products_per_sec):
             "modular_products_per_sumcheck": products, "modular_products_per_sec": rate,
             "valu_product_rate_of_the_chip": peak_products_per_sec,
             "frac_of_the_valu_product_rate": rate / peak_products_per_sec if peak_products_per_sec else None,
+            "valu_product_rate_fixed": PEAK_PRODUCTS_PER_SEC, "frac_of_the_fixed_valu_product_rate": rate / PEAK_PRODUCTS_PER_SEC,
             "note": "elapsed time of the passes' kernels (HIP events); the hand-offs between them are the host transcript's"}
 
 
