@@ -554,26 +554,35 @@ int run_layer_batch_impl(gkr_ctx* ctx, int batch, int k_i, int k, const uint8_t*
         uint32_t tail_m = 0;   // log2 of the host tables' length (before the pending fold), while the tail is active
         for (int phase = 0; phase < 2 && rc == GKR_OK; ++phase) {
             Fr *Tw = Wb, *Tx = U, *Ty = V;
-            if (phase == 1 && tail_active) {
-                // what is left of Wb -- the 2^jp entries the last pass's weights bind into W(u) -- is on the host: back to the device,
-                // where the c-phase's set-up reads it
-                for (int b = 0; b < batch; ++b)
-                    HIP_TRY(ctx, hipMemcpyAsync(Wb + (size_t)b * wlen, h_tail + (size_t)b * 3 * tail_stride, sizeof(Fr) << jp, hipMemcpyHostToDevice, s));
-            }
+            // what is left of Wb -- the 2^jp entries the last pass's weights bind into W(u) -- is on the host when the b-phase ended in
+            // the host tail.  The wide layers' fused set-up reads it where it is (pinned memory; one wave per proof); the other forms
+            // get it back on the device by a copy KERNEL (a hipMemcpyAsync here cost ~25 us of the chain: the round path makes no
+            // transfer call of the runtime).
+            const bool wu_from_host_tail = phase == 1 && tail_active && wide && !shard;
+            if (phase == 1 && tail_active && !wu_from_host_tail)
+                gkr::launch_copy_rows(h_tail, 3 * tail_stride * 8, Wb, wlen * 8, 8u << jp, (uint32_t)batch, s);
             tail_active = false;
             const double t_ph1 = dbg_sections ? now_us_dbg() : 0.0;
             if (phase == 1) {
                 // all of b is bound: the rows of a, m at u = (r_1 .. r_k), then the c-phase's tables X = a_u + W(u) m_u,
                 // Y = W(u) a_u (W(u): the last b pass's fold of what is left of Wb)
                 for (int b = 0; b < batch; ++b) memcpy(h_u + (size_t)b * k, out_r[b], sizeof(gkr_fr) * k);
-                gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s);
-                bool c_tables_done = false;   // (one rank holds all gates and the rows come from segments: the row pass writes X, Y too)
+                // (a wide layer whose gates are all on this rank: the eq-table launch also leaves W(u), and the row pass writes the
+                // c-phase's tables X, Y itself -- no k_prod_c_setup launch, no pass over the rows)
+                const gkr::CPhaseFuse fuse{wu_from_host_tail ? h_tail : Wb, h_pw, Xc, Yc, jp};
+                Fr* d_wu = nullptr;
+                if (wide && !shard) WS(ctx, "layer.wu", Fr, (size_t)batch, d_wu);
+                gkr::launch_eq_table(reinterpret_cast<const Fr*>(h_u), (uint32_t)k, 0u, (uint32_t)k, d_eq, true, (uint32_t)batch, s, d_wu ? &fuse : nullptr, d_wu,
+                                     (uint32_t)(wu_from_host_tail ? 3 * tail_stride : wlen));
+                bool c_tables_done = false;   // (one rank holds all gates: the row pass writes X, Y too)
                 {
                     Timed t(ctx, "gate_rows", (double)span.count * 8.0 * batch);
-                    const gkr::CPhaseFuse fuse{Wb, h_pw, Xc, Yc, jp};
-                    if (wide)
-                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, d_eq, A, M, lb, item_partials, gate_arrive, s, sets, plan_counts);
-                    else
+                    if (wide) {
+                        const gkr::WideCFuse wfuse{d_wu, Xc, Yc};
+                        gkr::launch_gate_rows_wide(span, (uint32_t)k_i, (uint32_t)k, g_plan, gkr::GateEq{E, e_hi, e_lo, kl}, d_eq, A, M, lb, item_partials, gate_arrive, s, sets, plan_counts,
+                                                   d_wu ? &wfuse : nullptr);
+                        c_tables_done = d_wu != nullptr;
+                    } else
                         c_tables_done = gkr::launch_gate_rows(span, (uint32_t)k_i, (uint32_t)k, g_offsets, g_cursor, g_list, e_hi, e_lo, kl, d_eq, A, M, lb,
                                                               segs, seg_partials, s, shard ? nullptr : &fuse, sets);
                 }

@@ -248,8 +248,11 @@ void launch_copy_words(const void* src, void* dst, size_t words, hipStream_t s);
 // rows x words: row r from src + r * src_stride_words to dst + r * dst_stride_words (32-bit words)
 void launch_copy_rows(const void* src, size_t src_stride_words, void* dst, size_t dst_stride_words, uint32_t words, uint32_t rows, hipStream_t s);
 // out[proof][g] = eq(points[proof * stride + first ..+nvars), g), nvars <= 28; points may be pinned host memory
+// wu_job / wu_out (both or neither): the launch also leaves W(u) = sum_{i < 2^jp} Wb[i] * weights[i] of every proof (Montgomery;
+// k_prod_c_setup's scalar) in wu_out[proof] -- the wide layers' row pass writes the c-phase's tables with it (WideCFuse)
+struct CPhaseFuse;
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
-                     hipStream_t s);
+                     hipStream_t s, const CPhaseFuse* wu_job = nullptr, Fr* wu_out = nullptr, uint32_t wstride = 0);
 // one launch for a layer's set-up: E_hi (canonical, kh leading coordinates of the proof's point), E_lo (Montgomery, kl
 // trailing ones), the two Montgomery copies of W (Wb null: none) and the 32 dependence flags per proof, in dep and -- when not null -- in
 // pinned host memory host_dep (k_layer_prologue)
@@ -294,8 +297,16 @@ size_t gate_plan_arrive_words(uint64_t gates, uint32_t k);     // zeroed u32 cou
 void gate_plan_counts_offsets(uint64_t gates, uint32_t k, size_t* half1_word_offset);   // where the second half's header starts in the plan
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
                          uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
+// fuse (may be null): the rows are not written; every bucket's (a_u, m_u) goes straight into the c-phase's tables
+// X = a_u + W(u) m_u, Y = W(u) a_u (k_prod_c_setup's arithmetic: one launch and 64 B of traffic per bucket less per sumcheck)
+struct WideCFuse {
+    const Fr* wu = nullptr;   // W(u) per proof, Montgomery, device memory (launch_eq_table's wu_out)
+    Fr* X = nullptr;
+    Fr* Y = nullptr;
+};
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr);
+                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets = nullptr, const GatePlanCounts* counts = nullptr,
+                           const WideCFuse* fuse = nullptr);
 // E (batch x 2^k_i, canonical) = the outer product of the prologue's half tables (e_hi canonical, e_lo_mont Montgomery, split at kl)
 void launch_eq_outer(const Fr* e_hi, const Fr* e_lo_mont, uint32_t k_i, uint32_t kl, Fr* E, uint32_t batch, hipStream_t s);
 // exclusive scan of n 32-bit counts (block_sums: n / 2048 + 1 words of scratch)

@@ -887,6 +887,22 @@ __device__ __forceinline__ void eq_table_part(const Fr* __restrict__ points, uin
     }
 }
 
+// W(u) = sum_{i < 2^jp} Wb[i] * weights[i] of one proof (Montgomery in, Montgomery out), by the calling wave's first lanes:
+// what k_prod_c_setup computes per block, once per proof (the eq-table launch of the c-phase leaves it for the wide row pass)
+__device__ __forceinline__ void c_phase_wu(const Fr* Wb, const Fr* weights, uint32_t jp, uint32_t wstride, uint32_t proof, Fr* wu_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Fr wu = fr_zero();
+    if (lane < (1u << jp)) wu = mont_mul(load_fr(Wb + (size_t)proof * wstride + lane), load_fr(weights + (size_t)proof * 8 + lane));
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+        Fr o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.l[j] = __shfl_down(wu.l[j], off, 64);
+        wu = fr_add(wu, o);
+    }
+    if (lane == 0) store_fr(wu_out + proof, wu);
+}
+
 // The same table for MANY variables (eq(u, .) of a wide layer: 2^20 entries x 20 factors were 237 us): a block owns 4096
 // consecutive entries, i.e. one value of the leading nvars - 12 index bits.  Its product over those bits once (four lanes,
 // strided factors, as above), the sixteen products over the next four bits, the 256 over the last eight from two
@@ -895,7 +911,8 @@ __device__ __forceinline__ void eq_table_part(const Fr* __restrict__ points, uin
 // thread's sixteen entries were a chain of 32 products -- 40 us for the eight blocks of a 2^15-entry table, on a device that
 // fourteen proving threads keep short of queues, not of lanes)
 __global__ void __launch_bounds__(1024) k_eq_table_split(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
-                                                        Fr* __restrict__ out, uint32_t montgomery) {
+                                                        Fr* __restrict__ out, uint32_t montgomery, const Fr* __restrict__ wu_Wb,
+                                                        const Fr* __restrict__ wu_weights, uint32_t wu_jp, uint32_t wu_wstride, Fr* __restrict__ wu_out) {
     __shared__ Fr s_f[2][32];
     __shared__ Fr s_a[16], s_b[16], s_hm[16], s_lo[256];
     __shared__ Fr s_hi;
@@ -937,11 +954,14 @@ __global__ void __launch_bounds__(1024) k_eq_table_split(const Fr* __restrict__ 
     const uint32_t m0 = (tid >> 8) * 4u;   // a quarter of the sixteen mid entries per 256 threads
 #pragma unroll
     for (uint32_t m = m0; m < m0 + 4u; ++m) store_fr(dst + (m << 8) + (tid & 255u), mont_mul(s_hm[m], lo));
+    if (wu_out && hi_idx == 0u && tid < 64u) c_phase_wu(wu_Wb, wu_weights, wu_jp, wu_wstride, proof, wu_out);
 }
 
 __global__ void __launch_bounds__(256) k_eq_table(const Fr* __restrict__ points, uint32_t stride, uint32_t first, uint32_t nvars,
-                                                  Fr* __restrict__ out, uint32_t montgomery) {
+                                                  Fr* __restrict__ out, uint32_t montgomery, const Fr* __restrict__ wu_Wb,
+                                                  const Fr* __restrict__ wu_weights, uint32_t wu_jp, uint32_t wu_wstride, Fr* __restrict__ wu_out) {
     eq_table_part(points, stride, first, nvars, out, montgomery, blockIdx.x, gridDim.x, blockIdx.y);
+    if (wu_out && blockIdx.x == 0u && threadIdx.x < 64u) c_phase_wu(wu_Wb, wu_weights, wu_jp, wu_wstride, blockIdx.y, wu_out);
 }
 
 // Everything a layer's sumcheck needs before its first gate pass, in ONE launch (seven launches of 5 - 20 us each sat
@@ -2165,13 +2185,18 @@ void launch_copy_rows(const void* src, size_t src_stride_words, void* dst, size_
 }
 
 void launch_eq_table(const Fr* points, uint32_t stride, uint32_t first, uint32_t nvars, Fr* out, bool montgomery, uint32_t batch,
-                     hipStream_t s) {
+                     hipStream_t s, const CPhaseFuse* wu_job, Fr* wu_out, uint32_t wstride) {
+    const Fr* wb = wu_job && wu_out ? wu_job->Wb : nullptr;
+    const Fr* ww = wu_job && wu_out ? wu_job->weights : nullptr;
+    const uint32_t jp = wu_job && wu_out ? wu_job->jp : 0u;
+    Fr* wo = wu_job && wu_out ? wu_out : nullptr;
     if (nvars >= 14) {   // many variables: a few products per block, two per entry (k_eq_table_split)
-        hipLaunchKernelGGL(k_eq_table_split, dim3(1u << (nvars - 12u), batch), dim3(1024), 0, s, points, stride, first, nvars, out, montgomery ? 1u : 0u);
+        hipLaunchKernelGGL(k_eq_table_split, dim3(1u << (nvars - 12u), batch), dim3(1024), 0, s, points, stride, first, nvars, out, montgomery ? 1u : 0u,
+                           wb, ww, jp, wstride, wo);
         return;
     }
     hipLaunchKernelGGL(k_eq_table, dim3(blocks_for((size_t)4 << nvars, 4096), batch), dim3(256), 0, s, points, stride, first, nvars, out,
-                       montgomery ? 1u : 0u);
+                       montgomery ? 1u : 0u, wb, ww, jp, wstride, wo);
 }
 
 void launch_layer_prologue(const Fr* points, uint32_t k_i, uint32_t kh, uint32_t kl, Fr* e_hi, Fr* e_lo, const Fr* W, Fr* Wb, Fr* Wc,

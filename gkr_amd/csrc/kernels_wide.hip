@@ -278,10 +278,29 @@ void launch_eq_outer(const Fr* e_hi, const Fr* e_lo_mont, uint32_t k_i, uint32_t
 // 0.077 / 0.093 at 2^20 gates over 2^20 values, profiles/r05/b_*.)
 constexpr uint32_t kSinglePerLane = 4;   // items of one gate (or none) a lane takes in one go
 
+// where a bucket's two sums go: the pass's output tables, or -- the row pass of a whole layer on one rank (WideCFuse) -- straight
+// into the c-phase's tables X = a_u + W(u) m_u, Y = W(u) a_u (a, m canonical, wu Montgomery: canonical products)
+template <bool ROWS>
+__device__ __forceinline__ void put_bucket(Fr* out0, Fr* out1, const WideCFuse& fuse, const Fr& wu, uint32_t b, const Fr& a, const Fr& m) {
+    if (ROWS && fuse.X) {
+        store_fr(fuse.X + b, fr_add(a, mont_mul(m, wu)));
+        store_fr(fuse.Y + b, mont_mul(a, wu));
+    } else {
+        store_fr(out0 + b, a);
+        store_fr(out1 + b, m);
+    }
+}
+
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__ plan, PlanLayout L, EqSource eq, const Fr* __restrict__ T,
                                                     uint32_t wstride, Fr* __restrict__ out0, Fr* __restrict__ out1, Fr* __restrict__ partials,
-                                                    size_t pstride, uint32_t gate_base, const GateSet* __restrict__ sets) {
+                                                    size_t pstride, uint32_t gate_base, const GateSet* __restrict__ sets, WideCFuse fuse) {
+    Fr wu = fr_zero();
+    if (ROWS && fuse.X) {
+        wu = load_fr(fuse.wu + blockIdx.y);
+        fuse.X += (size_t)blockIdx.y * wstride;
+        fuse.Y += (size_t)blockIdx.y * wstride;
+    }
     if (sets) plan = sets[blockIdx.y].plan;
     plan += ROWS ? L.half_words : 0;
     const uint32_t lane = threadIdx.x & 63u, w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -328,10 +347,12 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
                 o1.l[i] = ROWS ? (mult ? p : 0u) : (mult ? 0u : p);
             }
             if (live[q]) {
-                Fr* dst0 = (d[q] >> 31) ? out0 + (d[q] & 0x7fffffffu) : partials + 2u * (size_t)slot[q];
-                Fr* dst1 = (d[q] >> 31) ? out1 + (d[q] & 0x7fffffffu) : partials + 2u * (size_t)slot[q] + 1u;
-                store_fr(dst0, o0);
-                store_fr(dst1, o1);
+                if (d[q] >> 31) {
+                    put_bucket<ROWS>(out0, out1, fuse, wu, d[q] & 0x7fffffffu, o0, o1);
+                } else {
+                    store_fr(partials + 2u * (size_t)slot[q], o0);
+                    store_fr(partials + 2u * (size_t)slot[q] + 1u, o1);
+                }
             }
         }
         return;
@@ -361,10 +382,12 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
             rp = fr_canonical(rp);
             rq = fr_canonical(rq);
         }
-        Fr* dst0 = whole ? out0 + (d & 0x7fffffffu) : partials + 2u * (size_t)plan[L.sorted + pos];
-        Fr* dst1 = whole ? out1 + (d & 0x7fffffffu) : partials + 2u * (size_t)plan[L.sorted + pos] + 1u;
-        store_fr(dst0, rp);
-        store_fr(dst1, rq);
+        if (whole) {
+            put_bucket<ROWS>(out0, out1, fuse, wu, d & 0x7fffffffu, rp, rq);
+        } else {
+            store_fr(partials + 2u * (size_t)plan[L.sorted + pos], rp);
+            store_fr(partials + 2u * (size_t)plan[L.sorted + pos] + 1u, rq);
+        }
     }
 }
 
@@ -377,7 +400,13 @@ __global__ void __launch_bounds__(256) k_items_pass(const uint32_t* __restrict__
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restrict__ plan, PlanLayout L, Fr* __restrict__ partials, size_t pstride,
                                                        Fr* __restrict__ out0, Fr* __restrict__ out1, uint32_t wstride, uint32_t multi_blocks,
-                                                       uint32_t* __restrict__ arrive, const GateSet* __restrict__ sets) {
+                                                       uint32_t* __restrict__ arrive, const GateSet* __restrict__ sets, WideCFuse fuse) {
+    Fr wu = fr_zero();
+    if (ROWS && fuse.X) {
+        wu = load_fr(fuse.wu + blockIdx.y);
+        fuse.X += (size_t)blockIdx.y * wstride;
+        fuse.Y += (size_t)blockIdx.y * wstride;
+    }
     if (sets) plan = sets[blockIdx.y].plan;
     plan += ROWS ? L.half_words : 0;
     Fr* base = partials + (size_t)blockIdx.y * pstride;
@@ -393,8 +422,7 @@ __global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restric
             acc_add_fr(a0, load_fr(part + 2u * (size_t)j));
             acc_add_fr(a1, load_fr(part + 2u * (size_t)j + 1u));
         }
-        store_fr(out0 + b, acc_reduce(a0));
-        store_fr(out1 + b, acc_reduce(a1));
+        put_bucket<ROWS>(out0, out1, fuse, wu, b, acc_reduce(a0), acc_reduce(a1));
         return;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = ((blockIdx.x - multi_blocks) * blockDim.x + threadIdx.x) >> 6,
@@ -431,8 +459,7 @@ __global__ void __launch_bounds__(256) k_items_combine(const uint32_t* __restric
             t0 = wave_sum(t0);
             t1 = wave_sum(t1);
             if (lane == 0) {
-                store_fr(out0 + b, acc_reduce(t0));
-                store_fr(out1 + b, acc_reduce(t1));
+                put_bucket<ROWS>(out0, out1, fuse, wu, b, acc_reduce(t0), acc_reduce(t1));
                 arrive[slot] = 0u;   // (the next pass's waves start after this kernel)
             }
         }
@@ -444,7 +471,8 @@ void gate_plan_counts_offsets(uint64_t gates, uint32_t k, size_t* half1_word_off
 
 template <bool ROWS>
 static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& ge, const Fr* T, Fr* out0, Fr* out1, LayerBatch lb,
-                                Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
+                                Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts, const WideCFuse* fuse_in = nullptr) {
+    const WideCFuse fuse = fuse_in ? *fuse_in : WideCFuse{};
     const PlanLayout L = plan_layout(span.count, k);
     const size_t pstride = gate_plan_partial_elems(span.count, k);
     const EqSource eq{ge.E, ge.e_hi, ge.e_lo_mont, k_i, ge.kl};
@@ -457,20 +485,20 @@ static void launch_items_pass_t(GateSpan span, uint32_t k_i, uint32_t k, const u
                    n_chunks = known ? counts->hdr[half][5] : L.cap_chunks;
     // (waves: one per group of two and more steps, one per kSinglePerLane groups of the rest -- at most `groups`)
     hipLaunchKernelGGL((k_items_pass<ROWS>), dim3((groups + 3u) / 4u, lb.batch), dim3(256), 0, s, plan, L, eq, T, (uint32_t)lb.wstride, out0, out1,
-                       partials, pstride, (uint32_t)span.base, sets);
+                       partials, pstride, (uint32_t)span.base, sets, fuse);
     if (known && n_multi == 0u && n_long == 0u) return;   // every bucket is one item: nothing to combine
     const uint32_t multi_blocks = (n_multi + 255u) / 256u;
     const uint32_t chunk_blocks = n_long ? (n_chunks < 1024u ? (n_chunks + 3u) / 4u : 256u) : 0u;
     hipLaunchKernelGGL((k_items_combine<ROWS>), dim3(multi_blocks + chunk_blocks, lb.batch), dim3(256), 0, s, plan, L, partials, pstride, out0, out1,
-                       (uint32_t)lb.wstride, multi_blocks, arrive, sets);
+                       (uint32_t)lb.wstride, multi_blocks, arrive, sets, fuse);
 }
 void launch_gate_uv_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* W, Fr* U, Fr* V, LayerBatch lb, Fr* partials,
                          uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
     launch_items_pass_t<false>(span, k_i, k, plan, eq, W, U, V, lb, partials, arrive, s, sets, counts);
 }
 void launch_gate_rows_wide(GateSpan span, uint32_t k_i, uint32_t k, const uint32_t* plan, const GateEq& eq, const Fr* eq_mont, Fr* A_row, Fr* M_row, LayerBatch lb,
-                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts) {
-    launch_items_pass_t<true>(span, k_i, k, plan, eq, eq_mont, A_row, M_row, lb, partials, arrive, s, sets, counts);
+                           Fr* partials, uint32_t* arrive, hipStream_t s, const GateSet* sets, const GatePlanCounts* counts, const WideCFuse* fuse) {
+    launch_items_pass_t<true>(span, k_i, k, plan, eq, eq_mont, A_row, M_row, lb, partials, arrive, s, sets, counts, fuse);
 }
 
 // every entry < r?  (a large W handed over in host memory is validated where it lands: the host loop over 2^20 entries
