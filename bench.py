@@ -831,8 +831,14 @@ def run_proofs(args, world):
         if inputs is not None:
             step_obj.prove_raw_many(ctx, inputs, threads)
     elapsed, each = timed_steps(world, ctx, step, args.warmup, args.steps)
+    # what was timed is checked on every rank: every proof of the last step through the library's verifier (gkr_verify)
+    native = native_verify_all(step_obj.circuits, step_obj._prepared["outs"]) if inputs is not None and not args.no_verify else None
+    bad_ranks = world.max_over_ranks(1.0 if native is not None and not native["ok"] else 0.0)
+    hashed = sum(int(arrs[1].sum()) for arrs in step_obj._prepared["outs"]) if inputs is not None else 0
     if world.rank == 0:
         emit({
+            "verified": {"ok": bad_ranks == 0.0, "all_ranks_ok": bad_ranks == 0.0, "gkr_verify_rank0": native},
+            "roofline": transcript_floor(hashed, 3, threads, elapsed / args.steps * 1e3),
             "metric": "aggregated proofs/sec", "value": args.proofs * subs * args.steps / elapsed, "unit": "proofs/s",
             "n_gpus": world.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x8 (BN254 Fr)", "data": "synthetic",
@@ -844,6 +850,8 @@ def run_proofs(args, world):
             "inputs_per_sec": args.proofs * args.steps / elapsed, "step_ms_each": [round(x * 1e3, 3) for x in each]})
     ctx.close()
     step_obj.close()
+    if bad_ranks:
+        raise SystemExit("WRONG RESULTS: gkr_verify rejected a proof of the last timed step")
 
 
 # ------------------------------------------------------------------------------------------------ mode: layer-split

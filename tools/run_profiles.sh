@@ -41,6 +41,9 @@ python tools/config3_accounts.py 64 14 20 > $OUT/config3_thread_and_piece_accoun
 bash tools/stats_wide.sh 20,20 24,18 > /dev/null 2>&1; cp gpurun_out/wide_stats_20_20.csv $OUT/kernel_stats_wide_layer_k_i20_k20.csv; cp gpurun_out/wide_stats_24_18.csv $OUT/kernel_stats_wide_layer_k_i24_k18.csv
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gkr_amd/csrc tools/ubench_cross.hip -o /tmp/ubench_cross > /dev/null 2>&1 && /tmp/ubench_cross > $OUT/ubench_product_pass_cross_sums.txt 2>&1
 bash tools/pmc_product_passes.sh 20,20 > $OUT/product_pass_pmc_k_i20_k20.txt 2>&1
+bash tools/pmc_gate_passes.sh > $OUT/seg_pass_pmc_counters_layer24.txt 2>&1
+bash tools/trace_wide_timeline.sh > $OUT/wide_layer_k_i20_k20_kernel_timeline.txt 2>&1
+bash tools/variants_ab.sh > $OUT/layer24_gate_pass_kernel_ms.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1
 bash tools/trace_layer_timeline.sh > $OUT/layer24_kernel_timeline.txt 2>&1
 bash tools/trace_mle_latency_timeline.sh > $OUT/mle_batch1_kernel_timeline.txt 2>&1
