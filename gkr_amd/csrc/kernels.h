@@ -284,8 +284,13 @@ struct GateEq {
     const Fr* e_lo_mont;
     uint32_t kl;
 };
-// the table is gathered while it stays in the 256 MiB Infinity Cache (k_i <= 22: 128 MiB per proof)
-constexpr uint32_t kGateEqTableMaxKi = 22;
+// eq(z, g) per gate: gathered from the materialised 2^k_i-entry table up to 2^20 gates (32 MiB per proof), formed from the two
+// half tables (one reduced product per gate, both halves cache-resident) beyond.  Same-box A/B, ms of gate passes + table
+// build per sumcheck, table / halves (profiles/r06/e_wide_eq_source_*): (20,15) 0.113 / 0.134, (20,20) 0.174 / 0.155, circom-
+// shaped (20,20) 0.195 / 0.204, (21,16) 0.184 / 0.153, (21,21) 0.327 / 0.288, (22,16) 0.306 / 0.238, (22,22) 0.697 / 0.575 -- the
+// table's random 32-byte reads move 128-byte lines, and from 64 MiB on that costs more than the product (round 5 kept the table
+// up to k_i = 22, while it stays in the 256 MiB Infinity Cache).
+constexpr uint32_t kGateEqTableMaxKi = 20;
 // The plan's counts as the host read them back when the plan was built (hdr[half]: [1] groups, [2] buckets of 2 .. 64 items, [3]
 // buckets of more, [5] their chunks): exact grids, and no combine launch for a half whose buckets are all one item.  In a lockstep
 // group: the largest count over the members.
