@@ -47,3 +47,30 @@ def test_launcher_builds_the_documented_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_the_stdout_line_of_a_full_record_stays_short():
+    """(CPU) compact_line on the full records committed under profiles/ (every leg of the default line, N = 1 and the two-rank
+    gloo run): under 6 000 bytes, every contract key, roofline / cpu_baseline / verified / legs with their scalar fields --
+    the bound BENCH_r05 broke (a 20 KB line the driver did not parse) cannot be broken again without a GPU noticing."""
+    import glob
+    import json
+    sys.path.insert(0, REPO)
+    import bench
+    records = sorted(glob.glob(os.path.join(REPO, "profiles", "r06", "z_bench_*detail.json")))
+    assert records, "no committed detail records"
+    for path in records:
+        full = json.load(open(path))
+        line = bench.compact_line(full)
+        text = json.dumps(line)
+        assert len(text.encode()) < bench.LINE_LIMIT, (path, len(text))
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config"):
+            assert key in line, (path, key)
+        assert line["value"] == float("%.9g" % full["value"]) and "workload" in line["config"]
+        if "roofline" in full and "achieved" in full["roofline"]:
+            for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+                assert key in line["roofline"], (path, key)
+        if os.path.basename(path) == "z_bench_default_detail.json":
+            assert set(line["legs"]) >= {"n16", "layer24", "wide20", "wide_prove", "config0", "config3", "multi_device", "large_r1cs"}
+            assert line["cpu_baseline"]["kind"] == "port" and line["verified"]["ok"] is True and line["exit"]["code"] == 0
