@@ -32,7 +32,7 @@ SYMBOLS = [
     "gkr_selftest_mul", "gkr_selftest_wide_sum", "gkr_selftest_fold", "gkr_selftest_dot", "gkr_selftest_hash8", "gkr_selftest_host_pass", "gkr_selftest_host_prod_pass", "gkr_selftest_host_tail", "gkr_selftest_pass_schedule", "gkr_selftest_line_restriction", "gkr_selftest_seg_item", "gkr_sumcheck_mle", "gkr_sumcheck_mle_batch_device",
     "gkr_sumcheck_layer", "gkr_sumcheck_layer_sharded", "gkr_sumcheck_layer_device", "gkr_resident_layer_create", "gkr_resident_layer_sumcheck", "gkr_resident_layer_sumcheck_wdev", "gkr_resident_layer_free", "gkr_exchange_limbs", "gkr_resident_layer_sumcheck_dev", "gkr_exchange_limbs_mle", "gkr_sumcheck_mle_sharded_dev", "gkr_exchange_rccl_unique_id", "gkr_exchange_rccl_create", "gkr_exchange_rccl_dev",
     "gkr_exchange_rccl_calls", "gkr_exchange_rccl_destroy", "gkr_exchange_rccl_error", "gkr_fr_widen", "gkr_fr_narrow", "gkr_predicate_tables", "gkr_layer_eval", "gkr_proof_sizes", "gkr_prove", "gkr_prove_batch",
-    "gkr_layer_from_wires", "gkr_values_from_terms", "gkr_terms_from_coeffs", "gkr_verify",
+    "gkr_layer_from_wires", "gkr_values_from_terms", "gkr_terms_from_coeffs", "gkr_prove_wires", "gkr_verify",
     "gkr_circom_meta", "gkr_circom_input_json", "gkr_circom_verifier_source", "gkr_circom_inject",
     "gkr_r1cs_parse", "gkr_r1cs_build", "gkr_r1cs_info", "gkr_r1cs_export", "gkr_r1cs_serialize", "gkr_r1cs_free",
     "gkr_wtns_parse", "gkr_wtns_serialize", "gkr_r1cs_compile", "gkr_layered_count", "gkr_layered_circuit",

@@ -263,6 +263,36 @@ int gkr_terms_from_coeffs(int k, const gkr_fr* coeffs, gkr_fr* out_terms, size_t
     return out_terms && count > capacity_terms ? GKR_ERR_NOMEM : GKR_OK;
 }
 
+int gkr_prove_wires(gkr_ctx* ctx, const gkr_wire_circuit* wc, const gkr_fr* input_terms, size_t n_input_terms, int require_zero_output,
+                    gkr_proof_buf* out) {
+    if (!ctx || !wc || !wc->k || !out || wc->depth < 1 || wc->depth > 4096 || !wc->n_add || !wc->n_mult || !wc->add_wire || !wc->mult_wire)
+        return GKR_ERR_INVALID;
+    const uint32_t L = wc->depth;
+    for (uint32_t i = 0; i <= L; ++i)
+        if (wc->k[i] > (i == 0 ? (uint32_t)GKR_MAX_K_I : (uint32_t)GKR_MAX_K_NEXT)) return GKR_ERR_INVALID;
+    std::vector<std::vector<uint8_t>> types(L);
+    std::vector<std::vector<uint32_t>> lefts(L), rights(L);
+    std::vector<const uint8_t*> p_types(L);
+    std::vector<const uint32_t*> p_lefts(L), p_rights(L);
+    for (uint32_t i = 0; i < L; ++i) {
+        const size_t gates = (size_t)1 << wc->k[i];
+        types[i].resize(gates);
+        lefts[i].resize(gates);
+        rights[i].resize(gates);
+        const int rc = gkr_layer_from_wires((int)wc->k[i], (int)wc->k[i + 1], wc->add_wire[i], wc->n_add[i], wc->mult_wire[i], wc->n_mult[i],
+                                            types[i].data(), lefts[i].data(), rights[i].data());
+        if (rc) return rc;
+        p_types[i] = types[i].data();
+        p_lefts[i] = lefts[i].data();
+        p_rights[i] = rights[i].data();
+    }
+    std::vector<gkr_fr> values((size_t)1 << wc->k[L]);
+    const int rv = gkr_values_from_terms((int)wc->k[L], input_terms, n_input_terms, values.data());
+    if (rv) return rv;
+    const gkr_circuit_desc desc = {L, wc->k, p_types.data(), p_lefts.data(), p_rights.data()};
+    return gkr_prove(ctx, &desc, values.data(), require_zero_output, out);
+}
+
 int gkr_verify(const gkr_circuit_desc* circuit, const gkr_proof_buf* proof, int threads, int* accept, uint32_t* failed_layer,
                uint32_t* failed_check) {
     if (!circuit || !proof || !accept || !circuit->k || circuit->depth < 1 || circuit->depth > 4096) return GKR_ERR_INVALID;

@@ -490,6 +490,22 @@ int  gkr_layer_from_wires(int k_i, int k_next, const gkr_fr *add_wire, size_t n_
 int  gkr_values_from_terms(int k, const gkr_fr *terms, size_t n_terms, gkr_fr *out_values);
 int  gkr_terms_from_coeffs(int k, const gkr_fr *coeffs, gkr_fr *out_terms, size_t capacity_terms, size_t *n_terms);
 
+/* prover::prove on exactly the reference's argument types, in ONE call (the three adapters above + gkr_prove): per layer i
+ * the wire vectors of Layer.wire (add_wire[i]: n_add[i] rows, mult_wire[i]: n_mult[i] rows of k[i] + 2 k[i+1] elements; a
+ * pointer may be NULL where its count is 0) and the input layer's term list Input.w[depth] (n_input_terms rows of 1 + k[depth]
+ * elements).  Everything else as gkr_prove.  The statuses of the adapters pass through (GKR_ERR_INVALID: wire vectors that do
+ * not describe a layer, a term that is not multilinear). */
+typedef struct {
+    uint32_t depth;                      /* number of gate layers L */
+    const uint32_t *k;                   /* L + 1 entries (GKRCircuit::get_k_list) */
+    const gkr_fr *const *add_wire;       /* L pointers */
+    const size_t *n_add;                 /* L counts */
+    const gkr_fr *const *mult_wire;
+    const size_t *n_mult;
+} gkr_wire_circuit;
+int  gkr_prove_wires(gkr_ctx *ctx, const gkr_wire_circuit *circuit, const gkr_fr *input_terms, size_t n_input_terms,
+                     int require_zero_output, gkr_proof_buf *out);
+
 /* ---- verifier (host only, no device) ------------------------------------------------------------------------------
  * The relations the reference's verifier checks (python/gkr.py:202-231 with python/sumcheck.py:55-70; verifier.circom:39-71
  * holds the same inside a circuit) on the Rust prover's Proof, which carries no `f` / `add` / `mult` fields: per layer

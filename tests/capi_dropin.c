@@ -125,6 +125,32 @@ int main(void) {
     uint32_t bad_layer = 0, bad_check = 0;
     CHECK(gkr_verify(&circuit, &proof, 1, &accept, &bad_layer, &bad_check));
 
+    /* the same proof through the ONE-call form on the reference's types (gkr_prove_wires): must give the same bytes */
+    {
+        const gkr_fr *adds[2] = {NULL, NULL}, *mults[2] = {w0, w1};
+        const size_t n_add[2] = {0, 0}, n_mult[2] = {2, 4};
+        gkr_wire_circuit wc = {2, k, adds, n_add, mults, n_mult};
+        gkr_proof_buf again;
+        uint32_t q_len2[2];
+        again.sumcheck_coeffs = calloc(sz.rounds * 3, sizeof(gkr_fr));
+        again.sumcheck_len = calloc(sz.rounds, sizeof(uint32_t));
+        again.sumcheck_r = calloc(sz.rounds, sizeof(gkr_fr));
+        again.q = calloc(sz.q_slots, sizeof(gkr_fr));
+        again.q_len = q_len2;
+        again.z = calloc(sz.z_values, sizeof(gkr_fr));
+        again.r = calloc(circuit.depth, sizeof(gkr_fr));
+        again.d_coeffs = calloc(sz.d_coeffs, sizeof(gkr_fr));
+        again.input_coeffs = calloc(sz.input_coeffs, sizeof(gkr_fr));
+        CHECK(gkr_prove_wires(ctx, &wc, terms, 3, 0, &again));
+        if (memcmp(again.sumcheck_coeffs, proof.sumcheck_coeffs, sz.rounds * 3 * sizeof(gkr_fr)) || memcmp(again.sumcheck_r, proof.sumcheck_r, sz.rounds * sizeof(gkr_fr)) ||
+            memcmp(again.q, proof.q, sz.q_slots * sizeof(gkr_fr)) || memcmp(again.z, proof.z, sz.z_values * sizeof(gkr_fr)) ||
+            memcmp(again.r, proof.r, circuit.depth * sizeof(gkr_fr)) || memcmp(again.d_coeffs, proof.d_coeffs, sz.d_coeffs * sizeof(gkr_fr)) ||
+            memcmp(again.input_coeffs, proof.input_coeffs, sz.input_coeffs * sizeof(gkr_fr)) || q_len2[0] != q_len[0] || q_len2[1] != q_len[1]) {
+            fprintf(stderr, "gkr_prove_wires and gkr_prove disagree\n");
+            return 4;
+        }
+    }
+
     /* ---- the Proof of gkr.rs:7-19 as JSON ---- */
     printf("{\"input_values\": ");
     print_vec(input_values, 4);
