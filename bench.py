@@ -142,14 +142,33 @@ def transcript_floor(hashed_elements, vector_len, threads, achieved_ms):
     once (Mimc7::multi_hash, sumcheck.rs:84,129,152: 91 rounds per element), the hashes of one sumcheck are a serial
     chain, those of different sumchecks are independent.  floor = hashed elements x the measured time per element on
     one thread (sixteen transcripts in IFMA lanes, measured now on this host) / threads."""
+    import threading
     from gkr_amd.prover import host_hash_us
     lanes16, scalar = host_hash_us(vector_len)
     per_elem = (lanes16 if lanes16 > 0 else scalar) / vector_len
     floor_ms = hashed_elements * per_elem / threads / 1e3
+    # The same micro-benchmark on ALL the leg's threads at once: what a thread's sixteen-lane hash takes while its neighbours
+    # hash too (AVX-512 clocks, shared caches, the cgroup's quota) -- the rate the step can really draw on.  Beside, not
+    # instead of, the one-thread figure `frac` is quoted against.
+    loaded = []
+    if lanes16 > 0 and threads > 1:
+        gate = threading.Barrier(threads)
+
+        def busy():
+            gate.wait()
+            mine = [host_hash_us(vector_len)[0] for _ in range(3)]
+            loaded.append(statistics.median(mine))
+        workers = [threading.Thread(target=busy) for _ in range(threads)]
+        [w.start() for w in workers]
+        [w.join() for w in workers]
+    loaded_us = statistics.median(loaded) if loaded else None
+    loaded_floor = hashed_elements * (loaded_us / vector_len) / threads / 1e3 if loaded_us else None
     return {"bound": "host transcript (MiMC7 hashing throughput of the host cores)", "hashed_elements_per_step": int(hashed_elements),
             "us_per_hash_16_lanes": lanes16, "us_per_hash_scalar": scalar, "vector_len_timed": vector_len, "threads": threads,
             "floor_ms": floor_ms, "achieved_ms": achieved_ms, "achieved_over_floor": achieved_ms / floor_ms if floor_ms else None,
-            "frac": floor_ms / achieved_ms if achieved_ms else None}
+            "frac": floor_ms / achieved_ms if achieved_ms else None,
+            "us_per_hash_16_lanes_all_threads_hashing": loaded_us, "floor_ms_all_threads_hashing": loaded_floor,
+            "frac_of_the_loaded_floor": loaded_floor / achieved_ms if loaded_floor and achieved_ms else None}
 
 
 def guarded(fn, seconds):
