@@ -252,6 +252,20 @@ def main():
         z0 = [0] * ks[0] if si % 2 == 0 else [rng.randrange(P) for _ in range(ks[0])]
         cases.append(dump_case("random_k{}_{}_{}".format("".join(map(str, ks)), mix, si), layers, inputs, z0))
         print("case", cases[-1]["name"], "ok")
+    # round 6: wider and deeper circuits through the same reference prover, from a generator of their own (the cases above and
+    # the plain-sumcheck fixtures below keep their bytes)
+    rng2 = random.Random(0xC0FFEE + 6)
+    more = [
+        ([3, 3], "mix"), ([2, 3, 3], "mix"), ([3, 3, 3], "mult"), ([1, 2, 3, 2], "mix"), ([3, 2, 3], "add"), ([4, 3], "mix"),
+        ([3, 4], "mix"), ([2, 2, 2, 2, 2], "mix"), ([5, 4], "mix"), ([4, 5, 3], "mix"), ([0, 3, 4], "mult"),
+    ]
+    for si, (ks, mix) in enumerate(more):
+        layers = random_layers(rng2, ks, mix)
+        # (every third case: a witness with few distinct values -- layers whose extension lacks variables, short q)
+        inputs = [rng2.randrange(P) for _ in range(1 << ks[-1])] if si % 3 != 2 else [rng2.randrange(2) for _ in range(1 << ks[-1])]
+        z0 = [0] * ks[0] if si % 2 == 0 else [rng2.randrange(P) for _ in range(ks[0])]
+        cases.append(dump_case("r6_k{}_{}_{}".format("".join(map(str, ks)), mix, si), layers, inputs, z0))
+        print("case", cases[-1]["name"], "ok")
     with open(os.path.join(HERE, "gkr_circuits.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "modulus": S(P), "cases": cases}, f, indent=1)
 
