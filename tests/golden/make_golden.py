@@ -274,15 +274,13 @@ def main():
     for n in (2, 3, 4, 5, 6):
         tables.append([rng.randrange(P) for _ in range(1 << n)])
     tables.append([rng.randrange(1, 100) for _ in range(16)])
-    # round 6: larger tables and the length rule's edge cases (a constant table, tables that do not depend on the last / the first
-    # variable), from a generator of their own: the seven cases above keep their bytes
+    # round 6: larger tables, from a generator of their own: the seven cases above keep their bytes.  (Tables that do not depend
+    # on a variable cannot be pinned here: the Rust prover drops a round vector's leading zero coefficient before hashing it
+    # (poly.rs:388-420), this Python prover hashes [0, c0] -- the transcripts part at that round.  Those cases are held against
+    # the oracle's restatement of the Rust rule in tests/test_gpu_parity.py.)
     rng3 = random.Random(0xC0FFEE + 60)
     tables.append([rng3.randrange(P) for _ in range(1 << 7)])
     tables.append([rng3.randrange(P) for _ in range(1 << 8)])
-    tables.append([5] * 16)
-    half = [rng3.randrange(P) for _ in range(16)]
-    tables.append([half[i >> 1] for i in range(32)])      # no dependence on the last variable
-    tables.append(half + half)                              # no dependence on the first variable
     for tbl in tables:
         n = (len(tbl) - 1).bit_length()
         g = ref_poly.get_ext(table_func(tbl, n), n)
